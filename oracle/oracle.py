@@ -1,0 +1,204 @@
+"""ctypes binding of oracle/libunwarp_oracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module (see the header of oracle/unwarp_oracle.c).  The functions mirror
+the reference signatures of discorpy/post/postprocessing.py (:111, :188, :255,
+:462) for float32 data and spline order 0/1.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libunwarp_oracle.so")
+
+POLY_KERNEL, POLY_NUMPY = 0, 1
+BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "unwarp_oracle.c")
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.run(["make", "-C", _HERE, "-B", "libunwarp_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        i64, dbl, i32 = C.c_int64, C.c_double, C.c_int
+        fp, dp, vp = C.POINTER(C.c_float), C.POINTER(C.c_double), C.c_void_p
+        L.orc_set_threads.argtypes = [i32]
+        L.orc_max_threads.restype = i32
+        L.orc_get_threads.restype = i32
+        L.orc_radial_coords.argtypes = [i64, i64, dbl, dbl, dp, i32, i32, i32, dp, dp]
+        L.orc_perspective_coords.argtypes = [i64, i64, dp, i32, dp, dp]
+        L.orc_unwarp_image_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, i32, i32, i32, i32]
+        L.orc_perspective_image_f32.argtypes = [fp, fp, i64, i64, i64, dp, i32, i32]
+        L.orc_unwarp_fused_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, dp, i32, i32, i32]
+        L.orc_remap_coords_f32.argtypes = [fp, fp, i64, i64, i64, vp, vp, i32, i64, i32, i32]
+        L.orc_unwarp_stack_rows_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, dbl, i64,
+                                                i32, i32, i32]
+        _lib = L
+    return _lib
+
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().orc_max_threads())
+
+
+def _f32c(a):
+    a = np.asarray(a)
+    if a.dtype != np.float32:
+        raise TypeError("oracle handles float32 data only")
+    return a
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _facts(list_fact):
+    return np.ascontiguousarray(np.asarray(list_fact, dtype=np.float64).reshape(-1))
+
+
+def _check(rc):
+    if rc != 0:
+        raise ValueError("oracle rejected its arguments (rc=%d)" % rc)
+
+
+def _row_stride(mat):
+    if mat.ndim != 2 or mat.strides[1] != mat.itemsize or mat.strides[0] % mat.itemsize:
+        raise ValueError("need unit column stride")
+    return mat.strides[0] // mat.itemsize
+
+
+def radial_coords(height, width, xcenter, ycenter, list_fact, poly=POLY_NUMPY, round_f32=True):
+    """(yd, xd) float64 planes of postprocessing.py:138-145."""
+    f = _facts(list_fact)
+    yd = np.empty((height, width), np.float64)
+    xd = np.empty((height, width), np.float64)
+    _check(lib().orc_radial_coords(height, width, float(xcenter), float(ycenter), _dp(f), f.size,
+                                   poly, int(round_f32), _dp(yd), _dp(xd)))
+    return yd, xd
+
+
+def perspective_coords(height, width, list_coef, round_f32=True):
+    c = _facts(list_coef)
+    yd = np.empty((height, width), np.float64)
+    xd = np.empty((height, width), np.float64)
+    _check(lib().orc_perspective_coords(height, width, _dp(c), int(round_f32), _dp(yd), _dp(xd)))
+    return yd, xd
+
+
+def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *,
+                          poly=POLY_NUMPY, blend=BLEND_SCIPY, coord_round_f32=True):
+    """postprocessing.py:111-148 for float32 `mat`, order 0/1 (mode is inert there)."""
+    mat = _f32c(mat)
+    (height, width) = mat.shape
+    f = _facts(list_fact)
+    out = np.empty((height, width), np.float32)
+    _check(lib().orc_unwarp_image_f32(_fp(mat), _fp(out), height, width, _row_stride(mat),
+                                      float(xcenter), float(ycenter), _dp(f), f.size, int(order),
+                                      int(coord_round_f32), poly, blend))
+    return out
+
+
+def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index=None, *,
+                              blend=BLEND_SCIPY):
+    """postprocessing.py:462-492."""
+    if len(list_coef) != 8:
+        raise ValueError("!!! Eight coefficients are required !!!")
+    mat = _f32c(mat)
+    (height, width) = mat.shape
+    out = np.empty((height, width), np.float32)
+    if map_index is None:
+        c = _facts(list_coef)
+        _check(lib().orc_perspective_image_f32(_fp(mat), _fp(out), height, width, _row_stride(mat),
+                                               _dp(c), int(order), blend))
+        return out
+    ycoord, xcoord = (np.ascontiguousarray(np.asarray(m).reshape(-1)) for m in map_index)
+    return remap_coords(mat, ycoord, xcoord, order=order, blend=blend).reshape(height, width)
+
+
+def remap_coords(mat, ycoord, xcoord, order=1, *, blend=BLEND_SCIPY):
+    """map_coordinates(mat, (ycoord, xcoord), order) for in-range coordinates."""
+    mat = _f32c(mat)
+    ycoord = np.ascontiguousarray(ycoord)
+    xcoord = np.ascontiguousarray(xcoord)
+    if ycoord.dtype != xcoord.dtype or ycoord.dtype not in (np.float32, np.float64):
+        raise TypeError("coordinates must both be float32 or both float64")
+    out = np.empty(ycoord.shape, np.float32)
+    _check(lib().orc_remap_coords_f32(_fp(mat), _fp(out), mat.shape[0], mat.shape[1], _row_stride(mat),
+                                      ycoord.ctypes.data, xcoord.ctypes.data,
+                                      int(ycoord.dtype == np.float64), ycoord.size, int(order), blend))
+    return out
+
+
+def unwarp_fused(mat, xcenter, ycenter, list_fact, list_coef, order=1, *, poly=POLY_NUMPY,
+                 blend=BLEND_SCIPY):
+    """One-pass perspective->radial remap (SURVEY.md section 8(d) cfg3 definition)."""
+    if len(list_coef) != 8:
+        raise ValueError("!!! Eight coefficients are required !!!")
+    mat = _f32c(mat)
+    (height, width) = mat.shape
+    f, c = _facts(list_fact), _facts(list_coef)
+    out = np.empty((height, width), np.float32)
+    _check(lib().orc_unwarp_fused_f32(_fp(mat), _fp(out), height, width, _row_stride(mat),
+                                      float(xcenter), float(ycenter), _dp(f), f.size, _dp(c),
+                                      int(order), poly, blend))
+    return out
+
+
+def unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, *, coord_round_f32,
+                      poly=POLY_NUMPY, blend=BLEND_SCIPY):
+    mat3D = np.ascontiguousarray(_f32c(mat3D))
+    (depth, height, width) = mat3D.shape
+    f = _facts(list_fact)
+    out = np.empty((depth, nrows, width), np.float32)
+    _check(lib().orc_unwarp_stack_rows_f32(_fp(mat3D), _fp(out), depth, height, width, float(xcenter),
+                                           float(ycenter), _dp(f), f.size, float(row_start), nrows,
+                                           int(coord_round_f32), poly, blend))
+    return out
+
+
+def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, poly=POLY_NUMPY,
+                          blend=BLEND_SCIPY):
+    """postprocessing.py:188-229 (float64 coordinates, float32 output)."""
+    if len(np.shape(mat3D)) < 3:
+        raise ValueError("Input must be a 3D data")
+    return unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, index, 1, coord_round_f32=False,
+                             poly=poly, blend=blend)[:, 0, :]
+
+
+def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *,
+                                 poly=POLY_NUMPY, blend=BLEND_SCIPY):
+    """postprocessing.py:255-313 (float32 coordinates, rows start..stop inclusive)."""
+    if len(np.shape(mat3D)) < 3:
+        raise ValueError("Input must be a 3D data")
+    height = np.shape(mat3D)[1]
+    index_list = np.arange(height, dtype=np.int16)
+    if stop_index == -1:
+        stop_index = height
+    if (start_index not in index_list) or (stop_index not in index_list):
+        raise ValueError("Selected index is out of the range")
+    return unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, start_index,
+                             stop_index - start_index + 1, coord_round_f32=True, poly=poly, blend=blend)

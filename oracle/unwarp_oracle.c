@@ -1,0 +1,344 @@
+/*
+ * oracle/unwarp_oracle.c -- CPU restatement of discorpy's backward-unwarp path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under discorpy_amd/ may import, link or
+ * call this file; it exists so that tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py can check (never replace) the HIP kernels.
+ *
+ * Parity status: PINNED.  tools/gen_golden.py imports the reference from
+ * /root/reference in the build container and stores its inputs/outputs under
+ * tests/golden/; tests/test_oracle_golden.py holds this file bit-equal to
+ * those vectors (poly_mode = NUMPY, blend_mode = SCIPY).
+ *
+ * What is restated (reference = /root/reference, discorpy 1.7.0):
+ *   discorpy/post/postprocessing.py:137-148   unwarp_image_backward
+ *   discorpy/post/postprocessing.py:211-229   unwarp_slice_backward
+ *   discorpy/post/postprocessing.py:281-313   unwarp_chunk_slices_backward (+ _mapping :250-252)
+ *   discorpy/post/postprocessing.py:448-459   _generate_perspective_map
+ *   discorpy/post/postprocessing.py:486-492   correct_perspective_image
+ * and the third-party inner loop those call, scipy.ndimage.map_coordinates
+ * (scipy is un-vendored and unpinned in the reference's setup.py:5-12; 1.15.3
+ * in the build container).  Its published algorithm for spline order <= 1 --
+ * C function NI_GeometricTransform + get_spline_interpolation_weights -- is:
+ *   order 1: s = floor(c); f = c - s; w0 = 1 - f; w1 = 1 - w0 (per axis);
+ *            taps (y0,x0),(y0,x1),(y1,x0),(y1,x1); each term is
+ *            ((double)v * wy) * wx; terms accumulated left to right from 0.0
+ *            in a double; the sum is cast to the output dtype.
+ *   order 0: index = floor(c + 0.5) per axis; value copied.
+ *   an out-of-range neighbour (only when c == len-1 exactly) is folded back
+ *   onto the edge sample by the boundary mode and carries weight 0.
+ * Because the callers clip every coordinate into [0, len-1] first, the
+ * `mode` argument cannot change the result for order <= 1.
+ *
+ * Two evaluation orders of the radial polynomial are provided:
+ *   ORC_POLY_NUMPY  (1): exactly the reference's expression
+ *        sum_i a_i * ru**i, left to right, ru**0 = 1, ru**1 = ru,
+ *        ru**2 = ru*ru, ru**i = pow(ru, i) for i >= 3
+ *        (postprocessing.py:142-143; numpy's scalar-power fast paths).
+ *   ORC_POLY_KERNEL (0): the order the HIP kernels use -- even/odd split in
+ *        r2 = xu^2 + yu^2 with fused multiply-adds:
+ *        E = a0 + r2*(a2 + r2*(a4 + ...)), O = a1 + r2*(a3 + ...),
+ *        B = fma(ru, O, E).
+ *   Both agree to ~2e-16 relative; after the float32 rounding of the
+ *   coordinates (postprocessing.py:144-145) they are bit-identical except when
+ *   a float64 coordinate lies within ~1e-12 px of a float32 rounding boundary.
+ *
+ * Three blend modes: ORC_BLEND_SCIPY (0) is scipy's arithmetic above,
+ * ORC_BLEND_F64LERP (1) and ORC_BLEND_F32LERP (2) restate the cheaper
+ * factorised forms the HIP kernels may be asked to use.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "unwarp_oracle.h"
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static int g_threads = 1;
+
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_threads(void) { return g_threads; }
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
+
+/* ---- radial polynomial ------------------------------------------------- */
+
+/* postprocessing.py:142-143 -- reference order */
+static inline double poly_numpy(const double *a, int n, double ru)
+{
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double p;
+        if (i == 0) p = 1.0;
+        else if (i == 1) p = ru;
+        else if (i == 2) p = ru * ru;
+        else p = pow(ru, (double)i);
+        double t = a[i] * p;
+        s = (i == 0) ? t : s + t;
+    }
+    return s;
+}
+
+/* kernel order: even/odd Horner in r2, fused */
+static inline double poly_kernel(const double *a, int n, double r2, double ru)
+{
+    if (n <= 0) return 0.0;
+    int ne = (n + 1) / 2, no = n / 2;
+    double E = a[2 * (ne - 1)];
+    for (int k = ne - 2; k >= 0; --k) E = fma(r2, E, a[2 * k]);
+    if (no == 0) return E;
+    double O = a[2 * (no - 1) + 1];
+    for (int k = no - 2; k >= 0; --k) O = fma(r2, O, a[2 * k + 1]);
+    return fma(ru, O, E);
+}
+
+static inline double clipd(double v, double lo, double hi)
+{
+    /* np.clip == minimum(maximum(v, lo), hi) */
+    v = v < lo ? lo : v;
+    v = v > hi ? hi : v;
+    return v;
+}
+
+/* one output pixel of the radial backward map; postprocessing.py:138-145 */
+static inline void radial_coord(double x, double y, double xc, double yc,
+                                const double *a, int n, int poly_mode,
+                                double wmax, double hmax, int round_f32,
+                                double *xd, double *yd)
+{
+    double xu = x - xc;
+    double yu = y - yc;
+    double r2 = xu * xu + yu * yu;          /* xu**2 + yu**2: two products, one add */
+    double ru = sqrt(r2);
+    double f = poly_mode == ORC_POLY_NUMPY ? poly_numpy(a, n, ru)
+                                           : poly_kernel(a, n, r2, ru);
+    double px = f * xu;
+    double py = f * yu;
+    double cx = clipd(xc + px, 0.0, wmax);
+    double cy = clipd(yc + py, 0.0, hmax);
+    if (round_f32) {
+        cx = (double)(float)cx;              /* np.float32(...) then widened by scipy */
+        cy = (double)(float)cy;
+    }
+    *xd = cx;
+    *yd = cy;
+}
+
+/* _generate_perspective_map; postprocessing.py:448-457 (numpy: no contraction) */
+static inline void persp_coord(double x, double y, const double *c,
+                               double wmax, double hmax, int round_f32,
+                               double *xd, double *yd)
+{
+    double den = (c[6] * x + c[7] * y) + 1.0;
+    double nx = (c[0] * x + c[1] * y) + c[2];
+    double ny = (c[3] * x + c[4] * y) + c[5];
+    double cx = clipd(nx / den, 0.0, wmax);
+    double cy = clipd(ny / den, 0.0, hmax);
+    if (round_f32) {
+        cx = (double)(float)cx;
+        cy = (double)(float)cy;
+    }
+    *xd = cx;
+    *yd = cy;
+}
+
+/* ---- scipy.ndimage.map_coordinates, order 0 / 1, coordinate inside [0,len-1] ---- */
+
+static inline int64_t fold_edge(int64_t i, int64_t len)
+{
+    /* every boundary mode maps index len -> a sample whose weight is 0 here;
+       'reflect' (d c b a | a b c d | d c b a) gives len-1 */
+    if (i < 0) return 0;
+    if (i > len - 1) return len - 1;
+    return i;
+}
+
+static inline float sample(const float *src, int64_t H, int64_t W,
+                           int64_t rs, int64_t cs, double y, double x,
+                           int order, int blend_mode)
+{
+    if (order == 0) {
+        int64_t iy = fold_edge((int64_t)floor(y + 0.5), H);
+        int64_t ix = fold_edge((int64_t)floor(x + 0.5), W);
+        return src[iy * rs + ix * cs];
+    }
+    double y0 = floor(y), x0 = floor(x);
+    double fy = y - y0, fx = x - x0;
+    int64_t iy0 = (int64_t)y0, ix0 = (int64_t)x0;
+    int64_t iy1 = fold_edge(iy0 + 1, H), ix1 = fold_edge(ix0 + 1, W);
+    iy0 = fold_edge(iy0, H);
+    ix0 = fold_edge(ix0, W);
+    float v00 = src[iy0 * rs + ix0 * cs], v01 = src[iy0 * rs + ix1 * cs];
+    float v10 = src[iy1 * rs + ix0 * cs], v11 = src[iy1 * rs + ix1 * cs];
+    if (blend_mode == ORC_BLEND_SCIPY) {
+        double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
+        double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
+        double t = 0.0;
+        t += ((double)v00 * wy0) * wx0;
+        t += ((double)v01 * wy0) * wx1;
+        t += ((double)v10 * wy1) * wx0;
+        t += ((double)v11 * wy1) * wx1;
+        return (float)t;
+    } else if (blend_mode == ORC_BLEND_F64LERP) {
+        double a = (double)v00, b = (double)v01, c = (double)v10, d = (double)v11;
+        double top = fma(fx, b - a, a);
+        double bot = fma(fx, d - c, c);
+        return (float)fma(fy, bot - top, top);
+    } else {
+        float gx = (float)fx, gy = (float)fy;
+        float top = fmaf(gx, v01 - v00, v00);
+        float bot = fmaf(gx, v11 - v10, v10);
+        return fmaf(gy, bot - top, top);
+    }
+}
+
+/* ---- public entry points ----------------------------------------------- */
+
+int orc_radial_coords(int64_t H, int64_t W, double xc, double yc,
+                      const double *fact, int nfact, int poly_mode,
+                      int round_f32, double *yd, double *xd)
+{
+    if (H < 0 || W < 0 || nfact < 0) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t y = 0; y < H; ++y)
+        for (int64_t x = 0; x < W; ++x)
+            radial_coord((double)x, (double)y, xc, yc, fact, nfact, poly_mode,
+                         (double)(W - 1), (double)(H - 1), round_f32,
+                         &xd[y * W + x], &yd[y * W + x]);
+    return 0;
+}
+
+int orc_perspective_coords(int64_t H, int64_t W, const double *coef,
+                           int round_f32, double *yd, double *xd)
+{
+    if (H < 0 || W < 0) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t y = 0; y < H; ++y)
+        for (int64_t x = 0; x < W; ++x)
+            persp_coord((double)x, (double)y, coef, (double)(W - 1),
+                        (double)(H - 1), round_f32, &xd[y * W + x], &yd[y * W + x]);
+    return 0;
+}
+
+/* unwarp_image_backward; postprocessing.py:137-148 */
+int orc_unwarp_image_f32(const float *src, float *dst, int64_t H, int64_t W,
+                         int64_t src_row_stride, double xc, double yc,
+                         const double *fact, int nfact, int order,
+                         int coord_round_f32, int poly_mode, int blend_mode)
+{
+    if (H <= 0 || W <= 0 || nfact < 0 || order < 0 || order > 1) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t y = 0; y < H; ++y) {
+        for (int64_t x = 0; x < W; ++x) {
+            double xd, yd;
+            radial_coord((double)x, (double)y, xc, yc, fact, nfact, poly_mode,
+                         (double)(W - 1), (double)(H - 1), coord_round_f32, &xd, &yd);
+            dst[y * W + x] = sample(src, H, W, src_row_stride, 1, yd, xd, order, blend_mode);
+        }
+    }
+    return 0;
+}
+
+/* correct_perspective_image with map_index=None; postprocessing.py:486-492 */
+int orc_perspective_image_f32(const float *src, float *dst, int64_t H, int64_t W,
+                              int64_t src_row_stride, const double *coef,
+                              int order, int blend_mode)
+{
+    if (H <= 0 || W <= 0 || order < 0 || order > 1) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t y = 0; y < H; ++y) {
+        for (int64_t x = 0; x < W; ++x) {
+            double xd, yd;
+            persp_coord((double)x, (double)y, coef, (double)(W - 1), (double)(H - 1), 1, &xd, &yd);
+            dst[y * W + x] = sample(src, H, W, src_row_stride, 1, yd, xd, order, blend_mode);
+        }
+    }
+    return 0;
+}
+
+/*
+ * Fused perspective -> radial map, ONE resampling (BASELINE config 3; definition
+ * SURVEY.md section 8(d) cfg3): (xp,yp) = float32(clip(Hmg(x,y))) as
+ * postprocessing.py:453-457, then the radial map of :141-145 evaluated at the
+ * (non-integer) position (xp,yp), float32-rounded, one sample of src.
+ * Its reference value is one map_coordinates call at these coordinates.
+ */
+int orc_unwarp_fused_f32(const float *src, float *dst, int64_t H, int64_t W,
+                         int64_t src_row_stride, double xc, double yc,
+                         const double *fact, int nfact, const double *coef,
+                         int order, int poly_mode, int blend_mode)
+{
+    if (H <= 0 || W <= 0 || nfact < 0 || order < 0 || order > 1) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t y = 0; y < H; ++y) {
+        for (int64_t x = 0; x < W; ++x) {
+            double xp, yp, xd, yd;
+            persp_coord((double)x, (double)y, coef, (double)(W - 1), (double)(H - 1), 1, &xp, &yp);
+            radial_coord(xp, yp, xc, yc, fact, nfact, poly_mode,
+                         (double)(W - 1), (double)(H - 1), 1, &xd, &yd);
+            dst[y * W + x] = sample(src, H, W, src_row_stride, 1, yd, xd, order, blend_mode);
+        }
+    }
+    return 0;
+}
+
+/* map_coordinates(mat, (ycoord, xcoord)) with caller-supplied coordinates:
+   correct_perspective_image(map_index=...) :489-491 and _mapping :250-251.
+   Coordinates outside [0,len-1] are clamped (the reference's callers never
+   produce them; scipy would apply `mode`). */
+int orc_remap_coords_f32(const float *src, float *dst, int64_t H, int64_t W,
+                         int64_t src_row_stride, const void *ycoord,
+                         const void *xcoord, int coord_is_f64, int64_t npts,
+                         int order, int blend_mode)
+{
+    if (H <= 0 || W <= 0 || npts < 0 || order < 0 || order > 1) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < npts; ++i) {
+        double y = coord_is_f64 ? ((const double *)ycoord)[i] : (double)((const float *)ycoord)[i];
+        double x = coord_is_f64 ? ((const double *)xcoord)[i] : (double)((const float *)xcoord)[i];
+        y = clipd(y, 0.0, (double)(H - 1));
+        x = clipd(x, 0.0, (double)(W - 1));
+        dst[i] = sample(src, H, W, src_row_stride, 1, y, x, order, blend_mode);
+    }
+    return 0;
+}
+
+/*
+ * unwarp_slice_backward (:211-229, coord_round_f32 = 0, nrows = 1) and
+ * unwarp_chunk_slices_backward (:281-313, coord_round_f32 = 1) over a
+ * (D,H,W) stack: out[d, r, x] for rows row_start .. row_start+nrows-1.
+ * The reference samples a row band mat3D[i, yd_min:yd_max, :] with
+ * band-relative coordinates; subtracting the integer yd_min is exact, so the
+ * result equals sampling the whole projection at absolute coordinates.
+ * row_start may be any double-representable number (the reference does not
+ * validate `index`, :215); rows are row_start + r.
+ */
+int orc_unwarp_stack_rows_f32(const float *vol, float *out, int64_t D, int64_t H,
+                              int64_t W, double xc, double yc, const double *fact,
+                              int nfact, double row_start, int64_t nrows,
+                              int coord_round_f32, int poly_mode, int blend_mode)
+{
+    if (D < 0 || H <= 0 || W <= 0 || nrows < 0 || nfact < 0) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t r = 0; r < nrows; ++r) {
+        for (int64_t x = 0; x < W; ++x) {
+            double xd, yd;
+            radial_coord((double)x, row_start + (double)r, xc, yc, fact, nfact, poly_mode,
+                         (double)(W - 1), (double)(H - 1), coord_round_f32, &xd, &yd);
+            for (int64_t d = 0; d < D; ++d)
+                out[(d * nrows + r) * W + x] =
+                    sample(vol + d * H * W, H, W, W, 1, yd, xd, 1, blend_mode);
+        }
+    }
+    return 0;
+}

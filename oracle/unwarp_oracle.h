@@ -1,0 +1,39 @@
+/* oracle/unwarp_oracle.h -- declarations for the CPU restatement (test infrastructure only). */
+#ifndef UNWARP_ORACLE_H
+#define UNWARP_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_POLY_KERNEL 0
+#define ORC_POLY_NUMPY 1
+#define ORC_BLEND_SCIPY 0
+#define ORC_BLEND_F64LERP 1
+#define ORC_BLEND_F32LERP 2
+
+void orc_set_threads(int n);
+int orc_get_threads(void);
+int orc_max_threads(void);
+
+int orc_radial_coords(int64_t H, int64_t W, double xc, double yc, const double *fact, int nfact,
+                      int poly_mode, int round_f32, double *yd, double *xd);
+int orc_perspective_coords(int64_t H, int64_t W, const double *coef, int round_f32, double *yd, double *xd);
+int orc_unwarp_image_f32(const float *src, float *dst, int64_t H, int64_t W, int64_t src_row_stride,
+                         double xc, double yc, const double *fact, int nfact, int order,
+                         int coord_round_f32, int poly_mode, int blend_mode);
+int orc_perspective_image_f32(const float *src, float *dst, int64_t H, int64_t W, int64_t src_row_stride,
+                              const double *coef, int order, int blend_mode);
+int orc_unwarp_fused_f32(const float *src, float *dst, int64_t H, int64_t W, int64_t src_row_stride,
+                         double xc, double yc, const double *fact, int nfact, const double *coef,
+                         int order, int poly_mode, int blend_mode);
+int orc_remap_coords_f32(const float *src, float *dst, int64_t H, int64_t W, int64_t src_row_stride,
+                         const void *ycoord, const void *xcoord, int coord_is_f64, int64_t npts,
+                         int order, int blend_mode);
+int orc_unwarp_stack_rows_f32(const float *vol, float *out, int64_t D, int64_t H, int64_t W,
+                              double xc, double yc, const double *fact, int nfact, double row_start,
+                              int64_t nrows, int coord_round_f32, int poly_mode, int blend_mode);
+#ifdef __cplusplus
+}
+#endif
+#endif
