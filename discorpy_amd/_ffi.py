@@ -1,0 +1,186 @@
+"""ctypes binding of libdiscorpy_hip.so (C ABI: include/discorpy_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` / ``make -C discorpy_amd/csrc`` into
+``discorpy_amd/lib/``.  There is no CPU fallback: if the library is missing or no HIP device is
+visible, the entry points of :mod:`discorpy_amd.post.postprocessing` raise.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdiscorpy_hip.so")
+
+OK, ERR_INVALID_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4
+MEM_HOST, MEM_DEVICE = 0, 1
+BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
+COORD_F32, COORD_F64 = 0, 1
+COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
+MAX_FACT = 32
+
+BLEND_BY_NAME = {"scipy": BLEND_SCIPY, "exact": BLEND_SCIPY, "f64": BLEND_F64LERP,
+                 "f64lerp": BLEND_F64LERP, "f32": BLEND_F32LERP, "f32lerp": BLEND_F32LERP}
+
+
+class HipLibraryMissing(ImportError):
+    pass
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# name -> (restype, argtypes); mirrors include/discorpy_hip.h declaration by declaration
+_i64, _dbl, _int, _vp, _sz = C.c_int64, C.c_double, C.c_int, C.c_void_p, C.c_size_t
+_dp = C.POINTER(C.c_double)
+SIGNATURES = {
+    "dcp_version": (_int, []),
+    "dcp_device_count": (_int, []),
+    "dcp_last_error": (C.c_char_p, []),
+    "dcp_set_option": (_int, [C.c_char_p, _int]),
+    "dcp_get_option": (_int, [C.c_char_p, C.POINTER(_int)]),
+    "dcp_unwarp_image_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int,
+                                    _int, _int, _int, _vp]),
+    "dcp_perspective_image_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),
+    "dcp_unwarp_fused_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dp, _int, _int,
+                                    _int, _int, _vp]),
+    "dcp_remap_coords_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _i64, _int, _int, _int,
+                                    _int, _vp]),
+    "dcp_unwarp_stack_rows_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,
+                                         _i64, _int, _int, _int, _int, _vp]),
+    "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
+    "dcp_free": (_int, [_vp, _int]),
+    "dcp_memcpy": (_int, [_vp, _vp, _sz, _int, _int, _vp]),
+    "dcp_stream_synchronize": (_int, [_int, _vp]),
+    "dcp_event_create": (_int, [C.POINTER(_vp), _int]),
+    "dcp_event_record": (_int, [_vp, _vp]),
+    "dcp_event_synchronize": (_int, [_vp]),
+    "dcp_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
+    "dcp_event_destroy": (_int, [_vp]),
+}
+
+
+def lib():
+    """Load the shared library (once) and declare every entry point."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                "libdiscorpy_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C discorpy_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    msg = lib().dcp_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc):
+    """Translate a DCP_ERR_* code into the exception the reference's callers expect."""
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == ERR_INVALID_ARG:
+        raise ValueError(msg)
+    if rc == ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise HipError(msg)
+
+
+def device_count():
+    return int(lib().dcp_device_count())
+
+
+def require_device():
+    n = device_count()
+    if n < 1:
+        raise HipError("no HIP device visible: the discorpy_amd unwarp path runs on the GPU only "
+                       "(no CPU fallback)")
+    return n
+
+
+def set_option(key, value):
+    check(lib().dcp_set_option(key.encode(), int(value)))
+
+
+def get_option(key):
+    v = C.c_int(0)
+    check(lib().dcp_get_option(key.encode(), C.byref(v)))
+    return v.value
+
+
+def fact_array(list_fact):
+    """(ctypes double array, n) for a coefficient sequence."""
+    vals = [float(v) for v in list_fact]
+    arr = (C.c_double * max(len(vals), 1))(*vals)
+    return arr, len(vals)
+
+
+class DeviceBuffer:
+    """Device allocation owned by Python (dcp_malloc / dcp_free)."""
+
+    def __init__(self, nbytes, device=-1):
+        self.nbytes = int(nbytes)
+        self.device = device
+        p = C.c_void_p()
+        check(lib().dcp_malloc(C.byref(p), self.nbytes, device))
+        self.ptr = p.value
+
+    def upload(self, array):
+        import numpy as np
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= self.nbytes
+        check(lib().dcp_memcpy(self.ptr, a.ctypes.data, a.nbytes, COPY_H2D, self.device, None))
+        return self
+
+    def download(self, shape, dtype):
+        import numpy as np
+        out = np.empty(shape, dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().dcp_memcpy(out.ctypes.data, self.ptr, out.nbytes, COPY_D2H, self.device, None))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().dcp_free(self.ptr, self.device)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self, device=-1):
+        p = C.c_void_p()
+        check(lib().dcp_event_create(C.byref(p), device))
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        check(lib().dcp_event_record(self.ptr, stream))
+
+    def synchronize(self):
+        check(lib().dcp_event_synchronize(self.ptr))
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        check(lib().dcp_event_elapsed_ms(self.ptr, stop.ptr, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().dcp_event_destroy(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass

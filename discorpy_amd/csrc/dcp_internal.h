@@ -1,0 +1,72 @@
+// dcp_internal.h -- shared between the HIP kernels (unwarp_kernels.hip) and the
+// C-ABI layer (unwarp_api.cpp).  Not installed; the public surface is
+// include/discorpy_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcp {
+
+constexpr int kMaxFact = 32;       // longest radial coefficient vector accepted
+constexpr int kInlineFact = 10;    // lengths 1..kInlineFact get a fully unrolled, SGPR-resident polynomial
+constexpr int kMaxTileRows = 64;   // rows one workgroup walks (runtime option tile_rows <= this)
+
+// sampler selector: order 0, or order 1 with one of the three blend arithmetics
+enum Sampler : int { kNearest = 0, kScipy = 1, kF64Lerp = 2, kF32Lerp = 3 };
+
+// what maps an output pixel to a source coordinate
+enum MapKind : int { kRadial = 0, kPersp = 1, kFused = 2 };
+
+struct ImageArgs {
+  const float* src;
+  float* dst;
+  int32_t H, W;            // output == source shape
+  int32_t src_stride;      // elements between source rows
+  int32_t src_col_stride;  // elements between source columns (1 on the fast path)
+  uint32_t src_bytes;      // extent of the source for the buffer descriptor
+  int32_t tiles_x, tiles_y;
+  int32_t tile_rows;       // rows per workgroup
+  int32_t xcd_remap;       // 1: contiguous band of tiles per XCD
+};
+
+struct MapArgs {
+  double xc, yc;
+  double fact[kMaxFact];
+  double coef[8];          // perspective c1..c8
+  int32_t nfact;
+};
+
+struct StackArgs {
+  const float* vol;
+  float* out;
+  int64_t proj_stride;     // elements between projections
+  int32_t D, H, W;
+  int32_t row_stride;      // elements between rows of a projection
+  double row_start;
+  int32_t nrows;
+  int32_t d_chunk;         // projections walked by one thread
+  uint32_t proj_bytes;
+};
+
+struct CoordArgs {
+  const void* ycoord;
+  const void* xcoord;
+  int64_t npts;
+  int32_t is_f64;
+};
+
+struct LaunchOpts {
+  int tile_rows = 16;
+  int xcd_remap = 1;
+  int coef_lds = 0;        // 1: force the LDS-staged coefficient path even for short vectors
+  int d_chunk = 16;
+};
+
+// launchers (unwarp_kernels.hip)
+hipError_t launch_image(MapKind kind, const ImageArgs& img, const MapArgs& map, int sampler,
+                        bool round_f32, const LaunchOpts& opts, hipStream_t stream);
+hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler, hipStream_t stream);
+hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bool round_f32,
+                        const LaunchOpts& opts, hipStream_t stream);
+
+}  // namespace dcp

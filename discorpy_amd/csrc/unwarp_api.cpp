@@ -1,0 +1,460 @@
+// unwarp_api.cpp -- the C ABI declared in include/discorpy_hip.h: argument validation,
+// error reporting, host<->device staging for DCP_MEM_HOST callers, tuning knobs, and thin
+// memory/stream/event helpers.  The kernels live in unwarp_kernels.hip.
+#include "../../include/discorpy_hip.h"
+#include "dcp_internal.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define DCP_HIP(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{1}, g_coef_lds{0}, g_d_chunk{16};
+
+dcp::LaunchOpts current_opts() {
+  dcp::LaunchOpts o;
+  o.tile_rows = g_tile_rows.load();
+  o.xcd_remap = g_xcd_remap.load();
+  o.coef_lds = g_coef_lds.load();
+  o.d_chunk = g_d_chunk.load();
+  return o;
+}
+
+// Selects `device` for the calling thread for the lifetime of the object (no-op for device < 0).
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t status = hipSuccess;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;
+    status = hipGetDevice(&prev);
+    if (status != hipSuccess) return;
+    if (prev != device) {
+      status = hipSetDevice(device);
+      switched = status == hipSuccess;
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// Grow-only device scratch used for DCP_MEM_HOST calls; one set per host thread.
+struct Staging {
+  void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[4] = {0, 0, 0, 0};
+  int device = -1;
+  ~Staging() { release(); }
+  void release() {
+    for (int i = 0; i < 4; ++i) {
+      if (buf[i]) (void)hipFree(buf[i]);
+      buf[i] = nullptr;
+      cap[i] = 0;
+    }
+  }
+  hipError_t get(int slot, size_t bytes, void** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != device) {
+      release();
+      device = dev;
+    }
+    if (bytes == 0) bytes = 4;
+    if (cap[slot] < bytes) {
+      if (buf[slot]) (void)hipFree(buf[slot]);
+      buf[slot] = nullptr;
+      cap[slot] = 0;
+      e = hipMalloc(&buf[slot], bytes);
+      if (e != hipSuccess) return e;
+      cap[slot] = bytes;
+    }
+    *out = buf[slot];
+    return hipSuccess;
+  }
+};
+thread_local Staging g_staging;
+
+int sampler_of(int order, int blend_mode, int* sampler) {
+  if (order == 0) {
+    *sampler = dcp::kNearest;
+    return DCP_OK;
+  }
+  if (order != 1)
+    return fail(DCP_ERR_UNSUPPORTED, "spline order %d is not implemented on the GPU path (only 0 and 1)", order);
+  switch (blend_mode) {
+    case DCP_BLEND_SCIPY: *sampler = dcp::kScipy; return DCP_OK;
+    case DCP_BLEND_F64LERP: *sampler = dcp::kF64Lerp; return DCP_OK;
+    case DCP_BLEND_F32LERP: *sampler = dcp::kF32Lerp; return DCP_OK;
+    default: return fail(DCP_ERR_INVALID_ARG, "unknown blend_mode %d", blend_mode);
+  }
+}
+
+int check_image(const void* src, const void* dst, int64_t H, int64_t W, int64_t rs, int64_t cs) {
+  if (!src || !dst) return fail(DCP_ERR_INVALID_ARG, "null image pointer");
+  if (H <= 0 || W <= 0) return fail(DCP_ERR_INVALID_ARG, "image must be non-empty (got %lld x %lld)", (long long)H, (long long)W);
+  if (cs < 1 || rs < 1) return fail(DCP_ERR_INVALID_ARG, "strides must be positive (row %lld, col %lld)", (long long)rs, (long long)cs);
+  if (rs < (W - 1) * cs + 1 && H > 1) return fail(DCP_ERR_INVALID_ARG, "row stride %lld overlaps rows of width %lld", (long long)rs, (long long)W);
+  // the gather addresses the source with 32-bit byte offsets
+  const double extent = ((double)(H - 1) * (double)rs + (double)(W - 1) * (double)cs + 1.0) * 4.0;
+  if (extent > 4294967040.0 || H > 2147483647LL / 2 || W > 2147483647LL / 2)
+    return fail(DCP_ERR_UNSUPPORTED, "source extent %.0f bytes exceeds the 4 GiB the 32-bit gather offsets address", extent);
+  return DCP_OK;
+}
+
+int fill_map(dcp::MapArgs* m, double xc, double yc, const double* fact, int nfact, const double* coef) {
+  memset(m, 0, sizeof(*m));
+  m->xc = xc;
+  m->yc = yc;
+  if (nfact < 0 || nfact > dcp::kMaxFact)
+    return fail(DCP_ERR_INVALID_ARG, "nfact = %d outside [0, %d]", nfact, dcp::kMaxFact);
+  if (nfact > 0 && !fact) return fail(DCP_ERR_INVALID_ARG, "null coefficient pointer");
+  for (int i = 0; i < nfact; ++i) m->fact[i] = fact[i];
+  m->nfact = nfact;
+  if (coef)
+    for (int i = 0; i < 8; ++i) m->coef[i] = coef[i];
+  return DCP_OK;
+}
+
+uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs) {
+  return (uint32_t)(((H - 1) * rs + (W - 1) * cs + 1) * 4);
+}
+
+// Shared driver of the three whole-image entry points.
+int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_t W, int64_t rs, int64_t cs,
+              const dcp::MapArgs& map, int sampler, bool round_f32, int mem_kind, int device, void* stream) {
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::ImageArgs img;
+  memset(&img, 0, sizeof(img));
+  img.H = (int32_t)H;
+  img.W = (int32_t)W;
+  const dcp::LaunchOpts opts = current_opts();
+  if (mem_kind == DCP_MEM_DEVICE) {
+    img.src = src;
+    img.dst = dst;
+    img.src_stride = (int32_t)rs;
+    img.src_col_stride = (int32_t)cs;
+    img.src_bytes = extent_bytes(H, W, rs, cs);
+    DCP_HIP(dcp::launch_image(kind, img, map, sampler, round_f32, opts, (hipStream_t)stream));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  // host memory: pack rows densely on the way in, run on the stream, copy back, synchronise
+  hipStream_t st = (hipStream_t)stream;
+  void *dsrc = nullptr, *ddst = nullptr;
+  const size_t frame = (size_t)H * (size_t)W * sizeof(float);
+  DCP_HIP(g_staging.get(0, frame, &dsrc));
+  DCP_HIP(g_staging.get(1, frame, &ddst));
+  if (cs == 1) {
+    DCP_HIP(hipMemcpy2DAsync(dsrc, (size_t)W * 4, src, (size_t)rs * 4, (size_t)W * 4, (size_t)H, hipMemcpyHostToDevice, st));
+    img.src_stride = (int32_t)W;
+    img.src_col_stride = 1;
+    img.src_bytes = (uint32_t)frame;
+  } else {
+    // column-strided host view (e.g. one channel of an interleaved HxWxC image): ship the
+    // enclosing extent and let the kernel's strided gather pick the channel
+    const size_t ext = extent_bytes(H, W, rs, cs);
+    DCP_HIP(g_staging.get(0, ext, &dsrc));
+    DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
+    img.src_stride = (int32_t)rs;
+    img.src_col_stride = (int32_t)cs;
+    img.src_bytes = (uint32_t)ext;
+  }
+  img.src = (const float*)dsrc;
+  img.dst = (float*)ddst;
+  DCP_HIP(dcp::launch_image(kind, img, map, sampler, round_f32, opts, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, frame, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcp_version(void) { return 100; }
+
+int dcp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* dcp_last_error(void) { return g_err; }
+
+int dcp_set_option(const char* key, int value) {
+  if (!key) return fail(DCP_ERR_INVALID_ARG, "null option key");
+  if (!strcmp(key, "tile_rows")) {
+    if (value < 1 || value > dcp::kMaxTileRows) return fail(DCP_ERR_INVALID_ARG, "tile_rows must be in [1, %d]", dcp::kMaxTileRows);
+    g_tile_rows = value;
+  } else if (!strcmp(key, "xcd_remap")) {
+    g_xcd_remap = value ? 1 : 0;
+  } else if (!strcmp(key, "coef_lds")) {
+    g_coef_lds = value ? 1 : 0;
+  } else if (!strcmp(key, "d_chunk")) {
+    if (value < 1) return fail(DCP_ERR_INVALID_ARG, "d_chunk must be >= 1");
+    g_d_chunk = value;
+  } else {
+    return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
+  }
+  return DCP_OK;
+}
+
+int dcp_get_option(const char* key, int* value) {
+  if (!key || !value) return fail(DCP_ERR_INVALID_ARG, "null argument");
+  if (!strcmp(key, "tile_rows")) *value = g_tile_rows;
+  else if (!strcmp(key, "xcd_remap")) *value = g_xcd_remap;
+  else if (!strcmp(key, "coef_lds")) *value = g_coef_lds;
+  else if (!strcmp(key, "d_chunk")) *value = g_d_chunk;
+  else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
+  return DCP_OK;
+}
+
+int dcp_unwarp_image_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                         int nfact, int order, int coord_round_f32, int blend_mode, int mem_kind, int device,
+                         void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  return run_image(dcp::kRadial, src, dst, height, width, src_row_stride, src_col_stride, map, sampler,
+                   coord_round_f32 != 0, mem_kind, device, stream);
+}
+
+int dcp_perspective_image_f32(const float* src, float* dst, int64_t height, int64_t width,
+                              int64_t src_row_stride, int64_t src_col_stride, const double* list_coef,
+                              int order, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
+  return run_image(dcp::kPersp, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
+                   mem_kind, device, stream);
+}
+
+int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                         int nfact, const double* list_coef, int order, int blend_mode, int mem_kind,
+                         int device, void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, list_coef)) != DCP_OK) return rc;
+  return run_image(dcp::kFused, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
+                   mem_kind, device, stream);
+}
+
+int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
+                         int64_t npts, int order, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
+  if (npts > 0 && (!ycoord || !xcoord)) return fail(DCP_ERR_INVALID_ARG, "null coordinate pointer");
+  if (coord_dtype != DCP_COORD_F32 && coord_dtype != DCP_COORD_F64)
+    return fail(DCP_ERR_INVALID_ARG, "unknown coord_dtype %d", coord_dtype);
+  if (npts > 2147483647LL * 256) return fail(DCP_ERR_UNSUPPORTED, "too many points");
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  if (npts == 0) return DCP_OK;
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::ImageArgs img;
+  memset(&img, 0, sizeof(img));
+  img.H = (int32_t)height;
+  img.W = (int32_t)width;
+  img.src_stride = (int32_t)src_row_stride;
+  img.src_col_stride = (int32_t)src_col_stride;
+  img.src_bytes = extent_bytes(height, width, src_row_stride, src_col_stride);
+  dcp::CoordArgs ca;
+  ca.npts = npts;
+  ca.is_f64 = coord_dtype == DCP_COORD_F64;
+  hipStream_t st = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    img.src = src;
+    img.dst = dst;
+    ca.ycoord = ycoord;
+    ca.xcoord = xcoord;
+    DCP_HIP(dcp::launch_coords(img, ca, sampler, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *dsrc, *ddst, *dy, *dx;
+  const size_t csz = (size_t)npts * (ca.is_f64 ? 8 : 4);
+  DCP_HIP(g_staging.get(0, img.src_bytes, &dsrc));
+  DCP_HIP(g_staging.get(1, (size_t)npts * 4, &ddst));
+  DCP_HIP(g_staging.get(2, csz, &dy));
+  DCP_HIP(g_staging.get(3, csz, &dx));
+  DCP_HIP(hipMemcpyAsync(dsrc, src, img.src_bytes, hipMemcpyHostToDevice, st));
+  DCP_HIP(hipMemcpyAsync(dy, ycoord, csz, hipMemcpyHostToDevice, st));
+  DCP_HIP(hipMemcpyAsync(dx, xcoord, csz, hipMemcpyHostToDevice, st));
+  img.src = (const float*)dsrc;
+  img.dst = (float*)ddst;
+  ca.ycoord = dy;
+  ca.xcoord = dx;
+  DCP_HIP(dcp::launch_coords(img, ca, sampler, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)npts * 4, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
+                              int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                              const double* list_fact, int nfact, double row_start, int64_t nrows,
+                              int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc, sampler;
+  if (depth < 0 || nrows < 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows");
+  if (height <= 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "projections must be non-empty");
+  if (depth > 0 && nrows > 0 && (!vol || !out)) return fail(DCP_ERR_INVALID_ARG, "null volume pointer");
+  if (height < 2 || width < 2) return fail(DCP_ERR_UNSUPPORTED, "stack path needs projections of at least 2 x 2");
+  if (row_stride < width || proj_stride < (height - 1) * row_stride + width)
+    return fail(DCP_ERR_INVALID_ARG, "strides overlap (row %lld, projection %lld)", (long long)row_stride, (long long)proj_stride);
+  if ((double)height * (double)row_stride * 4.0 > 4294967040.0)
+    return fail(DCP_ERR_UNSUPPORTED, "one projection exceeds the 4 GiB the 32-bit gather offsets address");
+  if (nrows > 65535) return fail(DCP_ERR_UNSUPPORTED, "nrows > 65535 in one call");
+  if (!std::isfinite(row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
+  if ((rc = sampler_of(1, blend_mode, &sampler)) != DCP_OK) return rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  if (depth == 0 || nrows == 0) return DCP_OK;
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::LaunchOpts opts = current_opts();
+  if ((depth + opts.d_chunk - 1) / opts.d_chunk > 65535) opts.d_chunk = (int)((depth + 65534) / 65535);
+  dcp::StackArgs st;
+  memset(&st, 0, sizeof(st));
+  st.D = (int32_t)depth;
+  st.H = (int32_t)height;
+  st.W = (int32_t)width;
+  st.row_start = row_start;
+  st.nrows = (int32_t)nrows;
+  hipStream_t hs = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    st.vol = vol;
+    st.out = out;
+    st.proj_stride = proj_stride;
+    st.row_stride = (int32_t)row_stride;
+    st.proj_bytes = (uint32_t)(((height - 1) * row_stride + width) * 4);
+    DCP_HIP(dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  // Host volume: only the row band the requested rows can reach is shipped (the reference slices
+  // mat3D[i, yd_min:yd_max, :] for the same reason, postprocessing.py:221-228).  The band is found
+  // conservatively on the host from the corner/centre extremes of |B|.
+  int64_t band0 = 0, band1 = height;  // TODO(perf): tighten; correctness does not depend on it
+  const int64_t bh = band1 - band0;
+  void *dvol, *dout;
+  const size_t pbytes = (size_t)bh * (size_t)width * 4;
+  DCP_HIP(g_staging.get(0, pbytes * (size_t)depth, &dvol));
+  DCP_HIP(g_staging.get(1, (size_t)depth * (size_t)nrows * (size_t)width * 4, &dout));
+  for (int64_t d = 0; d < depth; ++d)
+    DCP_HIP(hipMemcpy2DAsync((char*)dvol + (size_t)d * pbytes, (size_t)width * 4,
+                             vol + d * proj_stride + band0 * row_stride, (size_t)row_stride * 4,
+                             (size_t)width * 4, (size_t)bh, hipMemcpyHostToDevice, hs));
+  st.vol = (const float*)dvol;
+  st.out = (float*)dout;
+  st.proj_stride = bh * width;
+  st.row_stride = (int32_t)width;
+  st.proj_bytes = (uint32_t)pbytes;
+  DCP_HIP(dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs));
+  DCP_HIP(hipMemcpyAsync(out, dout, (size_t)depth * (size_t)nrows * (size_t)width * 4, hipMemcpyDeviceToHost, hs));
+  DCP_HIP(hipStreamSynchronize(hs));
+  return DCP_OK;
+}
+
+int dcp_malloc(void** ptr, size_t bytes, int device) {
+  if (!ptr) return fail(DCP_ERR_INVALID_ARG, "null out pointer");
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  DCP_HIP(hipMalloc(ptr, bytes ? bytes : 4));
+  return DCP_OK;
+}
+
+int dcp_free(void* ptr, int device) {
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  DCP_HIP(hipFree(ptr));
+  return DCP_OK;
+}
+
+int dcp_memcpy(void* dst, const void* src, size_t bytes, int kind, int device, void* stream) {
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipMemcpyKind k;
+  switch (kind) {
+    case DCP_COPY_H2D: k = hipMemcpyHostToDevice; break;
+    case DCP_COPY_D2H: k = hipMemcpyDeviceToHost; break;
+    case DCP_COPY_D2D: k = hipMemcpyDeviceToDevice; break;
+    default: return fail(DCP_ERR_INVALID_ARG, "unknown copy kind %d", kind);
+  }
+  DCP_HIP(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
+  if (kind != DCP_COPY_D2D) DCP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return DCP_OK;
+}
+
+int dcp_stream_synchronize(int device, void* stream) {
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  DCP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return DCP_OK;
+}
+
+int dcp_event_create(void** event, int device) {
+  if (!event) return fail(DCP_ERR_INVALID_ARG, "null out pointer");
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipEvent_t e;
+  DCP_HIP(hipEventCreate(&e));
+  *event = (void*)e;
+  return DCP_OK;
+}
+
+int dcp_event_record(void* event, void* stream) {
+  DCP_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return DCP_OK;
+}
+
+int dcp_event_synchronize(void* event) {
+  DCP_HIP(hipEventSynchronize((hipEvent_t)event));
+  return DCP_OK;
+}
+
+int dcp_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!ms) return fail(DCP_ERR_INVALID_ARG, "null out pointer");
+  DCP_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return DCP_OK;
+}
+
+int dcp_event_destroy(void* event) {
+  DCP_HIP(hipEventDestroy((hipEvent_t)event));
+  return DCP_OK;
+}
+
+}  // extern "C"

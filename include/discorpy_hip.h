@@ -1,0 +1,124 @@
+/*
+ * discorpy_hip.h -- C ABI of libdiscorpy_hip.so: the MI355X (gfx950) implementation of the
+ * backward-unwarp path of discorpy.post.postprocessing.
+ *
+ * The reference is pure Python (no FFI of its own); each entry point below replaces the body of
+ * one reference function, cited as file:line under /root/reference.  INTEGRATION.md shows the
+ * ctypes stub a discorpy maintainer would add to call them.
+ *
+ * Conventions
+ *   - every function returns DCP_OK (0) or a negative DCP_ERR_* code; dcp_last_error() returns a
+ *     thread-local, human-readable message for the last failure on the calling thread.
+ *   - images are float32, row-major; `src_row_stride` / `src_col_stride` are in ELEMENTS, the
+ *     output is always dense (height x width).  x = column index, y = row index.
+ *   - mem_kind DCP_MEM_HOST: pointers are host memory, the library stages H2D/D2H itself and
+ *     returns after the result is in `dst`.  DCP_MEM_DEVICE: pointers are device memory on
+ *     `device`, the kernel is enqueued on `stream` (a hipStream_t, NULL = default stream) and the
+ *     call returns without synchronising; the caller owns the memory and its lifetime.
+ *   - device < 0 means "the calling thread's current HIP device".
+ *   - order: 0 nearest (floor(c + 0.5)), 1 bilinear.  Higher spline orders are not implemented.
+ *   - blend_mode (order 1 only): DCP_BLEND_SCIPY reproduces scipy.ndimage.map_coordinates'
+ *     float64 arithmetic bit for bit; DCP_BLEND_F64LERP is the factorised float64 form (equal to
+ *     it to <= 1 float32 ulp, in practice bit-equal); DCP_BLEND_F32LERP is float32 arithmetic
+ *     (<= 2 float32 ulp of the largest tap; opt-in).
+ */
+#ifndef DISCORPY_HIP_H
+#define DISCORPY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCP_OK 0
+#define DCP_ERR_INVALID_ARG (-1)
+#define DCP_ERR_HIP (-2)
+#define DCP_ERR_UNSUPPORTED (-3)
+#define DCP_ERR_NO_DEVICE (-4)
+
+#define DCP_MEM_HOST 0
+#define DCP_MEM_DEVICE 1
+
+#define DCP_BLEND_SCIPY 0
+#define DCP_BLEND_F64LERP 1
+#define DCP_BLEND_F32LERP 2
+
+#define DCP_COORD_F32 0
+#define DCP_COORD_F64 1
+
+#define DCP_MAX_FACT 32
+
+/* ---- library / device ---- */
+int dcp_version(void);                 /* major*10000 + minor*100 + patch */
+int dcp_device_count(void);            /* number of HIP devices, 0 if none / no driver */
+const char* dcp_last_error(void);
+
+/* Tuning knobs (process-wide): "tile_rows" (1..64, rows walked by one workgroup), "xcd_remap"
+ * (0/1), "coef_lds" (0/1: force LDS-staged polynomial coefficients), "d_chunk" (projections per
+ * thread in the stack kernel).  Returns DCP_ERR_INVALID_ARG for an unknown key. */
+int dcp_set_option(const char* key, int value);
+int dcp_get_option(const char* key, int* value);
+
+/* ---- the hot path ---- */
+
+/* discorpy/post/postprocessing.py:111-148  unwarp_image_backward
+ * dst[y,x] = sample(src, clip(yc + B*yu), clip(xc + B*xu)),  B = sum_i list_fact[i] * ru^i,
+ * xu = x - xcenter, yu = y - ycenter, ru = sqrt(xu^2 + yu^2), evaluated in float64.
+ * coord_round_f32 = 1 rounds the clipped coordinates to float32 as :144-145 does. */
+int dcp_unwarp_image_f32(const float* src, float* dst, int64_t height, int64_t width,
+                         int64_t src_row_stride, int64_t src_col_stride, double xcenter, double ycenter,
+                         const double* list_fact, int nfact, int order, int coord_round_f32, int blend_mode,
+                         int mem_kind, int device, void* stream);
+
+/* discorpy/post/postprocessing.py:444-459 (_generate_perspective_map) + :486-492
+ * (correct_perspective_image, map_index=None).  list_coef = c1..c8 of the backward homography in
+ * (x, y) convention (discorpy/proc/processing.py:1254-1270). */
+int dcp_perspective_image_f32(const float* src, float* dst, int64_t height, int64_t width,
+                              int64_t src_row_stride, int64_t src_col_stride, const double* list_coef,
+                              int order, int blend_mode, int mem_kind, int device, void* stream);
+
+/* One-pass composition (BASELINE config 3): the float32-rounded perspective coordinate of
+ * :453-457 is fed to the radial map of :141-145 and the source is sampled once.  NOT equal to
+ * calling the two functions above in sequence (that is two resamplings, demo_05.py:127,147). */
+int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                         int nfact, const double* list_coef, int order, int blend_mode, int mem_kind,
+                         int device, void* stream);
+
+/* discorpy/post/postprocessing.py:489-491 (map_index given) and :250-251 (_mapping):
+ * dst[i] = sample(src, ycoord[i], xcoord[i]) for npts caller-supplied coordinates of type
+ * coord_dtype (DCP_COORD_F32 / DCP_COORD_F64), clamped to the image. */
+int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
+                         int64_t npts, int order, int blend_mode, int mem_kind, int device, void* stream);
+
+/* discorpy/post/postprocessing.py:188-229 (unwarp_slice_backward: nrows = 1, coord_round_f32 = 0)
+ * and :255-313 (unwarp_chunk_slices_backward: coord_round_f32 = 1) over a (depth, height, width)
+ * stack: out[d, r, x] (dense, depth x nrows x width) = projection d sampled bilinearly at the
+ * radial source coordinate of output pixel (row_start + r, x).  proj_stride / row_stride are the
+ * element strides of `vol` between projections / rows. */
+int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
+                              int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                              const double* list_fact, int nfact, double row_start, int64_t nrows,
+                              int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream);
+
+/* ---- device memory / stream / event helpers (so a host language needs no other GPU runtime) ---- */
+int dcp_malloc(void** ptr, size_t bytes, int device);
+int dcp_free(void* ptr, int device);
+#define DCP_COPY_H2D 0
+#define DCP_COPY_D2H 1
+#define DCP_COPY_D2D 2
+int dcp_memcpy(void* dst, const void* src, size_t bytes, int kind, int device, void* stream);
+int dcp_stream_synchronize(int device, void* stream);
+int dcp_event_create(void** event, int device);
+int dcp_event_record(void* event, void* stream);
+int dcp_event_synchronize(void* event);
+int dcp_event_elapsed_ms(void* start, void* stop, float* ms);
+int dcp_event_destroy(void* event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DISCORPY_HIP_H */
