@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""bench.py -- Mpixels/s of the backward unwarp on MI355X (BASELINE.json metric).
+
+Workload at every N: BASELINE config 2 -- 4096x4096 float32 frames, 5-term backward polynomial
+(coef_dot_05 rescaled), bilinear -- device-resident.  One "step" is one pass of the hot path over
+a batch of `--batch` DISTINCT frames (default 24: 3.2 GB of input+output per GPU, so the 256 MiB
+Infinity Cache cannot hold the working set and the kernel streams from HBM).  With N > 1 every
+rank unwarps its own batch (independent frames, no data-path collective): weak scaling.
+
+    python bench.py                      # 1 GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` for the
+dominant kernel and `cpu_baseline` (oracle/unwarp_oracle.c timed on the host cores).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from discorpy_amd import _ffi as F  # noqa: E402
+from discorpy_amd import configs  # noqa: E402
+
+BLEND_NAMES = {"scipy": F.BLEND_SCIPY, "f64lerp": F.BLEND_F64LERP, "f32lerp": F.BLEND_F32LERP}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=24, help="distinct frames per step (ring size)")
+    ap.add_argument("--blend", default="f64lerp", choices=sorted(BLEND_NAMES))
+    ap.add_argument("--order", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, img, blend, threads):
+    """Time the oracle (a C port of the reference arithmetic) on the host: whole 4096^2 frames."""
+    from oracle import oracle as orc
+    ncores = orc.max_threads()
+    t = threads if threads > 0 else min(ncores, 64)
+    orc.set_threads(t)
+    kw = dict(order=cfg["order"], poly=orc.POLY_NUMPY, blend=orc.BLEND_SCIPY)
+    orc.unwarp_image_backward(img, cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], **kw)  # warm
+    frames, t0 = 0, time.perf_counter()
+    while True:
+        orc.unwarp_image_backward(img, cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], **kw)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt * t >= 20.0 or frames >= 64:   # ~20 CPU-seconds of work
+            break
+    mpix = frames * img.size / dt / 1e6
+    return {"value": round(mpix, 2), "unit": "Mpixels/s", "cores": t, "kind": "port",
+            "sample": "%d full %dx%d frames of the bench workload, reference arithmetic order "
+                      "(numpy-order polynomial, scipy blend), %d OpenMP threads of %d host cores, %.2f s wall"
+                      % (frames, img.shape[0], img.shape[1], t, ncores, dt)}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = world
+    if a.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+
+    L = F.lib()
+    F.require_device()
+    dev = local_rank if world > 1 else -1
+    cfg = configs.cfg2()
+    cfg["order"] = a.order
+    H, W = cfg["shape"]
+    blend = BLEND_NAMES[a.blend]
+    rng = np.random.default_rng(cfg["seed"] + 1000 * rank)
+    fa, nf = F.fact_array(cfg["list_fact"])
+
+    # device-resident batch: `batch` distinct input frames + as many output frames
+    srcs, dsts, img0 = [], [], None
+    for i in range(a.batch):
+        img = rng.random((H, W), dtype=np.float32)
+        if i == 0:
+            img0 = img
+        srcs.append(F.DeviceBuffer(img.nbytes, dev).upload(img))
+        dsts.append(F.DeviceBuffer(img.nbytes, dev))
+
+    def step():
+        for s, d in zip(srcs, dsts):
+            rc = L.dcp_unwarp_image_f32(s.ptr, d.ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"], fa, nf,
+                                        a.order, 1, blend, F.MEM_DEVICE, dev, None)
+            if rc:
+                F.check(rc)
+
+    def sync():
+        F.check(L.dcp_stream_synchronize(dev, None))
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    e0, e1 = F.Event(dev), F.Event(dev)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        step()
+    e1.record()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    wall = time.perf_counter() - t0
+    dev_ms = e0.elapsed_ms(e1)            # HIP events on the launch stream: device time of the K steps
+    if dist is not None:
+        import torch
+        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall, dev_ms = float(tt[0]), float(tt[1])
+
+    if rank == 0:
+        launches = a.steps * a.batch
+        pix_per_launch = H * W
+        total_pix = launches * pix_per_launch * n_gpus
+        value = total_pix / wall / 1e6
+        launch_us = dev_ms * 1e3 / launches
+        achieved = configs.BYTES_PER_PIXEL * pix_per_launch / (launch_us * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpixels/s backward unwarp (4096x4096, 5-term poly, bilinear)",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64 coordinates / f32 pixels",
+            "data": "synthetic (numpy default_rng uniform [0,1) float32 frames, device-resident)",
+            "config": {"workload": cfg["name"], "frames_per_step_per_gpu": a.batch, "height": H, "width": W,
+                       "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True,
+                       "parallelism": "independent frames per GPU (no collective)" if n_gpus > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "kernel": "remap_tile_kernel<Radial,NF=5>", "launch_us": round(launch_us, 3),
+                         "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch)},
+        }
+        if n_gpus == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, img0, blend, a.cpu_threads)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdiscorpy_hip.so")
+LIB_PATH = os.environ.get("DCP_LIB_PATH") or os.path.join(_HERE, "lib", "libdiscorpy_hip.so")
 
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -49,6 +49,7 @@ SIGNATURES = {
                                     _int, _vp]),
     "dcp_unwarp_stack_rows_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,
                                          _i64, _int, _int, _int, _int, _vp]),
+    "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
     "dcp_free": (_int, [_vp, _int]),
     "dcp_memcpy": (_int, [_vp, _vp, _sz, _int, _int, _vp]),
@@ -115,6 +116,13 @@ def get_option(key):
     v = C.c_int(0)
     check(lib().dcp_get_option(key.encode(), C.byref(v)))
     return v.value
+
+
+def debug_counters(reset=True):
+    """(tiles whose box did not fit, tiles whose containment vote failed) since the last reset."""
+    out = (C.c_uint64 * 2)()
+    check(lib().dcp_debug_counters(out, 2, int(reset)))
+    return int(out[0]), int(out[1])
 
 
 def fact_array(list_fact):

@@ -27,6 +27,8 @@ struct ImageArgs {
   int32_t tiles_x, tiles_y;
   int32_t tile_rows;       // rows per workgroup
   int32_t xcd_remap;       // 1: contiguous band of tiles per XCD
+  int32_t pipe_depth;      // rows of gathers in flight per thread (1, 2 or 4)
+  int32_t lds_gather;      // 1: stage the source box of each wave tile in LDS (remap_lds_kernel)
 };
 
 struct MapArgs {
@@ -57,7 +59,9 @@ struct CoordArgs {
 
 struct LaunchOpts {
   int tile_rows = 16;
-  int xcd_remap = 1;
+  int xcd_remap = 0;
+  int pipe_depth = 2;
+  int lds_gather = 0;
   int coef_lds = 0;        // 1: force the LDS-staged coefficient path even for short vectors
   int d_chunk = 16;
 };
@@ -68,5 +72,7 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img, const MapArgs& map, 
 hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler, hipStream_t stream);
 hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream);
+
+hipError_t read_lds_stats(unsigned long long* out, bool reset);
 
 }  // namespace dcp

@@ -29,7 +29,7 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{1}, g_coef_lds{0}, g_d_chunk{16};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{0}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{0};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -37,6 +37,8 @@ dcp::LaunchOpts current_opts() {
   o.xcd_remap = g_xcd_remap.load();
   o.coef_lds = g_coef_lds.load();
   o.d_chunk = g_d_chunk.load();
+  o.pipe_depth = g_pipe_depth.load();
+  o.lds_gather = g_lds_gather.load();
   return o;
 }
 
@@ -212,6 +214,11 @@ int dcp_set_option(const char* key, int value) {
     g_xcd_remap = value ? 1 : 0;
   } else if (!strcmp(key, "coef_lds")) {
     g_coef_lds = value ? 1 : 0;
+  } else if (!strcmp(key, "lds_gather")) {
+    g_lds_gather = value ? 1 : 0;
+  } else if (!strcmp(key, "pipe_depth")) {
+    if (value != 1 && value != 2 && value != 4) return fail(DCP_ERR_INVALID_ARG, "pipe_depth must be 1, 2 or 4");
+    g_pipe_depth = value;
   } else if (!strcmp(key, "d_chunk")) {
     if (value < 1) return fail(DCP_ERR_INVALID_ARG, "d_chunk must be >= 1");
     g_d_chunk = value;
@@ -227,6 +234,8 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "xcd_remap")) *value = g_xcd_remap;
   else if (!strcmp(key, "coef_lds")) *value = g_coef_lds;
   else if (!strcmp(key, "d_chunk")) *value = g_d_chunk;
+  else if (!strcmp(key, "pipe_depth")) *value = g_pipe_depth;
+  else if (!strcmp(key, "lds_gather")) *value = g_lds_gather;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }
@@ -386,6 +395,16 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
   DCP_HIP(dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs));
   DCP_HIP(hipMemcpyAsync(out, dout, (size_t)depth * (size_t)nrows * (size_t)width * 4, hipMemcpyDeviceToHost, hs));
   DCP_HIP(hipStreamSynchronize(hs));
+  return DCP_OK;
+}
+
+int dcp_debug_counters(uint64_t* out, int n, int reset) {
+  if (!out || n < 2) return fail(DCP_ERR_INVALID_ARG, "need room for 2 counters");
+  unsigned long long v[2];
+  DCP_HIP(hipDeviceSynchronize());
+  DCP_HIP(dcp::read_lds_stats(v, reset != 0));
+  out[0] = v[0];
+  out[1] = v[1];
   return DCP_OK;
 }
 

@@ -33,6 +33,25 @@ namespace dcp {
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kBlock = 256;
+#ifndef DCP_PIPE_DEPTH
+#define DCP_PIPE_DEPTH 2
+#endif
+constexpr int kPipeDepth = DCP_PIPE_DEPTH;
+#ifndef DCP_STORE_AUX
+#define DCP_STORE_AUX 0  // cache-policy bits of the output store (experiments: 2 = nt)
+#endif
+#ifndef DCP_LOAD_AUX
+#define DCP_LOAD_AUX 0
+#endif
+#ifndef DCP_SETPRIO
+#define DCP_SETPRIO 0
+#endif
+#ifndef DCP_PF_ROWS
+#define DCP_PF_ROWS 0   // > 0: LDS-DMA touch of the source DCP_PF_ROWS rows below the current taps (L2 prefetch)
+#endif
+#ifndef DCP_ABLATE
+#define DCP_ABLATE 0   // experiments: 1 = no gather loads, 2 = no store, 3 = neither (tools/ablate.sh)
+#endif
 
 // ------------------------------------------------------------------ fp64 helpers
 
@@ -53,22 +72,40 @@ __device__ __forceinline__ double sqrt_rn(double x) {
 // needed: E = a0 + r2 (a2 + r2 (a4 + ...)), O = a1 + r2 (a3 + ...), B = fma(ru, O, E).
 // Same operation order as poly_kernel() in oracle/unwarp_oracle.c.
 template <int NF>
-__device__ __forceinline__ double poly_inline(const double* __restrict__ a, double r2, double ru) {
+__device__ __forceinline__ double poly_inline(const double* __restrict__ a, double lead_e, double lead_o,
+                                              double r2, double ru) {
+  // lead_e / lead_o: the highest even / odd coefficient, passed separately so the caller can pin
+  // them in VGPRs (a VOP3 fma takes one SGPR operand; the first Horner step would need two)
   if constexpr (NF == 0) {
     return 0.0;
   } else {
     constexpr int ne = (NF + 1) / 2, no = NF / 2;
-    double E = a[2 * (ne - 1)];
+    double E = lead_e;
 #pragma unroll
     for (int k = ne - 2; k >= 0; --k) E = __builtin_fma(r2, E, a[2 * k]);
     if constexpr (no == 0) {
       return E;
     } else {
-      double O = a[2 * (no - 1) + 1];
+      double O = lead_o;
 #pragma unroll
       for (int k = no - 2; k >= 0; --k) O = __builtin_fma(r2, O, a[2 * k + 1]);
       return __builtin_fma(ru, O, E);
     }
+  }
+}
+template <int NF>
+__device__ __forceinline__ void poly_leads(const double* __restrict__ a, double* lead_e, double* lead_o) {
+  *lead_e = 0.0;
+  *lead_o = 0.0;
+  if constexpr (NF > 0) {
+    double e = a[2 * ((NF + 1) / 2 - 1)];
+    asm volatile("" : "+v"(e));
+    *lead_e = e;
+  }
+  if constexpr (NF > 1) {
+    double o = a[2 * (NF / 2 - 1) + 1];
+    asm volatile("" : "+v"(o));
+    *lead_o = o;
   }
 }
 
@@ -83,116 +120,137 @@ __device__ __forceinline__ double poly_lds(const double* s_coef, int nf, double 
   return __builtin_fma(ru, O, E);
 }
 
+// ------------------------------------------------------------------ wave64 min / max (DPP)
+
+// Reduction over the 64 lanes in six DPP steps (row_shr 1,2,4,8 inside each 16-lane row, then
+// row_bcast 15 and 31 across rows); the result lands in lane 63 and is read to an SGPR.  Lanes
+// that receive nothing in a step keep their own value (old == src).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {
+  const int b = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
+}
+template <bool IS_MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+#define DCP_STEP(CTRL, MASK) v = IS_MAX ? __builtin_fmaxf(v, dpp_take<CTRL, MASK>(v)) : __builtin_fminf(v, dpp_take<CTRL, MASK>(v))
+  DCP_STEP(0x111, 0xf);   // row_shr:1
+  DCP_STEP(0x112, 0xf);   // row_shr:2
+  DCP_STEP(0x114, 0xf);   // row_shr:4
+  DCP_STEP(0x118, 0xf);   // row_shr:8
+  DCP_STEP(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
+  DCP_STEP(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
+#undef DCP_STEP
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // ------------------------------------------------------------------ sampler
 
 struct SrcView {
   __amdgpu_buffer_rsrc_t rsrc;
+  __amdgpu_buffer_rsrc_t pf_rsrc;   // the same image seen DCP_PF_ROWS rows further down (prefetch)
+  float* pf_sink;                   // 256 B of LDS per wave the prefetch lands in (never read)
   int32_t W, H;
   int32_t stride;      // elements
   int32_t cstride;     // elements
 };
 
-template <typename WT>
-struct Pos {
-  uint32_t off;        // byte offset of tap (y0, x0)
-  uint32_t dx, dy;     // byte distance to the x+1 / y+1 taps (safe path only)
-  WT fx, fy;
+// One bilinear (or nearest) fetch in flight: the issued loads plus the two fractions.
+// PAIR: the x0/x1 taps of a row are one 8-byte load (needs unit column stride, W,H >= 2).
+template <int SAMPLER, bool PAIR, typename CT>
+struct Fetch {
+  u32x2 a, b;          // PAIR: rows y0 / y0+1.  !PAIR: a = (v00, v01), b = (v10, v11)
+  CT fx, fy;
 };
 
-// Coordinates are already inside [0, W-1] x [0, H-1].
-// PAIR: the x0/x1 taps are one 8-byte load, so x0 is held <= W-2 (and y0 <= H-2): at the
-// far edge the weight pair becomes (0, 1) on (W-2, W-1) instead of scipy's (1, 0) on
-// (W-1, reflected W-1) -- the same value for finite data.
-template <bool PAIR, typename CT>
-__device__ __forceinline__ Pos<CT> locate(const SrcView& s, CT xc, CT yc) {
-  Pos<CT> p;
+// Coordinates are already inside [0, W-1] x [0, H-1].  The base tap is held at x0 <= W-2,
+// y0 <= H-2: at the far edge the fraction becomes 1 on (len-2, len-1) instead of scipy's 0 on
+// (len-1, folded len-1) -- the same value for finite data, and no out-of-range tap exists.
+template <int SAMPLER, bool PAIR, typename CT>
+__device__ __forceinline__ Fetch<SAMPLER, PAIR, CT> fetch(const SrcView& s, CT xc, CT yc) {
+  Fetch<SAMPLER, PAIR, CT> f;
   int xi = (int)xc, yi = (int)yc;   // truncation == floor for non-negative coordinates
-  if constexpr (PAIR) {
+  if constexpr (SAMPLER == kNearest) {
+    // order 0: index = floor(c + 0.5)  (round half up, not rint)
+    xi += (xc - (CT)xi >= (CT)0.5) ? 1 : 0;
+    yi += (yc - (CT)yi >= (CT)0.5) ? 1 : 0;
+    uint32_t off;
+    if constexpr (PAIR) off = (__umul24(yi, s.stride) + (uint32_t)xi) << 2;
+    else off = ((uint32_t)yi * (uint32_t)s.stride + (uint32_t)xi * (uint32_t)s.cstride) * 4u;
+    f.a.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0);
+    f.fx = f.fy = (CT)0;
+    return f;
+  } else if constexpr (PAIR) {
     xi = min(xi, s.W - 2);
     yi = min(yi, s.H - 2);
-    p.dx = 4u;
-    p.dy = (uint32_t)s.stride * 4u;
+    f.fx = xc - (CT)xi;             // exact
+    f.fy = yc - (CT)yi;
+    const uint32_t off = (__umul24(yi, s.stride) + (uint32_t)xi) << 2;
+#if DCP_ABLATE & 1
+    f.a.x = off; f.a.y = off + 1; f.b.x = off + 2; f.b.y = off + 3;
+#elif DCP_ABLATE == 4   // two perfectly coalesced dword loads instead of the gather (timing experiment)
+    const uint32_t ido = (blockIdx.x * 16u * (uint32_t)s.stride + threadIdx.x + ((uint32_t)yi & 15u) * s.stride) << 2;
+    f.a.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, ido, 0, 0); f.a.y = off;
+    f.b.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, ido, s.stride * 4, 0); f.b.y = off + 1;
+#elif DCP_ABLATE == 8   // the same gather as four dword loads
+    f.a.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0);
+    f.a.y = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off + 4, 0, 0);
+    f.b.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, s.stride * 4, 0);
+    f.b.y = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off + 4, s.stride * 4, 0);
+#else
+    f.a = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, off, 0, DCP_LOAD_AUX);
+    f.b = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, off, s.stride * 4, DCP_LOAD_AUX);
+#endif
+#if DCP_PF_ROWS > 0
+    if (s.pf_sink)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(s.pf_rsrc, (__attribute__((address_space(3))) void*)s.pf_sink, 4, off,
+                                               0, 0, 0);
+#endif
+    return f;
   } else {
     // any stride, any size: same base-tap rule per axis, four 4-byte loads
     xi = min(xi, max(s.W - 2, 0));
     yi = min(yi, max(s.H - 2, 0));
-    p.dx = s.W >= 2 ? (uint32_t)s.cstride * 4u : 0u;
-    p.dy = s.H >= 2 ? (uint32_t)s.stride * 4u : 0u;
+    f.fx = xc - (CT)xi;
+    f.fy = yc - (CT)yi;
+    const uint32_t dx = s.W >= 2 ? (uint32_t)s.cstride * 4u : 0u;
+    const uint32_t dy = s.H >= 2 ? (uint32_t)s.stride * 4u : 0u;
+    const uint32_t off = ((uint32_t)yi * (uint32_t)s.stride + (uint32_t)xi * (uint32_t)s.cstride) * 4u;
+    f.a.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0);
+    f.a.y = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off + dx, 0, 0);
+    f.b.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off + dy, 0, 0);
+    f.b.y = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off + dy + dx, 0, 0);
+    return f;
   }
-  p.fx = xc - (CT)xi;               // exact
-  p.fy = yc - (CT)yi;
-  p.off = ((uint32_t)yi * (uint32_t)s.stride + (uint32_t)xi * (uint32_t)s.cstride) * 4u;
-  return p;
-}
-
-// order 0: index = floor(c + 0.5)  (round half up, not rint)
-template <typename CT>
-__device__ __forceinline__ uint32_t locate_nearest(const SrcView& s, CT xc, CT yc) {
-  int xi = (int)xc, yi = (int)yc;
-  xi += (xc - (CT)xi >= (CT)0.5) ? 1 : 0;
-  yi += (yc - (CT)yi >= (CT)0.5) ? 1 : 0;
-  return ((uint32_t)yi * (uint32_t)s.stride + (uint32_t)xi * (uint32_t)s.cstride) * 4u;
-}
-
-struct Taps {
-  float v00, v01, v10, v11;
-};
-
-template <bool PAIR, typename WT>
-__device__ __forceinline__ Taps gather(const __amdgpu_buffer_rsrc_t rsrc, const Pos<WT>& p, int row_bytes) {
-  Taps t;
-  if constexpr (PAIR) {
-    u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, p.off, 0, 0);
-    u32x2 b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, p.off, row_bytes, 0);
-    t.v00 = __uint_as_float(a.x);
-    t.v01 = __uint_as_float(a.y);
-    t.v10 = __uint_as_float(b.x);
-    t.v11 = __uint_as_float(b.y);
-  } else {
-    t.v00 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, p.off, 0, 0));
-    t.v01 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, p.off + p.dx, 0, 0));
-    t.v10 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, p.off + p.dy, 0, 0));
-    t.v11 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, p.off + p.dy + p.dx, 0, 0));
-  }
-  return t;
 }
 
 // The three order-1 arithmetics (same as sample() in oracle/unwarp_oracle.c).
-template <int SAMPLER, typename WT>
-__device__ __forceinline__ float blend(const Taps& t, WT fx_, WT fy_) {
-  if constexpr (SAMPLER == kScipy) {
+template <int SAMPLER, bool PAIR, typename CT>
+__device__ __forceinline__ float finish(const Fetch<SAMPLER, PAIR, CT>& f) {
+  const float v00 = __uint_as_float(f.a.x), v01 = __uint_as_float(f.a.y);
+  const float v10 = __uint_as_float(f.b.x), v11 = __uint_as_float(f.b.y);
+  if constexpr (SAMPLER == kNearest) {
+    return v00;
+  } else if constexpr (SAMPLER == kScipy) {
     // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right
-    double fx = (double)fx_, fy = (double)fy_;
-    double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
-    double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
-    double acc = ((double)t.v00 * wy0) * wx0;
-    acc += ((double)t.v01 * wy0) * wx1;
-    acc += ((double)t.v10 * wy1) * wx0;
-    acc += ((double)t.v11 * wy1) * wx1;
+    const double fx = (double)f.fx, fy = (double)f.fy;
+    const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
+    const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
+    double acc = ((double)v00 * wy0) * wx0;
+    acc += ((double)v01 * wy0) * wx1;
+    acc += ((double)v10 * wy1) * wx0;
+    acc += ((double)v11 * wy1) * wx1;
     return (float)acc;
   } else if constexpr (SAMPLER == kF64Lerp) {
-    double fx = (double)fx_, fy = (double)fy_;
-    double a = (double)t.v00, b = (double)t.v01, c = (double)t.v10, d = (double)t.v11;
-    double top = __builtin_fma(fx, b - a, a);
-    double bot = __builtin_fma(fx, d - c, c);
+    const double fx = (double)f.fx, fy = (double)f.fy;
+    const double a = (double)v00, b = (double)v01, c = (double)v10, d = (double)v11;
+    const double top = __builtin_fma(fx, b - a, a);
+    const double bot = __builtin_fma(fx, d - c, c);
     return (float)__builtin_fma(fy, bot - top, top);
   } else {
-    float fx = (float)fx_, fy = (float)fy_;
-    float top = __builtin_fmaf(fx, t.v01 - t.v00, t.v00);
-    float bot = __builtin_fmaf(fx, t.v11 - t.v10, t.v10);
+    const float fx = (float)f.fx, fy = (float)f.fy;
+    const float top = __builtin_fmaf(fx, v01 - v00, v00);
+    const float bot = __builtin_fmaf(fx, v11 - v10, v10);
     return __builtin_fmaf(fy, bot - top, top);
-  }
-}
-
-template <int SAMPLER, bool PAIR, typename CT>
-__device__ __forceinline__ float sample(const SrcView& s, CT xc, CT yc) {
-  if constexpr (SAMPLER == kNearest) {
-    uint32_t off = locate_nearest<CT>(s, xc, yc);
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0));
-  } else {
-    Pos<CT> p = locate<PAIR, CT>(s, xc, yc);
-    Taps t = gather<PAIR, CT>(s.rsrc, p, s.stride * 4);
-    return blend<SAMPLER, CT>(t, p.fx, p.fy);
   }
 }
 
@@ -224,6 +282,8 @@ __device__ __forceinline__ SrcView make_view(const float* base, uint32_t bytes, 
                                              int cstride) {
   SrcView s;
   s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+  s.pf_rsrc = s.rsrc;
+  s.pf_sink = nullptr;
   s.W = W;
   s.H = H;
   s.stride = stride;
@@ -233,12 +293,113 @@ __device__ __forceinline__ SrcView make_view(const float* base, uint32_t bytes, 
 
 // ------------------------------------------------------------------ K1 / K2 / K3
 
+constexpr double kTinyR2 = 1e-300;   // keeps rsq finite at the centre pixel; absorbed everywhere else
+
+// Per-column (thread) invariants of the coordinate map.
+struct ColCtx {
+  double cx0, cx1, cx2;      // radial: xu, xu^2, -.  perspective/fused: c7*x, c1*x, c4*x
+  double lead_e, lead_o;     // leading even / odd polynomial coefficient pinned in VGPRs
+};
+
+template <int KIND, int NF>
+__device__ __forceinline__ ColCtx make_col(const MapArgs& map, int x) {
+  ColCtx c;
+  const double xd_ = (double)x;
+  if constexpr (KIND == kRadial) {
+    c.cx0 = xd_ - map.xc;
+    c.cx1 = c.cx0 * c.cx0;
+    c.cx2 = 0.0;
+  } else {
+    c.cx0 = map.coef[6] * xd_;
+    c.cx1 = map.coef[0] * xd_;
+    c.cx2 = map.coef[3] * xd_;
+  }
+  c.lead_e = c.lead_o = 0.0;
+  if constexpr (NF >= 0 && KIND != kPersp) poly_leads<NF>(map.fact, &c.lead_e, &c.lead_o);
+  return c;
+}
+
+// Per-row invariants written to LDS by one thread per row: radial (yu, max(yu^2, tiny)),
+// perspective (c8*y, c2*y, c5*y).
+template <int KIND, int RW>
+__device__ __forceinline__ void fill_row(const MapArgs& map, double (*row)[RW], int slot, double y) {
+  if constexpr (KIND == kRadial) {
+    const double yu = y - map.yc;
+    const double yu2 = yu * yu;
+    row[slot][0] = yu;
+    // r2 = xu^2 + yu^2 must stay > 0 for rsq; the bias is absorbed by the addition unless
+    // xu == yu == 0, where the coordinate is xc + B*0 whatever B is.
+    row[slot][1] = yu2 > kTinyR2 ? yu2 : kTinyR2;
+  } else {
+    row[slot][0] = map.coef[7] * y;   // c8*y
+    row[slot][1] = map.coef[1] * y;   // c2*y
+    row[slot][2] = map.coef[4] * y;   // c5*y
+  }
+}
+
+// Source coordinate (float64, unclipped) of the pixel in column ctx / LDS row slot k.
+template <int KIND, int NF, int RW>
+__device__ __forceinline__ void map_coord(const MapArgs& map, const double (*s_row)[RW], const double* s_coef,
+                                          const ColCtx& c, int k, float wmaxf, float hmaxf, double* xd_out,
+                                          double* yd_out) {
+  double xd, yd;
+  if constexpr (KIND == kRadial) {
+    const double yu = s_row[k][0];
+    const double r2 = c.cx1 + s_row[k][1];
+    // correctly rounded sqrt (see sqrt_rn) without the zero select: r2 > 0 here
+    double g, h;
+    {
+      const double y = __builtin_amdgcn_rsq(r2);
+      g = r2 * y;
+      h = 0.5 * y;
+      const double r = __builtin_fma(-h, g, 0.5);
+      g = __builtin_fma(g, r, g);
+      h = __builtin_fma(h, r, h);
+      const double d = __builtin_fma(-g, g, r2);
+      g = __builtin_fma(d, h, g);
+    }
+    double f;
+    if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, c.lead_e, c.lead_o, r2, g);
+    else f = poly_lds(s_coef, map.nfact, r2, g);
+    xd = __builtin_fma(f, c.cx0, map.xc);
+    yd = __builtin_fma(f, yu, map.yc);
+  } else {
+    // postprocessing.py:453-455, numpy order: (c7*x + c8*y) + 1.0 etc., true divisions
+    const double den = (c.cx0 + s_row[k][0]) + 1.0;
+    const double nx = (c.cx1 + s_row[k][1]) + map.coef[2];
+    const double ny = (c.cx2 + s_row[k][2]) + map.coef[5];
+    xd = nx / den;
+    yd = ny / den;
+    if constexpr (KIND == kFused) {
+      // float32-rounded perspective coordinate, then the radial map evaluated there
+      const double xp = (double)round_clip_f32(xd, wmaxf);
+      const double yp = (double)round_clip_f32(yd, hmaxf);
+      const double xu = xp - map.xc;
+      const double yu = yp - map.yc;
+      const double xx = xu * xu;
+      const double yy = yu * yu;
+      const double r2 = xx + yy;
+      const double ru = sqrt_rn(r2);
+      double f;
+      if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, c.lead_e, c.lead_o, r2, ru);
+      else f = poly_lds(s_coef, map.nfact, r2, ru);
+      xd = __builtin_fma(f, xu, map.xc);
+      yd = __builtin_fma(f, yu, map.yc);
+    }
+  }
+  *xd_out = xd;
+  *yd_out = yd;
+}
+
 // NF >= 0: polynomial length known at compile time, coefficients read from kernarg (SGPRs).
 // NF == -1: runtime length, coefficients staged in LDS.
-template <int KIND, int NF, int SAMPLER, bool ROUND32, bool PAIR>
+// PD: rows in flight per thread (software pipeline depth of the gather).
+template <int KIND, int NF, int SAMPLER, bool ROUND32, bool PAIR, int PD>
 __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img, const MapArgs map) {
-  __shared__ double s_row[kMaxTileRows][4];
+  __shared__ double s_row[kMaxTileRows + PD][4];
   __shared__ double s_coef[kMaxFact];
+  using CT = typename std::conditional<ROUND32, float, double>::type;
+  using FetchT = Fetch<SAMPLER, PAIR, CT>;
 
   const int tile = logical_tile(img.xcd_remap);
   const int ty = tile / img.tiles_x;
@@ -247,90 +408,254 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
   const int x = tx * kBlock + (int)threadIdx.x;
   const int rows = min(img.tile_rows, img.H - y0);
 
-  // per-row invariants -> LDS
-  if ((int)threadIdx.x < rows) {
-    const double y = (double)(y0 + (int)threadIdx.x);
-    if constexpr (KIND == kRadial) {
-      const double yu = y - map.yc;
-      s_row[threadIdx.x][0] = yu;
-      s_row[threadIdx.x][1] = yu * yu;
-    } else {
-      s_row[threadIdx.x][0] = map.coef[7] * y;   // c8*y
-      s_row[threadIdx.x][1] = map.coef[1] * y;   // c2*y
-      s_row[threadIdx.x][2] = map.coef[4] * y;   // c5*y
-    }
-  }
+  // per-row invariants -> LDS.  PD rows past the tile are filled too: the pipeline below runs
+  // ahead by PD rows and simply discards what it computed for them.
+  if ((int)threadIdx.x < img.tile_rows + PD)
+    fill_row<KIND, 4>(map, s_row, threadIdx.x, (double)(y0 + (int)threadIdx.x));
   if constexpr (NF < 0 && KIND != kPersp) {
     if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
   }
   __syncthreads();
   if (x >= img.W) return;
 
-  const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, img.src_col_stride);
+  SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, img.src_col_stride);
+#if DCP_PF_ROWS > 0
+  __shared__ float s_pf[4][64];
+  {
+    const uint32_t skip = (uint32_t)DCP_PF_ROWS * (uint32_t)img.src_stride * 4u;
+    if (skip < img.src_bytes) {
+      src.pf_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)img.src + skip), 0,
+                                                      (int)(img.src_bytes - skip), 0x00020000);
+      src.pf_sink = s_pf[__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)];
+    }
+  }
+#endif
   const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
   const double wmaxd = (double)(img.W - 1), hmaxd = (double)(img.H - 1);
-  float* __restrict__ out = img.dst + (size_t)y0 * (size_t)img.W + (size_t)x;
+  // output rows through one buffer descriptor per row built on the scalar unit: lane offset
+  // x*4 in a VGPR; a row past the image gets num_records = 0, i.e. the store is dropped
+  const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
+  const char* out_base = (const char*)(img.dst + (size_t)y0 * (size_t)img.W);
+  const uint32_t xoff = (uint32_t)x * 4u;
+  const ColCtx col = make_col<KIND, NF>(map, x);
 
-  // per-column invariants -> registers
-  const double xd_ = (double)x;
-  double cx0, cx1, cx2;
-  if constexpr (KIND == kRadial) {
-    cx0 = xd_ - map.xc;        // xu
-    cx1 = cx0 * cx0;           // xu^2
-    cx2 = 0.0;
-  } else {
-    cx0 = map.coef[6] * xd_;   // c7*x
-    cx1 = map.coef[0] * xd_;   // c1*x
-    cx2 = map.coef[3] * xd_;   // c4*x
+  // source coordinate of row k of the tile and the gather it starts
+  auto issue = [&](int k) -> FetchT {
+    double xd, yd;
+    map_coord<KIND, NF, 4>(map, s_row, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+    if constexpr (ROUND32) {
+      return fetch<SAMPLER, PAIR, float>(src, round_clip_f32(xd, wmaxf), round_clip_f32(yd, hmaxf));
+    } else {
+      return fetch<SAMPLER, PAIR, double>(src, clip_f64(xd, wmaxd), clip_f64(yd, hmaxd));
+    }
+  };
+
+#if DCP_SETPRIO == 1
+  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) __builtin_amdgcn_s_setprio(2);
+#elif DCP_SETPRIO == 2
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
+#elif DCP_SETPRIO == 3
+  switch (blockIdx.x & 3) {
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    case 3: __builtin_amdgcn_s_setprio(3); break;
+    default: break;
+  }
+#endif
+  // software pipeline: PD rows of gathers in flight per thread
+  FetchT q[PD];
+#pragma unroll
+  for (int j = 0; j < PD; ++j) q[j] = issue(j);
+  for (int k = 0; k < rows; k += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const float v = finish<SAMPLER, PAIR, CT>(q[j]);
+      const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(out_base + (size_t)(k + j) * row_bytes_out), 0, (k + j < rows) ? (int)row_bytes_out : 0,
+          0x00020000);
+#if DCP_ABLATE & 2
+      if (v == 123.456f)
+#endif
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, 0, DCP_STORE_AUX);
+      q[j] = issue(k + j + PD);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K1 / K2 / K3, LDS-staged gather
+
+// The same maps as remap_tile_kernel, float32-rounded coordinates, order 1, unit column stride.
+// Each WAVE owns a 64-wide x 16-tall output tile:
+//   phase 1a every lane evaluates the source coordinates of the first and last row of its column;
+//            the four corner pixels of the tile predict the bounding box of all its taps;
+//   fill     the wave starts copying that box -- at most kBoxW x kBoxH floats -- from HBM/L2 into
+//            its own LDS slab with row-contiguous 4-byte-per-lane LDS-DMA loads (one 256 B line
+//            pair per instruction, the access shape the vector L1 serves fastest);
+//   phase 1b the other 14 rows are evaluated while the fill is in flight, and every lane checks
+//            that all its taps lie inside the predicted box (one ballot);
+//   phase 2  every lane gathers its four taps from LDS (two ds_read2_b32), blends and stores.
+// A box that does not fit (strong minification or skew) or a failed containment vote makes the
+// wave fall back to the direct global gather for that tile.  No workgroup barrier is needed after the row table is built:
+// slabs are wave-private and a wave's LDS operations execute in order.
+// statistics of the staged path (bumped only when a wave leaves it): [0] box did not fit,
+// [1] containment vote failed.  Read through dcp_debug_counters().
+__device__ unsigned long long g_lds_stats[2];
+
+constexpr int kLdsTW = 64, kLdsTH = 16;
+constexpr int kBoxW = 80, kBoxH = 24;
+
+template <int KIND, int NF, int SAMPLER>
+__global__ void __launch_bounds__(kBlock, 5) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
+  // 4 x 7680 B slabs + row table + coefficients <= 32 KB: five workgroups (20 waves) per CU
+  __shared__ float s_box[4][kBoxH * kBoxW];
+  __shared__ double s_row[4 * kLdsTH][KIND == kRadial ? 2 : 4];
+  __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
+  using FetchT = Fetch<SAMPLER, true, float>;
+
+  // the wave index is wave-uniform by construction; say so, or every descriptor derived from it
+  // is treated as divergent and wrapped in a waterfall loop
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int tile = logical_tile(img.xcd_remap);
+  const int ty = tile / img.tiles_x;
+  const int tx = tile - ty * img.tiles_x;
+  const int yblk = ty * (4 * kLdsTH);
+  const int y0 = yblk + wave * kLdsTH;            // first row of this wave's tile
+  const int x = tx * kLdsTW + lane;
+
+  if ((int)threadIdx.x < 4 * kLdsTH)
+    fill_row<KIND, (KIND == kRadial ? 2 : 4)>(map, s_row, threadIdx.x, (double)min(yblk + (int)threadIdx.x, img.H - 1));
+  if constexpr (NF < 0 && KIND != kPersp) {
+    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
+  }
+  __syncthreads();
+  if (y0 >= img.H) return;                        // whole wave past the image (wave-uniform)
+  const int rows = min(kLdsTH, img.H - y0);
+
+  const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
+  const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
+  const ColCtx col = make_col<KIND, NF>(map, min(x, img.W - 1));
+  const auto* rowtab = s_row + wave * kLdsTH;
+
+  float* box = s_box[wave];
+  const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
+  const char* out_base = (const char*)(img.dst + (size_t)y0 * (size_t)img.W);
+  const uint32_t xoff = (uint32_t)x * 4u;         // lanes with x >= W: the store is out of range and dropped
+  // one descriptor for the rows of the tile that exist; the row offset goes through the scalar
+  // offset (not bounds-checked, hence the explicit row and column predicates)
+  const __amdgpu_buffer_rsrc_t dst =
+      __builtin_amdgcn_make_buffer_rsrc((void*)out_base, 0, (int)((uint32_t)rows * row_bytes_out), 0x00020000);
+  const bool col_ok = x < img.W;
+  auto store_row = [&](int k, float v) {
+    if (k < rows && col_ok)
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
+                                            DCP_STORE_AUX);
+  };
+
+  // ---- phase 1a: first and last row of the tile; their end lanes are the tile's four corners
+  float xf[kLdsTH], yf[kLdsTH];
+  auto eval_row = [&](int k) {
+    double xd, yd;
+    map_coord<KIND, NF, (KIND == kRadial ? 2 : 4)>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+    xf[k] = round_clip_f32(xd, wmaxf);
+    yf[k] = round_clip_f32(yd, hmaxf);
+  };
+  eval_row(0);
+  eval_row(kLdsTH - 1);
+
+  // ---- predicted source box: hull of the corner taps grown by one pixel.  The map is smooth, so
+  // the taps of the other 1020 pixels stay inside it (the bulge of a 64-pixel arc is ~0.01 px);
+  // phase 1b verifies that for every pixel and the wave falls back to the direct gather if not.
+  int cx0, cx1, cy0, cy1;
+  {
+    const int xa = (int)xf[0], xb = (int)xf[kLdsTH - 1], ya = (int)yf[0], yb = (int)yf[kLdsTH - 1];
+    const int xa0 = __builtin_amdgcn_readlane(xa, 0), xa1 = __builtin_amdgcn_readlane(xa, 63);
+    const int xb0 = __builtin_amdgcn_readlane(xb, 0), xb1 = __builtin_amdgcn_readlane(xb, 63);
+    const int ya0 = __builtin_amdgcn_readlane(ya, 0), ya1 = __builtin_amdgcn_readlane(ya, 63);
+    const int yb0 = __builtin_amdgcn_readlane(yb, 0), yb1 = __builtin_amdgcn_readlane(yb, 63);
+    cx0 = min(min(xa0, xa1), min(xb0, xb1));
+    cx1 = max(max(xa0, xa1), max(xb0, xb1));
+    cy0 = min(min(ya0, ya1), min(yb0, yb1));
+    cy1 = max(max(ya0, ya1), max(yb0, yb1));
+  }
+  const int bx0 = max(min(cx0 - 1, img.W - 2), 0);
+  const int bx1 = min(cx1 + 2, img.W - 1);          // last column held (tap x0+1 of the largest x0, +1 margin)
+  const int by0 = max(min(cy0 - 1, img.H - 2), 0);
+  const int by1 = min(cy1 + 2, img.H - 1);
+  const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+  const bool fits = bw <= kBoxW && bh <= kBoxH;
+
+  // ---- fill: box rows by0..by1, columns bx0..bx1, row-contiguous 4-byte-per-lane loads that
+  // land directly in LDS (buffer_load ... lds, no VGPR round trip).  The row advances through the
+  // scalar offset; lanes past the box width are masked off.  All rows are in flight at once and
+  // complete underneath phase 1b.
+  if (fits) {
+    const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
+    const uint32_t rstep = (uint32_t)img.src_stride * 4u;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    if (lane < bw) {
+#pragma unroll 2
+      for (int r = 0; r < bh; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(box + r * kBoxW), 4, lane * 4,
+                                                 org + (uint32_t)r * rstep, 0, 0);
+    }
+    if (lane + 64 < bw) {
+      // instruction offset 256 moves both the global and the LDS address to column 64
+#pragma unroll 2
+      for (int r = 0; r < bh; ++r)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(box + r * kBoxW), 4, lane * 4,
+                                                 org + (uint32_t)r * rstep, 256, 0);
+    }
   }
 
-#pragma unroll 2
-  for (int k = 0; k < rows; ++k) {
-    double xd, yd;             // source coordinate, float64, not yet clipped
-    if constexpr (KIND == kRadial) {
-      const double yu = s_row[k][0];
-      const double r2 = cx1 + s_row[k][1];
-      const double ru = sqrt_rn(r2);
-      double f;
-      if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, r2, ru);
-      else f = poly_lds(s_coef, map.nfact, r2, ru);
-      const double px = f * cx0;
-      const double py = f * yu;
-      xd = map.xc + px;
-      yd = map.yc + py;
-    } else {
-      // postprocessing.py:453-455, numpy order: (c7*x + c8*y) + 1.0 etc., true divisions
-      const double den = (cx0 + s_row[k][0]) + 1.0;
-      const double nx = (cx1 + s_row[k][1]) + map.coef[2];
-      const double ny = (cx2 + s_row[k][2]) + map.coef[5];
-      xd = nx / den;
-      yd = ny / den;
-      if constexpr (KIND == kFused) {
-        // float32-rounded perspective coordinate, then the radial map evaluated there
-        const double xp = (double)round_clip_f32(xd, wmaxf);
-        const double yp = (double)round_clip_f32(yd, hmaxf);
-        const double xu = xp - map.xc;
-        const double yu = yp - map.yc;
-        const double xx = xu * xu;
-        const double yy = yu * yu;
-        const double r2 = xx + yy;
-        const double ru = sqrt_rn(r2);
-        double f;
-        if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, r2, ru);
-        else f = poly_lds(s_coef, map.nfact, r2, ru);
-        const double px = f * xu;
-        const double py = f * yu;
-        xd = map.xc + px;
-        yd = map.yc + py;
-      }
+  // ---- phase 1b: the other rows, and this lane's extremes for the containment vote
+  float xmn = __builtin_fminf(xf[0], xf[kLdsTH - 1]), xmx = __builtin_fmaxf(xf[0], xf[kLdsTH - 1]);
+  float ymn = __builtin_fminf(yf[0], yf[kLdsTH - 1]), ymx = __builtin_fmaxf(yf[0], yf[kLdsTH - 1]);
+#pragma unroll
+  for (int k = 1; k < kLdsTH - 1; ++k) {
+    eval_row(k);
+    xmn = __builtin_fminf(xmn, xf[k]);
+    xmx = __builtin_fmaxf(xmx, xf[k]);
+    ymn = __builtin_fminf(ymn, yf[k]);
+    ymx = __builtin_fmaxf(ymx, yf[k]);
+  }
+  // tap columns are min(floor(xf), W-2) and +1: inside [bx0, bx1] iff xf >= bx0 and
+  // (xf < bx1 or the box already ends at the image edge)
+  const bool inside = xmn >= (float)bx0 && (xmx < (float)bx1 || bx1 == img.W - 1) && ymn >= (float)by0 &&
+                      (ymx < (float)by1 || by1 == img.H - 1);
+  const bool staged = fits && __builtin_amdgcn_ballot_w64(!inside) == 0;
+  if (!staged && lane == 0) atomicAdd(&g_lds_stats[fits ? 1 : 0], 1ull);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+  if (staged) {
+    // ---- phase 2: taps from LDS, blend, store
+    const int boxorg = by0 * kBoxW + bx0;
+#pragma unroll
+    for (int k = 0; k < kLdsTH; ++k) {
+      FetchT f;
+      const int xi = min((int)xf[k], img.W - 2), yi = min((int)yf[k], img.H - 2);
+      f.fx = xf[k] - (float)xi;
+      f.fy = yf[k] - (float)yi;
+      const int idx = __mul24(yi, kBoxW) + (xi - boxorg);
+      f.a.x = __float_as_uint(box[idx]);
+      f.a.y = __float_as_uint(box[idx + 1]);
+      f.b.x = __float_as_uint(box[idx + kBoxW]);
+      f.b.y = __float_as_uint(box[idx + kBoxW + 1]);
+      store_row(k, finish<SAMPLER, true, float>(f));
     }
-    float v;
-    if constexpr (ROUND32) {
-      v = sample<SAMPLER, PAIR, float>(src, round_clip_f32(xd, wmaxf), round_clip_f32(yd, hmaxf));
-    } else {
-      v = sample<SAMPLER, PAIR, double>(src, clip_f64(xd, wmaxd), clip_f64(yd, hmaxd));
+  } else {
+    // ---- box too large for the slab: direct global gather for this tile
+#pragma unroll
+    for (int k = 0; k < kLdsTH; ++k) {
+      const FetchT f = fetch<SAMPLER, true, float>(src, xf[k], yf[k]);
+      store_row(k, finish<SAMPLER, true, float>(f));
     }
-    out[(size_t)k * (size_t)img.W] = v;
   }
 }
 
@@ -348,7 +673,8 @@ __global__ void __launch_bounds__(kBlock) remap_coords_kernel(const ImageArgs im
   xc = xc > wmax ? wmax : xc;
   yc = yc < (CT)0 ? (CT)0 : yc;
   yc = yc > hmax ? hmax : yc;
-  img.dst[i] = sample<SAMPLER, PAIR, CT>(src, xc, yc);
+  const Fetch<SAMPLER, PAIR, CT> f = fetch<SAMPLER, PAIR, CT>(src, xc, yc);
+  img.dst[i] = finish<SAMPLER, PAIR, CT>(f);
 }
 
 // ------------------------------------------------------------------ K4: rows of a (D,H,W) stack
@@ -374,18 +700,16 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
   const double r2 = xu * xu + yu * yu;
   const double ru = sqrt_rn(r2);
   double f;
-  if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, r2, ru);
-  else f = poly_lds(s_coef, map.nfact, r2, ru);
-  const double px = f * xu;
-  const double py = f * yu;
-  const double xd = map.xc + px;
-  const double yd = map.yc + py;
+  if constexpr (NF >= 0) {
+    double lead_e, lead_o;
+    poly_leads<NF>(map.fact, &lead_e, &lead_o);
+    f = poly_inline<NF>(map.fact, lead_e, lead_o, r2, ru);
+  } else {
+    f = poly_lds(s_coef, map.nfact, r2, ru);
+  }
+  const double xd = __builtin_fma(f, xu, map.xc);
+  const double yd = __builtin_fma(f, yu, map.yc);
 
-  SrcView s;
-  s.W = st.W;
-  s.H = st.H;
-  s.stride = st.row_stride;
-  s.cstride = 1;
   using CT = typename std::conditional<ROUND32, float, double>::type;
   CT xc, yc;
   if constexpr (ROUND32) {
@@ -395,7 +719,12 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
     xc = clip_f64(xd, (double)(st.W - 1));
     yc = clip_f64(yd, (double)(st.H - 1));
   }
-  const Pos<CT> p = locate<true, CT>(s, xc, yc);
+  // base tap and fractions once; per projection only the descriptor base moves
+  int xi = min((int)xc, st.W - 2), yi = min((int)yc, st.H - 2);
+  Fetch<SAMPLER, true, CT> ft;
+  ft.fx = xc - (CT)xi;
+  ft.fy = yc - (CT)yi;
+  const uint32_t off = (__umul24(yi, st.row_stride) + (uint32_t)xi) << 2;
   const int row_bytes = st.row_stride * 4;
   const float* base = st.vol + (size_t)d0 * (size_t)st.proj_stride;
   float* out = st.out + ((size_t)d0 * (size_t)st.nrows + (size_t)r) * (size_t)st.W + (size_t)x;
@@ -404,8 +733,9 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
   for (int d = d0; d < d1; ++d) {
     const __amdgpu_buffer_rsrc_t rsrc =
         __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)st.proj_bytes, 0x00020000);
-    const Taps t = gather<true, CT>(rsrc, p, row_bytes);
-    *out = blend<SAMPLER, CT>(t, p.fx, p.fy);
+    ft.a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
+    ft.b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, row_bytes, 0);
+    *out = finish<SAMPLER, true, CT>(ft);
     base += st.proj_stride;
     out += out_step;
   }
@@ -416,13 +746,43 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
 template <int KIND, int NF, int SAMPLER, bool ROUND32, bool PAIR>
 static hipError_t launch_one(const ImageArgs& img, const MapArgs& map, hipStream_t stream) {
   const int nb = img.tiles_x * img.tiles_y;
-  hipLaunchKernelGGL((remap_tile_kernel<KIND, NF, SAMPLER, ROUND32, PAIR>), dim3(nb), dim3(kBlock), 0, stream,
-                     img, map);
+  if constexpr (KIND == kRadial && NF >= 0) {
+    // the headline path also exists with 1 and 4 rows in flight (option pipe_depth) for A/B runs
+    if (img.pipe_depth == 1) {
+      hipLaunchKernelGGL((remap_tile_kernel<KIND, NF, SAMPLER, ROUND32, PAIR, 1>), dim3(nb), dim3(kBlock), 0,
+                         stream, img, map);
+      return hipGetLastError();
+    }
+    if (img.pipe_depth >= 4) {
+      hipLaunchKernelGGL((remap_tile_kernel<KIND, NF, SAMPLER, ROUND32, PAIR, 4>), dim3(nb), dim3(kBlock), 0,
+                         stream, img, map);
+      return hipGetLastError();
+    }
+  }
+  hipLaunchKernelGGL((remap_tile_kernel<KIND, NF, SAMPLER, ROUND32, PAIR, kPipeDepth>), dim3(nb), dim3(kBlock),
+                     0, stream, img, map);
+  return hipGetLastError();
+}
+
+template <int KIND, int NF, int SAMPLER>
+static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {
+  ImageArgs img = img_in;
+  img.tiles_x = (img.W + kLdsTW - 1) / kLdsTW;
+  img.tiles_y = (img.H + 4 * kLdsTH - 1) / (4 * kLdsTH);
+  const int nb = img.tiles_x * img.tiles_y;
+  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER>), dim3(nb), dim3(kBlock), 0, stream, img, map);
   return hipGetLastError();
 }
 
 template <int KIND, int NF>
 static hipError_t launch_fast(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
+  if (img.lds_gather && sampler != kNearest) {
+    switch (sampler) {
+      case kScipy: return launch_lds<KIND, NF, kScipy>(img, map, stream);
+      case kF64Lerp: return launch_lds<KIND, NF, kF64Lerp>(img, map, stream);
+      default: return launch_lds<KIND, NF, kF32Lerp>(img, map, stream);
+    }
+  }
   switch (sampler) {
     case kNearest: return launch_one<KIND, NF, kNearest, true, true>(img, map, stream);
     case kScipy: return launch_one<KIND, NF, kScipy, true, true>(img, map, stream);
@@ -451,6 +811,8 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
   img.tiles_x = (img.W + kBlock - 1) / kBlock;
   img.tiles_y = (img.H + tr - 1) / tr;
   img.xcd_remap = opts.xcd_remap;
+  img.pipe_depth = opts.pipe_depth;
+  img.lds_gather = opts.lds_gather;
   // the 8-byte pair gather needs unit column stride and at least a 2x2 image
   const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2;
   const int nf = map.nfact;
@@ -538,6 +900,13 @@ static hipError_t launch_stack_t(const StackArgs& st, const MapArgs& map, int sa
       break;
   }
   return hipGetLastError();
+}
+
+hipError_t read_lds_stats(unsigned long long* out, bool reset) {
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lds_stats), sizeof(g_lds_stats));
+  if (e != hipSuccess || !reset) return e;
+  const unsigned long long zero[2] = {0, 0};
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_lds_stats), zero, sizeof(zero));
 }
 
 hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler, bool round_f32,

@@ -104,6 +104,11 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
                               const double* list_fact, int nfact, double row_start, int64_t nrows,
                               int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream);
 
+/* Diagnostics of the LDS-staged gather on the current device: out[0] = wave tiles whose source
+ * box did not fit the LDS slab, out[1] = wave tiles whose containment vote failed (both fall back
+ * to the direct gather).  Synchronises the device. */
+int dcp_debug_counters(uint64_t* out, int n, int reset);
+
 /* ---- device memory / stream / event helpers (so a host language needs no other GPU runtime) ---- */
 int dcp_malloc(void** ptr, size_t bytes, int device);
 int dcp_free(void* ptr, int device);

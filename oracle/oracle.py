@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libunwarp_oracle.so")
 
-POLY_KERNEL, POLY_NUMPY = 0, 1
+POLY_KERNEL, POLY_NUMPY, POLY_KERNEL_MULADD = 0, 1, 2
 BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
 
 

@@ -38,7 +38,9 @@
  *   ORC_POLY_KERNEL (0): the order the HIP kernels use -- even/odd split in
  *        r2 = xu^2 + yu^2 with fused multiply-adds:
  *        E = a0 + r2*(a2 + r2*(a4 + ...)), O = a1 + r2*(a3 + ...),
- *        B = fma(ru, O, E).
+ *        B = fma(ru, O, E); xd = fma(B, xu, xc), yd = fma(B, yu, yc).
+ *   ORC_POLY_KERNEL_MULADD (2): kernel polynomial, but xc + B*xu as a separate
+ *        multiply and add (kept for the flip-rate comparison in tools/flip_rate.py).
  *   Both agree to ~2e-16 relative; after the float32 rounding of the
  *   coordinates (postprocessing.py:144-145) they are bit-identical except when
  *   a float64 coordinate lies within ~1e-12 px of a float32 rounding boundary.
@@ -122,10 +124,18 @@ static inline void radial_coord(double x, double y, double xc, double yc,
     double ru = sqrt(r2);
     double f = poly_mode == ORC_POLY_NUMPY ? poly_numpy(a, n, ru)
                                            : poly_kernel(a, n, r2, ru);
-    double px = f * xu;
-    double py = f * yu;
-    double cx = clipd(xc + px, 0.0, wmax);
-    double cy = clipd(yc + py, 0.0, hmax);
+    double sx, sy;
+    if (poly_mode == ORC_POLY_KERNEL) {
+        sx = fma(f, xu, xc);                 /* kernel order: one rounding instead of two */
+        sy = fma(f, yu, yc);
+    } else {
+        double px = f * xu;
+        double py = f * yu;
+        sx = xc + px;
+        sy = yc + py;
+    }
+    double cx = clipd(sx, 0.0, wmax);
+    double cy = clipd(sy, 0.0, hmax);
     if (round_f32) {
         cx = (double)(float)cx;              /* np.float32(...) then widened by scipy */
         cy = (double)(float)cy;

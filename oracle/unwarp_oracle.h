@@ -8,6 +8,7 @@ extern "C" {
 
 #define ORC_POLY_KERNEL 0
 #define ORC_POLY_NUMPY 1
+#define ORC_POLY_KERNEL_MULADD 2 /* flip-rate comparison only (tools/flip_rate.py) */
 #define ORC_BLEND_SCIPY 0
 #define ORC_BLEND_F64LERP 1
 #define ORC_BLEND_F32LERP 2

@@ -63,32 +63,39 @@ NR = 20
 ring_src = [F.DeviceBuffer(img.nbytes).upload(img) for _ in range(NR)]
 ring_dst = [F.DeviceBuffer(img.nbytes) for _ in range(NR)]
 fa, n = F.fact_array(fact)
-ref = None
-for blend in (1, 0, 2):
-    for order in (1, 0):
-        if order == 0 and blend != 1:
-            continue
-        for tr in (4, 8, 16, 32):
-            F.set_option("tile_rows", tr)
-            for xr in (1, 0):
-                F.set_option("xcd_remap", xr)
-                e0, e1 = F.Event(), F.Event()
-                for w in range(NR):
-                    F.check(L.dcp_unwarp_image_f32(ring_src[w].ptr, ring_dst[w].ptr, H, W, W, 1, xc, yc, fa, n,
-                                                   order, 1, blend, F.MEM_DEVICE, -1, None))
-                reps = 100
-                e0.record()
-                for r in range(reps):
-                    k = r % NR
-                    F.check(L.dcp_unwarp_image_f32(ring_src[k].ptr, ring_dst[k].ptr, H, W, W, 1, xc, yc, fa, n,
-                                                   order, 1, blend, F.MEM_DEVICE, -1, None))
-                e1.record()
-                e1.synchronize()
-                ms = e0.elapsed_ms(e1) / reps
-                print("cfg2 order=%d blend=%-7s tile_rows=%2d xcd=%d : %.2f us  %.0f Mpix/s  %.2f TB/s algorithmic"
-                      % (order, NAMES[blend], tr, xr, ms * 1e3, H * W / ms / 1e3, 8.0 * H * W / ms / 1e9), flush=True)
+def time_cfg(order, blend, reps=100):
+    e0, e1 = F.Event(), F.Event()
+    for w in range(NR):
+        F.check(L.dcp_unwarp_image_f32(ring_src[w].ptr, ring_dst[w].ptr, H, W, W, 1, xc, yc, fa, n,
+                                       order, 1, blend, F.MEM_DEVICE, -1, None))
+    e0.record()
+    for r in range(reps):
+        k = r % NR
+        F.check(L.dcp_unwarp_image_f32(ring_src[k].ptr, ring_dst[k].ptr, H, W, W, 1, xc, yc, fa, n,
+                                       order, 1, blend, F.MEM_DEVICE, -1, None))
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_ms(e1) / reps
+
+
+for pd in (1, 2, 4):
+    F.set_option("pipe_depth", pd)
+    for tr in (8, 16, 32):
+        F.set_option("tile_rows", tr)
+        for xr in (0, 1):
+            F.set_option("xcd_remap", xr)
+            ms = time_cfg(1, 1)
+            print("cfg2 f64lerp pd=%d tile_rows=%2d xcd=%d : %.2f us  %.0f Mpix/s  %.2f TB/s algorithmic"
+                  % (pd, tr, xr, ms * 1e3, H * W / ms / 1e3, 8.0 * H * W / ms / 1e9), flush=True)
 F.set_option("tile_rows", 16)
-F.set_option("xcd_remap", 1)
+F.set_option("xcd_remap", 0)
+for pd in (2, 4):
+    F.set_option("pipe_depth", pd)
+    for order, blend in [(1, 0), (1, 1), (1, 2), (0, 0)]:
+        ms = time_cfg(order, blend)
+        print("cfg2 pd=%d order=%d blend=%-7s : %.2f us  %.0f Mpix/s  %.2f TB/s algorithmic"
+              % (pd, order, NAMES[blend], ms * 1e3, H * W / ms / 1e3, 8.0 * H * W / ms / 1e9), flush=True)
+F.set_option("pipe_depth", 2)
 t = time.time()
 ref = orc.unwarp_image_backward(img, xc, yc, fact, order=1, poly=orc.POLY_KERNEL, blend=1)
 print("oracle 4096^2 with %d threads: %.3f s" % (orc.lib().orc_get_threads(), time.time() - t))

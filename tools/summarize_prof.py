@@ -1,0 +1,54 @@
+"""Condense the rocprofv3 CSV output of tools/profile.sh into one text/JSON summary."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(root, pattern):
+    return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
+
+
+def main(out):
+    summary = {"kernels": {}, "counters": {}}
+    # timing pass: kernel_stats.csv / kernel_trace.csv
+    for f in find(os.path.join(out, "trace"), "*kernel_stats.csv"):
+        for row in csv.DictReader(open(f)):
+            summary["kernels"][row["Name"]] = {k: row[k] for k in row if k != "Name"}
+    durations = defaultdict(list)
+    for f in find(os.path.join(out, "trace"), "*kernel_trace.csv"):
+        for row in csv.DictReader(open(f)):
+            durations[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    for k, v in durations.items():
+        v.sort()
+        summary["kernels"].setdefault(k, {})["trace"] = {
+            "calls": len(v), "avg_ns": sum(v) / len(v), "median_ns": v[len(v) // 2], "min_ns": v[0], "max_ns": v[-1]}
+    # counter passes: counter_collection.csv, one row per (dispatch, counter)
+    for d in sorted(os.listdir(out)):
+        p = os.path.join(out, d)
+        if not os.path.isdir(p) or d == "trace":
+            continue
+        acc = defaultdict(lambda: defaultdict(list))
+        for f in find(p, "*counter_collection.csv"):
+            for row in csv.DictReader(open(f)):
+                acc[row["Kernel_Name"]][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for kern, cs in acc.items():
+            for c, vals in cs.items():
+                # skip the warm-up dispatches: average the last half
+                tail = vals[len(vals) // 2:]
+                summary["counters"].setdefault(kern, {})[c] = {"per_launch": sum(tail) / len(tail), "n": len(vals)}
+    json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+    for k, v in summary["kernels"].items():
+        print("KERNEL", k[:100])
+        for kk, vv in v.items():
+            print("   ", kk, vv)
+    for kern, cs in summary["counters"].items():
+        print("COUNTERS", kern[:100])
+        for c in sorted(cs):
+            print("    %-44s %18.1f  (n=%d)" % (c, cs[c]["per_launch"], cs[c]["n"]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
