@@ -62,6 +62,30 @@ SIGNATURES = {
 }
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do not
+    work (whichever initialises second sees no device), so when torch is installed its copy is
+    loaded first -- without importing torch -- and libdiscorpy_hip.so, which only asks for the
+    SONAME, binds to it.  Either import order then works.  DISCORPY_AMD_SYSTEM_HIP=1 opts out."""
+    if os.environ.get("DISCORPY_AMD_SYSTEM_HIP") == "1":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        return cand
+    except OSError:
+        return None
+
+
 def lib():
     """Load the shared library (once) and declare every entry point."""
     global _lib
@@ -70,6 +94,7 @@ def lib():
             raise HipLibraryMissing(
                 "libdiscorpy_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C discorpy_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

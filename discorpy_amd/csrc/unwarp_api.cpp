@@ -142,6 +142,48 @@ uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs) {
   return (uint32_t)(((H - 1) * rs + (W - 1) * cs + 1) * 4);
 }
 
+// Rows of a projection that the radial map of output rows row_start .. row_start+nrows-1 can
+// touch: [*b0, *b1).  Evaluated in double on the host with the kernels' operation order and
+// widened by one row on each side, so a 1-ulp difference from the device cannot matter.
+void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0,
+                   int64_t* b1) {
+  double ymin = 1e300, ymax = -1e300;
+  const int n = m.nfact, ne = (n + 1) / 2, no = n / 2;
+  for (int64_t r = 0; r < nrows; ++r) {
+    const double yu = (row_start + (double)r) - m.yc;
+    for (int64_t x = 0; x < W; ++x) {
+      const double xu = (double)x - m.xc;
+      const double r2 = xu * xu + yu * yu;
+      const double ru = std::sqrt(r2);
+      double f = 0.0;
+      if (n > 0) {
+        double E = m.fact[2 * (ne - 1)];
+        for (int k = ne - 2; k >= 0; --k) E = std::fma(r2, E, m.fact[2 * k]);
+        f = E;
+        if (no > 0) {
+          double O = m.fact[2 * (no - 1) + 1];
+          for (int k = no - 2; k >= 0; --k) O = std::fma(r2, O, m.fact[2 * k + 1]);
+          f = std::fma(ru, O, E);
+        }
+      }
+      double yd = std::fma(f, yu, m.yc);
+      if (!(yd >= 0.0)) yd = 0.0;               // also catches NaN
+      if (yd > (double)(H - 1)) yd = (double)(H - 1);
+      if (yd < ymin) ymin = yd;
+      if (yd > ymax) ymax = yd;
+    }
+  }
+  int64_t lo = (int64_t)std::floor(ymin) - 1, hi = (int64_t)std::floor(ymax) + 3;
+  if (lo < 0) lo = 0;
+  if (hi > H) hi = H;
+  if (hi - lo < 2) {  // the gather needs two rows
+    lo = lo > 0 ? lo - 1 : lo;
+    hi = lo + 2 <= H ? (hi > lo + 2 ? hi : lo + 2) : H;
+  }
+  *b0 = lo;
+  *b1 = hi;
+}
+
 // Shared driver of the three whole-image entry points.
 int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_t W, int64_t rs, int64_t cs,
               const dcp::MapArgs& map, int sampler, bool round_f32, int mem_kind, int device, void* stream) {
@@ -375,23 +417,32 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
   }
   if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
   // Host volume: only the row band the requested rows can reach is shipped (the reference slices
-  // mat3D[i, yd_min:yd_max, :] for the same reason, postprocessing.py:221-228).  The band is found
-  // conservatively on the host from the corner/centre extremes of |B|.
-  int64_t band0 = 0, band1 = height;  // TODO(perf): tighten; correctness does not depend on it
+  // mat3D[i, yd_min:yd_max, :] for the same reason, postprocessing.py:221-228).  The band is the
+  // hull of the source rows evaluated on the host, grown by a safety row on each side; the
+  // kernel keeps addressing rows by their absolute index.
+  int64_t band0 = 0, band1 = height;
+  host_row_band(map, height, width, row_start, nrows, &band0, &band1);
   const int64_t bh = band1 - band0;
   void *dvol, *dout;
   const size_t pbytes = (size_t)bh * (size_t)width * 4;
   DCP_HIP(g_staging.get(0, pbytes * (size_t)depth, &dvol));
   DCP_HIP(g_staging.get(1, (size_t)depth * (size_t)nrows * (size_t)width * 4, &dout));
-  for (int64_t d = 0; d < depth; ++d)
-    DCP_HIP(hipMemcpy2DAsync((char*)dvol + (size_t)d * pbytes, (size_t)width * 4,
-                             vol + d * proj_stride + band0 * row_stride, (size_t)row_stride * 4,
-                             (size_t)width * 4, (size_t)bh, hipMemcpyHostToDevice, hs));
-  st.vol = (const float*)dvol;
+  for (int64_t d = 0; d < depth; ++d) {
+    const float* hsrc = vol + d * proj_stride + band0 * row_stride;
+    char* ddst = (char*)dvol + (size_t)d * pbytes;
+    if (row_stride == width) {
+      DCP_HIP(hipMemcpyAsync(ddst, hsrc, pbytes, hipMemcpyHostToDevice, hs));
+    } else {
+      DCP_HIP(hipMemcpy2DAsync(ddst, (size_t)width * 4, hsrc, (size_t)row_stride * 4, (size_t)width * 4,
+                               (size_t)bh, hipMemcpyHostToDevice, hs));
+    }
+  }
+  // absolute row indexing: shift the base up by band0 rows (never dereferenced below the band)
+  st.vol = (const float*)dvol - band0 * width;
   st.out = (float*)dout;
   st.proj_stride = bh * width;
   st.row_stride = (int32_t)width;
-  st.proj_bytes = (uint32_t)pbytes;
+  st.proj_bytes = (uint32_t)((size_t)band1 * (size_t)width * 4);
   DCP_HIP(dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs));
   DCP_HIP(hipMemcpyAsync(out, dout, (size_t)depth * (size_t)nrows * (size_t)width * 4, hipMemcpyDeviceToHost, hs));
   DCP_HIP(hipStreamSynchronize(hs));

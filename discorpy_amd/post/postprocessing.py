@@ -1,0 +1,337 @@
+"""MI355X drop-in for the remap functions of ``discorpy.post.postprocessing``.
+
+Same names, positional arguments, defaults and error messages as the reference
+(``/root/reference/discorpy/post/postprocessing.py``):
+
+* :func:`unwarp_image_backward`         reference lines 111-148
+* :func:`unwarp_slice_backward`         reference lines 188-229
+* :func:`unwarp_chunk_slices_backward`  reference lines 255-313
+* :func:`correct_perspective_image`     reference lines 462-492
+
+plus :func:`unwarp_perspective_fused`, the one-pass composition BASELINE config 3 asks for.
+
+Every call runs a hand-written HIP kernel through the C ABI of ``libdiscorpy_hip.so``
+(``include/discorpy_hip.h``).  There is no CPU path: a missing library or GPU raises.
+
+Inputs may be
+
+* ``numpy.ndarray`` (host): the library stages host<->device copies itself and a NumPy array is
+  returned -- the plumbing-compatible mode, dominated by PCIe;
+* a ``torch.Tensor`` on a ROCm device: zero-copy, the kernel is enqueued on torch's current
+  stream and a tensor on the same device is returned -- the mode the throughput numbers are for.
+
+What differs from the reference, on purpose:
+
+* data must be float32 (what ``discorpy.losa.load_image`` / ``load_hdf_file`` produce); other
+  dtypes raise ``NotImplementedError`` instead of silently taking another code path;
+* spline ``order`` 0 and 1 only (``order >= 2`` raises ``NotImplementedError``).  For these
+  orders ``mode`` cannot influence the result because every coordinate is clipped into the image
+  first; it is validated and otherwise ignored;
+* keyword-only extras: ``blend`` selects the bilinear arithmetic (``"f64lerp"`` default: float64
+  factorised lerp, within one float32 ulp of scipy and bit-equal in practice; ``"scipy"``:
+  scipy's exact float64 operation order; ``"f32"``: float32 lerp, opt-in).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .. import _ffi as F
+
+__all__ = ["unwarp_image_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
+           "correct_perspective_image", "unwarp_perspective_fused", "remap_coordinates"]
+
+_MODES = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+
+
+# --------------------------------------------------------------------------- array plumbing
+
+def _is_torch(a):
+    return type(a).__module__.split(".")[0] == "torch" and hasattr(a, "data_ptr")
+
+
+def _default_blend():
+    return os.environ.get("DISCORPY_AMD_BLEND", "f64lerp")
+
+
+def _blend_code(blend):
+    name = _default_blend() if blend is None else blend
+    try:
+        return F.BLEND_BY_NAME[str(name).lower()]
+    except KeyError:
+        raise ValueError("unknown blend %r (expected one of %s)" % (name, sorted(F.BLEND_BY_NAME)))
+
+
+def _check_order_mode(order, mode):
+    if mode not in _MODES:
+        # scipy's own message for an unknown boundary mode
+        raise RuntimeError("boundary mode not supported")
+    order = int(order)
+    if order < 0 or order > 5:
+        raise RuntimeError("spline order not supported")
+    if order > 1:
+        raise NotImplementedError("spline order %d is not implemented on the GPU path (orders 0 and 1 are)" % order)
+    return order
+
+
+class _Image:
+    """A float32 2-D / 3-D array handed to the C ABI: pointer, element strides, memory kind."""
+
+    def __init__(self, a, ndim):
+        self.torch = _is_torch(a)
+        if self.torch:
+            if not a.is_cuda:
+                a = a.detach().cpu().numpy()
+                self.torch = False
+        if self.torch:
+            import torch
+            if a.dtype != torch.float32:
+                raise NotImplementedError("only float32 data is implemented on the GPU path (got %s)" % a.dtype)
+            self.shape = tuple(a.shape)
+            self.strides = tuple(a.stride())
+            self.ptr = a.data_ptr()
+            self.mem = F.MEM_DEVICE
+            self.device = a.device.index if a.device.index is not None else torch.cuda.current_device()
+            self.stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.keep = a
+        else:
+            a = np.asarray(a)
+            if a.dtype != np.float32:
+                raise NotImplementedError("only float32 data is implemented on the GPU path (got %s)" % a.dtype)
+            if any(s < 0 for s in a.strides) or any(s % 4 for s in a.strides):
+                a = np.ascontiguousarray(a)
+            self.shape = a.shape
+            self.strides = tuple(s // 4 for s in a.strides)
+            self.ptr = a.ctypes.data
+            self.mem = F.MEM_HOST
+            self.device = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
+            self.stream = None
+            self.keep = a
+        if len(self.shape) != ndim:
+            raise ValueError("expected a %d-D array" % ndim)
+
+    def empty(self, shape):
+        """Fresh float32 output of the same kind (device tensor / NumPy array) as the input."""
+        if self.torch:
+            import torch
+            out = torch.empty(shape, dtype=torch.float32, device=self.keep.device)
+            return out, out.data_ptr()
+        out = np.empty(shape, np.float32)
+        return out, out.ctypes.data
+
+    def dense_rows(self):
+        """2-D image with unit or constant column stride and non-overlapping rows, else a copy."""
+        h, w = self.shape
+        rs, cs = self.strides
+        ok = cs >= 1 and rs >= 1 and (h == 1 or rs >= (w - 1) * cs + 1)
+        if ok:
+            return self
+        if self.torch:
+            return _Image(self.keep.contiguous(), 2)
+        return _Image(np.ascontiguousarray(self.keep), 2)
+
+
+def _coefs(values, what):
+    try:
+        vals = [float(v) for v in values]
+    except TypeError:
+        raise TypeError("%s must be a sequence of numbers" % what)
+    return vals
+
+
+# --------------------------------------------------------------------------- public functions
+
+def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *, blend=None):
+    """
+    Unwarp an image using a backward model (reference ``postprocessing.py:111-148``).
+
+    Parameters
+    ----------
+    mat : array_like
+        2D float32 array (NumPy array or ROCm torch tensor).
+    xcenter : float
+        Center of distortion in x-direction.
+    ycenter : float
+        Center of distortion in y-direction.
+    list_fact : list of float
+        Polynomial coefficients of the backward model.
+    order : int, optional.
+        The order of the spline interpolation (0 or 1).
+    mode : {'reflect', 'grid-mirror', 'constant', 'grid-constant', 'nearest',
+           'mirror', 'grid-wrap', 'wrap'}, optional
+        Accepted for compatibility; inert for order <= 1.
+
+    Returns
+    -------
+    array_like
+        2D array. Distortion-corrected image, same kind and dtype as the input.
+    """
+    (height, width) = mat.shape
+    order = _check_order_mode(order, mode)
+    bcode = _blend_code(blend)
+    img = _Image(mat, 2).dense_rows()
+    fact = _coefs(list_fact, "list_fact")
+    fa, nf = F.fact_array(fact)
+    out, optr = img.empty((height, width))
+    F.require_device()
+    F.check(F.lib().dcp_unwarp_image_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
+                                         float(xcenter), float(ycenter), fa, nf, order, 1, bcode,
+                                         img.mem, img.device, img.stream))
+    return out
+
+
+def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=None):
+    """
+    Generate an unwarped slice [:,index.:] of a 3D dataset, i.e. one unwarped sinogram of a 3D
+    tomographic data (reference ``postprocessing.py:188-229``).  Coordinates stay float64, the
+    result is float32 of shape (depth, width).
+    """
+    if len(mat3D.shape) < 3:
+        raise ValueError("Input must be a 3D data")
+    (depth, height, width) = mat3D.shape
+    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend)[:, 0, :]
+
+
+def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *, blend=None):
+    """
+    Generate a chunk of unwarped slices [:,start_index: stop_index, :] used for tomographic data
+    (reference ``postprocessing.py:255-313``).  Rows ``start_index .. stop_index`` INCLUSIVE;
+    coordinates are rounded to float32 as the reference does; ``stop_index=-1`` raises, as it
+    does in the reference (:285-288).
+    """
+    if (len(mat3D.shape) < 3):
+        raise ValueError("Input must be a 3D data")
+    (depth, height, width) = mat3D.shape
+    index_list = np.arange(height, dtype=np.int16)
+    if stop_index == -1:
+        stop_index = height
+    if (start_index not in index_list) or (stop_index not in index_list):
+        raise ValueError("Selected index is out of the range")
+    nrows = int(stop_index) - int(start_index) + 1
+    if nrows < 1:
+        # np.arange(start, stop + 1) is empty in the reference and map_coordinates then fails
+        raise ValueError("Selected index is out of the range")
+    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend)
+
+
+def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend):
+    bcode = _blend_code(blend)
+    vol = _Image(mat3D, 3)
+    depth, height, width = vol.shape
+    if depth == 0:
+        return vol.empty((0, nrows, width))[0]
+    ps, rs, cs = vol.strides
+    if cs != 1 or rs < width or (depth > 1 and ps < (height - 1) * rs + width):
+        vol = _Image(vol.keep.contiguous() if vol.torch else np.ascontiguousarray(vol.keep), 3)
+        ps, rs, cs = vol.strides
+    fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
+    out, optr = vol.empty((depth, nrows, width))
+    F.require_device()
+    F.check(F.lib().dcp_unwarp_stack_rows_f32(vol.ptr, optr, depth, height, width, ps if depth > 1 else height * rs,
+                                              rs, float(xcenter), float(ycenter), fa, nf, float(row_start), nrows,
+                                              int(round_f32), bcode, vol.mem, vol.device, vol.stream))
+    return out
+
+
+def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index=None, *, blend=None):
+    """
+    Apply perspective correction to an image (reference ``postprocessing.py:462-492``).
+
+    Parameters
+    ----------
+    mat : array_like
+        2D float32 array. Image for correction.
+    list_coef : list of floats
+        Coefficients of the backward-mapping matrix (c1..c8, (x, y) convention).
+    order : int, optional.
+        The order of the spline interpolation (0 or 1).
+    mode : str, optional
+        Accepted for compatibility; inert for order <= 1.
+    map_index : array_like
+        Indices for mapping, (ycoords, xcoords) with height*width points. Generated if None.
+
+    Returns
+    -------
+    array_like
+        Corrected image.
+    """
+    if len(list_coef) != 8:
+        raise ValueError("!!! Eight coefficients are required !!!")
+    (height, width) = mat.shape
+    order = _check_order_mode(order, mode)
+    bcode = _blend_code(blend)
+    img = _Image(mat, 2).dense_rows()
+    if map_index is not None:
+        ymap, xmap = map_index[0], map_index[1]
+        return remap_coordinates(mat, ymap, xmap, order=order, blend=blend).reshape((height, width))
+    ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
+    out, optr = img.empty((height, width))
+    F.require_device()
+    F.check(F.lib().dcp_perspective_image_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], ca,
+                                              order, bcode, img.mem, img.device, img.stream))
+    return out
+
+
+def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=1, mode="reflect", *, blend=None):
+    """
+    Perspective and radial correction in ONE resampling (BASELINE config 3).
+
+    For output pixel (x, y): (xp, yp) = float32(clip(H(x, y))) exactly as ``_generate_perspective_map``
+    (reference :448-457), then the radial backward map of :141-145 evaluated at (xp, yp),
+    float32-rounded, and one sample of ``mat``.  This is NOT equal to
+    ``correct_perspective_image(unwarp_image_backward(mat, ...), list_coef)``, which resamples
+    twice (reference ``examples/readthedocs_demo/demo_05.py:127,147``); on a noise image the two
+    differ by up to 0.5.  Its oracle is one ``map_coordinates`` call at the composed coordinates.
+    """
+    if len(list_coef) != 8:
+        raise ValueError("!!! Eight coefficients are required !!!")
+    (height, width) = mat.shape
+    order = _check_order_mode(order, mode)
+    bcode = _blend_code(blend)
+    img = _Image(mat, 2).dense_rows()
+    fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
+    ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
+    out, optr = img.empty((height, width))
+    F.require_device()
+    F.check(F.lib().dcp_unwarp_fused_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
+                                         float(xcenter), float(ycenter), fa, nf, ca, order, bcode,
+                                         img.mem, img.device, img.stream))
+    return out
+
+
+def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=None):
+    """
+    ``scipy.ndimage.map_coordinates(mat, (ycoords, xcoords), order, mode)`` for coordinates that lie
+    inside the image (the ``map_index=`` path of ``correct_perspective_image`` :489-491 and
+    ``_mapping`` :250-251).  Coordinates outside are clamped to the image.  Returns an array
+    shaped like ``ycoords``.
+    """
+    (height, width) = mat.shape
+    order = _check_order_mode(order, mode)
+    bcode = _blend_code(blend)
+    img = _Image(mat, 2).dense_rows()
+    if img.torch:
+        import torch
+        yc = torch.as_tensor(ycoords, device=img.keep.device)
+        xc = torch.as_tensor(xcoords, device=img.keep.device)
+        dt = torch.float32 if (yc.dtype == torch.float32 and xc.dtype == torch.float32) else torch.float64
+        yc = yc.to(dt).contiguous()
+        xc = xc.to(dt).contiguous()
+        if yc.numel() != xc.numel():
+            raise RuntimeError("invalid shape for coordinate array")
+        cdt = F.COORD_F32 if dt == torch.float32 else F.COORD_F64
+        npts, yptr, xptr, shape = yc.numel(), yc.data_ptr(), xc.data_ptr(), tuple(yc.shape)
+    else:
+        yc, xc = np.asarray(ycoords), np.asarray(xcoords)
+        dt = np.float32 if (yc.dtype == np.float32 and xc.dtype == np.float32) else np.float64
+        yc = np.ascontiguousarray(yc, dtype=dt)
+        xc = np.ascontiguousarray(xc, dtype=dt)
+        if yc.size != xc.size:
+            raise RuntimeError("invalid shape for coordinate array")
+        cdt = F.COORD_F32 if dt == np.float32 else F.COORD_F64
+        npts, yptr, xptr, shape = yc.size, yc.ctypes.data, xc.ctypes.data, yc.shape
+    out, optr = img.empty(shape)
+    F.require_device()
+    F.check(F.lib().dcp_remap_coords_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], yptr, xptr,
+                                         cdt, npts, order, bcode, img.mem, img.device, img.stream))
+    return out

@@ -1,0 +1,83 @@
+"""Depth-sharded unwarp of a tomography stack across the GPUs of one node.
+
+Every projection of a ``(depth, height, width)`` stack is independent
+(reference ``discorpy/post/postprocessing.py:226-228, 310-312`` loop over ``depth`` with no carried
+state), so rank ``g`` of ``G`` holds projections ``[d0, d1)``, runs the stack kernel on them, and
+ONE exchange -- an all-gather along the depth axis (RCCL over xGMI with the ``nccl`` backend) --
+reassembles the ``(depth, nrows, width)`` sinogram block on every rank.  Depth is the outermost
+axis of the result, so each rank's contribution is one contiguous block.
+
+One process per GPU (``torch.distributed``); the reference has no distributed code to mirror.
+"""
+import numpy as np
+
+
+def shard_bounds(depth, world_size, rank):
+    """Contiguous depth range [d0, d1) of `rank`; the first depth % world_size ranks get one more."""
+    if world_size < 1 or not 0 <= rank < world_size:
+        raise ValueError("rank %d outside world of %d" % (rank, world_size))
+    base, rem = divmod(int(depth), world_size)
+    d0 = rank * base + min(rank, rem)
+    return d0, d0 + base + (1 if rank < rem else 0)
+
+
+def row_shard_bounds(nrows, world_size, rank):
+    """Alternative with NO collective: rank owns output rows [r0, r1) of every projection."""
+    return shard_bounds(nrows, world_size, rank)
+
+
+def _hip_rows(local_vol, xcenter, ycenter, list_fact, row_start, nrows, coord_round_f32, blend):
+    from .post import postprocessing as pp
+    return pp._stack_rows(local_vol, xcenter, ycenter, list_fact, float(row_start), int(nrows),
+                          bool(coord_round_f32), blend)
+
+
+def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_start, nrows, *,
+                         coord_round_f32=True, gather=True, group=None, blend=None, compute=None):
+    """
+    Rows ``row_start .. row_start+nrows-1`` of the corrected stack from a depth-sharded volume.
+
+    Parameters
+    ----------
+    local_vol : torch.Tensor
+        This rank's projections ``[d0, d1)`` (``shard_bounds(depth, world, rank)``), float32,
+        shape ``(d1 - d0, height, width)``, on this rank's GPU.
+    depth : int
+        Depth of the whole stack.
+    coord_round_f32 : bool
+        True = ``unwarp_chunk_slices_backward`` semantics, False = ``unwarp_slice_backward``.
+    gather : bool
+        True: all-gather along depth, every rank returns ``(depth, nrows, width)``.
+        False: return the local ``(d1 - d0, nrows, width)`` block only.
+    compute : callable, optional
+        Replaces the HIP kernel call (signature of ``_hip_rows``); used by the CPU ``gloo`` tests to
+        exercise the sharding and the collective without a GPU.
+    """
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    d0, d1 = shard_bounds(depth, world, rank)
+    if local_vol.shape[0] != d1 - d0:
+        raise ValueError("rank %d holds %d projections, its shard of depth %d is [%d, %d)"
+                         % (rank, local_vol.shape[0], depth, d0, d1))
+    fn = _hip_rows if compute is None else compute
+    local = fn(local_vol, xcenter, ycenter, list_fact, row_start, nrows, coord_round_f32, blend)
+    if not torch.is_tensor(local):
+        local = torch.from_numpy(np.ascontiguousarray(local))
+    if not gather or world == 1:
+        return local
+    width = local.shape[2]
+    counts = [shard_bounds(depth, world, r)[1] - shard_bounds(depth, world, r)[0] for r in range(world)]
+    if len(set(counts)) == 1:
+        out = torch.empty((depth, nrows, width), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    # ragged shards: pad to the largest, gather, trim
+    m = max(counts)
+    pad = torch.zeros((m, nrows, width), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    buf = torch.empty((world * m, nrows, width), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(buf, pad, group=group)
+    return torch.cat([buf[r * m:r * m + counts[r]] for r in range(world)], dim=0)

@@ -1,0 +1,51 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    with np.load(os.path.join(GOLDEN, name + ".npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """The CPU oracle (built on demand with gcc) -- the checker, never the thing under test."""
+    from oracle import oracle as o
+    o.build()
+    o.set_threads(min(16, o.max_threads()))
+    return o
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The HIP library with a visible device; fails (not skips) if either is missing on a GPU run."""
+    from discorpy_amd import _ffi as F
+    F.lib()
+    F.require_device()
+    return F
+
+
+def noise(seed, shape):
+    return np.random.default_rng(int(seed)).random(tuple(int(v) for v in shape), dtype=np.float32)
+
+
+def ulp_diff(a, b):
+    """Distance in float32 ulps between two float32 arrays (finite values)."""
+    ia = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)
+    ib = np.ascontiguousarray(b, dtype=np.float32).view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, -(ia & 0x7FFFFFFF), ia)
+    ib = np.where(ib < 0, -(ib & 0x7FFFFFFF), ib)
+    return np.abs(ia - ib)

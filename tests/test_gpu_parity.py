@@ -1,0 +1,377 @@
+"""GPU suite (-m gpu): the HIP kernels, called through the C ABI by the reference-shaped Python
+front end, against (a) the reference's own outputs in tests/golden/, (b) the CPU oracle on seeded
+inputs, and (c) size-independent properties at the BASELINE sizes.
+
+Bar: bit-exact for order 0 and for blend="scipy"; the default blend ("f64lerp") may differ from
+scipy's arithmetic by at most one float32 ulp (and in these vectors does not differ at all).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, noise, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+from discorpy_amd import configs  # noqa: E402
+from discorpy_amd.post import postprocessing as pp  # noqa: E402
+
+
+def kernel_oracle(orc, blend):
+    return dict(poly=orc.POLY_KERNEL, blend={"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP,
+                                              "f32": orc.BLEND_F32LERP}[blend])
+
+
+# --------------------------------------------------------------------------- (a) golden vectors
+
+@pytest.mark.parametrize("blend", ["scipy", "f64lerp"])
+def test_g1_reference_box_image(hip, blend):
+    g = golden("g1_box64")
+    a = (g["mat"], float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    assert np.array_equal(pp.unwarp_image_backward(*a, blend=blend), g["out_order1"])
+    assert np.array_equal(pp.unwarp_image_backward(*a, order=0), g["out_order0"])
+    # the reference's own assertion (tests/test_postprocessing.py:83-85)
+    vals = np.mean(pp.unwarp_image_backward(*a), axis=0)[11:-10]
+    pos = len(vals) // 2
+    assert vals[0] < vals[pos] and vals[-1] < vals[pos]
+
+
+@pytest.mark.parametrize("blend", ["scipy", "f64lerp"])
+def test_g2_reference_slice_and_chunk(hip, blend):
+    g = golden("g2_stripes10x64x64")
+    vol = np.repeat(g["mat"][None], int(g["depth"]), axis=0)
+    a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    s = pp.unwarp_slice_backward(vol, *a, int(g["index"]), blend=blend)
+    assert s.dtype == np.float32 and s.shape == (10, 64) and np.array_equal(s, g["slice_out"])
+    c = pp.unwarp_chunk_slices_backward(vol, *a, int(g["start"]), int(g["stop"]), blend=blend)
+    assert c.shape == (10, 11, 64) and np.array_equal(c, g["chunk_out"])
+    # the reference's own assertions (tests/test_postprocessing.py:107-108, 121-123)
+    y0 = int(g["index"])
+    assert np.max(vol[:, y0, :] - s) > 0.1
+    assert np.max(vol[:, y0 - 5, :] - c[:, 0, :]) > 0.1 and np.max(vol[:, y0 + 5, :] - c[:, -1, :]) > 0.1
+
+
+@pytest.mark.parametrize("blend", ["scipy", "f64lerp"])
+def test_g3_reference_perspective(hip, blend):
+    g = golden("g3_perspective64")
+    c1 = pp.correct_perspective_image(g["mat"], list(g["coef_backward"]), blend=blend)
+    assert np.array_equal(c1, g["cor_backward"])
+    c2 = pp.correct_perspective_image(c1, list(g["coef_forward"]), blend=blend)
+    assert np.array_equal(c2, g["cor_forward_of_backward"])
+    assert np.array_equal(pp.correct_perspective_image(g["mat"], list(g["coef_backward"]), order=0),
+                          g["cor_backward_order0"])
+    # the reference's own assertions (tests/test_postprocessing.py:226-238)
+    l0, l1, l2 = np.mean(g["mat"], axis=1), np.mean(c1, axis=1), np.mean(c2, axis=1)
+    assert len(l1[l1 > 0]) > len(l0[l0 > 0]) and np.argmax(l0) == np.argmax(l2)
+
+
+@pytest.mark.parametrize("blend", ["scipy", "f64lerp"])
+def test_g4_config1_dot_pattern_05(hip, blend):
+    g = golden("g4_dot_pattern_05")
+    out = pp.unwarp_image_backward(g["crop_in"], float(g["crop_xcenter"]), float(g["crop_ycenter"]),
+                                   list(g["list_fact"]), blend=blend)
+    assert np.array_equal(out, g["crop_out"])
+
+
+@pytest.mark.parametrize("name", ["g5_cfg2_160", "g5_offcentre_150x200", "g5_cfg5_9term_144"])
+def test_g5_configs_reduced(hip, name):
+    g = golden(name)
+    img = noise(g["seed"], g["shape"])
+    a = (img, float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    assert np.array_equal(pp.unwarp_image_backward(*a, blend="scipy"), g["out_order1"])
+    assert np.array_equal(pp.unwarp_image_backward(*a, order=0), g["out_order0"])
+    assert ulp_diff(pp.unwarp_image_backward(*a), g["out_order1"]).max() <= 1
+    assert np.max(np.abs(pp.unwarp_image_backward(*a, blend="f32").astype(np.float64) - g["out_order1"])) <= 1e-5
+
+
+def test_g6_stack_rows(hip):
+    g = golden("g6_stack3x800x1280")
+    vol = noise(g["seed"], g["shape"])
+    a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    for r in g["rows"]:
+        assert np.array_equal(pp.unwarp_slice_backward(vol, *a, int(r), blend="scipy"), g["slice_%d" % r])
+    assert np.array_equal(pp.unwarp_slice_backward(vol, *a, 400.5, blend="scipy"), g["slice_frac_400p5"])
+    for key, (s0, s1) in {"chunk_395_402": (395, 402), "chunk_0_2": (0, 2), "chunk_797_799": (797, 799)}.items():
+        assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, s0, s1, blend="scipy"), g[key])
+        assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a, s0, s1), g[key]).max() <= 1
+
+
+def test_g7_fused_and_two_pass(hip):
+    g = golden("g7_fused144")
+    img = noise(g["seed"], g["shape"])
+    r = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    coef = list(g["list_coef"])
+    assert np.array_equal(pp.unwarp_perspective_fused(img, *r, coef, blend="scipy"), g["fused_out"])
+    two = pp.correct_perspective_image(pp.unwarp_image_backward(img, *r, blend="scipy"), coef, blend="scipy")
+    assert np.array_equal(two, g["twopass_out"])
+    assert np.array_equal(pp.correct_perspective_image(img, coef, blend="scipy"), g["persp_out"])
+    # map_index= path with the reference's own float32 coordinate planes
+    via_map = pp.correct_perspective_image(img, coef, map_index=(g["yd"].reshape(-1, 1), g["xd"].reshape(-1, 1)),
+                                           blend="scipy")
+    assert np.array_equal(via_map, g["fused_out"])
+
+
+def test_g8_clipping_stress_all_modes(hip):
+    g = golden("g8_clip120x180")
+    img = noise(g["seed"], g["shape"])
+    a = (img, float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+        assert np.array_equal(pp.unwarp_image_backward(*a, mode=mode, blend="scipy"), g["out_order1"])
+        assert np.array_equal(pp.unwarp_image_backward(*a, order=0, mode=mode), g["out_order0"])
+
+
+def test_g9_explicit_coordinates(hip):
+    g = golden("g9_points33x47")
+    img = noise(g["seed"], g["shape"])
+    assert np.array_equal(pp.remap_coordinates(img, g["ys"], g["xs"], order=0), g["out_order0"])
+    assert np.array_equal(pp.remap_coordinates(img, g["ys"], g["xs"], blend="scipy"), g["out_order1"])
+    assert np.array_equal(pp.remap_coordinates(img, g["ys64"], g["xs64"], order=0), g["out64_order0"])
+    assert np.array_equal(pp.remap_coordinates(img, g["ys64"], g["xs64"], blend="scipy"), g["out64_order1"])
+
+
+# --------------------------------------------------------------------------- (b) oracle, seeded inputs
+
+SHAPES = [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (16, 64), (17, 65), (63, 257), (300, 517), (129, 1031)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("blend", ["scipy", "f64lerp", "f32"])
+def test_radial_matches_oracle_on_ragged_shapes(hip, orc, shape, blend):
+    img = (noise(hash(shape) % 1000, shape) * 255).astype(np.float32)
+    xc, yc = 0.43 * shape[1], 0.61 * shape[0]
+    fact = [1.01, -4e-4, 3e-7]
+    want = orc.unwarp_image_backward(img, xc, yc, fact, **kernel_oracle(orc, blend))
+    assert np.array_equal(pp.unwarp_image_backward(img, xc, yc, fact, blend=blend), want)
+    want0 = orc.unwarp_image_backward(img, xc, yc, fact, order=0, poly=orc.POLY_KERNEL)
+    assert np.array_equal(pp.unwarp_image_backward(img, xc, yc, fact, order=0), want0)
+
+
+@pytest.mark.parametrize("nfact", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 17, 32])
+def test_every_polynomial_length(hip, orc, nfact):
+    """1..10 terms run the SGPR-resident unrolled polynomial, the rest the LDS-staged one."""
+    img = noise(nfact, (90, 140))
+    rng = np.random.default_rng(100 + nfact)
+    fact = [1.0] + [float(rng.uniform(-1, 1)) * 10.0 ** (-2.2 * i) for i in range(1, nfact)]
+    fact = fact[:nfact]
+    want = orc.unwarp_image_backward(img, 70.3, 44.9, fact, **kernel_oracle(orc, "scipy"))
+    assert np.array_equal(pp.unwarp_image_backward(img, 70.3, 44.9, fact, blend="scipy"), want)
+    hip.set_option("coef_lds", 1)
+    try:
+        assert np.array_equal(pp.unwarp_image_backward(img, 70.3, 44.9, fact, blend="scipy"), want)
+    finally:
+        hip.set_option("coef_lds", 0)
+    with pytest.raises(ValueError):
+        pp.unwarp_image_backward(img, 1, 1, [1.0] * 33)
+
+
+def test_centre_on_a_pixel_and_far_outside(hip, orc):
+    img = noise(9, (64, 96))
+    for xc, yc in [(32.0, 16.0), (0.0, 0.0), (-500.0, 40.0), (2000.0, -3000.0), (95.0, 63.0)]:
+        for fact in ([1.0, 3e-3], [0.0, 1e-2], [1.3, 2e-3, -1e-5]):
+            want = orc.unwarp_image_backward(img, xc, yc, fact, **kernel_oracle(orc, "scipy"))
+            assert np.array_equal(pp.unwarp_image_backward(img, xc, yc, fact, blend="scipy"), want)
+
+
+def test_tuning_knobs_do_not_change_results(hip, orc):
+    img = noise(4, (200, 700))
+    a = (img, 333.3, 80.8, list(configs.COEF_DOT_05))
+    want = orc.unwarp_image_backward(*a, **kernel_oracle(orc, "f64lerp"))
+    keys = {"tile_rows": [1, 3, 8, 16, 64], "pipe_depth": [1, 2, 4], "xcd_remap": [0, 1], "lds_gather": [0, 1]}
+    for key, vals in keys.items():
+        old = hip.get_option(key)
+        try:
+            for v in vals:
+                hip.set_option(key, v)
+                assert np.array_equal(pp.unwarp_image_backward(*a), want), (key, v)
+        finally:
+            hip.set_option(key, old)
+
+
+def test_lds_staged_gather_and_its_fallbacks(hip, orc):
+    """remap_lds_kernel: staged tiles, tiles whose source box does not fit (strong minification),
+    partial tiles at the right and bottom edges -- all bit-equal to the direct gather."""
+    old = hip.get_option("lds_gather")
+    hip.set_option("lds_gather", 1)
+    try:
+        hip.debug_counters()
+        for shape, xc, yc, fact in [((130, 200), 99.0, 61.0, [1.0, 1e-4]),         # gentle: all staged
+                                    ((97, 333), 150.0, 40.0, [1.0, 2e-3]),         # strong barrel
+                                    ((64, 64), 31.5, 31.5, [2.5]),                 # 2.5x minification: box too large
+                                    ((100, 100), 50.0, 50.0, [0.2, 1e-2])]:
+            img = noise(shape[0], shape)
+            for blend in ("scipy", "f64lerp", "f32"):
+                want = orc.unwarp_image_backward(img, xc, yc, fact, **kernel_oracle(orc, blend))
+                assert np.array_equal(pp.unwarp_image_backward(img, xc, yc, fact, blend=blend), want)
+        nofit, vote = hip.debug_counters()
+        assert nofit > 0            # the minification case must have exercised the fallback
+    finally:
+        hip.set_option("lds_gather", old)
+
+
+def test_strided_and_padded_sources(hip, orc):
+    rgb = noise(7, (120, 150, 3))
+    a = (74.0, 59.5, [1.0, 1e-3, 2e-6])
+    for ch in range(3):
+        view = rgb[:, :, ch]                                    # column stride 3 (demo_06.py:111-113)
+        want = orc.unwarp_image_backward(np.ascontiguousarray(view), *a, **kernel_oracle(orc, "scipy"))
+        assert np.array_equal(pp.unwarp_image_backward(view, *a, blend="scipy"), want)
+    padded = np.zeros((120, 256), np.float32)
+    padded[:, :150] = rgb[:, :, 0]
+    want = orc.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, 0]), *a, **kernel_oracle(orc, "scipy"))
+    assert np.array_equal(pp.unwarp_image_backward(padded[:, :150], *a, blend="scipy"), want)
+    assert np.array_equal(pp.unwarp_image_backward(rgb[::-1, :, 0], *a, blend="scipy"),
+                          orc.unwarp_image_backward(np.ascontiguousarray(rgb[::-1, :, 0]), *a,
+                                                    **kernel_oracle(orc, "scipy")))
+    band = noise(8, (5, 90, 130))[2, 10:70, :]                  # row-band view of a projection
+    assert np.array_equal(pp.unwarp_image_backward(band, 60.0, 30.0, [1.0, 1e-3], blend="scipy"),
+                          orc.unwarp_image_backward(np.ascontiguousarray(band), 60.0, 30.0, [1.0, 1e-3],
+                                                    **kernel_oracle(orc, "scipy")))
+
+
+@pytest.mark.parametrize("shape", [(2, 2), (33, 47), (128, 300), (257, 130)])
+def test_perspective_and_fused_match_oracle(hip, orc, shape):
+    img = noise(shape[1], shape)
+    h, w = shape
+    coef = [0.97, -0.02, 0.03 * w, 0.015, 0.95, 0.02 * h, -2e-5 * 64 / w, 3e-5 * 64 / h]
+    for blend in ("scipy", "f64lerp", "f32"):
+        ob = kernel_oracle(orc, blend)["blend"]
+        assert np.array_equal(pp.correct_perspective_image(img, coef, blend=blend),
+                              orc.correct_perspective_image(img, coef, blend=ob))
+        for fact in ([1.0, 1e-3], list(configs.COEF_DOT_05), [1.0, -1e-3, 2e-6, 1e-9, 1e-12, 1e-15]):
+            assert np.array_equal(pp.unwarp_perspective_fused(img, 0.45 * w, 0.55 * h, fact, coef, blend=blend),
+                                  orc.unwarp_fused(img, 0.45 * w, 0.55 * h, fact, coef, poly=orc.POLY_KERNEL, blend=ob))
+    assert np.array_equal(pp.correct_perspective_image(img, coef, order=0),
+                          orc.correct_perspective_image(img, coef, order=0))
+    assert np.array_equal(pp.unwarp_perspective_fused(img, 0.45 * w, 0.55 * h, [1.0, 1e-3], coef, order=0),
+                          orc.unwarp_fused(img, 0.45 * w, 0.55 * h, [1.0, 1e-3], coef, order=0, poly=orc.POLY_KERNEL))
+
+
+def test_stack_rows_match_oracle(hip, orc):
+    vol = noise(13, (7, 120, 200))
+    a = (97.3, 66.1, [1.004, -6e-5, 3e-7])
+    for index in (0, 1, 59, 60.25, 119, -3, 130):              # the reference does not validate `index`
+        want = orc.unwarp_slice_backward(vol, *a, index, **kernel_oracle(orc, "scipy"))
+        assert np.array_equal(pp.unwarp_slice_backward(vol, *a, index, blend="scipy"), want)
+    for s0, s1 in [(0, 0), (0, 119), (40, 70), (118, 119)]:
+        for blend in ("scipy", "f64lerp", "f32"):
+            want = orc.unwarp_chunk_slices_backward(vol, *a, s0, s1, **kernel_oracle(orc, blend))
+            assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, s0, s1, blend=blend), want)
+    for key, vals in {"d_chunk": [1, 3, 64]}.items():
+        old = hip.get_option(key)
+        try:
+            for v in vals:
+                hip.set_option(key, v)
+                assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, 40, 70, blend="scipy"),
+                                      orc.unwarp_chunk_slices_backward(vol, *a, 40, 70, **kernel_oracle(orc, "scipy")))
+        finally:
+            hip.set_option(key, old)
+    empty = pp.unwarp_slice_backward(np.zeros((0, 8, 8), np.float32), 4, 4, [1.0], 3)
+    assert empty.shape == (0, 8)
+    # non-contiguous stack (every other projection, a row band): handled by the front end
+    assert np.array_equal(pp.unwarp_slice_backward(vol[::2], *a, 59, blend="scipy"),
+                          orc.unwarp_slice_backward(np.ascontiguousarray(vol[::2]), *a, 59, **kernel_oracle(orc, "scipy")))
+
+
+def test_explicit_coordinates_match_oracle(hip, orc):
+    img = noise(3, (70, 90))
+    rng = np.random.default_rng(5)
+    for dt in (np.float32, np.float64):
+        ys = (rng.random(5000) * 75 - 3).astype(dt)            # includes out-of-image values: clamped
+        xs = (rng.random(5000) * 96 - 3).astype(dt)
+        for order, blend in [(0, "scipy"), (1, "scipy"), (1, "f64lerp"), (1, "f32")]:
+            want = orc.remap_coords(img, ys, xs, order=order, blend=kernel_oracle(orc, blend)["blend"])
+            assert np.array_equal(pp.remap_coordinates(img, ys, xs, order=order, blend=blend), want)
+    assert pp.remap_coordinates(img, np.zeros((0,), np.float32), np.zeros((0,), np.float32)).shape == (0,)
+
+
+def test_device_resident_tensors_take_the_same_path(hip, orc):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("torch sees no ROCm device on a GPU run")
+    img = noise(2, (260, 410))
+    a = (201.0, 133.0, list(configs.COEF_DOT_05))
+    want = orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "scipy"))
+    t = torch.from_numpy(img).cuda()
+    out = pp.unwarp_image_backward(t, *a, blend="scipy")
+    assert out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == img.shape
+    assert np.array_equal(out.cpu().numpy(), want)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):                                  # kernels follow torch's current stream
+        out2 = pp.unwarp_image_backward(t, *a, blend="scipy")
+    s.synchronize()
+    assert np.array_equal(out2.cpu().numpy(), want)
+    chan = torch.from_numpy(noise(3, (64, 80, 3))).cuda()[:, :, 1]          # strided device view
+    assert np.array_equal(pp.unwarp_image_backward(chan, 40.0, 30.0, [1.0, 1e-3], blend="scipy").cpu().numpy(),
+                          orc.unwarp_image_backward(np.ascontiguousarray(chan.cpu().numpy()), 40.0, 30.0, [1.0, 1e-3],
+                                                    **kernel_oracle(orc, "scipy")))
+    vol = torch.from_numpy(noise(4, (5, 100, 140))).cuda()
+    got = pp.unwarp_chunk_slices_backward(vol, 70.0, 50.0, [1.0, 2e-3], 20, 40, blend="scipy")
+    assert got.is_cuda and np.array_equal(
+        got.cpu().numpy(), orc.unwarp_chunk_slices_backward(vol.cpu().numpy(), 70.0, 50.0, [1.0, 2e-3], 20, 40,
+                                                            **kernel_oracle(orc, "scipy")))
+
+
+# --------------------------------------------------------------------------- (c) BASELINE sizes
+
+def test_cfg2_full_frame_against_oracle_and_properties(hip, orc):
+    c = configs.cfg2()
+    h, w = c["shape"]
+    img = noise(c["seed"], (h, w))
+    a = (img, c["xcenter"], c["ycenter"], c["list_fact"])
+    out = pp.unwarp_image_backward(*a)
+    want = orc.unwarp_image_backward(*a, **kernel_oracle(orc, "f64lerp"))
+    assert np.array_equal(out, want)
+    assert np.array_equal(pp.unwarp_image_backward(*a, order=0),
+                          orc.unwarp_image_backward(*a, order=0, poly=orc.POLY_KERNEL))
+    # reference arithmetic order (numpy polynomial, scipy blend): same pixels up to rounding-boundary
+    # coordinates, of which SURVEY.md section 7 expects ~0-2 per frame
+    ref = orc.unwarp_image_backward(*a, poly=orc.POLY_NUMPY, blend=orc.BLEND_SCIPY)
+    differing = int(np.count_nonzero(ulp_diff(out, ref) > 1))
+    assert differing <= 4, differing
+    # identity model: every coordinate is an integer, the frame must come back bit for bit
+    assert np.array_equal(pp.unwarp_image_backward(img, 17.0, 4000.5, [1.0]), img)
+    # a constant frame stays constant whatever the map
+    const = np.full((h, w), np.float32(0.3))
+    assert np.array_equal(pp.unwarp_image_backward(const, c["xcenter"], c["ycenter"], c["list_fact"]), const)
+    # chunk rows of a 1-projection stack == the same rows of the image result
+    rows = pp.unwarp_chunk_slices_backward(img[None], c["xcenter"], c["ycenter"], c["list_fact"], 1000, 1015)
+    assert np.array_equal(rows[0], out[1000:1016])
+
+
+def test_cfg3_fused_full_frame(hip, orc):
+    c = configs.cfg3()
+    h, w = c["shape"]
+    img = noise(c["seed"] + 1, (h, w))
+    out = pp.unwarp_perspective_fused(img, c["xcenter"], c["ycenter"], c["list_fact"], c["list_coef"])
+    want = orc.unwarp_fused(img, c["xcenter"], c["ycenter"], c["list_fact"], c["list_coef"],
+                            **kernel_oracle(orc, "f64lerp"))
+    assert np.array_equal(out, want)
+    # integer translation through the homography: out[y, x] = in[y + 7, x + 5], edges replicated
+    shift = [1.0, 0.0, 5.0, 0.0, 1.0, 7.0, 0.0, 0.0]
+    moved = pp.correct_perspective_image(img, shift)
+    assert np.array_equal(moved[:h - 7, :w - 5], img[7:, 5:])
+    assert np.array_equal(moved[h - 7:, :w - 5], np.broadcast_to(img[h - 1, 5:], (7, w - 5)))
+
+
+def test_cfg5_nine_term_8192_frame(hip, orc):
+    c = configs.cfg5()
+    h, w = c["shape"]
+    img = noise(c["seed"], (h, w))
+    a = (img, c["xcenter"], c["ycenter"], c["list_fact"])
+    out = pp.unwarp_image_backward(*a)
+    assert np.array_equal(out, orc.unwarp_image_backward(*a, **kernel_oracle(orc, "f64lerp")))
+    hip.set_option("coef_lds", 1)                               # LDS-staged coefficients: same bits
+    try:
+        assert np.array_equal(pp.unwarp_image_backward(*a), out)
+    finally:
+        hip.set_option("coef_lds", 0)
+
+
+def test_cfg4_stack_sample(hip, orc):
+    """A (12, 2560, 2560) sample of config 4: one sinogram and a 16-row chunk."""
+    c = configs.cfg4(depth=12)
+    vol = noise(c["seed"], c["shape"])
+    a = (c["xcenter"], c["ycenter"], c["list_fact"])
+    assert np.array_equal(pp.unwarp_slice_backward(vol, *a, 1277),
+                          orc.unwarp_slice_backward(vol, *a, 1277, **kernel_oracle(orc, "f64lerp")))
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, 2000, 2015),
+                          orc.unwarp_chunk_slices_backward(vol, *a, 2000, 2015, **kernel_oracle(orc, "f64lerp")))

@@ -1,0 +1,153 @@
+"""CPU suite, part 2: the C ABI loads and exports what include/discorpy_hip.h declares; the Python
+front end validates like the reference (same exception types and messages) before touching a GPU.
+No compute call is made here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from discorpy_amd import _ffi as F
+from discorpy_amd.post import postprocessing as pp
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "discorpy_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dcp_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_built_in_tree():
+    assert os.path.exists(F.LIB_PATH), "run __graft_entry__.build() first"
+    assert os.path.realpath(F.LIB_PATH).startswith(os.path.realpath(ROOT))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = F.lib()
+    names = declared_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), "header declares %s but the library does not export it" % n
+        assert n in F.SIGNATURES, "%s has no ctypes signature in _ffi.SIGNATURES" % n
+    assert sorted(F.SIGNATURES) == names
+
+
+def test_version_and_device_count_do_not_need_a_gpu():
+    assert F.lib().dcp_version() >= 100
+    assert F.device_count() >= 0
+
+
+def test_options_round_trip():
+    for key, val in [("tile_rows", 8), ("pipe_depth", 4), ("xcd_remap", 1), ("coef_lds", 1), ("d_chunk", 32),
+                     ("lds_gather", 1)]:
+        old = F.get_option(key)
+        F.set_option(key, val)
+        assert F.get_option(key) == val
+        F.set_option(key, old)
+    with pytest.raises(ValueError, match="unknown option"):
+        F.set_option("no_such_knob", 1)
+    with pytest.raises(ValueError):
+        F.set_option("tile_rows", 1000)
+    with pytest.raises(ValueError):
+        F.set_option("pipe_depth", 3)
+
+
+def test_abi_rejects_bad_arguments_before_any_gpu_work():
+    L = F.lib()
+    fa, n = F.fact_array([1.0, 1e-3])
+    buf = np.zeros((4, 4), np.float32)
+    p = buf.ctypes.data
+    bad = [
+        L.dcp_unwarp_image_f32(None, p, 4, 4, 4, 1, 0.0, 0.0, fa, n, 1, 1, 0, F.MEM_HOST, -1, None),
+        L.dcp_unwarp_image_f32(p, p, 0, 4, 4, 1, 0.0, 0.0, fa, n, 1, 1, 0, F.MEM_HOST, -1, None),
+        L.dcp_unwarp_image_f32(p, p, 4, 4, 2, 1, 0.0, 0.0, fa, n, 1, 1, 0, F.MEM_HOST, -1, None),
+        L.dcp_unwarp_image_f32(p, p, 4, 4, 4, 1, 0.0, 0.0, fa, 33, 1, 1, 0, F.MEM_HOST, -1, None),
+        L.dcp_unwarp_image_f32(p, p, 4, 4, 4, 1, 0.0, 0.0, fa, n, 1, 1, 7, F.MEM_HOST, -1, None),
+        L.dcp_perspective_image_f32(p, p, 4, 4, 4, 1, None, 1, 0, F.MEM_HOST, -1, None),
+        L.dcp_remap_coords_f32(p, p, 4, 4, 4, 1, p, p, 5, 16, 1, 0, F.MEM_HOST, -1, None),
+        L.dcp_unwarp_stack_rows_f32(p, p, 1, 4, 4, 16, 2, 0.0, 0.0, fa, n, 0.0, 1, 1, 0, F.MEM_HOST, -1, None),
+    ]
+    assert all(rc == F.ERR_INVALID_ARG for rc in bad), bad
+    assert "blend_mode" in F.last_error() or len(F.last_error()) > 0
+    assert L.dcp_unwarp_image_f32(p, p, 4, 4, 4, 1, 0.0, 0.0, fa, n, 3, 1, 0, F.MEM_HOST, -1, None) == F.ERR_UNSUPPORTED
+    with pytest.raises(NotImplementedError, match="order 3"):
+        F.check(F.ERR_UNSUPPORTED)
+
+
+# ---- reference error behaviour, raised on the host before the device is needed
+
+def test_perspective_needs_eight_coefficients():
+    with pytest.raises(ValueError, match="!!! Eight coefficients are required !!!"):
+        pp.correct_perspective_image(np.zeros((4, 4), np.float32), [1.0] * 7)
+    with pytest.raises(ValueError, match="!!! Eight coefficients are required !!!"):
+        pp.unwarp_perspective_fused(np.zeros((4, 4), np.float32), 1, 1, [1.0], [1.0] * 9)
+
+
+def test_stack_functions_need_3d_input():
+    flat = np.zeros((8, 8), np.float32)
+    with pytest.raises(ValueError, match="Input must be a 3D data"):
+        pp.unwarp_slice_backward(flat, 4, 4, [1.0], 2)
+    with pytest.raises(ValueError, match="Input must be a 3D data"):
+        pp.unwarp_chunk_slices_backward(flat, 4, 4, [1.0], 1, 2)
+
+
+def test_chunk_index_validation_matches_the_reference():
+    vol = np.zeros((2, 8, 8), np.float32)
+    for start, stop in [(-1, 3), (0, 8), (3, 99), (0, -1), (2.5, 4)]:
+        with pytest.raises(ValueError, match="Selected index is out of the range"):
+            pp.unwarp_chunk_slices_backward(vol, 4, 4, [1.0], start, stop)
+
+
+def test_image_shape_errors_surface_like_the_reference():
+    with pytest.raises(ValueError, match="too many values to unpack"):
+        pp.unwarp_image_backward(np.zeros((2, 3, 4), np.float32), 1, 1, [1.0])
+    with pytest.raises(AttributeError):
+        pp.unwarp_image_backward([[1.0, 2.0]], 1, 1, [1.0])
+
+
+def test_unsupported_inputs_fail_loudly_instead_of_falling_back():
+    img = np.zeros((4, 4), np.float32)
+    with pytest.raises(NotImplementedError, match="order 3"):
+        pp.unwarp_image_backward(img, 1, 1, [1.0], order=3)
+    with pytest.raises(NotImplementedError, match="float32"):
+        pp.unwarp_image_backward(img.astype(np.float64), 1, 1, [1.0])
+    with pytest.raises(NotImplementedError, match="float32"):
+        pp.unwarp_image_backward(img.astype(np.uint8), 1, 1, [1.0])
+    with pytest.raises(RuntimeError, match="boundary mode not supported"):
+        pp.unwarp_image_backward(img, 1, 1, [1.0], mode="bogus")
+    with pytest.raises(ValueError, match="unknown blend"):
+        pp.unwarp_image_backward(img, 1, 1, [1.0], blend="bf16")
+
+
+def test_no_silent_cpu_path(monkeypatch):
+    """With no device the product path must raise -- it must never route through the oracle."""
+    monkeypatch.setattr(F, "device_count", lambda: 0)
+    with pytest.raises(F.HipError, match="no CPU fallback"):
+        pp.unwarp_image_backward(np.zeros((4, 4), np.float32), 1, 1, [1.0])
+    import discorpy_amd
+    pkg = os.path.dirname(discorpy_amd.__file__)
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(dirpath, f)
+            if f.endswith(".py"):
+                text = open(path).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), path
+                assert "libunwarp_oracle" not in text, path
+            elif f.endswith((".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(path).read()
+                assert not re.search(r"#\s*include[^\n]*oracle", text), path
+                assert "libunwarp_oracle" not in text and "-lunwarp_oracle" not in text, path
+
+
+def test_coefficient_file_of_the_reference_parses():
+    """data/coef_dot_05.txt format ('key : value' per line, loadersaver.py:768-776) -> configs constants."""
+    from discorpy_amd import configs
+    text = ("xcenter : 588.692801577\nycenter : 462.092631791\nfactor0 : 1.00227490554\n"
+            "factor1 : -2.99523692178e-05\nfactor2 : 8.99519088e-08\nfactor3 : -1.57066461911e-10\n"
+            "factor4 : 8.08880211618e-14\n")
+    vals = [float(line.split()[-1]) for line in text.splitlines()]
+    assert vals[0] == configs.XCENTER_DOT_05 and vals[1] == configs.YCENTER_DOT_05
+    assert tuple(vals[2:]) == configs.COEF_DOT_05

@@ -1,0 +1,161 @@
+"""CPU suite, part 1: oracle/unwarp_oracle.c is held bit-equal to the reference's outputs.
+
+The vectors in tests/golden/ were produced by tools/gen_golden.py, which imports the reference
+(discorpy 1.7.0 + scipy 1.15.3) in the build container.  ORC_POLY_NUMPY + ORC_BLEND_SCIPY is the
+reference's own arithmetic order; ORC_POLY_KERNEL is the order the HIP kernels use and must land
+on the same float32 coordinates.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, noise, ulp_diff
+
+POLYS = ["numpy", "kernel"]
+
+
+def poly_of(orc, name):
+    return orc.POLY_NUMPY if name == "numpy" else orc.POLY_KERNEL
+
+
+@pytest.mark.parametrize("poly", POLYS)
+def test_g1_reference_box_image(orc, poly):
+    g = golden("g1_box64")
+    for order in (0, 1):
+        out = orc.unwarp_image_backward(g["mat"], g["xcenter"], g["ycenter"], g["list_fact"], order=order,
+                                        poly=poly_of(orc, poly))
+        assert np.array_equal(out, g["out_order%d" % order])
+
+
+@pytest.mark.parametrize("poly", POLYS)
+def test_g2_reference_slice_and_chunk(orc, poly):
+    g = golden("g2_stripes10x64x64")
+    vol = np.repeat(g["mat"][None], int(g["depth"]), axis=0)
+    p = poly_of(orc, poly)
+    s = orc.unwarp_slice_backward(vol, g["xcenter"], g["ycenter"], g["list_fact"], int(g["index"]), poly=p)
+    assert s.dtype == np.float32 and np.array_equal(s, g["slice_out"])
+    c = orc.unwarp_chunk_slices_backward(vol, g["xcenter"], g["ycenter"], g["list_fact"], int(g["start"]),
+                                         int(g["stop"]), poly=p)
+    assert c.shape == g["chunk_out"].shape and np.array_equal(c, g["chunk_out"])
+
+
+def test_g3_reference_perspective(orc):
+    g = golden("g3_perspective64")
+    c1 = orc.correct_perspective_image(g["mat"], g["coef_backward"])
+    assert np.array_equal(c1, g["cor_backward"])
+    assert np.array_equal(orc.correct_perspective_image(c1, g["coef_forward"]), g["cor_forward_of_backward"])
+    assert np.array_equal(orc.correct_perspective_image(g["mat"], g["coef_backward"], order=0),
+                          g["cor_backward_order0"])
+
+
+@pytest.mark.parametrize("poly", POLYS)
+def test_g4_dot_pattern_05(orc, poly):
+    g = golden("g4_dot_pattern_05")
+    out = orc.unwarp_image_backward(g["crop_in"], g["crop_xcenter"], g["crop_ycenter"], g["list_fact"],
+                                    poly=poly_of(orc, poly))
+    assert np.array_equal(out, g["crop_out"])
+
+
+@pytest.mark.parametrize("poly", POLYS)
+@pytest.mark.parametrize("name", ["g5_cfg2_160", "g5_offcentre_150x200", "g5_cfg5_9term_144"])
+def test_g5_configs_reduced(orc, name, poly):
+    g = golden(name)
+    img = noise(g["seed"], g["shape"])
+    p = poly_of(orc, poly)
+    yd, xd = orc.radial_coords(int(g["shape"][0]), int(g["shape"][1]), g["xcenter"], g["ycenter"], g["list_fact"],
+                               poly=p)
+    assert np.array_equal(yd.astype(np.float32), g["yd"]) and np.array_equal(xd.astype(np.float32), g["xd"])
+    for order in (0, 1):
+        out = orc.unwarp_image_backward(img, g["xcenter"], g["ycenter"], g["list_fact"], order=order, poly=p)
+        assert np.array_equal(out, g["out_order%d" % order])
+
+
+@pytest.mark.parametrize("poly", POLYS)
+def test_g6_stack_rows(orc, poly):
+    g = golden("g6_stack3x800x1280")
+    vol = noise(g["seed"], g["shape"])
+    p = poly_of(orc, poly)
+    a = (g["xcenter"], g["ycenter"], g["list_fact"])
+    for r in g["rows"]:
+        assert np.array_equal(orc.unwarp_slice_backward(vol, *a, int(r), poly=p), g["slice_%d" % r])
+    assert np.array_equal(orc.unwarp_slice_backward(vol, *a, 400.5, poly=p), g["slice_frac_400p5"])
+    for key, (s0, s1) in {"chunk_395_402": (395, 402), "chunk_0_2": (0, 2), "chunk_797_799": (797, 799)}.items():
+        assert np.array_equal(orc.unwarp_chunk_slices_backward(vol, *a, s0, s1, poly=p), g[key])
+
+
+def test_chunk_equals_image_rows_and_slice_differs(orc):
+    """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
+    g = golden("g6_stack3x800x1280")
+    vol = noise(g["seed"], g["shape"])
+    a = (g["xcenter"], g["ycenter"], g["list_fact"])
+    img_out = orc.unwarp_image_backward(vol[1], *a)
+    chunk = orc.unwarp_chunk_slices_backward(vol, *a, 395, 402)
+    assert np.array_equal(chunk[1], img_out[395:403])
+    sl = orc.unwarp_slice_backward(vol, *a, 400)
+    assert not np.array_equal(sl[1], img_out[400])
+    assert np.max(np.abs(sl[1] - img_out[400])) < 1e-3
+
+
+@pytest.mark.parametrize("poly", POLYS)
+def test_g7_fused_is_one_resampling(orc, poly):
+    g = golden("g7_fused144")
+    img = noise(g["seed"], g["shape"])
+    p = poly_of(orc, poly)
+    fused = orc.unwarp_fused(img, g["xcenter"], g["ycenter"], g["list_fact"], g["list_coef"], poly=p)
+    assert np.array_equal(fused, g["fused_out"])
+    two = orc.correct_perspective_image(orc.unwarp_image_backward(img, g["xcenter"], g["ycenter"], g["list_fact"],
+                                                                  poly=p), g["list_coef"])
+    assert np.array_equal(two, g["twopass_out"])
+    assert np.array_equal(orc.correct_perspective_image(img, g["list_coef"]), g["persp_out"])
+    assert np.max(np.abs(fused - two)) > 0.05          # a different operator, not a rounding variant
+
+
+@pytest.mark.parametrize("poly", POLYS)
+def test_g8_clipping_stress(orc, poly):
+    g = golden("g8_clip120x180")
+    assert float(g["clipped_fraction"]) > 0.4
+    img = noise(g["seed"], g["shape"])
+    for order in (0, 1):
+        out = orc.unwarp_image_backward(img, g["xcenter"], g["ycenter"], g["list_fact"], order=order,
+                                        poly=poly_of(orc, poly))
+        assert np.array_equal(out, g["out_order%d" % order])
+
+
+def test_g9_explicit_coordinates(orc):
+    g = golden("g9_points33x47")
+    img = noise(g["seed"], g["shape"])
+    for order in (0, 1):
+        assert np.array_equal(orc.remap_coords(img, g["ys"], g["xs"], order=order), g["out_order%d" % order])
+        assert np.array_equal(orc.remap_coords(img, g["ys64"], g["xs64"], order=order), g["out64_order%d" % order])
+
+
+def test_cheaper_blends_stay_within_their_stated_bounds(orc):
+    """f64lerp: <= 1 float32 ulp of scipy's result; f32lerp: <= 2 ulp of the largest tap."""
+    img = (noise(5, (97, 131)) * 255).astype(np.float32)
+    a = (61.3, 40.2, [1.02, -3e-4, 2e-6])
+    ref = orc.unwarp_image_backward(img, *a, blend=orc.BLEND_SCIPY)
+    f64 = orc.unwarp_image_backward(img, *a, blend=orc.BLEND_F64LERP)
+    f32 = orc.unwarp_image_backward(img, *a, blend=orc.BLEND_F32LERP)
+    assert ulp_diff(ref, f64).max() <= 1
+    assert np.max(np.abs(f32.astype(np.float64) - ref)) <= 2 * np.spacing(np.float32(255.0))
+
+
+def test_strided_sources(orc):
+    rgb = noise(7, (40, 50, 3))
+    ch = rgb[:, :, 1]
+    a = (24.0, 19.5, [1.0, 1e-3])
+    assert np.array_equal(orc.unwarp_image_backward(np.ascontiguousarray(ch), *a),
+                          orc.unwarp_image_backward(np.ascontiguousarray(ch).copy(), *a))
+    padded = np.zeros((40, 64), np.float32)
+    padded[:, :50] = ch
+    assert np.array_equal(orc.unwarp_image_backward(padded[:, :50], *a),
+                          orc.unwarp_image_backward(np.ascontiguousarray(ch), *a))
+
+
+def test_degenerate_shapes(orc):
+    for shape in [(1, 1), (1, 9), (9, 1), (2, 2), (2, 7)]:
+        img = noise(3, shape)
+        out = orc.unwarp_image_backward(img, 0.4 * shape[1], 0.6 * shape[0], [1.0, 1e-2])
+        assert out.shape == shape and np.all(np.isfinite(out))
+    one = np.full((1, 1), 3.5, np.float32)
+    assert orc.unwarp_image_backward(one, 0.0, 0.0, [1.0])[0, 0] == np.float32(3.5)
+    assert orc.unwarp_image_backward(one, 0.0, 0.0, [])[0, 0] == np.float32(3.5)   # empty list_fact: B = 0

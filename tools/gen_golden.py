@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (discorpy 1.7.0 at /root/reference).
+
+Runs only in the build container (the reference never travels to the GPU box).  Each fixture
+holds the inputs (or the seed that regenerates them) and the reference's outputs; nothing of the
+reference's source is stored.  SURVEY.md section 8(c) lists the cases G1..G9.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import scipy.ndimage as ndi  # noqa: E402
+from scipy.ndimage import map_coordinates  # noqa: E402
+import discorpy.post.postprocessing as post  # noqa: E402
+import discorpy.proc.processing as proc  # noqa: E402
+from discorpy_amd import configs  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("%-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
+
+
+def f64(v):
+    return np.asarray(v, dtype=np.float64)
+
+
+# ---- G1: the reference's own unwarp_image_backward test input (tests/test_postprocessing.py:77-85)
+hei = wid = 64
+mat = np.zeros((hei, wid), dtype=np.float32)
+mat[4:-3, 4:-3] = 1.0
+fact = [1.0, 3.0 * 10 ** (-3)]
+save("g1_box64", mat=mat, xcenter=f64(wid // 2), ycenter=f64(hei // 2), list_fact=f64(fact),
+     out_order1=post.unwarp_image_backward(mat, wid // 2, hei // 2, fact),
+     out_order0=post.unwarp_image_backward(mat, wid // 2, hei // 2, fact, order=0))
+
+# ---- G2: the reference's slice / chunk test volume (tests/test_postprocessing.py:98-123)
+mat = np.zeros((hei, wid), dtype=np.float32)
+mat[:, 6:-8:8] = 1.0
+mat = np.float32(ndi.binary_dilation(np.int16(mat), iterations=1))
+mat3d = np.zeros((10, hei, wid), dtype=np.float32)
+mat3d[:] = mat
+x0, y0 = wid // 2, hei // 2
+save("g2_stripes10x64x64", mat=mat, depth=np.int64(10), xcenter=f64(x0), ycenter=f64(y0), list_fact=f64(fact),
+     index=np.int64(y0), slice_out=post.unwarp_slice_backward(mat3d, x0, y0, fact, y0),
+     start=np.int64(y0 - 5), stop=np.int64(y0 + 5),
+     chunk_out=post.unwarp_chunk_slices_backward(mat3d, x0, y0, fact, y0 - 5, y0 + 5))
+
+# ---- G3: the reference's perspective test (tests/test_postprocessing.py:205-238)
+hor_line1 = np.asarray([[10.0 + 2 * i / 32, i] for i in range(64)])
+hor_line2 = np.asarray([[60.0 - 5 * i / 32, i] for i in range(64)])
+ver_line1 = np.asarray([[i, 5.0 + 3 * i / 32] for i in range(64)])
+ver_line2 = np.asarray([[i, 60.0 - 3 * i / 32] for i in range(64)])
+src_pts, tgt_pts = proc.generate_source_target_perspective_points(
+    [hor_line1, hor_line2], [ver_line1, ver_line2], equal_dist=False, scale="mean", optimizing=False)
+pers_f = proc.calc_perspective_coefficients(src_pts, tgt_pts, mapping="forward")
+pers_b = proc.calc_perspective_coefficients(src_pts, tgt_pts, mapping="backward")
+mat = np.zeros((64, 64), dtype=np.float32)
+mat[10:11] = np.float32(1.0)
+mat[45:46] = np.float32(0.5)
+cor1 = post.correct_perspective_image(mat, pers_b)
+cor2 = post.correct_perspective_image(cor1, pers_f)
+save("g3_perspective64", mat=mat, coef_backward=f64(pers_b), coef_forward=f64(pers_f), cor_backward=cor1,
+     cor_forward_of_backward=cor2, cor_backward_order0=post.correct_perspective_image(mat, pers_b, order=0))
+
+# ---- G4: config 1 -- data/dot_pattern_05.jpg + data/coef_dot_05.txt.  The decoded JPEG is a data
+# file of the reference; a 160x192 crop around the centre of distortion and eight full output rows
+# are kept (JPEG decoding is library dependent: never decode on the GPU box).
+from PIL import Image  # noqa: E402
+img = np.array(Image.open("/root/reference/data/dot_pattern_05.jpg"), dtype=np.float32)
+assert img.shape == configs.DOT_05_SHAPE
+with open("/root/reference/data/coef_dot_05.txt") as fh:
+    vals = [float(line.split()[-1]) for line in fh if line.strip()]
+xc, yc, coef = vals[0], vals[1], vals[2:]
+assert abs(xc - configs.XCENTER_DOT_05) < 1e-9 and len(coef) == 5
+full = post.unwarp_image_backward(img, xc, yc, coef)
+rows = np.array([0, 10, 137, 400, 462, 463, 700, 799])
+crop = (slice(384, 544), slice(492, 684))      # 160 x 192 window holding the centre (462, 588)
+crop_in = np.ascontiguousarray(img[crop])
+# the same call on the crop alone (centre shifted): a self-contained input/output pair
+crop_out = post.unwarp_image_backward(crop_in, xc - 492, yc - 384, coef)
+save("g4_dot_pattern_05", crop_in=crop_in, crop_xcenter=f64(xc - 492), crop_ycenter=f64(yc - 384),
+     list_fact=f64(coef), crop_out=crop_out, full_rows=rows, full_out_rows=full[rows],
+     full_stats=f64([img.min(), img.max(), img.mean(), full.mean(), full[400, 640], full[10, 10], full[799, 1279]]),
+     full_in_rows_band=img[395:406])
+
+# ---- G5: configs 2 / 5 at reduced size, seeded noise; float32 coordinate planes kept
+def coords_ref(h, w, xc, yc, fact):
+    xu = np.arange(w) - xc
+    yu = np.arange(h) - yc
+    xm, ym = np.meshgrid(xu, yu)
+    ru = np.sqrt(xm ** 2 + ym ** 2)
+    fm = np.sum(np.asarray([f * ru ** i for i, f in enumerate(fact)]), axis=0)
+    return (np.float32(np.clip(yc + fm * ym, 0, h - 1)), np.float32(np.clip(xc + fm * xm, 0, w - 1)))
+
+
+for name, (h, w), seed, (xc5, yc5, fact5) in [
+        ("g5_cfg2_160", (160, 160), 11, configs.rescale_model(160)),
+        ("g5_offcentre_150x200", (150, 200), 12, (configs.rescale_model(200)[0] + 60.25,
+                                                  configs.rescale_model(200)[1] - 37.5,
+                                                  configs.rescale_model(200)[2])),
+        ("g5_cfg5_9term_144", (144, 144), 13, (72.3, 77.7,
+                                               [a * (8192 / 144) ** i for i, a in enumerate(configs.CFG5_FACT)]))]:
+    im = np.random.default_rng(seed).random((h, w), dtype=np.float32)
+    yd, xd = coords_ref(h, w, xc5, yc5, fact5)
+    save(name, seed=np.int64(seed), shape=np.array([h, w]), xcenter=f64(xc5), ycenter=f64(yc5), list_fact=f64(fact5),
+         yd=yd, xd=xd, out_order1=post.unwarp_image_backward(im, xc5, yc5, fact5),
+         out_order0=post.unwarp_image_backward(im, xc5, yc5, fact5, order=0))
+
+# ---- G6: slice / chunk on a (6, 800, 1280)-shaped problem, coef_dot_05, rows 0, 14, 400, 799
+vol = np.random.default_rng(21).random((3, 800, 1280), dtype=np.float32)
+c = configs
+g6 = dict(seed=np.int64(21), shape=np.array(vol.shape), xcenter=f64(c.XCENTER_DOT_05), ycenter=f64(c.YCENTER_DOT_05),
+          list_fact=f64(c.COEF_DOT_05), rows=np.array([0, 14, 400, 799]))
+for r in (0, 14, 400, 799):
+    g6["slice_%d" % r] = post.unwarp_slice_backward(vol, c.XCENTER_DOT_05, c.YCENTER_DOT_05, c.COEF_DOT_05, r)
+g6["slice_frac_400p5"] = post.unwarp_slice_backward(vol, c.XCENTER_DOT_05, c.YCENTER_DOT_05, c.COEF_DOT_05, 400.5)
+g6["chunk_395_402"] = post.unwarp_chunk_slices_backward(vol, c.XCENTER_DOT_05, c.YCENTER_DOT_05, c.COEF_DOT_05, 395, 402)
+g6["chunk_0_2"] = post.unwarp_chunk_slices_backward(vol, c.XCENTER_DOT_05, c.YCENTER_DOT_05, c.COEF_DOT_05, 0, 2)
+g6["chunk_797_799"] = post.unwarp_chunk_slices_backward(vol, c.XCENTER_DOT_05, c.YCENTER_DOT_05, c.COEF_DOT_05, 797, 799)
+save("g6_stack3x800x1280", **g6)
+
+# ---- G7: fused perspective -> radial, one map_coordinates call at the composed coordinates
+h = w = 144
+im = np.random.default_rng(31).random((h, w), dtype=np.float32)
+s = 4096 / w
+coef7 = list(configs.CFG3_COEF)
+# rescale the 4096^2 homography to a 256^2 frame: x' = x/s  =>  c3,c6 / s ; c7,c8 * s
+coef7 = [coef7[0], coef7[1], coef7[2] / s, coef7[3], coef7[4], coef7[5] / s, coef7[6] * s, coef7[7] * s]
+xc7, yc7, fact7 = configs.rescale_model(w)
+yp, xp = post._generate_perspective_map(im, coef7)
+xp = np.float64(xp.reshape(h, w))
+yp = np.float64(yp.reshape(h, w))
+xu = xp - xc7
+yu = yp - yc7
+ru = np.sqrt(xu ** 2 + yu ** 2)
+fm = np.sum(np.asarray([f * ru ** i for i, f in enumerate(fact7)]), axis=0)
+xd = np.float32(np.clip(xc7 + fm * xu, 0, w - 1))
+yd = np.float32(np.clip(yc7 + fm * yu, 0, h - 1))
+fused = map_coordinates(im, (yd.reshape(-1, 1), xd.reshape(-1, 1)), order=1, mode="reflect").reshape(h, w)
+twopass = post.correct_perspective_image(post.unwarp_image_backward(im, xc7, yc7, fact7), coef7)
+save("g7_fused144", seed=np.int64(31), shape=np.array([h, w]), xcenter=f64(xc7), ycenter=f64(yc7), list_fact=f64(fact7),
+     list_coef=f64(coef7), fused_out=fused, twopass_out=twopass, yd=yd, xd=xd,
+     persp_out=post.correct_perspective_image(im, coef7))
+
+# ---- G8: clipping stress -- 55 % of the coordinates clipped; all eight modes must agree
+h, w = 120, 180
+im = np.random.default_rng(41).random((h, w), dtype=np.float32)
+fact8 = [1.3, 2e-3]
+outs = {}
+for order in (0, 1):
+    base = post.unwarp_image_backward(im, 90.0, 60.0, fact8, order=order, mode="reflect")
+    for mode in ("grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+        assert np.array_equal(base, post.unwarp_image_backward(im, 90.0, 60.0, fact8, order=order, mode=mode)), mode
+    outs["out_order%d" % order] = base
+yd, xd = coords_ref(h, w, 90.0, 60.0, fact8)
+save("g8_clip120x180", seed=np.int64(41), shape=np.array([h, w]), xcenter=f64(90.0), ycenter=f64(60.0),
+     list_fact=f64(fact8), clipped_fraction=f64(np.mean((xd == 0) | (xd == w - 1) | (yd == 0) | (yd == h - 1))), **outs)
+
+# ---- G9: explicit coordinates incl. half-integers (order 0 rounds half up), edges, tiny fractions
+im = np.random.default_rng(51).random((33, 47), dtype=np.float32)
+ys = np.array([0.0, 0.5, 1.5, 2.5, 31.5, 32.0, 15.25, 7.999999, 1e-30, 31.999998, 0.49999997, 12.5, 20.0, 3.5],
+              dtype=np.float32)
+xs = np.array([0.0, 0.5, 2.5, 45.5, 46.0, 46.0, 22.75, 1e-20, 0.49999997, 45.999996, 10.5, 0.0, 46.0, 44.5],
+              dtype=np.float32)
+rng = np.random.default_rng(52)
+ys = np.concatenate([ys, (rng.random(500) * 32).astype(np.float32)])
+xs = np.concatenate([xs, (rng.random(500) * 46).astype(np.float32)])
+yd64 = rng.random(300) * 32
+xd64 = rng.random(300) * 46
+save("g9_points33x47", seed=np.int64(51), shape=np.array([33, 47]), ys=ys, xs=xs,
+     out_order0=map_coordinates(im, (ys, xs), order=0, mode="reflect"),
+     out_order1=map_coordinates(im, (ys, xs), order=1, mode="reflect"),
+     ys64=yd64, xs64=xd64, out64_order1=map_coordinates(im, (yd64, xd64), order=1, mode="reflect"),
+     out64_order0=map_coordinates(im, (yd64, xd64), order=0, mode="reflect"))
+print("done")
