@@ -27,6 +27,14 @@ run tcp --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum T
 run tcp2 --kernel-trace --pmc TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum
 # (TA_* / TD_* counter passes hang rocprofv3 on this pool -- not collected)
 run sq3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_LEVEL_WAVES SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT
+# calibration of FETCH_SIZE / WRITE_SIZE on kernels that move exactly 1 GiB each way
+if [ -n "${CALIB:-1}" ]; then
+  hipcc --offload-arch=gfx950 -O3 -o /tmp/calib_copy $ROOT/tools/calib_copy.hip > "$OUT/calib_build.log" 2>&1
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$OUT/calib_$c" -o out -- /tmp/calib_copy > "$OUT/calib_$c.log" 2>&1
+    echo "pass calib_$c rc=$?"
+  done
+fi
 cd "$ROOT"
 python tools/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 cat "$OUT/summary.txt"

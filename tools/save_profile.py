@@ -1,0 +1,27 @@
+"""Copy the judged part of a tools/profile.sh run from gpurun_out/ (scratch) into profiles/ (tracked):
+   python tools/save_profile.py gpurun_out/prof_r01 r01 [--latest]"""
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "summary.txt"), os.path.join(dst, tag + "_rocprofv3_summary.txt"))
+shutil.copy(os.path.join(src, "summary.json"), os.path.join(dst, tag + "_rocprofv3_summary.json"))
+for name in ("out_kernel_stats.csv",):
+    p = os.path.join(src, "trace", name)
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, tag + "_kernel_stats.csv"))
+summ = json.load(open(os.path.join(src, "summary.json")))
+if "--latest" in sys.argv:
+    best = None
+    for k, v in summ.get("traffic", {}).items():
+        if "remap_tile_kernel" in k or "remap_lds_kernel" in k:
+            best = dict(v, kernel=k, source=tag + "_rocprofv3_summary.json")
+    if best:
+        json.dump(best, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
+        print("pmc_latest.json:", best)
+print("saved", tag)

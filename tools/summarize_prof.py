@@ -39,7 +39,33 @@ def main(out):
                 # skip the warm-up dispatches: average the last half
                 tail = vals[len(vals) // 2:]
                 summary["counters"].setdefault(kern, {})[c] = {"per_launch": sum(tail) / len(tail), "n": len(vals)}
+    # calibration: kernels that move exactly 2^30 bytes each way -> bytes per reported KB
+    calib = {}
+    for kern, cs in summary["counters"].items():
+        if kern.startswith("calib_"):
+            for c, v in cs.items():
+                if c in ("FETCH_SIZE", "WRITE_SIZE") and v["per_launch"] > 0:
+                    calib.setdefault(c, {})[kern.split("(")[0]] = (2.0 ** 30) / (v["per_launch"] * 1024.0)
+    summary["calibration_true_bytes_per_reported_byte"] = calib
+    # HBM traffic of the unwarp kernels: reported KB x 1024 x calibration factor of the matching
+    # access shape (dwordx2 gather for reads when available, else the coalesced dword copy)
+    fr = calib.get("FETCH_SIZE", {})
+    fw = calib.get("WRITE_SIZE", {})
+    rf = fr.get("calib_gather_dwordx2", fr.get("calib_copy_dword", 2.0))
+    wf = fw.get("calib_copy_dword", 1.0)
+    traffic = {}
+    for kern, cs in summary["counters"].items():
+        if "remap_" in kern or "stack_rows" in kern:
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                rd = cs["FETCH_SIZE"]["per_launch"] * 1024.0 * rf
+                wr = cs["WRITE_SIZE"]["per_launch"] * 1024.0 * wf
+                traffic[kern] = {"read_bytes": rd, "write_bytes": wr, "hbm_bytes_per_launch": rd + wr,
+                                 "read_factor": rf, "write_factor": wf}
+    summary["traffic"] = traffic
     json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
+    print("CALIBRATION (true bytes per reported byte):", json.dumps(calib))
+    for k, v in traffic.items():
+        print("TRAFFIC", k[:80], json.dumps(v))
     for k, v in summary["kernels"].items():
         print("KERNEL", k[:100])
         for kk, vv in v.items():
