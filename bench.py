@@ -72,18 +72,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # test hooks (single-GPU boxes): DCP_BENCH_BACKEND=gloo + DCP_BENCH_DEVICE=0 let two ranks share one GPU
+    backend = os.environ.get("DCP_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("DCP_BENCH_DEVICE", local_rank))
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     n_gpus = world
     if a.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
 
     L = F.lib()
     F.require_device()
-    dev = local_rank if world > 1 else -1
+    dev = dev_index if world > 1 else -1
     cfg = configs.cfg2()
     cfg["order"] = a.order
     H, W = cfg["shape"]
@@ -133,7 +139,7 @@ def main():
     dev_ms = e0.elapsed_ms(e1)            # HIP events on the launch stream: device time of the K steps
     if dist is not None:
         import torch
-        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
 

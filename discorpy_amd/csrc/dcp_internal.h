@@ -59,9 +59,9 @@ struct CoordArgs {
 
 struct LaunchOpts {
   int tile_rows = 16;
-  int xcd_remap = 0;
+  int xcd_remap = 2;
   int pipe_depth = 2;
-  int lds_gather = 0;
+  int lds_gather = 1;
   int coef_lds = 0;        // 1: force the LDS-staged coefficient path even for short vectors
   int d_chunk = 16;
 };

@@ -29,7 +29,7 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{0}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{0};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -253,7 +253,8 @@ int dcp_set_option(const char* key, int value) {
     if (value < 1 || value > dcp::kMaxTileRows) return fail(DCP_ERR_INVALID_ARG, "tile_rows must be in [1, %d]", dcp::kMaxTileRows);
     g_tile_rows = value;
   } else if (!strcmp(key, "xcd_remap")) {
-    g_xcd_remap = value ? 1 : 0;
+    if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "xcd_remap must be 0, 1 or 2");
+    g_xcd_remap = value;
   } else if (!strcmp(key, "coef_lds")) {
     g_coef_lds = value ? 1 : 0;
   } else if (!strcmp(key, "lds_gather")) {

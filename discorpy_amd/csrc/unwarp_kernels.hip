@@ -38,7 +38,7 @@ constexpr int kBlock = 256;
 #endif
 constexpr int kPipeDepth = DCP_PIPE_DEPTH;
 #ifndef DCP_STORE_AUX
-#define DCP_STORE_AUX 0  // cache-policy bits of the output store (experiments: 2 = nt)
+#define DCP_STORE_AUX 2  // cache-policy bits of the output store: 2 = nt (streamed once, never re-read here)
 #endif
 #ifndef DCP_LOAD_AUX
 #define DCP_LOAD_AUX 0
@@ -266,16 +266,48 @@ __device__ __forceinline__ double clip_f64(double v, double hi) {
 
 // ------------------------------------------------------------------ tile bookkeeping
 
-// blockIdx.x -> tile.  The dispatcher places workgroup b on XCD b % 8; with xcd_remap each XCD
-// gets one contiguous band of tiles, so the one-row halo shared by vertically adjacent tiles is
-// re-read from that XCD's own L2 instead of from another die's (speed only, never correctness).
-__device__ __forceinline__ int logical_tile(int xcd_remap) {
-  int b = blockIdx.x;
-  if (!xcd_remap) return b;
-  int nb = gridDim.x;
-  int per = nb >> 3, rem = nb & 7;
-  int xcd = b & 7, j = b >> 3;
-  return xcd * per + min(xcd, rem) + j;
+// blockIdx.x -> tile (tx, ty).  The dispatcher places workgroup b on XCD b % 8 (observed, used for
+// speed only).  xcd_remap:
+//   0  row-major tile order: horizontally adjacent tiles land on different XCDs
+//   1  each XCD gets a contiguous run of row-major tiles (a horizontal band of the image)
+//   2  each XCD gets a vertical stripe of tile columns and sweeps it row by row: neighbours in x
+//      and y share an L2 (their source boxes overlap), while the eight XCDs together still touch
+//      one full-width band of rows at a time (even spread over the HBM channels)
+__device__ __forceinline__ void logical_tile(int xcd_remap, int tiles_x, int* tx, int* ty) {
+  const int b = blockIdx.x;
+  if (xcd_remap == 0) {
+    *ty = b / tiles_x;
+    *tx = b - *ty * tiles_x;
+    return;
+  }
+  const int nb = gridDim.x;
+  const int per = nb >> 3, rem = nb & 7;
+  const int xcd = b & 7, j = b >> 3;
+  const int lin = xcd * per + min(xcd, rem) + j;     // position in the XCD-contiguous enumeration
+  if (xcd_remap == 1) {
+    *ty = lin / tiles_x;
+    *tx = lin - *ty * tiles_x;
+    return;
+  }
+  // enumeration: stripe by stripe; inside a stripe row by row.  Stripe s spans columns
+  // [s*wq + min(s, wr), ...) with width wq + (s < wr), wq = tiles_x / 8, wr = tiles_x % 8.
+  const int tiles_y = nb / tiles_x;
+  const int wq = tiles_x >> 3, wr = tiles_x & 7;
+  const int big = (wq + 1) * tiles_y;                 // tiles in one of the first wr (wider) stripes
+  int s, off;
+  if (lin < wr * big) {
+    s = lin / big;
+    off = lin - s * big;
+  } else {
+    const int l2 = lin - wr * big;
+    const int small = max(wq, 1) * tiles_y;
+    s = wr + l2 / small;
+    off = l2 - (s - wr) * small;
+  }
+  const int w = wq + (s < wr ? 1 : 0);
+  const int x0 = s * wq + min(s, wr);
+  *ty = off / w;
+  *tx = x0 + (off - *ty * w);
 }
 
 __device__ __forceinline__ SrcView make_view(const float* base, uint32_t bytes, int W, int H, int stride,
@@ -401,9 +433,8 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
   using CT = typename std::conditional<ROUND32, float, double>::type;
   using FetchT = Fetch<SAMPLER, PAIR, CT>;
 
-  const int tile = logical_tile(img.xcd_remap);
-  const int ty = tile / img.tiles_x;
-  const int tx = tile - ty * img.tiles_x;
+  int tx, ty;
+  logical_tile(img.xcd_remap, img.tiles_x, &tx, &ty);
   const int y0 = ty * img.tile_rows;
   const int x = tx * kBlock + (int)threadIdx.x;
   const int rows = min(img.tile_rows, img.H - y0);
@@ -507,10 +538,22 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
 __device__ unsigned long long g_lds_stats[2];
 
 constexpr int kLdsTW = 64, kLdsTH = 16;
-constexpr int kBoxW = 80, kBoxH = 24;
+#ifndef DCP_BOXW
+#define DCP_BOXW 80
+#endif
+#ifndef DCP_BOXH
+#define DCP_BOXH 24
+#endif
+#ifndef DCP_LDS_MARGIN
+#define DCP_LDS_MARGIN 1
+#endif
+#ifndef DCP_LDS_WAVES
+#define DCP_LDS_WAVES 5
+#endif
+constexpr int kBoxW = DCP_BOXW, kBoxH = DCP_BOXH;
 
 template <int KIND, int NF, int SAMPLER>
-__global__ void __launch_bounds__(kBlock, 5) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
+__global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
   // 4 x 7680 B slabs + row table + coefficients <= 32 KB: five workgroups (20 waves) per CU
   __shared__ float s_box[4][kBoxH * kBoxW];
   __shared__ double s_row[4 * kLdsTH][KIND == kRadial ? 2 : 4];
@@ -521,9 +564,8 @@ __global__ void __launch_bounds__(kBlock, 5) remap_lds_kernel(const ImageArgs im
   // is treated as divergent and wrapped in a waterfall loop
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
-  const int tile = logical_tile(img.xcd_remap);
-  const int ty = tile / img.tiles_x;
-  const int tx = tile - ty * img.tiles_x;
+  int tx, ty;
+  logical_tile(img.xcd_remap, img.tiles_x, &tx, &ty);
   const int yblk = ty * (4 * kLdsTH);
   const int y0 = yblk + wave * kLdsTH;            // first row of this wave's tile
   const int x = tx * kLdsTW + lane;
@@ -546,16 +588,8 @@ __global__ void __launch_bounds__(kBlock, 5) remap_lds_kernel(const ImageArgs im
   const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
   const char* out_base = (const char*)(img.dst + (size_t)y0 * (size_t)img.W);
   const uint32_t xoff = (uint32_t)x * 4u;         // lanes with x >= W: the store is out of range and dropped
-  // one descriptor for the rows of the tile that exist; the row offset goes through the scalar
-  // offset (not bounds-checked, hence the explicit row and column predicates)
   const __amdgpu_buffer_rsrc_t dst =
       __builtin_amdgcn_make_buffer_rsrc((void*)out_base, 0, (int)((uint32_t)rows * row_bytes_out), 0x00020000);
-  const bool col_ok = x < img.W;
-  auto store_row = [&](int k, float v) {
-    if (k < rows && col_ok)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
-                                            DCP_STORE_AUX);
-  };
 
   // ---- phase 1a: first and last row of the tile; their end lanes are the tile's four corners
   float xf[kLdsTH], yf[kLdsTH];
@@ -583,10 +617,10 @@ __global__ void __launch_bounds__(kBlock, 5) remap_lds_kernel(const ImageArgs im
     cy0 = min(min(ya0, ya1), min(yb0, yb1));
     cy1 = max(max(ya0, ya1), max(yb0, yb1));
   }
-  const int bx0 = max(min(cx0 - 1, img.W - 2), 0);
-  const int bx1 = min(cx1 + 2, img.W - 1);          // last column held (tap x0+1 of the largest x0, +1 margin)
-  const int by0 = max(min(cy0 - 1, img.H - 2), 0);
-  const int by1 = min(cy1 + 2, img.H - 1);
+  const int bx0 = max(min(cx0 - DCP_LDS_MARGIN, img.W - 2), 0);
+  const int bx1 = min(cx1 + 1 + DCP_LDS_MARGIN, img.W - 1);   // last column held: tap x0+1 of the largest x0 (+ margin)
+  const int by0 = max(min(cy0 - DCP_LDS_MARGIN, img.H - 2), 0);
+  const int by1 = min(cy1 + 1 + DCP_LDS_MARGIN, img.H - 1);
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   const bool fits = bw <= kBoxW && bh <= kBoxH;
 
@@ -633,28 +667,59 @@ __global__ void __launch_bounds__(kBlock, 5) remap_lds_kernel(const ImageArgs im
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
+  // one descriptor for the rows of the tile that exist; the row offset goes through the scalar
+  // offset (not bounds-checked, hence the explicit row and column predicates)
+  if (!(x < img.W)) return;                      // no cross-lane work from here on
   if (staged) {
-    // ---- phase 2: taps from LDS, blend, store
-    const int boxorg = by0 * kBoxW + bx0;
+    // ---- phase 2: taps from LDS, blend, store.  Byte address of tap (y0, x0) in the slab:
+    // (y0 - by0) * pitch + (x0 - bx0) floats = y0 * (4 pitch) + (4 x0 - 4 (by0 pitch + bx0))
+    const uint32_t negorg4 = (uint32_t)(-(by0 * kBoxW + bx0) * 4);
+    const char* boxb = (const char*)box;
+    // A box that ends before the last image column/row cannot contain the clipped coordinate
+    // W-1 / H-1, so interior tiles need no base-tap clamp: floor and fraction are one op each.
+    const bool interior = bx1 < img.W - 1 && by1 < img.H - 1;
+    auto tile_rows_loop = [&](auto full, auto inner) {
 #pragma unroll
-    for (int k = 0; k < kLdsTH; ++k) {
-      FetchT f;
-      const int xi = min((int)xf[k], img.W - 2), yi = min((int)yf[k], img.H - 2);
-      f.fx = xf[k] - (float)xi;
-      f.fy = yf[k] - (float)yi;
-      const int idx = __mul24(yi, kBoxW) + (xi - boxorg);
-      f.a.x = __float_as_uint(box[idx]);
-      f.a.y = __float_as_uint(box[idx + 1]);
-      f.b.x = __float_as_uint(box[idx + kBoxW]);
-      f.b.y = __float_as_uint(box[idx + kBoxW + 1]);
-      store_row(k, finish<SAMPLER, true, float>(f));
-    }
+      for (int k = 0; k < kLdsTH; ++k) {
+        FetchT f;
+        int xi, yi;
+        if constexpr (decltype(inner)::value) {
+          xi = (int)xf[k];
+          yi = (int)yf[k];
+          f.fx = __builtin_amdgcn_fractf(xf[k]);      // x - floor(x), exact
+          f.fy = __builtin_amdgcn_fractf(yf[k]);
+        } else {
+          xi = min((int)xf[k], img.W - 2);
+          yi = min((int)yf[k], img.H - 2);
+          f.fx = xf[k] - (float)xi;
+          f.fy = yf[k] - (float)yi;
+        }
+        uint32_t addr;
+        const uint32_t xa = ((uint32_t)xi << 2) + negorg4;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kBoxW * 4), "v"(xa));
+        const float* t = (const float*)(boxb + addr);
+        f.a.x = __float_as_uint(t[0]);
+        f.a.y = __float_as_uint(t[1]);
+        f.b.x = __float_as_uint(t[kBoxW]);
+        f.b.y = __float_as_uint(t[kBoxW + 1]);
+        const float v = finish<SAMPLER, true, float>(f);
+        if (decltype(full)::value || k < rows)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
+                                                DCP_STORE_AUX);
+      }
+    };
+    if (rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{});
+    else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
+    else tile_rows_loop(std::false_type{}, std::false_type{});
   } else {
-    // ---- box too large for the slab: direct global gather for this tile
+    // ---- box too large for the slab, or a tap outside the predicted box: direct global gather
 #pragma unroll
     for (int k = 0; k < kLdsTH; ++k) {
       const FetchT f = fetch<SAMPLER, true, float>(src, xf[k], yf[k]);
-      store_row(k, finish<SAMPLER, true, float>(f));
+      const float v = finish<SAMPLER, true, float>(f);
+      if (k < rows)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
+                                              DCP_STORE_AUX);
     }
   }
 }

@@ -172,10 +172,10 @@ def test_centre_on_a_pixel_and_far_outside(hip, orc):
 
 
 def test_tuning_knobs_do_not_change_results(hip, orc):
-    img = noise(4, (200, 700))
-    a = (img, 333.3, 80.8, list(configs.COEF_DOT_05))
+    img = noise(4, (200, 1700))          # 27 tile columns: uneven XCD stripes
+    a = (img, 833.3, 80.8, list(configs.COEF_DOT_05))
     want = orc.unwarp_image_backward(*a, **kernel_oracle(orc, "f64lerp"))
-    keys = {"tile_rows": [1, 3, 8, 16, 64], "pipe_depth": [1, 2, 4], "xcd_remap": [0, 1], "lds_gather": [0, 1]}
+    keys = {"tile_rows": [1, 3, 8, 16, 64], "pipe_depth": [1, 2, 4], "xcd_remap": [0, 1, 2], "lds_gather": [0, 1]}
     for key, vals in keys.items():
         old = hip.get_option(key)
         try:
