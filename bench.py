@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    ap.add_argument("--option", action="append", default=[], help="kernel option key=value (dcp_set_option)")
     return ap.parse_args()
 
 
@@ -89,6 +90,9 @@ def main():
 
     L = F.lib()
     F.require_device()
+    for kv in a.option:
+        k, v = kv.split("=")
+        F.set_option(k, int(v))
     dev = dev_index if world > 1 else -1
     cfg = configs.cfg2()
     cfg["order"] = a.order

@@ -545,7 +545,7 @@ constexpr int kLdsTW = 64, kLdsTH = 16;
 #define DCP_BOXH 24
 #endif
 #ifndef DCP_LDS_MARGIN
-#define DCP_LDS_MARGIN 1
+#define DCP_LDS_MARGIN 0   // extra pixels around the corner hull (0: ~1 tile per 16384 fails the vote on cfg2)
 #endif
 #ifndef DCP_LDS_WAVES
 #define DCP_LDS_WAVES 5
@@ -624,44 +624,66 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   const bool fits = bw <= kBoxW && bh <= kBoxH;
 
-  // ---- fill: box rows by0..by1, columns bx0..bx1, row-contiguous 4-byte-per-lane loads that
-  // land directly in LDS (buffer_load ... lds, no VGPR round trip).  The row advances through the
-  // scalar offset; lanes past the box width are masked off.  All rows are in flight at once and
-  // complete underneath phase 1b.
+  // ---- fill: box rows by0..by1 from column bx0, row-contiguous loads that land directly in LDS
+  // (buffer_load ... lds, no VGPR round trip).  The row group advances through the scalar offset.
+  // All rows are in flight at once and complete underneath phase 1b.  (The slab is filled to its
+  // full 80-float pitch: up to 12 columns more than the box needs, from cache lines the
+  // neighbouring tile fetches anyway.)
   if (fits) {
+    // 16 bytes per lane: 20 lanes cover one slab row (pitch 80 floats), so one instruction fills
+    // three consecutive box rows (lanes 0-59) and the LDS image stays lane-linear as LDS-DMA needs
     const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
     const uint32_t rstep = (uint32_t)img.src_stride * 4u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    if (lane < bw) {
+    static_assert(kBoxW == 80, "the fill maps 20 lanes of 16 bytes to one slab row");
+    const int lrow = lane / 20, lcol = lane - lrow * 20;
+    const uint32_t voff = (uint32_t)lrow * rstep + (uint32_t)lcol * 16u;
+    if (lane < 60) {
 #pragma unroll 2
-      for (int r = 0; r < bh; ++r)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(box + r * kBoxW), 4, lane * 4,
-                                                 org + (uint32_t)r * rstep, 0, 0);
-    }
-    if (lane + 64 < bw) {
-      // instruction offset 256 moves both the global and the LDS address to column 64
-#pragma unroll 2
-      for (int r = 0; r < bh; ++r)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(box + r * kBoxW), 4, lane * 4,
-                                                 org + (uint32_t)r * rstep, 256, 0);
+      for (int r = 0; r < bh; r += 3) {
+        // the whole offset goes through the VGPR so that the descriptor's bounds check sees it:
+        // the slab pitch can reach past the last image column / the end of the source buffer,
+        // where the load must return zeros instead of touching memory
+        if (r + lrow < bh)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(box + r * kBoxW), 16,
+                                                   voff + (org + (uint32_t)r * rstep), 0, 0, 0);
+      }
     }
   }
 
-  // ---- phase 1b: the other rows, and this lane's extremes for the containment vote
+  // ---- phase 1b: the other rows, and this lane's extremes for the containment vote.
+  // When the predicted box lies strictly inside the image the clip is skipped: a coordinate that
+  // would have been clipped is then outside the box, fails the vote below and the fallback path
+  // clips it.  (Border tiles keep the clip: their clipped coordinates are legitimate box members.)
+  const bool box_inside = cx0 - DCP_LDS_MARGIN >= 0 && cx1 + 1 + DCP_LDS_MARGIN <= img.W - 1 &&
+                          cy0 - DCP_LDS_MARGIN >= 0 && cy1 + 1 + DCP_LDS_MARGIN <= img.H - 1;
   float xmn = __builtin_fminf(xf[0], xf[kLdsTH - 1]), xmx = __builtin_fmaxf(xf[0], xf[kLdsTH - 1]);
   float ymn = __builtin_fminf(yf[0], yf[kLdsTH - 1]), ymx = __builtin_fmaxf(yf[0], yf[kLdsTH - 1]);
+  auto rows_1b = [&](auto noclip) {
 #pragma unroll
-  for (int k = 1; k < kLdsTH - 1; ++k) {
-    eval_row(k);
-    xmn = __builtin_fminf(xmn, xf[k]);
-    xmx = __builtin_fmaxf(xmx, xf[k]);
-    ymn = __builtin_fminf(ymn, yf[k]);
-    ymx = __builtin_fmaxf(ymx, yf[k]);
-  }
-  // tap columns are min(floor(xf), W-2) and +1: inside [bx0, bx1] iff xf >= bx0 and
-  // (xf < bx1 or the box already ends at the image edge)
-  const bool inside = xmn >= (float)bx0 && (xmx < (float)bx1 || bx1 == img.W - 1) && ymn >= (float)by0 &&
-                      (ymx < (float)by1 || by1 == img.H - 1);
+    for (int k = 1; k < kLdsTH - 1; ++k) {
+      double xd, yd;
+      map_coord<KIND, NF, (KIND == kRadial ? 2 : 4)>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+      if constexpr (decltype(noclip)::value) {
+        xf[k] = (float)xd;
+        yf[k] = (float)yd;
+      } else {
+        xf[k] = round_clip_f32(xd, wmaxf);
+        yf[k] = round_clip_f32(yd, hmaxf);
+      }
+      xmn = __builtin_fminf(xmn, xf[k]);
+      xmx = __builtin_fmaxf(xmx, xf[k]);
+      ymn = __builtin_fminf(ymn, yf[k]);
+      ymx = __builtin_fmaxf(ymx, yf[k]);
+    }
+  };
+  const bool unclipped = box_inside && fits;
+  if (unclipped) rows_1b(std::true_type{});
+  else rows_1b(std::false_type{});
+  // tap columns are min(floor(xf), W-2) and +1: inside [bx0, bx1] iff xf >= bx0 and (xf < bx1 or
+  // the coordinate was clipped and the box ends at the image edge)
+  const bool inside = xmn >= (float)bx0 && (xmx < (float)bx1 || (!unclipped && bx1 == img.W - 1)) &&
+                      ymn >= (float)by0 && (ymx < (float)by1 || (!unclipped && by1 == img.H - 1));
   const bool staged = fits && __builtin_amdgcn_ballot_w64(!inside) == 0;
   if (!staged && lane == 0) atomicAdd(&g_lds_stats[fits ? 1 : 0], 1ull);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -694,8 +716,8 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
           f.fx = xf[k] - (float)xi;
           f.fy = yf[k] - (float)yi;
         }
-        uint32_t addr;
-        const uint32_t xa = ((uint32_t)xi << 2) + negorg4;
+        uint32_t addr, xa;
+        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kBoxW * 4), "v"(xa));
         const float* t = (const float*)(boxb + addr);
         f.a.x = __float_as_uint(t[0]);
@@ -715,7 +737,8 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
     // ---- box too large for the slab, or a tap outside the predicted box: direct global gather
 #pragma unroll
     for (int k = 0; k < kLdsTH; ++k) {
-      const FetchT f = fetch<SAMPLER, true, float>(src, xf[k], yf[k]);
+      const FetchT f = fetch<SAMPLER, true, float>(src, __builtin_amdgcn_fmed3f(xf[k], 0.0f, wmaxf),
+                                                   __builtin_amdgcn_fmed3f(yf[k], 0.0f, hmaxf));
       const float v = finish<SAMPLER, true, float>(f);
       if (k < rows)
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,

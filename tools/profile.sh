@@ -11,8 +11,9 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
 cd /tmp
-run() { # name, rocprof args...
+run() { # name, rocprof args...   (PASSES="trace fetch" restricts the passes that run)
   local name=$1; shift
+  if [ -n "${PASSES:-}" ] && ! echo " $PASSES " | grep -q " $name "; then return; fi
   timeout 120 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o out -- $BENCH > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
