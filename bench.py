@@ -172,7 +172,8 @@ def main():
                        "parallelism": "independent frames per GPU (no collective)" if n_gpus > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "remap_tile_kernel<Radial,NF=5>", "launch_us": round(launch_us, 3),
+                         "kernel": ("remap_lds_kernel<Radial,NF=5>" if F.get_option("lds_gather") and a.order == 1
+                                    else "remap_tile_kernel<Radial,NF=5>"), "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch)},
         }
         if n_gpus == 1 and not a.no_cpu_baseline:

@@ -863,14 +863,17 @@ static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStr
 }
 
 template <int KIND, int NF>
-static hipError_t launch_fast(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
-  if (img.lds_gather && sampler != kNearest) {
-    switch (sampler) {
-      case kScipy: return launch_lds<KIND, NF, kScipy>(img, map, stream);
-      case kF64Lerp: return launch_lds<KIND, NF, kF64Lerp>(img, map, stream);
-      default: return launch_lds<KIND, NF, kF32Lerp>(img, map, stream);
-    }
+static hipError_t launch_lds_any(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
+  switch (sampler) {
+    case kScipy: return launch_lds<KIND, NF, kScipy>(img, map, stream);
+    case kF64Lerp: return launch_lds<KIND, NF, kF64Lerp>(img, map, stream);
+    default: return launch_lds<KIND, NF, kF32Lerp>(img, map, stream);
   }
+}
+
+template <int KIND, int NF>
+static hipError_t launch_fast(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
+  if (img.lds_gather && sampler != kNearest) return launch_lds_any<KIND, NF>(img, map, sampler, stream);
   switch (sampler) {
     case kNearest: return launch_one<KIND, NF, kNearest, true, true>(img, map, stream);
     case kScipy: return launch_one<KIND, NF, kScipy, true, true>(img, map, stream);
@@ -905,7 +908,10 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
   const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2;
   const int nf = map.nfact;
 
+  // order-1 remaps of dense float32 images with float32 coordinates: LDS-staged gather
+  const bool lds = pair && round_f32 && opts.lds_gather && sampler != kNearest;
   if (kind == kPersp) {
+    if (lds) return launch_lds_any<kPersp, -1>(img, map, sampler, stream);
     if (pair) return launch_generic<kPersp, true, true>(img, map, sampler, stream);
     return launch_generic<kPersp, true, false>(img, map, sampler, stream);
   }
@@ -925,6 +931,7 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
         default: break;
       }
     }
+    if (lds) return launch_lds_any<kRadial, -1>(img, map, sampler, stream);
     if (pair) {
       if (round_f32) return launch_generic<kRadial, true, true>(img, map, sampler, stream);
       return launch_generic<kRadial, false, true>(img, map, sampler, stream);
@@ -940,6 +947,7 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
       default: break;
     }
   }
+  if (lds) return launch_lds_any<kFused, -1>(img, map, sampler, stream);
   if (pair) return launch_generic<kFused, true, true>(img, map, sampler, stream);
   return launch_generic<kFused, true, false>(img, map, sampler, stream);
 }

@@ -51,11 +51,16 @@ def main(out):
     # access shape (dwordx2 gather for reads when available, else the coalesced dword copy)
     fr = calib.get("FETCH_SIZE", {})
     fw = calib.get("WRITE_SIZE", {})
-    rf = fr.get("calib_gather_dwordx2", fr.get("calib_copy_dword", 2.0))
     wf = fw.get("calib_copy_dword", 1.0)
     traffic = {}
     for kern, cs in summary["counters"].items():
         if "remap_" in kern or "stack_rows" in kern:
+            # remap_lds_kernel streams 16-byte-per-lane row segments (the dwordx4 copy shape); the
+            # direct kernels gather 8-byte tap pairs at 4-byte lane stride (the dwordx2 gather shape)
+            if "remap_lds_kernel" in kern:
+                rf = fr.get("calib_copy_dwordx4", 2.0)
+            else:
+                rf = fr.get("calib_gather_dwordx2", fr.get("calib_copy_dword", 2.0))
             if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
                 rd = cs["FETCH_SIZE"]["per_launch"] * 1024.0 * rf
                 wr = cs["WRITE_SIZE"]["per_launch"] * 1024.0 * wf
