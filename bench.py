@@ -42,6 +42,12 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (dcp_set_option)")
+    ap.add_argument("--workload", default="frame", choices=["frame", "stack"],
+                    help="frame: BASELINE config 2 (default, the headline metric); stack: config 4, the "
+                         "(depth, 2560, 2560) stack sharded over the ranks by depth + all-gather")
+    ap.add_argument("--depth", type=int, default=2048, help="stack workload: total number of projections")
+    ap.add_argument("--rows", type=int, default=2560, help="stack workload: output rows per step (2560 = whole stack)")
+    ap.add_argument("--no-gather", action="store_true", help="stack workload: skip the all-gather")
     return ap.parse_args()
 
 
@@ -65,6 +71,92 @@ def cpu_baseline(cfg, img, blend, threads):
             "sample": "%d full %dx%d frames of the bench workload, reference arithmetic order "
                       "(numpy-order polynomial, scipy blend), %d OpenMP threads of %d host cores, %.2f s wall"
                       % (frames, img.shape[0], img.shape[1], t, ncores, dt)}
+
+
+def stack_main(a, world, rank, dev, dist, backend):
+    """BASELINE config 4: strong scaling -- the stack is fixed, ranks own contiguous depth shards."""
+    from discorpy_amd import stack as st
+    L = F.lib()
+    cfg = configs.cfg4(a.depth)
+    D, H, W = cfg["shape"]
+    d0, d1 = st.shard_bounds(D, world, rank)
+    dl = d1 - d0
+    nrows = a.rows
+    fa, nf = F.fact_array(cfg["list_fact"])
+    blend = BLEND_NAMES[a.blend]
+    gather = world > 1 and not a.no_gather
+    if gather:
+        import torch
+        vol_t = torch.empty((dl, H, W), dtype=torch.float32, device="cuda")
+        out_t = torch.empty((dl, nrows, W), dtype=torch.float32, device="cuda")
+        full_t = torch.empty((D, nrows, W), dtype=torch.float32, device="cuda")
+        vol_ptr, out_ptr = vol_t.data_ptr(), out_t.data_ptr()
+        stream = torch.cuda.current_stream().cuda_stream
+    else:
+        vol_b = F.DeviceBuffer(dl * H * W * 4, dev)
+        out_b = F.DeviceBuffer(dl * nrows * W * 4, dev)
+        vol_ptr, out_ptr, stream = vol_b.ptr, out_b.ptr, None
+    # synthetic projections: one host chunk of noise, replicated on the device
+    chunk = np.random.default_rng(cfg["seed"] + rank).random((min(dl, 16), H, W), dtype=np.float32)
+    done = 0
+    while done < dl:
+        n = min(chunk.shape[0], dl - done)
+        F.check(L.dcp_memcpy(vol_ptr + done * H * W * 4, chunk.ctypes.data, n * H * W * 4, F.COPY_H2D, dev, None))
+        done += n
+    uneven = len({st.shard_bounds(D, world, r)[1] - st.shard_bounds(D, world, r)[0] for r in range(world)}) > 1
+    if gather and uneven:
+        raise SystemExit("stack workload: depth must divide evenly over the ranks for the timed all-gather")
+
+    def step():
+        F.check(L.dcp_unwarp_stack_rows_f32(vol_ptr, out_ptr, dl, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf,
+                                            0.0, nrows, 1, blend, F.MEM_DEVICE, dev, stream))
+        if gather:
+            dist.all_gather_into_tensor(full_t, out_t)
+
+    def sync():
+        F.check(L.dcp_stream_synchronize(dev, None))
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt[0])
+    if rank == 0:
+        vox = float(D) * nrows * W * a.steps
+        ms = wall * 1e3 / a.steps
+        per_gpu_bytes = configs.BYTES_PER_PIXEL * dl * nrows * W
+        achieved = per_gpu_bytes / (ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "Mpixels/s unwarp of a (depth, 2560, 2560) stack, rows of every projection (+ all-gather)",
+            "value": round(vox / wall / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64 coordinates / f32 pixels",
+            "data": "synthetic (uniform [0,1) float32 projections, device-resident)",
+            "config": {"workload": cfg["name"], "depth": D, "rows": nrows, "width": W, "depth_per_gpu": dl,
+                       "all_gather": bool(gather), "blend": a.blend,
+                       "parallelism": "depth-sharded, %s" % ("RCCL all-gather of the (depth, rows, W) block" if gather
+                                                            else "no collective")},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "stack_rows_kernel (per GPU, step time includes the all-gather when enabled)"}}),
+            flush=True)
 
 
 def main():
@@ -94,6 +186,11 @@ def main():
         k, v = kv.split("=")
         F.set_option(k, int(v))
     dev = dev_index if world > 1 else -1
+    if a.workload == "stack":
+        stack_main(a, world, rank, dev, dist, backend)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     cfg = configs.cfg2()
     cfg["order"] = a.order
     H, W = cfg["shape"]
