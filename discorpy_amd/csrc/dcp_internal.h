@@ -36,6 +36,7 @@ struct MapArgs {
   double fact[kMaxFact];
   double coef[8];          // perspective c1..c8
   int32_t nfact;
+  int32_t fast_div;        // 1: operands of the homography division stay in the normal range over the image
 };
 
 struct StackArgs {

@@ -138,6 +138,29 @@ int fill_map(dcp::MapArgs* m, double xc, double yc, const double* fact, int nfac
   return DCP_OK;
 }
 
+// The shared-reciprocal division of the perspective kernels (div2_rn) is exact while nothing
+// leaves the normal range: every coefficient is 0 or of moderate magnitude, and the denominator
+// c7*x + c8*y + 1 keeps one sign and a moderate magnitude over the whole image (checked at the four
+// corners; it is affine in x and y).
+int homography_is_tame(const double* c, int64_t H, int64_t W) {
+  for (int i = 0; i < 8; ++i) {
+    const double a = std::fabs(c[i]);
+    if (!(a == 0.0 || (a > 1e-100 && a < 1e100))) return 0;
+  }
+  const double xs[2] = {0.0, (double)(W - 1)}, ys[2] = {0.0, (double)(H - 1)};
+  double lo = 1e300, hi = -1e300;
+  for (double x : xs)
+    for (double y : ys) {
+      const double d = (c[6] * x + c[7] * y) + 1.0;
+      lo = d < lo ? d : lo;
+      hi = d > hi ? d : hi;
+    }
+  if (!(lo > 0.0 || hi < 0.0)) return 0;
+  const double m = std::fabs(lo) < std::fabs(hi) ? std::fabs(lo) : std::fabs(hi);
+  const double M = std::fabs(lo) > std::fabs(hi) ? std::fabs(lo) : std::fabs(hi);
+  return m > 1e-6 && M < 1e6;
+}
+
 uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs) {
   return (uint32_t)(((H - 1) * rs + (W - 1) * cs + 1) * 4);
 }
@@ -305,6 +328,7 @@ int dcp_perspective_image_f32(const float* src, float* dst, int64_t height, int6
   if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
   dcp::MapArgs map;
   if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
+  map.fast_div = homography_is_tame(list_coef, height, width);
   return run_image(dcp::kPersp, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
                    mem_kind, device, stream);
 }
@@ -319,6 +343,7 @@ int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t w
   if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
   dcp::MapArgs map;
   if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, list_coef)) != DCP_OK) return rc;
+  map.fast_div = homography_is_tame(list_coef, height, width);
   return run_image(dcp::kFused, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
                    mem_kind, device, stream);
 }

@@ -327,6 +327,25 @@ __device__ __forceinline__ SrcView make_view(const float* base, uint32_t bytes, 
 
 constexpr double kTinyR2 = 1e-300;   // keeps rsq finite at the centre pixel; absorbed everywhere else
 
+// nx/den and ny/den, both correctly rounded, from ONE refined reciprocal (v_rcp_f64 + two Newton
+// steps, then a residual correction per quotient).  Valid while no intermediate leaves the normal
+// range -- the C ABI checks the homography and the image size on the host and otherwise leaves
+// MapArgs::fast_div at 0 (compiler's full IEEE division).  tools/ubench_div.hip: 0 mismatches
+// against the host's division on 3.3e7 quotients.
+__device__ __forceinline__ void div2_rn(double nx, double ny, double den, double* qx, double* qy) {
+  double r = __builtin_amdgcn_rcp(den);
+  double e = __builtin_fma(-den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = nx * r;
+  double t = __builtin_fma(-den, q, nx);
+  *qx = __builtin_fma(t, r, q);
+  q = ny * r;
+  t = __builtin_fma(-den, q, ny);
+  *qy = __builtin_fma(t, r, q);
+}
+
 // Per-column (thread) invariants of the coordinate map.
 struct ColCtx {
   double cx0, cx1, cx2;      // radial: xu, xu^2, -.  perspective/fused: c7*x, c1*x, c4*x
@@ -370,7 +389,7 @@ __device__ __forceinline__ void fill_row(const MapArgs& map, double (*row)[RW], 
 }
 
 // Source coordinate (float64, unclipped) of the pixel in column ctx / LDS row slot k.
-template <int KIND, int NF, int RW>
+template <int KIND, int NF, int RW, int FASTDIV = -1>   // FASTDIV: 1 / 0 fixed at compile time, -1 = map.fast_div
 __device__ __forceinline__ void map_coord(const MapArgs& map, const double (*s_row)[RW], const double* s_coef,
                                           const ColCtx& c, int k, float wmaxf, float hmaxf, double* xd_out,
                                           double* yd_out) {
@@ -400,8 +419,12 @@ __device__ __forceinline__ void map_coord(const MapArgs& map, const double (*s_r
     const double den = (c.cx0 + s_row[k][0]) + 1.0;
     const double nx = (c.cx1 + s_row[k][1]) + map.coef[2];
     const double ny = (c.cx2 + s_row[k][2]) + map.coef[5];
-    xd = nx / den;
-    yd = ny / den;
+    if (FASTDIV == 1 || (FASTDIV < 0 && map.fast_div)) {
+      div2_rn(nx, ny, den, &xd, &yd);
+    } else {
+      xd = nx / den;
+      yd = ny / den;
+    }
     if constexpr (KIND == kFused) {
       // float32-rounded perspective coordinate, then the radial map evaluated there
       const double xp = (double)round_clip_f32(xd, wmaxf);
@@ -659,11 +682,12 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
                           cy0 - DCP_LDS_MARGIN >= 0 && cy1 + 1 + DCP_LDS_MARGIN <= img.H - 1;
   float xmn = __builtin_fminf(xf[0], xf[kLdsTH - 1]), xmx = __builtin_fmaxf(xf[0], xf[kLdsTH - 1]);
   float ymn = __builtin_fminf(yf[0], yf[kLdsTH - 1]), ymx = __builtin_fmaxf(yf[0], yf[kLdsTH - 1]);
-  auto rows_1b = [&](auto noclip) {
+  auto rows_1b = [&](auto noclip, auto fastdiv) {
 #pragma unroll
     for (int k = 1; k < kLdsTH - 1; ++k) {
       double xd, yd;
-      map_coord<KIND, NF, (KIND == kRadial ? 2 : 4)>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+      map_coord<KIND, NF, (KIND == kRadial ? 2 : 4), decltype(fastdiv)::value>(map, rowtab, s_coef, col, k, wmaxf,
+                                                                               hmaxf, &xd, &yd);
       if constexpr (decltype(noclip)::value) {
         xf[k] = (float)xd;
         yf[k] = (float)yd;
@@ -678,8 +702,15 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
     }
   };
   const bool unclipped = box_inside && fits;
-  if (unclipped) rows_1b(std::true_type{});
-  else rows_1b(std::false_type{});
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (KIND == kRadial || !map.fast_div) {
+    if (unclipped) rows_1b(std::true_type{}, I0{});
+    else rows_1b(std::false_type{}, I0{});
+  } else {
+    if (unclipped) rows_1b(std::true_type{}, I1{});
+    else rows_1b(std::false_type{}, I1{});
+  }
   // tap columns are min(floor(xf), W-2) and +1: inside [bx0, bx1] iff xf >= bx0 and (xf < bx1 or
   // the coordinate was clipped and the box ends at the image edge)
   const bool inside = xmn >= (float)bx0 && (xmx < (float)bx1 || (!unclipped && bx1 == img.W - 1)) &&

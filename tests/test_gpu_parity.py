@@ -245,6 +245,26 @@ def test_perspective_and_fused_match_oracle(hip, orc, shape):
                           orc.unwarp_fused(img, 0.45 * w, 0.55 * h, [1.0, 1e-3], coef, order=0, poly=orc.POLY_KERNEL))
 
 
+def test_wild_homographies_take_the_full_division(hip, orc):
+    """A denominator that changes sign inside the image, or huge coefficients, disable the
+    shared-reciprocal division on the host side; results must still equal IEEE division."""
+    img = noise(21, (96, 130))
+    h, w = img.shape
+    wild = [[1.0, 0.0, 0.0, 0.0, 1.0, 0.0, -1.0 / (w / 2 + 0.37), 0.0],          # pole inside the image
+            [1.0, 0.1, 3.0, 0.05, 1.0, 2.0, 0.0, -1.0 / (h / 3 + 0.21)],
+            [1e150, 0.0, 0.0, 0.0, 1e-150, 0.0, 0.0, 0.0],                         # out-of-range magnitudes
+            [0.9, 0.0, 4.0, 0.0, 1.1, -3.0, 1e-3, 2e-3]]                           # tame control
+    for coef in wild:
+        for blend in ("scipy", "f64lerp"):
+            ob = kernel_oracle(orc, blend)["blend"]
+            assert np.array_equal(pp.correct_perspective_image(img, coef, blend=blend),
+                                  orc.correct_perspective_image(img, coef, blend=ob))
+            assert np.array_equal(pp.unwarp_perspective_fused(img, 60.0, 50.0, [1.0, 1e-3], coef, blend=blend),
+                                  orc.unwarp_fused(img, 60.0, 50.0, [1.0, 1e-3], coef, poly=orc.POLY_KERNEL, blend=ob))
+        assert np.array_equal(pp.correct_perspective_image(img, coef, order=0),
+                              orc.correct_perspective_image(img, coef, order=0))
+
+
 def test_stack_rows_match_oracle(hip, orc):
     vol = noise(13, (7, 120, 200))
     a = (97.3, 66.1, [1.004, -6e-5, 3e-7])
