@@ -55,6 +55,8 @@ constexpr int kPipeDepth = DCP_PIPE_DEPTH;
 
 // ------------------------------------------------------------------ fp64 helpers
 
+constexpr double kTinyR2 = 1e-300;   // keeps rsq finite at the centre pixel; absorbed everywhere else
+
 // Correctly rounded sqrt for finite x >= 0 (no range scaling: r2 is bounded by the image size).
 __device__ __forceinline__ double sqrt_rn(double x) {
   double y = __builtin_amdgcn_rsq(x);          // ~2^-24 relative
@@ -66,6 +68,18 @@ __device__ __forceinline__ double sqrt_rn(double x) {
   double d = __builtin_fma(-g, g, x);          // exact residual
   g = __builtin_fma(d, h, g);                  // correctly rounded
   return x == 0.0 ? 0.0 : g;
+}
+
+// The same for x > 0 (no zero select).
+__device__ __forceinline__ double sqrt_pos(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
 }
 
 // B(ru) = sum a_i ru^i, split into even and odd powers so that only one multiply by ru is
@@ -325,7 +339,6 @@ __device__ __forceinline__ SrcView make_view(const float* base, uint32_t bytes, 
 
 // ------------------------------------------------------------------ K1 / K2 / K3
 
-constexpr double kTinyR2 = 1e-300;   // keeps rsq finite at the centre pixel; absorbed everywhere else
 
 // nx/den and ny/den, both correctly rounded, from ONE refined reciprocal (v_rcp_f64 + two Newton
 // steps, then a residual correction per quotient).  Valid while no intermediate leaves the normal
@@ -397,18 +410,7 @@ __device__ __forceinline__ void map_coord(const MapArgs& map, const double (*s_r
   if constexpr (KIND == kRadial) {
     const double yu = s_row[k][0];
     const double r2 = c.cx1 + s_row[k][1];
-    // correctly rounded sqrt (see sqrt_rn) without the zero select: r2 > 0 here
-    double g, h;
-    {
-      const double y = __builtin_amdgcn_rsq(r2);
-      g = r2 * y;
-      h = 0.5 * y;
-      const double r = __builtin_fma(-h, g, 0.5);
-      g = __builtin_fma(g, r, g);
-      h = __builtin_fma(h, r, h);
-      const double d = __builtin_fma(-g, g, r2);
-      g = __builtin_fma(d, h, g);
-    }
+    const double g = sqrt_pos(r2);                 // r2 > 0 (row table)
     double f;
     if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, c.lead_e, c.lead_o, r2, g);
     else f = poly_lds(s_coef, map.nfact, r2, g);
@@ -433,8 +435,10 @@ __device__ __forceinline__ void map_coord(const MapArgs& map, const double (*s_r
       const double yu = yp - map.yc;
       const double xx = xu * xu;
       const double yy = yu * yu;
-      const double r2 = xx + yy;
-      const double ru = sqrt_rn(r2);
+      // as in the radial branch: keep rsq finite at the centre; there xu == yu == 0 and the
+      // coordinate is xc + B*0 whatever B is
+      const double r2 = __builtin_fmax(xx + yy, kTinyR2);
+      const double ru = sqrt_pos(r2);
       double f;
       if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, c.lead_e, c.lead_o, r2, ru);
       else f = poly_lds(s_coef, map.nfact, r2, ru);
