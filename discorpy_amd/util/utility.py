@@ -1,0 +1,149 @@
+"""Colour / padded unwarp on the GPU path.
+
+``unwarp_color_image_backward`` has the signature and semantics of the reference
+(``/root/reference/discorpy/util/utility.py:278-342``): optional padding, then the backward radial
+unwarp of every channel at the SAME float32 coordinates.  Channels are processed as dense planes
+by the image kernel of :mod:`discorpy_amd.post.postprocessing`.
+
+``find_point_to_point`` is the closed-form point mapping of ``utility.py:192-230`` (host, NumPy).
+"""
+import numpy as np
+
+from ..post import postprocessing as _pp
+
+__all__ = ["unwarp_color_image_backward", "find_point_to_point"]
+
+
+def find_point_to_point(points, xcenter, ycenter, list_fact, output_order="xy"):
+    """
+    Corresponding point in the other space: ``centre + B(r) * (point - centre)`` with
+    ``B(r) = sum_i list_fact[i] * r**i`` (reference ``utility.py:192-230``).  ``points`` is
+    ``(row_index, column_index)``; the result is ``(x, y)`` or, with ``output_order="yx"``, ``(y, x)``.
+    """
+    xi, yi = points[1] - xcenter, points[0] - ycenter
+    ri = np.sqrt(xi * xi + yi * yi)
+    factor = np.float64(np.sum(list_fact * np.power(ri, np.arange(len(list_fact)))))
+    xo = xcenter + factor * xi
+    yo = ycenter + factor * yi
+    return (xo, yo) if output_order == "xy" else (yo, xo)
+
+
+def _calc_pad(pad, height, width, xcenter, ycenter, list_fact):
+    """Pad widths (top, bottom, left, right); reference ``utility.py:233-275``."""
+    t_pad, b_pad, l_pad, r_pad = 0, 0, 0, 0
+    if isinstance(pad, bool):
+        if pad is True:
+            # automatic width: needs the forward model fitted from the backward one -- the one-off
+            # CPU fit of discorpy.proc (out of scope here); use it when discorpy is installed
+            try:
+                import discorpy.proc.processing as proc
+            except ImportError:
+                raise NotImplementedError(
+                    "pad=True needs discorpy.proc.transform_coef_backward_and_forward (the CPU model fit, "
+                    "not part of this package); install discorpy or pass explicit pad widths")
+            ref_points = [[i - ycenter, j - xcenter] for i in np.linspace(0, height, 40)
+                          for j in np.linspace(0, width, 40)]
+            list_tfact = proc.transform_coef_backward_and_forward(list_fact, ref_points=ref_points)
+            xu_tl, yu_tl = find_point_to_point((0, 0), xcenter, ycenter, list_tfact)
+            xu_tr, yu_tr = find_point_to_point((0, width - 1), xcenter, ycenter, list_tfact)
+            xu_br, yu_br = find_point_to_point((height - 1, width - 1), xcenter, ycenter, list_tfact)
+            xu_bl, yu_bl = find_point_to_point((height - 1, 0), xcenter, ycenter, list_tfact)
+            l_val = min(xu_tl, xu_bl)
+            if l_val < 0:
+                l_pad = int(-l_val)
+            r_val = max(xu_tr, xu_br)
+            if r_val > width:
+                r_pad = int(r_val - width)
+            t_val = min(yu_tl, yu_tr)
+            if t_val < 0:
+                t_pad = int(-t_val)
+            b_val = max(yu_bl, yu_br)
+            if b_val > height:
+                b_pad = int(b_val - height)
+    elif isinstance(pad, int):
+        t_pad = b_pad = l_pad = r_pad = pad
+    elif isinstance(pad, tuple) or isinstance(pad, list):
+        if len(pad) != 4:
+            raise ValueError("Incorrect format!!! Please use a tuple/list of "
+                             "(top_pad, bottom_pad, left_pad, right_pad)")
+        t_pad, b_pad, l_pad, r_pad = pad
+    else:
+        raise ValueError("Invalid format of the 'pad' parameter!!!")
+    return t_pad, b_pad, l_pad, r_pad
+
+
+def _pad_device(t, pad_width, mode):
+    """numpy.pad for a ROCm tensor: source indices come from numpy.pad on an index ramp, so the
+    'edge', 'reflect', 'symmetric' and 'wrap' modes follow numpy's definition exactly."""
+    import torch
+    if all(p == (0, 0) for p in pad_width):
+        return t
+    if mode == "constant":
+        out = torch.zeros([s + a + b for s, (a, b) in zip(t.shape, pad_width)], dtype=t.dtype, device=t.device)
+        sl = tuple(slice(a, a + s) for s, (a, _) in zip(t.shape, pad_width))
+        out[sl] = t
+        return out
+    if mode not in ("edge", "reflect", "symmetric", "wrap"):
+        raise NotImplementedError("pad_mode %r is not implemented for device tensors (use a NumPy array, "
+                                  "or one of constant/edge/reflect/symmetric/wrap)" % mode)
+    for axis, (a, b) in enumerate(pad_width):
+        if a or b:
+            idx = np.pad(np.arange(t.shape[axis]), (a, b), mode=mode)
+            t = t.index_select(axis, torch.as_tensor(idx, device=t.device))
+    return t
+
+
+def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", pad=False,
+                                pad_mode='constant', *, blend=None):
+    """
+    Unwarp a color image using a backward model (reference ``utility.py:278-342``).
+
+    Parameters
+    ----------
+    mat : array_like
+        2D/3D float32 array (H, W) or (H, W, C); NumPy array or ROCm torch tensor.
+    xcenter, ycenter : float
+        Center of distortion (of the UNPADDED image, as in the reference).
+    list_fact : list of float
+        Polynomial coefficients of the backward model.
+    order : int, optional.
+        The order of the spline interpolation (0 or 1).
+    mode : str, optional
+        Accepted for compatibility; inert for order <= 1.
+    pad : bool, int, or tuple of int.
+        Use to keep the original view.  ``True`` (automatic width) needs discorpy's CPU model fit.
+    pad_mode : str
+        numpy.pad mode ('constant', 'reflect', 'edge', 'mean', 'linear_ramp', 'symmetric', ...).
+
+    Returns
+    -------
+    array_like
+        2D/3D array. Distortion-corrected image, shape of the padded input.
+    """
+    (height, width) = mat.shape[:2]
+    t_pad, b_pad, l_pad, r_pad = _calc_pad(pad, height, width, xcenter, ycenter, list_fact)
+    num_dim = len(mat.shape)
+    if num_dim == 2:
+        pad_width = [(t_pad, b_pad), (l_pad, r_pad)]
+    else:
+        pad_width = [(t_pad, b_pad), (l_pad, r_pad), (0, 0)]
+    is_torch = _pp._is_torch(mat) and mat.is_cuda
+    if is_torch:
+        mat_pad = _pad_device(mat, pad_width, pad_mode)
+    else:
+        mat_pad = np.pad(np.asarray(mat), pad_width, mode=pad_mode)
+    xcenter = xcenter + l_pad
+    ycenter = ycenter + t_pad
+    if num_dim == 2:
+        return _pp.unwarp_image_backward(mat_pad, xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
+    # channels as dense planes: one coordinate map, C gathers
+    if is_torch:
+        import torch
+        planes = mat_pad.permute(2, 0, 1).contiguous()
+        out = torch.stack([_pp.unwarp_image_backward(planes[i], xcenter, ycenter, list_fact, order=order, mode=mode,
+                                                     blend=blend) for i in range(planes.shape[0])])
+        return out.permute(1, 2, 0)
+    planes = np.ascontiguousarray(np.moveaxis(mat_pad, 2, 0))
+    mat_corr = [_pp.unwarp_image_backward(planes[i], xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
+                for i in range(planes.shape[0])]
+    return np.moveaxis(np.asarray(mat_corr), 0, 2)

@@ -184,4 +184,15 @@ save("g9_points33x47", seed=np.int64(51), shape=np.array([33, 47]), ys=ys, xs=xs
      out_order1=map_coordinates(im, (ys, xs), order=1, mode="reflect"),
      ys64=yd64, xs64=xd64, out64_order1=map_coordinates(im, (yd64, xd64), order=1, mode="reflect"),
      out64_order0=map_coordinates(im, (yd64, xd64), order=0, mode="reflect"))
+# ---- G10: util.unwarp_color_image_backward (utility.py:278-342): channels, explicit pads, pad modes
+import discorpy.util.utility as util  # noqa: E402
+rgb = np.random.default_rng(61).random((40, 56, 3), dtype=np.float32)
+fact10 = [1.0, 4e-3, 2e-5]
+g10 = dict(seed=np.int64(61), shape=np.array(rgb.shape), xcenter=f64(27.4), ycenter=f64(19.1), list_fact=f64(fact10))
+g10["nopad"] = util.unwarp_color_image_backward(rgb, 27.4, 19.1, fact10)
+g10["pad_3_5_2_7_edge"] = util.unwarp_color_image_backward(rgb, 27.4, 19.1, fact10, pad=(3, 5, 2, 7), pad_mode="edge")
+g10["pad_4_constant"] = util.unwarp_color_image_backward(rgb, 27.4, 19.1, fact10, pad=4)
+g10["pad_4_reflect_order0"] = util.unwarp_color_image_backward(rgb, 27.4, 19.1, fact10, order=0, pad=4, pad_mode="reflect")
+g10["gray_pad_6_mean"] = util.unwarp_color_image_backward(rgb[:, :, 1], 27.4, 19.1, fact10, pad=6, pad_mode="mean")
+save("g10_color40x56x3", **g10)
 print("done")
