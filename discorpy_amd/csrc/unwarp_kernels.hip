@@ -40,18 +40,6 @@ constexpr int kPipeDepth = DCP_PIPE_DEPTH;
 #ifndef DCP_STORE_AUX
 #define DCP_STORE_AUX 2  // cache-policy bits of the output store: 2 = nt (streamed once, never re-read here)
 #endif
-#ifndef DCP_LOAD_AUX
-#define DCP_LOAD_AUX 0
-#endif
-#ifndef DCP_SETPRIO
-#define DCP_SETPRIO 0
-#endif
-#ifndef DCP_PF_ROWS
-#define DCP_PF_ROWS 0   // > 0: LDS-DMA touch of the source DCP_PF_ROWS rows below the current taps (L2 prefetch)
-#endif
-#ifndef DCP_ABLATE
-#define DCP_ABLATE 0   // experiments: 1 = no gather loads, 2 = no store, 3 = neither (tools/ablate.sh)
-#endif
 
 // ------------------------------------------------------------------ fp64 helpers
 
@@ -134,35 +122,10 @@ __device__ __forceinline__ double poly_lds(const double* s_coef, int nf, double 
   return __builtin_fma(ru, O, E);
 }
 
-// ------------------------------------------------------------------ wave64 min / max (DPP)
-
-// Reduction over the 64 lanes in six DPP steps (row_shr 1,2,4,8 inside each 16-lane row, then
-// row_bcast 15 and 31 across rows); the result lands in lane 63 and is read to an SGPR.  Lanes
-// that receive nothing in a step keep their own value (old == src).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_take(float v) {
-  const int b = __float_as_int(v);
-  return __int_as_float(__builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false));
-}
-template <bool IS_MAX>
-__device__ __forceinline__ float wave_reduce(float v) {
-#define DCP_STEP(CTRL, MASK) v = IS_MAX ? __builtin_fmaxf(v, dpp_take<CTRL, MASK>(v)) : __builtin_fminf(v, dpp_take<CTRL, MASK>(v))
-  DCP_STEP(0x111, 0xf);   // row_shr:1
-  DCP_STEP(0x112, 0xf);   // row_shr:2
-  DCP_STEP(0x114, 0xf);   // row_shr:4
-  DCP_STEP(0x118, 0xf);   // row_shr:8
-  DCP_STEP(0x142, 0xa);   // row_bcast:15 -> rows 1, 3
-  DCP_STEP(0x143, 0xc);   // row_bcast:31 -> rows 2, 3
-#undef DCP_STEP
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 // ------------------------------------------------------------------ sampler
 
 struct SrcView {
   __amdgpu_buffer_rsrc_t rsrc;
-  __amdgpu_buffer_rsrc_t pf_rsrc;   // the same image seen DCP_PF_ROWS rows further down (prefetch)
-  float* pf_sink;                   // 256 B of LDS per wave the prefetch lands in (never read)
   int32_t W, H;
   int32_t stride;      // elements
   int32_t cstride;     // elements
@@ -199,26 +162,8 @@ __device__ __forceinline__ Fetch<SAMPLER, PAIR, CT> fetch(const SrcView& s, CT x
     f.fx = xc - (CT)xi;             // exact
     f.fy = yc - (CT)yi;
     const uint32_t off = (__umul24(yi, s.stride) + (uint32_t)xi) << 2;
-#if DCP_ABLATE & 1
-    f.a.x = off; f.a.y = off + 1; f.b.x = off + 2; f.b.y = off + 3;
-#elif DCP_ABLATE == 4   // two perfectly coalesced dword loads instead of the gather (timing experiment)
-    const uint32_t ido = (blockIdx.x * 16u * (uint32_t)s.stride + threadIdx.x + ((uint32_t)yi & 15u) * s.stride) << 2;
-    f.a.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, ido, 0, 0); f.a.y = off;
-    f.b.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, ido, s.stride * 4, 0); f.b.y = off + 1;
-#elif DCP_ABLATE == 8   // the same gather as four dword loads
-    f.a.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0);
-    f.a.y = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off + 4, 0, 0);
-    f.b.x = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, s.stride * 4, 0);
-    f.b.y = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off + 4, s.stride * 4, 0);
-#else
-    f.a = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, off, 0, DCP_LOAD_AUX);
-    f.b = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, off, s.stride * 4, DCP_LOAD_AUX);
-#endif
-#if DCP_PF_ROWS > 0
-    if (s.pf_sink)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(s.pf_rsrc, (__attribute__((address_space(3))) void*)s.pf_sink, 4, off,
-                                               0, 0, 0);
-#endif
+    f.a = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, off, 0, 0);
+    f.b = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, off, s.stride * 4, 0);
     return f;
   } else {
     // any stride, any size: same base-tap rule per axis, four 4-byte loads
@@ -328,8 +273,6 @@ __device__ __forceinline__ SrcView make_view(const float* base, uint32_t bytes, 
                                              int cstride) {
   SrcView s;
   s.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
-  s.pf_rsrc = s.rsrc;
-  s.pf_sink = nullptr;
   s.W = W;
   s.H = H;
   s.stride = stride;
@@ -476,18 +419,7 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
   __syncthreads();
   if (x >= img.W) return;
 
-  SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, img.src_col_stride);
-#if DCP_PF_ROWS > 0
-  __shared__ float s_pf[4][64];
-  {
-    const uint32_t skip = (uint32_t)DCP_PF_ROWS * (uint32_t)img.src_stride * 4u;
-    if (skip < img.src_bytes) {
-      src.pf_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)img.src + skip), 0,
-                                                      (int)(img.src_bytes - skip), 0x00020000);
-      src.pf_sink = s_pf[__builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)];
-    }
-  }
-#endif
+  const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, img.src_col_stride);
   const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
   const double wmaxd = (double)(img.W - 1), hmaxd = (double)(img.H - 1);
   // output rows through one buffer descriptor per row built on the scalar unit: lane offset
@@ -508,23 +440,6 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
     }
   };
 
-#if DCP_SETPRIO == 1
-  if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 1) __builtin_amdgcn_s_setprio(2);
-#elif DCP_SETPRIO == 2
-  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) & 3) {
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    case 3: __builtin_amdgcn_s_setprio(3); break;
-    default: break;
-  }
-#elif DCP_SETPRIO == 3
-  switch (blockIdx.x & 3) {
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    case 3: __builtin_amdgcn_s_setprio(3); break;
-    default: break;
-  }
-#endif
   // software pipeline: PD rows of gathers in flight per thread
   FetchT q[PD];
 #pragma unroll
@@ -536,9 +451,6 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
       const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(out_base + (size_t)(k + j) * row_bytes_out), 0, (k + j < rows) ? (int)row_bytes_out : 0,
           0x00020000);
-#if DCP_ABLATE & 2
-      if (v == 123.456f)
-#endif
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, 0, DCP_STORE_AUX);
       q[j] = issue(k + j + PD);
     }
