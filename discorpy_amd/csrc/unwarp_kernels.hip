@@ -504,7 +504,19 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
   int tx, ty;
-  logical_tile(img.xcd_remap, img.tiles_x, &tx, &ty);
+  if (img.xcd_remap == 2) {
+    // stripe order without divisions: a 2-D grid whose x extent is 8 * (widest stripe); the
+    // linear workgroup id is y * gridDim.x + x, so XCD = blockIdx.x & 7 owns stripe blockIdx.x & 7
+    // and all stripes sweep the image row by row together.  Narrower stripes have a few idle
+    // workgroups at their right end.
+    const int s = blockIdx.x & 7, c = blockIdx.x >> 3;
+    const int wq = img.tiles_x >> 3, wr = img.tiles_x & 7;
+    if (c >= wq + (s < wr ? 1 : 0)) return;
+    tx = s * wq + min(s, wr) + c;
+    ty = blockIdx.y;
+  } else {
+    logical_tile(img.xcd_remap, img.tiles_x, &tx, &ty);
+  }
   const int yblk = ty * (4 * kLdsTH);
   const int y0 = yblk + wave * kLdsTH;            // first row of this wave's tile
   const int x = tx * kLdsTW + lane;
@@ -575,8 +587,9 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
     const uint32_t rstep = (uint32_t)img.src_stride * 4u;
     typedef __attribute__((address_space(3))) void* lds_ptr;
     static_assert(kBoxW == 80, "the fill maps 20 lanes of 16 bytes to one slab row");
-    const int lrow = lane / 20, lcol = lane - lrow * 20;
-    const uint32_t voff = (uint32_t)lrow * rstep + (uint32_t)lcol * 16u;
+    const int lrow = (int)(__umul24((uint32_t)lane, 13u) >> 8);        // lane / 20 for lane < 64
+    const int lcol = lane - lrow * 20;
+    const uint32_t voff = __umul24((uint32_t)lrow, rstep) + (uint32_t)lcol * 16u;   // rows < 16 MB
     if (lane < 60) {
 #pragma unroll 2
       for (int r = 0; r < bh; r += 3) {
@@ -804,8 +817,9 @@ static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStr
   ImageArgs img = img_in;
   img.tiles_x = (img.W + kLdsTW - 1) / kLdsTW;
   img.tiles_y = (img.H + 4 * kLdsTH - 1) / (4 * kLdsTH);
-  const int nb = img.tiles_x * img.tiles_y;
-  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER>), dim3(nb), dim3(kBlock), 0, stream, img, map);
+  dim3 grid(img.tiles_x * img.tiles_y);
+  if (img.xcd_remap == 2) grid = dim3(8 * ((img.tiles_x + 7) / 8), img.tiles_y);   // see the kernel's tile order
+  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER>), grid, dim3(kBlock), 0, stream, img, map);
   return hipGetLastError();
 }
 
