@@ -33,6 +33,10 @@ def orc():
 def hip():
     """The HIP library with a visible device; fails (not skips) if either is missing on a GPU run."""
     from discorpy_amd import _ffi as F
+    if not os.path.exists(F.LIB_PATH):
+        # a fresh checkout on the GPU box: compile in-tree (hipcc is part of the image)
+        import __graft_entry__
+        __graft_entry__.build()
     F.lib()
     F.require_device()
     return F
