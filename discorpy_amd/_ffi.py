@@ -15,6 +15,7 @@ MEM_HOST, MEM_DEVICE = 0, 1
 BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
 COORD_F32, COORD_F64 = 0, 1
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
+MAP_RADIAL, MAP_PERSPECTIVE, MAP_FUSED = 0, 1, 2
 MAX_FACT = 32
 
 BLEND_BY_NAME = {"scipy": BLEND_SCIPY, "exact": BLEND_SCIPY, "f64": BLEND_F64LERP,
@@ -49,6 +50,7 @@ SIGNATURES = {
                                     _int, _vp]),
     "dcp_unwarp_stack_rows_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,
                                          _i64, _int, _int, _int, _int, _vp]),
+    "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
     "dcp_free": (_int, [_vp, _int]),

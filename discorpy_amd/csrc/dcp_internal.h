@@ -71,6 +71,8 @@ struct LaunchOpts {
 hipError_t launch_image(MapKind kind, const ImageArgs& img, const MapArgs& map, int sampler,
                         bool round_f32, const LaunchOpts& opts, hipStream_t stream);
 hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler, hipStream_t stream);
+hipError_t launch_coord_map(MapKind kind, const ImageArgs& img, const MapArgs& map, float* ymap, float* xmap,
+                            hipStream_t stream);
 hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream);
 

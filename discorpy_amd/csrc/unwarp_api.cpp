@@ -475,6 +475,44 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
   return DCP_OK;
 }
 
+int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t width, int map_kind, double xcenter,
+                           double ycenter, const double* list_fact, int nfact, const double* list_coef, int mem_kind,
+                           int device, void* stream) {
+  int rc;
+  if (!ymap || !xmap) return fail(DCP_ERR_INVALID_ARG, "null map pointer");
+  if (height <= 0 || width <= 0 || height > 1073741823LL || width > 1073741823LL)
+    return fail(DCP_ERR_INVALID_ARG, "map must be non-empty (got %lld x %lld)", (long long)height, (long long)width);
+  if (map_kind < DCP_MAP_RADIAL || map_kind > DCP_MAP_FUSED) return fail(DCP_ERR_INVALID_ARG, "unknown map_kind %d", map_kind);
+  if (map_kind != DCP_MAP_RADIAL && !list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, map_kind == DCP_MAP_PERSPECTIVE ? nullptr : list_fact,
+                     map_kind == DCP_MAP_PERSPECTIVE ? 0 : nfact, map_kind == DCP_MAP_RADIAL ? nullptr : list_coef)) != DCP_OK)
+    return rc;
+  if (map_kind != DCP_MAP_RADIAL) map.fast_div = homography_is_tame(list_coef, height, width);
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::ImageArgs img;
+  memset(&img, 0, sizeof(img));
+  img.H = (int32_t)height;
+  img.W = (int32_t)width;
+  const dcp::MapKind kind = map_kind == DCP_MAP_RADIAL ? dcp::kRadial : map_kind == DCP_MAP_PERSPECTIVE ? dcp::kPersp : dcp::kFused;
+  hipStream_t st = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    DCP_HIP(dcp::launch_coord_map(kind, img, map, ymap, xmap, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *dy, *dx;
+  const size_t plane = (size_t)height * (size_t)width * 4;
+  DCP_HIP(g_staging.get(2, plane, &dy));
+  DCP_HIP(g_staging.get(3, plane, &dx));
+  DCP_HIP(dcp::launch_coord_map(kind, img, map, (float*)dy, (float*)dx, st));
+  DCP_HIP(hipMemcpyAsync(ymap, dy, plane, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipMemcpyAsync(xmap, dx, plane, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
 int dcp_debug_counters(uint64_t* out, int n, int reset) {
   if (!out || n < 2) return fail(DCP_ERR_INVALID_ARG, "need room for 2 counters");
   unsigned long long v[2];

@@ -6,6 +6,7 @@
 //   remap_tile_kernel<Fused>    K3  perspective o radial in one pass
 //   stack_rows_kernel           K4  unwarp_slice_backward / unwarp_chunk_slices_backward  :211-229,:281-313
 //   remap_coords_kernel         K5  map_index= / _mapping            postprocessing.py:250-251,489-491
+//   coord_map_kernel            K6  the float32 (yd, xd) planes      postprocessing.py:144-145,444-459
 //
 // Design (see DESIGN.md for the numbers):
 //  * one thread per output pixel column, 64-wide wavefronts along x, a workgroup of 4 waves
@@ -725,6 +726,38 @@ __global__ void __launch_bounds__(kBlock) remap_coords_kernel(const ImageArgs im
   img.dst[i] = finish<SAMPLER, PAIR, CT>(f);
 }
 
+// ------------------------------------------------------------------ K6: coordinate maps
+
+// The float32 (yd, xd) planes themselves -- _generate_perspective_map (postprocessing.py:444-459)
+// and the xd_mat / yd_mat of unwarp_image_backward (:144-145) -- for callers that reuse a map
+// (map_index=, cv2.remap).  Same coordinate code as the remap kernels, no sampling.
+template <int KIND>
+__global__ void __launch_bounds__(kBlock) coord_map_kernel(const ImageArgs img, const MapArgs map, float* ymap,
+                                                           float* xmap) {
+  __shared__ double s_row[kMaxTileRows][4];
+  __shared__ double s_coef[kMaxFact];
+  const int ty = blockIdx.x / img.tiles_x;
+  const int tx = blockIdx.x - ty * img.tiles_x;
+  const int y0 = ty * img.tile_rows;
+  const int x = tx * kBlock + (int)threadIdx.x;
+  const int rows = min(img.tile_rows, img.H - y0);
+  if ((int)threadIdx.x < rows) fill_row<KIND, 4>(map, s_row, threadIdx.x, (double)(y0 + (int)threadIdx.x));
+  if constexpr (KIND != kPersp) {
+    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
+  }
+  __syncthreads();
+  if (x >= img.W) return;
+  const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
+  const ColCtx col = make_col<KIND, -1>(map, x);
+  for (int k = 0; k < rows; ++k) {
+    double xd, yd;
+    map_coord<KIND, -1, 4>(map, s_row, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+    const size_t o = (size_t)(y0 + k) * (size_t)img.W + (size_t)x;
+    ymap[o] = round_clip_f32(yd, hmaxf);
+    xmap[o] = round_clip_f32(xd, wmaxf);
+  }
+}
+
 // ------------------------------------------------------------------ K4: rows of a (D,H,W) stack
 
 // out[d, r, x] = projection d sampled at the radial source coordinate of (row_start + r, x).
@@ -940,6 +973,21 @@ hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler,
                   : launch_coords_t<kF32Lerp, false>(img, ca, stream);
   }
 #undef DCP_COORDS
+}
+
+hipError_t launch_coord_map(MapKind kind, const ImageArgs& img_in, const MapArgs& map, float* ymap, float* xmap,
+                            hipStream_t stream) {
+  ImageArgs img = img_in;
+  img.tile_rows = 16;
+  img.tiles_x = (img.W + kBlock - 1) / kBlock;
+  img.tiles_y = (img.H + img.tile_rows - 1) / img.tile_rows;
+  const dim3 grid(img.tiles_x * img.tiles_y);
+  switch (kind) {
+    case kRadial: hipLaunchKernelGGL((coord_map_kernel<kRadial>), grid, dim3(kBlock), 0, stream, img, map, ymap, xmap); break;
+    case kPersp: hipLaunchKernelGGL((coord_map_kernel<kPersp>), grid, dim3(kBlock), 0, stream, img, map, ymap, xmap); break;
+    default: hipLaunchKernelGGL((coord_map_kernel<kFused>), grid, dim3(kBlock), 0, stream, img, map, ymap, xmap); break;
+  }
+  return hipGetLastError();
 }
 
 template <int NF, bool ROUND32>

@@ -39,7 +39,8 @@ import numpy as np
 from .. import _ffi as F
 
 __all__ = ["unwarp_image_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
-           "correct_perspective_image", "unwarp_perspective_fused", "remap_coordinates"]
+           "correct_perspective_image", "unwarp_perspective_fused", "remap_coordinates",
+           "generate_radial_map", "generate_fused_map"]
 
 _MODES = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
 
@@ -270,6 +271,56 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     F.check(F.lib().dcp_perspective_image_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], ca,
                                               order, bcode, img.mem, img.device, img.stream))
     return out
+
+
+def _coordinate_map(shape, kind, xcenter, ycenter, list_fact, list_coef, like):
+    (height, width) = shape
+    fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
+    ca, _ = F.fact_array(_coefs(list_coef, "list_coef")) if list_coef is not None else (None, 0)
+    if like is not None and _is_torch(like) and like.is_cuda:
+        import torch
+        ymap = torch.empty((height, width), dtype=torch.float32, device=like.device)
+        xmap = torch.empty((height, width), dtype=torch.float32, device=like.device)
+        yp, xp, mem = ymap.data_ptr(), xmap.data_ptr(), F.MEM_DEVICE
+        dev = like.device.index if like.device.index is not None else torch.cuda.current_device()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+    else:
+        ymap = np.empty((height, width), np.float32)
+        xmap = np.empty((height, width), np.float32)
+        yp, xp, mem = ymap.ctypes.data, xmap.ctypes.data, F.MEM_HOST
+        dev, stream = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1")), None
+    F.require_device()
+    F.check(F.lib().dcp_coordinate_map_f32(yp, xp, height, width, kind, float(xcenter), float(ycenter), fa, nf, ca, mem,
+                                           dev, stream))
+    return ymap, xmap
+
+
+def _generate_perspective_map(mat, list_coef):
+    """
+    Generate mapping indices between images (reference ``postprocessing.py:444-459``): the tuple
+    ``(yd, xd)`` of float32 arrays of shape ``(height*width, 1)`` that ``correct_perspective_image``
+    accepts as ``map_index``.
+    """
+    (height, width) = mat.shape
+    ymap, xmap = _coordinate_map((height, width), F.MAP_PERSPECTIVE, 0.0, 0.0, [], list_coef, mat)
+    return ymap.reshape((-1, 1)), xmap.reshape((-1, 1))
+
+
+def generate_radial_map(shape, xcenter, ycenter, list_fact, *, like=None):
+    """
+    The float32 ``(yd_mat, xd_mat)`` planes of ``unwarp_image_backward`` (reference :141-145) for an
+    image of ``shape`` -- e.g. for ``cv2.remap(img, xd_mat, yd_mat, ...)`` as
+    ``discorpy/util/utility.py:425-435`` does, or for ``remap_coordinates``.  ``like`` = a device
+    tensor to get device-resident maps.
+    """
+    return _coordinate_map(tuple(shape), F.MAP_RADIAL, xcenter, ycenter, list_fact, None, like)
+
+
+def generate_fused_map(shape, xcenter, ycenter, list_fact, list_coef, *, like=None):
+    """The composed perspective -> radial map of :func:`unwarp_perspective_fused`, as (yd, xd)."""
+    if len(list_coef) != 8:
+        raise ValueError("!!! Eight coefficients are required !!!")
+    return _coordinate_map(tuple(shape), F.MAP_FUSED, xcenter, ycenter, list_fact, list_coef, like)
 
 
 def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=1, mode="reflect", *, blend=None):

@@ -104,6 +104,20 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
                               const double* list_fact, int nfact, double row_start, int64_t nrows,
                               int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream);
 
+/* The float32 source-coordinate planes themselves, ymap / xmap of height*width floats each:
+ * DCP_MAP_RADIAL       yd_mat / xd_mat of unwarp_image_backward, discorpy/post/postprocessing.py:141-145
+ * DCP_MAP_PERSPECTIVE  _generate_perspective_map, :444-459 (list_fact ignored)
+ * DCP_MAP_FUSED        the composed map of dcp_unwarp_fused_f32
+ * for callers that reuse a map (map_index= of correct_perspective_image :478-479, cv2.remap as in
+ * discorpy/util/utility.py:425-435).  Feeding the planes to dcp_remap_coords_f32 reproduces the
+ * corresponding image entry point bit for bit. */
+#define DCP_MAP_RADIAL 0
+#define DCP_MAP_PERSPECTIVE 1
+#define DCP_MAP_FUSED 2
+int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t width, int map_kind, double xcenter,
+                           double ycenter, const double* list_fact, int nfact, const double* list_coef, int mem_kind,
+                           int device, void* stream);
+
 /* Diagnostics of the LDS-staged gather on the current device: out[0] = wave tiles whose source
  * box did not fit the LDS slab, out[1] = wave tiles whose containment vote failed (both fall back
  * to the direct gather).  Synchronises the device. */

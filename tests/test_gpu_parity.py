@@ -110,6 +110,42 @@ def test_g7_fused_and_two_pass(hip):
     assert np.array_equal(via_map, g["fused_out"])
 
 
+def test_coordinate_planes_equal_the_references(hip, orc):
+    """The float32 (yd, xd) planes computed on the GPU against the planes numpy produced in the
+    reference (postprocessing.py:141-145, 444-459): the sharpest statement of coordinate parity."""
+    for name in ("g5_cfg2_160", "g5_offcentre_150x200", "g5_cfg5_9term_144", "g7_fused144"):
+        g = golden(name)
+        shape = tuple(int(v) for v in g["shape"])
+        if name == "g7_fused144":
+            yd, xd = pp.generate_fused_map(shape, float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]),
+                                           list(g["list_coef"]))
+        else:
+            yd, xd = pp.generate_radial_map(shape, float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+        assert yd.dtype == np.float32 and np.array_equal(yd, g["yd"]) and np.array_equal(xd, g["xd"]), name
+    # _generate_perspective_map: same call, same return shape as the reference; feeding it back as
+    # map_index reproduces correct_perspective_image
+    g = golden("g7_fused144")
+    img = noise(g["seed"], g["shape"])
+    ymap, xmap = pp._generate_perspective_map(img, list(g["list_coef"]))
+    assert ymap.shape == (img.size, 1) and xmap.shape == (img.size, 1) and ymap.dtype == np.float32
+    oy, ox = orc.perspective_coords(img.shape[0], img.shape[1], list(g["list_coef"]))
+    assert np.array_equal(ymap.reshape(img.shape), oy.astype(np.float32))
+    assert np.array_equal(xmap.reshape(img.shape), ox.astype(np.float32))
+    assert np.array_equal(pp.correct_perspective_image(img, list(g["list_coef"]), map_index=(ymap, xmap), blend="scipy"),
+                          g["persp_out"])
+    # full cfg2 frame: every one of the 33.5 M coordinates against the oracle's kernel order
+    c = configs.cfg2()
+    yd, xd = pp.generate_radial_map(c["shape"], c["xcenter"], c["ycenter"], c["list_fact"])
+    oy, ox = orc.radial_coords(c["shape"][0], c["shape"][1], c["xcenter"], c["ycenter"], c["list_fact"],
+                               poly=orc.POLY_KERNEL)
+    assert np.array_equal(yd, oy.astype(np.float32)) and np.array_equal(xd, ox.astype(np.float32))
+    # ... and against numpy's own evaluation order: 0-2 rounding-boundary coordinates per frame
+    ny, nx = orc.radial_coords(c["shape"][0], c["shape"][1], c["xcenter"], c["ycenter"], c["list_fact"],
+                               poly=orc.POLY_NUMPY)
+    flips = int((yd != ny.astype(np.float32)).sum() + (xd != nx.astype(np.float32)).sum())
+    assert flips <= 4, flips
+
+
 def test_g8_clipping_stress_all_modes(hip):
     g = golden("g8_clip120x180")
     img = noise(g["seed"], g["shape"])
