@@ -1,17 +1,21 @@
 // unwarp_kernels.hip -- hand-written gfx950 (CDNA4 / MI355X) kernels for the backward
 // unwarp path of discorpy (reference: /root/reference/discorpy/post/postprocessing.py).
 //
-//   remap_tile_kernel<Radial>   K1  unwarp_image_backward            postprocessing.py:137-148
-//   remap_tile_kernel<Persp>    K2  correct_perspective_image        postprocessing.py:448-459,486-492
-//   remap_tile_kernel<Fused>    K3  perspective o radial in one pass
+//   remap_lds_kernel / remap_tile_kernel <Radial>  K1  unwarp_image_backward      postprocessing.py:137-148
+//   remap_lds_kernel / remap_tile_kernel <Persp>   K2  correct_perspective_image  postprocessing.py:448-459,486-492
+//   remap_lds_kernel / remap_tile_kernel <Fused>   K3  perspective o radial in one pass
 //   stack_rows_kernel           K4  unwarp_slice_backward / unwarp_chunk_slices_backward  :211-229,:281-313
 //   remap_coords_kernel         K5  map_index= / _mapping            postprocessing.py:250-251,489-491
 //   coord_map_kernel            K6  the float32 (yd, xd) planes      postprocessing.py:144-145,444-459
 //
 // Design (see DESIGN.md for the numbers):
-//  * one thread per output pixel column, 64-wide wavefronts along x, a workgroup of 4 waves
-//    walks `tile_rows` rows of a 256-pixel-wide tile: stores are 256 B contiguous per wave
-//    instruction, the two source rows a wave gathers from are ~260 B contiguous each.
+//  * one thread per output pixel column, 64-wide wavefronts along x: a wave's store is 256 B
+//    contiguous.  The default order-1 kernel (remap_lds_kernel) gives every wave a 64 x 16 output
+//    tile, predicts the tile's source box from its four corner pixels, copies the box into a
+//    wave-private LDS slab with row-contiguous 16-byte LDS-DMA loads while the remaining
+//    coordinates are computed, and gathers the four taps of every pixel from LDS.  The direct
+//    kernel (remap_tile_kernel) gathers tap pairs from global memory with 8-byte buffer loads;
+//    it serves order 0, float64 coordinates, strided / degenerate sources and the fallback.
 //  * the coordinate polynomial is evaluated in fp64 (the reference computes float64 and only
 //    then rounds to float32, postprocessing.py:144-145; an fp32 evaluation changes 34 % of the
 //    coordinates by one ulp).  Everything that does not depend on x is staged once per
@@ -19,9 +23,10 @@
 //    does not depend on y lives in registers across the row loop; coefficients are SGPR
 //    resident (kernarg) for vectors of <= 10 terms and staged in LDS for longer ones.
 //  * sqrt is the correctly rounded fp64 result built from v_rsq_f64 + one coupled Newton
-//    step + one residual correction (validated against the host sqrt in tools/ubench.hip).
-//  * the gather uses raw buffer loads: a 32-bit byte offset per lane, the second row through
-//    the scalar offset, hardware bounds checking; the two taps of a row are one 8-byte load.
+//    step + one residual correction (tools/ubench.hip); the two homography divisions share one
+//    refined reciprocal and are correctly rounded too (tools/ubench_div.hip).
+//  * every global access goes through a buffer descriptor: a 32-bit byte offset per lane, row
+//    steps through the scalar offset, hardware bounds checking.
 //  * no MFMA: the op is a remap (8 B of HBM traffic per pixel), not a contraction.
 //
 // Build with -ffp-contract=off: every fused multiply-add below is written explicitly so that
