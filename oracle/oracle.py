@@ -49,8 +49,51 @@ def lib():
         L.orc_remap_coords_f32.argtypes = [fp, fp, i64, i64, i64, vp, vp, i32, i64, i32, i32]
         L.orc_unwarp_stack_rows_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, dbl, i64,
                                                 i32, i32, i32]
+        L.orc_spline_pad.argtypes = [i32]
+        L.orc_spline_coefficients_f32.argtypes = [fp, i64, i64, i64, i32, i32, dp]
+        L.orc_remap_spline_f32.argtypes = [fp, fp, i64, i64, i64, i32, dbl, dbl, dp, i32, dp, vp, vp, i32, i64, i32, i32,
+                                           i32, dp]
         _lib = L
     return _lib
+
+
+MODES = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+
+
+def _spline(mat, map_kind, order, mode, xcenter=0.0, ycenter=0.0, list_fact=(), list_coef=None, ycoord=None,
+            xcoord=None, poly=1):
+    """order 2..5: scipy's prefiltered spline interpolation (oracle/unwarp_oracle.c, spline section)."""
+    mat = _f32c(mat)
+    (height, width) = mat.shape
+    m = MODES.index(mode)
+    pad = lib().orc_spline_pad(m)
+    work = np.empty((height + 2 * pad, width + 2 * pad), np.float64)
+    f = _facts(list_fact)
+    c = _facts(list_coef if list_coef is not None else [0.0] * 8)
+    if map_kind == 2:
+        yc_, xc_ = np.ascontiguousarray(ycoord), np.ascontiguousarray(xcoord)
+        if yc_.dtype != xc_.dtype or yc_.dtype not in (np.float32, np.float64):
+            raise TypeError("coordinates must both be float32 or both float64")
+        out = np.empty(yc_.shape, np.float32)
+        yp, xp, is64, n = yc_.ctypes.data, xc_.ctypes.data, int(yc_.dtype == np.float64), yc_.size
+    else:
+        out = np.empty((height, width), np.float32)
+        yp = xp = None
+        is64, n = 0, 0
+    _check(lib().orc_remap_spline_f32(_fp(mat), _fp(out), height, width, _row_stride(mat), map_kind, float(xcenter),
+                                      float(ycenter), _dp(f), f.size, _dp(c), yp, xp, is64, n, int(order), m, poly,
+                                      _dp(work)))
+    return out
+
+
+def spline_coefficients(mat, order, mode):
+    mat = _f32c(mat)
+    (height, width) = mat.shape
+    m = MODES.index(mode)
+    pad = lib().orc_spline_pad(m)
+    work = np.empty((height + 2 * pad, width + 2 * pad), np.float64)
+    _check(lib().orc_spline_coefficients_f32(_fp(mat), height, width, _row_stride(mat), int(order), m, _dp(work)))
+    return work
 
 
 def set_threads(n):
@@ -112,6 +155,8 @@ def perspective_coords(height, width, list_coef, round_f32=True):
 def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *,
                           poly=POLY_NUMPY, blend=BLEND_SCIPY, coord_round_f32=True):
     """postprocessing.py:111-148 for float32 `mat`, order 0/1 (mode is inert there)."""
+    if int(order) >= 2:
+        return _spline(mat, 0, order, mode, xcenter, ycenter, list_fact, poly=poly)
     mat = _f32c(mat)
     (height, width) = mat.shape
     f = _facts(list_fact)
@@ -129,6 +174,11 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
         raise ValueError("!!! Eight coefficients are required !!!")
     mat = _f32c(mat)
     (height, width) = mat.shape
+    if int(order) >= 2:
+        if map_index is None:
+            return _spline(mat, 1, order, mode, list_coef=list_coef)
+        ycoord, xcoord = (np.ascontiguousarray(np.asarray(m).reshape(-1)) for m in map_index)
+        return _spline(mat, 2, order, mode, ycoord=ycoord, xcoord=xcoord).reshape(height, width)
     out = np.empty((height, width), np.float32)
     if map_index is None:
         c = _facts(list_coef)
@@ -139,8 +189,10 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     return remap_coords(mat, ycoord, xcoord, order=order, blend=blend).reshape(height, width)
 
 
-def remap_coords(mat, ycoord, xcoord, order=1, *, blend=BLEND_SCIPY):
+def remap_coords(mat, ycoord, xcoord, order=1, *, blend=BLEND_SCIPY, mode="reflect"):
     """map_coordinates(mat, (ycoord, xcoord), order) for in-range coordinates."""
+    if int(order) >= 2:
+        return _spline(mat, 2, order, mode, ycoord=ycoord, xcoord=xcoord)
     mat = _f32c(mat)
     ycoord = np.ascontiguousarray(ycoord)
     xcoord = np.ascontiguousarray(xcoord)

@@ -359,3 +359,258 @@ int orc_unwarp_stack_rows_f32(const float *vol, float *out, int64_t D, int64_t H
     }
     return 0;
 }
+
+/* ======================================================================================
+ * Spline orders 2..5: scipy.ndimage.map_coordinates with prefilter.
+ *
+ * Published algorithm (scipy ndimage: ni_splines.c / ni_interpolation.c, after Thevenaz et al.):
+ *  1. modes 'nearest' and 'grid-constant' pad the input by 12 samples (edge values / zeros);
+ *  2. the (padded) image is turned into B-spline coefficients, float64, by a separable recursive
+ *     filter, axis 0 then axis 1: gain prod (1-z)(1-1/z) over the poles z of the order, then per
+ *     pole a causal and an anti-causal pass with EXACT initial values for the boundary extension
+ *     'reflect' (half-sample symmetric; modes reflect, grid-mirror), periodic (grid-wrap) or
+ *     'mirror' (whole-sample symmetric; every other mode);
+ *  3. a point is the (order+1)^2-tap sum  t += (c * wy) * wx,  taps row-major from
+ *     floor(c) - order/2 (odd orders) or floor(c + 0.5) - order/2 (even orders), with the
+ *     centred B-spline weights; taps outside the array fold back by the boundary mode
+ *     ('constant' and 'wrap' fold like 'mirror' for in-range coordinates).
+ * Pinned against scipy 1.15.3 for all 8 modes x 4 orders by tests/golden/g11_* (float32-equal).
+ * The reference reaches this path through order=3 in examples/readthedocs_demo/demo_07.py:60.
+ * ====================================================================================== */
+
+static int spline_poles(int order, double *z)
+{
+    switch (order) {
+    case 2: z[0] = sqrt(8.0) - 3.0; return 1;
+    case 3: z[0] = sqrt(3.0) - 2.0; return 1;
+    case 4: z[0] = sqrt(664.0 - sqrt(438976.0)) + sqrt(304.0) - 19.0;
+            z[1] = sqrt(664.0 + sqrt(438976.0)) - sqrt(304.0) - 19.0; return 2;
+    case 5: z[0] = sqrt(67.5 - sqrt(4436.25)) + sqrt(26.25) - 6.5;
+            z[1] = sqrt(67.5 + sqrt(4436.25)) - sqrt(26.25) - 6.5; return 2;
+    default: return 0;
+    }
+}
+
+/* filter kinds */
+#define SPL_MIRROR 0
+#define SPL_REFLECT 1
+#define SPL_WRAP 2
+
+static int spline_filter_kind(int mode)
+{
+    if (mode == ORC_MODE_REFLECT || mode == ORC_MODE_GRID_MIRROR) return SPL_REFLECT;
+    if (mode == ORC_MODE_GRID_WRAP) return SPL_WRAP;
+    return SPL_MIRROR;
+}
+
+/* in-place recursive filter of n samples with stride s */
+static void spline_filter_line(double *c, int64_t n, int64_t s, const double *poles, int npoles, int kind)
+{
+    if (n < 2) return;
+    double lam = 1.0;
+    for (int p = 0; p < npoles; ++p) lam *= (1.0 - poles[p]) * (1.0 - 1.0 / poles[p]);
+    for (int64_t i = 0; i < n; ++i) c[i * s] *= lam;
+    for (int p = 0; p < npoles; ++p) {
+        const double z = poles[p];
+        if (kind == SPL_REFLECT) {
+            double z_i = z;
+            const double z_n = pow(z, (double)n);
+            const double c0 = c[0];
+            double acc = c[0] + z_n * c[(n - 1) * s];
+            for (int64_t i = 1; i < n; ++i) {
+                acc += z_i * (c[i * s] + z_n * c[(n - 1 - i) * s]);
+                z_i *= z;
+            }
+            c[0] = acc * z / (1.0 - z_i * z_i) + c0;
+            for (int64_t i = 1; i < n; ++i) c[i * s] += z * c[(i - 1) * s];
+            c[(n - 1) * s] *= z / (z - 1.0);
+            for (int64_t i = n - 2; i >= 0; --i) c[i * s] = z * (c[(i + 1) * s] - c[i * s]);
+        } else if (kind == SPL_MIRROR) {
+            double z_i = z;
+            const double z_n_1 = pow(z, (double)(n - 1));
+            double acc = c[0] + z_n_1 * c[(n - 1) * s];
+            for (int64_t i = 1; i < n - 1; ++i) {
+                acc += z_i * (c[i * s] + z_n_1 * c[(n - 1 - i) * s]);
+                z_i *= z;
+            }
+            c[0] = acc / (1.0 - z_n_1 * z_n_1);
+            for (int64_t i = 1; i < n; ++i) c[i * s] += z * c[(i - 1) * s];
+            c[(n - 1) * s] = (z / (z * z - 1.0)) * (c[(n - 1) * s] + z * c[(n - 2) * s]);
+            for (int64_t i = n - 2; i >= 0; --i) c[i * s] = z * (c[(i + 1) * s] - c[i * s]);
+        } else {
+            double z_i = z, acc = c[0];
+            for (int64_t i = n - 1; i > 0; --i) {
+                acc += z_i * c[i * s];
+                z_i *= z;
+            }
+            c[0] = acc / (1.0 - z_i);
+            for (int64_t i = 1; i < n; ++i) c[i * s] += z * c[(i - 1) * s];
+            z_i = z;
+            acc = c[(n - 1) * s];
+            for (int64_t i = 0; i < n - 1; ++i) {
+                acc += z_i * c[i * s];
+                z_i *= z;
+            }
+            c[(n - 1) * s] = acc * z / (z_i - 1.0);
+            for (int64_t i = n - 2; i >= 0; --i) c[i * s] = z * (c[(i + 1) * s] - c[i * s]);
+        }
+    }
+}
+
+int orc_spline_pad(int mode) { return (mode == ORC_MODE_NEAREST || mode == ORC_MODE_GRID_CONSTANT) ? 12 : 0; }
+
+/* coefficients of the (padded) image: coef is (H + 2 pad) x (W + 2 pad) doubles */
+int orc_spline_coefficients_f32(const float *src, int64_t H, int64_t W, int64_t src_row_stride, int order,
+                                int mode, double *coef)
+{
+    double poles[2];
+    const int np = spline_poles(order, poles);
+    if (np == 0 || H <= 0 || W <= 0) return -1;
+    const int pad = orc_spline_pad(mode);
+    const int64_t Hp = H + 2 * pad, Wp = W + 2 * pad;
+    for (int64_t y = 0; y < Hp; ++y)
+        for (int64_t x = 0; x < Wp; ++x) {
+            int64_t sy = y - pad, sx = x - pad;
+            double v;
+            if (mode == ORC_MODE_GRID_CONSTANT && (sy < 0 || sy >= H || sx < 0 || sx >= W)) v = 0.0;
+            else {
+                sy = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy);
+                sx = sx < 0 ? 0 : (sx > W - 1 ? W - 1 : sx);
+                v = (double)src[sy * src_row_stride + sx];
+            }
+            coef[y * Wp + x] = v;
+        }
+    const int kind = spline_filter_kind(mode);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t x = 0; x < Wp; ++x) spline_filter_line(coef + x, Hp, Wp, poles, np, kind);   /* axis 0 */
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t y = 0; y < Hp; ++y) spline_filter_line(coef + y * Wp, Wp, 1, poles, np, kind); /* axis 1 */
+    return 0;
+}
+
+/* centred B-spline weights; returns the first tap index */
+static int64_t spline_weights(int order, double x, double *w)
+{
+    double s, t;
+    if (order & 1) s = floor(x);
+    else s = floor(x + 0.5);
+    t = x - s;
+    const int64_t start = (int64_t)s - order / 2;
+    double y = t, z = 1.0 - t, t2;
+    switch (order) {
+    case 2:
+        w[1] = 0.75 - t * t;
+        y = 0.5 + t;
+        w[2] = 0.5 * y * y;
+        w[0] = 1.0 - w[1] - w[2];
+        break;
+    case 3:
+        w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
+        w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
+        w[0] = z * z * z / 6.0;
+        w[3] = 1.0 - w[0] - w[1] - w[2];
+        break;
+    case 4:
+        t2 = t * t;
+        w[2] = t2 * (t2 * 0.25 - 0.625) + 115.0 / 192.0;
+        y = 1.0 + t;
+        z = 1.0 - t;
+        w[1] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        w[3] = z * (z * (z * (5.0 - z) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+        y = 0.5 - t;
+        y *= y;
+        w[0] = y * y / 24.0;
+        w[4] = 1.0 - w[0] - w[1] - w[2] - w[3];
+        break;
+    default: /* 5 */
+        t2 = y * y;
+        w[2] = t2 * (t2 * (0.25 - y / 12.0) - 0.5) + 0.55;
+        t2 = z * z;
+        w[3] = t2 * (t2 * (0.25 - z / 12.0) - 0.5) + 0.55;
+        y += 1.0;
+        w[1] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        y = z + 1.0;
+        w[4] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+        t2 = z * z;
+        w[0] = t2 * t2 * z / 120.0;
+        w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
+        break;
+    }
+    return start;
+}
+
+static inline int64_t spline_fold(int64_t i, int64_t n, int mode)
+{
+    if (i >= 0 && i < n) return i;
+    if (mode == ORC_MODE_REFLECT || mode == ORC_MODE_GRID_MIRROR) {
+        const int64_t s2 = 2 * n;
+        i %= s2;
+        if (i < 0) i += s2;
+        return i < n ? i : s2 - 1 - i;
+    }
+    if (mode == ORC_MODE_GRID_WRAP) {
+        i %= n;
+        return i < 0 ? i + n : i;
+    }
+    if (mode == ORC_MODE_NEAREST || mode == ORC_MODE_GRID_CONSTANT) /* padded: cannot happen for in-range points */
+        return i < 0 ? 0 : n - 1;
+    if (n == 1) return 0;                     /* mirror, constant, wrap */
+    const int64_t s2 = 2 * n - 2;
+    i %= s2;
+    if (i < 0) i += s2;
+    return i < n ? i : s2 - i;
+}
+
+/* one point of the padded coefficient array; (y, x) are coordinates in the UNPADDED image */
+static inline float spline_sample(const double *coef, int64_t Hp, int64_t Wp, int pad, double y, double x,
+                                  int order, int mode)
+{
+    double wy[6], wx[6];
+    const int64_t sy = spline_weights(order, y + (double)pad, wy);
+    const int64_t sx = spline_weights(order, x + (double)pad, wx);
+    double t = 0.0;
+    for (int j = 0; j <= order; ++j) {
+        const int64_t iy = spline_fold(sy + j, Hp, mode);
+        for (int i = 0; i <= order; ++i) {
+            const int64_t ix = spline_fold(sx + i, Wp, mode);
+            t += (coef[iy * Wp + ix] * wy[j]) * wx[i];
+        }
+    }
+    return (float)t;
+}
+
+/* map_kind: 0 radial (unwarp_image_backward), 1 perspective (correct_perspective_image), 2 explicit
+   coordinates (float32 / float64, clamped to the image) */
+int orc_remap_spline_f32(const float *src, float *dst, int64_t H, int64_t W, int64_t src_row_stride, int map_kind,
+                         double xc, double yc, const double *fact, int nfact, const double *coef8,
+                         const void *ycoord, const void *xcoord, int coord_is_f64, int64_t npts, int order,
+                         int mode, int poly_mode, double *workspace)
+{
+    if (order < 2 || order > 5 || mode < 0 || mode > 7) return -1;
+    if (orc_spline_coefficients_f32(src, H, W, src_row_stride, order, mode, workspace) != 0) return -1;
+    const int pad = orc_spline_pad(mode);
+    const int64_t Hp = H + 2 * pad, Wp = W + 2 * pad;
+    if (map_kind == 2) {
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (int64_t i = 0; i < npts; ++i) {
+            double y = coord_is_f64 ? ((const double *)ycoord)[i] : (double)((const float *)ycoord)[i];
+            double x = coord_is_f64 ? ((const double *)xcoord)[i] : (double)((const float *)xcoord)[i];
+            y = clipd(y, 0.0, (double)(H - 1));
+            x = clipd(x, 0.0, (double)(W - 1));
+            dst[i] = spline_sample(workspace, Hp, Wp, pad, y, x, order, mode);
+        }
+        return 0;
+    }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t y = 0; y < H; ++y)
+        for (int64_t x = 0; x < W; ++x) {
+            double xd, yd;
+            if (map_kind == 0)
+                radial_coord((double)x, (double)y, xc, yc, fact, nfact, poly_mode, (double)(W - 1), (double)(H - 1), 1,
+                             &xd, &yd);
+            else
+                persp_coord((double)x, (double)y, coef8, (double)(W - 1), (double)(H - 1), 1, &xd, &yd);
+            dst[y * W + x] = spline_sample(workspace, Hp, Wp, pad, yd, xd, order, mode);
+        }
+    return 0;
+}

@@ -13,6 +13,16 @@ extern "C" {
 #define ORC_BLEND_F64LERP 1
 #define ORC_BLEND_F32LERP 2
 
+/* scipy boundary modes, in the order of the reference's docstrings (postprocessing.py:128-130) */
+#define ORC_MODE_REFLECT 0
+#define ORC_MODE_GRID_MIRROR 1
+#define ORC_MODE_CONSTANT 2
+#define ORC_MODE_GRID_CONSTANT 3
+#define ORC_MODE_NEAREST 4
+#define ORC_MODE_MIRROR 5
+#define ORC_MODE_GRID_WRAP 6
+#define ORC_MODE_WRAP 7
+
 void orc_set_threads(int n);
 int orc_get_threads(void);
 int orc_max_threads(void);
@@ -34,6 +44,13 @@ int orc_remap_coords_f32(const float *src, float *dst, int64_t H, int64_t W, int
 int orc_unwarp_stack_rows_f32(const float *vol, float *out, int64_t D, int64_t H, int64_t W,
                               double xc, double yc, const double *fact, int nfact, double row_start,
                               int64_t nrows, int coord_round_f32, int poly_mode, int blend_mode);
+int orc_spline_pad(int mode);
+int orc_spline_coefficients_f32(const float *src, int64_t H, int64_t W, int64_t src_row_stride, int order, int mode,
+                                double *coef);
+int orc_remap_spline_f32(const float *src, float *dst, int64_t H, int64_t W, int64_t src_row_stride, int map_kind,
+                         double xc, double yc, const double *fact, int nfact, const double *coef8,
+                         const void *ycoord, const void *xcoord, int coord_is_f64, int64_t npts, int order,
+                         int mode, int poly_mode, double *workspace);
 #ifdef __cplusplus
 }
 #endif

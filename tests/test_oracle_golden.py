@@ -159,3 +159,26 @@ def test_degenerate_shapes(orc):
     one = np.full((1, 1), 3.5, np.float32)
     assert orc.unwarp_image_backward(one, 0.0, 0.0, [1.0])[0, 0] == np.float32(3.5)
     assert orc.unwarp_image_backward(one, 0.0, 0.0, [])[0, 0] == np.float32(3.5)   # empty list_fact: B = 0
+
+
+# ---------------------------------------------------------------- spline orders 2..5
+
+MODES = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_g11_spline_orders_every_mode(orc, order):
+    g = golden("g11_spline45x60")
+    img = noise(g["seed"], g["shape"])
+    for mode in MODES:
+        out = orc.unwarp_image_backward(img, g["xcenter"], g["ycenter"], g["list_fact"], order=order, mode=mode)
+        assert np.array_equal(out, g["radial_o%d_%s" % (order, mode)]), (order, mode)
+    assert np.array_equal(orc.remap_coords(img, g["pts_y"], g["pts_x"], order=order), g["points_o%d_reflect" % order])
+
+
+def test_g11_perspective_order3_every_mode(orc):
+    g = golden("g11_spline45x60")
+    img = noise(g["seed"], g["shape"])
+    for mode in MODES:
+        assert np.array_equal(orc.correct_perspective_image(img, g["list_coef"], order=3, mode=mode),
+                              g["persp_o3_%s" % mode]), mode

@@ -195,4 +195,22 @@ g10["pad_4_constant"] = util.unwarp_color_image_backward(rgb, 27.4, 19.1, fact10
 g10["pad_4_reflect_order0"] = util.unwarp_color_image_backward(rgb, 27.4, 19.1, fact10, order=0, pad=4, pad_mode="reflect")
 g10["gray_pad_6_mean"] = util.unwarp_color_image_backward(rgb[:, :, 1], 27.4, 19.1, fact10, pad=6, pad_mode="mean")
 save("g10_color40x56x3", **g10)
+# ---- G11: spline orders 2..5 (map_coordinates with prefilter), every boundary mode
+im = np.random.default_rng(71).random((45, 60), dtype=np.float32)
+fact11 = [1.0, 3e-3, 2e-5]
+coef11 = [0.97, -0.02, 2.0, 0.015, 0.95, 1.5, -2e-4, 3e-4]
+g11 = dict(seed=np.int64(71), shape=np.array(im.shape), xcenter=f64(31.3), ycenter=f64(21.8), list_fact=f64(fact11),
+           list_coef=f64(coef11))
+MODES = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+for order in (2, 3, 4, 5):
+    for mode in MODES:
+        g11["radial_o%d_%s" % (order, mode)] = post.unwarp_image_backward(im, 31.3, 21.8, fact11, order=order, mode=mode)
+for mode in MODES:
+    g11["persp_o3_%s" % mode] = post.correct_perspective_image(im, coef11, order=3, mode=mode)   # demo_07.py:60 uses order=3
+pts_y = (np.random.default_rng(72).random(500) * 44).astype(np.float32)
+pts_x = (np.random.default_rng(73).random(500) * 59).astype(np.float32)
+g11["pts_y"], g11["pts_x"] = pts_y, pts_x
+for order in (2, 3, 4, 5):
+    g11["points_o%d_reflect" % order] = map_coordinates(im, (pts_y, pts_x), order=order, mode="reflect")
+save("g11_spline45x60", **g11)
 print("done")
