@@ -50,6 +50,11 @@ SIGNATURES = {
                                     _int, _vp]),
     "dcp_unwarp_stack_rows_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,
                                          _i64, _int, _int, _int, _int, _vp]),
+    "dcp_unwarp_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int, _int,
+                                           _int, _vp]),
+    "dcp_perspective_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),
+    "dcp_remap_coords_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _i64, _int, _int, _int,
+                                           _int, _vp]),
     "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),

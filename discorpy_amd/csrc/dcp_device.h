@@ -1,0 +1,121 @@
+// dcp_device.h -- device-side fp64 building blocks shared by unwarp_kernels.hip and
+// spline_kernels.hip: correctly rounded sqrt and homography division, the even/odd polynomial,
+// the float32 round-and-clip.  Every fused multiply-add is explicit (build with -ffp-contract=off)
+// so that the arithmetic is the same sequence of IEEE operations as oracle/unwarp_oracle.c.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dcp {
+
+// ------------------------------------------------------------------ fp64 helpers
+
+constexpr double kTinyR2 = 1e-300;   // keeps rsq finite at the centre pixel; absorbed everywhere else
+
+// Correctly rounded sqrt for finite x >= 0 (no range scaling: r2 is bounded by the image size).
+__device__ __forceinline__ double sqrt_rn(double x) {
+  double y = __builtin_amdgcn_rsq(x);          // ~2^-24 relative
+  double g = x * y;
+  double h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);                  // ~2^-47
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);          // exact residual
+  g = __builtin_fma(d, h, g);                  // correctly rounded
+  return x == 0.0 ? 0.0 : g;
+}
+
+// The same for x > 0 (no zero select).
+__device__ __forceinline__ double sqrt_pos(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  return __builtin_fma(d, h, g);
+}
+
+// B(ru) = sum a_i ru^i, split into even and odd powers so that only one multiply by ru is
+// needed: E = a0 + r2 (a2 + r2 (a4 + ...)), O = a1 + r2 (a3 + ...), B = fma(ru, O, E).
+// Same operation order as poly_kernel() in oracle/unwarp_oracle.c.
+template <int NF>
+__device__ __forceinline__ double poly_inline(const double* __restrict__ a, double lead_e, double lead_o,
+                                              double r2, double ru) {
+  // lead_e / lead_o: the highest even / odd coefficient, passed separately so the caller can pin
+  // them in VGPRs (a VOP3 fma takes one SGPR operand; the first Horner step would need two)
+  if constexpr (NF == 0) {
+    return 0.0;
+  } else {
+    constexpr int ne = (NF + 1) / 2, no = NF / 2;
+    double E = lead_e;
+#pragma unroll
+    for (int k = ne - 2; k >= 0; --k) E = __builtin_fma(r2, E, a[2 * k]);
+    if constexpr (no == 0) {
+      return E;
+    } else {
+      double O = lead_o;
+#pragma unroll
+      for (int k = no - 2; k >= 0; --k) O = __builtin_fma(r2, O, a[2 * k + 1]);
+      return __builtin_fma(ru, O, E);
+    }
+  }
+}
+template <int NF>
+__device__ __forceinline__ void poly_leads(const double* __restrict__ a, double* lead_e, double* lead_o) {
+  *lead_e = 0.0;
+  *lead_o = 0.0;
+  if constexpr (NF > 0) {
+    double e = a[2 * ((NF + 1) / 2 - 1)];
+    asm volatile("" : "+v"(e));
+    *lead_e = e;
+  }
+  if constexpr (NF > 1) {
+    double o = a[2 * (NF / 2 - 1) + 1];
+    asm volatile("" : "+v"(o));
+    *lead_o = o;
+  }
+}
+
+__device__ __forceinline__ double poly_lds(const double* s_coef, int nf, double r2, double ru) {
+  if (nf <= 0) return 0.0;
+  const int ne = (nf + 1) >> 1, no = nf >> 1;
+  double E = s_coef[2 * (ne - 1)];
+  for (int k = ne - 2; k >= 0; --k) E = __builtin_fma(r2, E, s_coef[2 * k]);
+  if (no == 0) return E;
+  double O = s_coef[2 * (no - 1) + 1];
+  for (int k = no - 2; k >= 0; --k) O = __builtin_fma(r2, O, s_coef[2 * k + 1]);
+  return __builtin_fma(ru, O, E);
+}
+
+// np.float32(np.clip(v, 0, len-1)) == clip(float32(v), 0, len-1): rounding is monotone and
+// both bounds are float32 numbers, so the clip is done after the conversion, in fp32.
+__device__ __forceinline__ float round_clip_f32(double v, float hi) {
+  return __builtin_amdgcn_fmed3f((float)v, 0.0f, hi);
+}
+__device__ __forceinline__ double clip_f64(double v, double hi) {
+  v = v < 0.0 ? 0.0 : v;
+  return v > hi ? hi : v;
+}
+
+// nx/den and ny/den, both correctly rounded, from ONE refined reciprocal (v_rcp_f64 + two Newton
+// steps, then a residual correction per quotient).  Valid while no intermediate leaves the normal
+// range -- the C ABI checks the homography and the image size on the host and otherwise leaves
+// MapArgs::fast_div at 0 (compiler's full IEEE division).  tools/ubench_div.hip: 0 mismatches
+// against the host's division on 3.3e7 quotients.
+__device__ __forceinline__ void div2_rn(double nx, double ny, double den, double* qx, double* qy) {
+  double r = __builtin_amdgcn_rcp(den);
+  double e = __builtin_fma(-den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-den, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  double q = nx * r;
+  double t = __builtin_fma(-den, q, nx);
+  *qx = __builtin_fma(t, r, q);
+  q = ny * r;
+  t = __builtin_fma(-den, q, ny);
+  *qy = __builtin_fma(t, r, q);
+}
+
+}  // namespace dcp

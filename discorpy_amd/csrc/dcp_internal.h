@@ -58,6 +58,21 @@ struct CoordArgs {
   int32_t is_f64;
 };
 
+// scipy boundary modes in the order of the reference's docstrings (postprocessing.py:128-130)
+enum BoundaryMode : int { kModeReflect = 0, kModeGridMirror, kModeConstant, kModeGridConstant, kModeNearest, kModeMirror,
+                          kModeGridWrap, kModeWrap };
+enum SplineFilterKind : int { kSplMirror = 0, kSplReflect = 1, kSplWrap = 2 };
+
+struct SplineArgs {
+  const float* src;
+  double* coef;            // (Hp x Wp) float64 workspace: padded image -> B-spline coefficients
+  int32_t H, W, src_stride, src_cstride;
+  int32_t Hp, Wp, pad;     // pad = 12 for 'nearest' / 'grid-constant', else 0
+  int32_t order, mode, filter_kind, npoles;
+  double poles[2];
+  double zpow[2][2];       // [axis][pole]: z^n (reflect) or z^(n-1) (mirror), evaluated on the host
+};
+
 struct LaunchOpts {
   int tile_rows = 16;
   int xcd_remap = 2;
@@ -77,5 +92,8 @@ hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bo
                         const LaunchOpts& opts, hipStream_t stream);
 
 hipError_t read_lds_stats(unsigned long long* out, bool reset);
+// spline_kernels.hip: map_kind 0 radial, 1 perspective, 2 explicit coordinates
+hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, float* dst,
+                         hipStream_t stream);
 
 }  // namespace dcp

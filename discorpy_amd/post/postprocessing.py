@@ -24,9 +24,10 @@ What differs from the reference, on purpose:
 
 * data must be float32 (what ``discorpy.losa.load_image`` / ``load_hdf_file`` produce); other
   dtypes raise ``NotImplementedError`` instead of silently taking another code path;
-* spline ``order`` 0 and 1 only (``order >= 2`` raises ``NotImplementedError``).  For these
-  orders ``mode`` cannot influence the result because every coordinate is clipped into the image
-  first (SURVEY.md section 0.5); it is validated and otherwise ignored;
+* for spline ``order`` 0 and 1 ``mode`` cannot influence the result because every coordinate is
+  clipped into the image first; it is validated and otherwise ignored.
+  Orders 2..5 run scipy's prefiltered B-spline interpolation on the GPU with all eight modes
+  (within one float32 ulp of scipy);
 * keyword-only extras: ``blend`` selects the bilinear arithmetic (``"f64lerp"`` default: float64
   factorised lerp, within one float32 ulp of scipy and bit-equal in practice; ``"scipy"``:
   scipy's exact float64 operation order; ``"f32"``: float32 lerp, opt-in).
@@ -70,8 +71,6 @@ def _check_order_mode(order, mode):
     order = int(order)
     if order < 0 or order > 5:
         raise RuntimeError("spline order not supported")
-    if order > 1:
-        raise NotImplementedError("spline order %d is not implemented on the GPU path (orders 0 and 1 are)" % order)
     return order
 
 
@@ -175,6 +174,11 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     fa, nf = F.fact_array(fact)
     out, optr = img.empty((height, width))
     F.require_device()
+    if order >= 2:
+        F.check(F.lib().dcp_unwarp_image_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
+                                                    float(xcenter), float(ycenter), fa, nf, order, _MODES.index(mode),
+                                                    img.mem, img.device, img.stream))
+        return out
     F.check(F.lib().dcp_unwarp_image_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
                                          float(xcenter), float(ycenter), fa, nf, order, 1, bcode,
                                          img.mem, img.device, img.stream))
@@ -264,10 +268,14 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     img = _Image(mat, 2).dense_rows()
     if map_index is not None:
         ymap, xmap = map_index[0], map_index[1]
-        return remap_coordinates(mat, ymap, xmap, order=order, blend=blend).reshape((height, width))
+        return remap_coordinates(mat, ymap, xmap, order=order, mode=mode, blend=blend).reshape((height, width))
     ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
     out, optr = img.empty((height, width))
     F.require_device()
+    if order >= 2:
+        F.check(F.lib().dcp_perspective_image_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
+                                                         ca, order, _MODES.index(mode), img.mem, img.device, img.stream))
+        return out
     F.check(F.lib().dcp_perspective_image_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], ca,
                                               order, bcode, img.mem, img.device, img.stream))
     return out
@@ -338,6 +346,9 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
         raise ValueError("!!! Eight coefficients are required !!!")
     (height, width) = mat.shape
     order = _check_order_mode(order, mode)
+    if order > 1:
+        raise NotImplementedError("the fused one-pass remap is implemented for orders 0 and 1 "
+                                  "(use remap_coordinates with generate_fused_map for a spline order)")
     bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
@@ -383,6 +394,11 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
         npts, yptr, xptr, shape = yc.size, yc.ctypes.data, xc.ctypes.data, yc.shape
     out, optr = img.empty(shape)
     F.require_device()
+    if order >= 2:
+        F.check(F.lib().dcp_remap_coords_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], yptr,
+                                                    xptr, cdt, npts, order, _MODES.index(mode), img.mem, img.device,
+                                                    img.stream))
+        return out
     F.check(F.lib().dcp_remap_coords_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], yptr, xptr,
                                          cdt, npts, order, bcode, img.mem, img.device, img.stream))
     return out

@@ -16,7 +16,7 @@
  *     `device`, the kernel is enqueued on `stream` (a hipStream_t, NULL = default stream) and the
  *     call returns without synchronising; the caller owns the memory and its lifetime.
  *   - device < 0 means "the calling thread's current HIP device".
- *   - order: 0 nearest (floor(c + 0.5)), 1 bilinear.  Higher spline orders are not implemented.
+ *   - order: 0 nearest (floor(c + 0.5)), 1 bilinear; orders 2..5 go through the *_spline_* entry points.
  *   - blend_mode (order 1 only): DCP_BLEND_SCIPY reproduces scipy.ndimage.map_coordinates'
  *     float64 arithmetic bit for bit; DCP_BLEND_F64LERP is the factorised float64 form (equal to
  *     it to <= 1 float32 ulp, in practice bit-equal); DCP_BLEND_F32LERP is float32 arithmetic
@@ -103,6 +103,32 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
                               int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
                               const double* list_fact, int nfact, double row_start, int64_t nrows,
                               int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream);
+
+/* ---- spline orders 2..5 (scipy.ndimage.map_coordinates with its B-spline prefilter) ----
+ * The same maps as dcp_unwarp_image_f32 / dcp_perspective_image_f32 / dcp_remap_coords_f32 for
+ * `order` in 2..5 -- what the reference computes when a caller passes order >= 2
+ * (discorpy/post/postprocessing.py:147, 491; examples/readthedocs_demo/demo_07.py:60 uses 3).  Here the
+ * boundary mode matters (prefilter boundary condition, tap folding, 12-sample padding for 'nearest'
+ * and 'grid-constant'):  0 reflect, 1 grid-mirror, 2 constant, 3 grid-constant, 4 nearest, 5 mirror,
+ * 6 grid-wrap, 7 wrap.  Results are within one float32 ulp of scipy's.  A float64 coefficient plane
+ * of (height + 2 pad) x (width + 2 pad) is kept per device by the library. */
+#define DCP_MODE_REFLECT 0
+#define DCP_MODE_GRID_MIRROR 1
+#define DCP_MODE_CONSTANT 2
+#define DCP_MODE_GRID_CONSTANT 3
+#define DCP_MODE_NEAREST 4
+#define DCP_MODE_MIRROR 5
+#define DCP_MODE_GRID_WRAP 6
+#define DCP_MODE_WRAP 7
+int dcp_unwarp_image_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                                int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                                int nfact, int order, int boundary_mode, int mem_kind, int device, void* stream);
+int dcp_perspective_image_spline_f32(const float* src, float* dst, int64_t height, int64_t width,
+                                     int64_t src_row_stride, int64_t src_col_stride, const double* list_coef, int order,
+                                     int boundary_mode, int mem_kind, int device, void* stream);
+int dcp_remap_coords_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                                int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
+                                int64_t npts, int order, int boundary_mode, int mem_kind, int device, void* stream);
 
 /* The float32 source-coordinate planes themselves, ymap / xmap of height*width floats each:
  * DCP_MAP_RADIAL       yd_mat / xd_mat of unwarp_image_backward, discorpy/post/postprocessing.py:141-145

@@ -164,6 +164,63 @@ def test_g9_explicit_coordinates(hip):
     assert np.array_equal(pp.remap_coordinates(img, g["ys64"], g["xs64"], blend="scipy"), g["out64_order1"])
 
 
+MODES = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+
+
+def spline_close(got, ref):
+    d = ulp_diff(got, ref)
+    return d.max() <= 1 and np.count_nonzero(d) <= max(2, got.size // 500)
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5])
+def test_g11_spline_orders_against_the_reference(hip, orc, order):
+    """Orders 2..5 (scipy's prefiltered B-splines): within one float32 ulp of the reference in every
+    boundary mode, and bit-equal to the oracle (same operations in the same order)."""
+    g = golden("g11_spline45x60")
+    img = noise(g["seed"], g["shape"])
+    a = (img, float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    for mode in MODES:
+        out = pp.unwarp_image_backward(*a, order=order, mode=mode)
+        assert spline_close(out, g["radial_o%d_%s" % (order, mode)]), (order, mode)
+        assert np.array_equal(out, orc.unwarp_image_backward(*a, order=order, mode=mode, poly=orc.POLY_KERNEL)), (order, mode)
+    pts = pp.remap_coordinates(img, g["pts_y"], g["pts_x"], order=order)
+    assert spline_close(pts, g["points_o%d_reflect" % order])
+    assert np.array_equal(pts, orc.remap_coords(img, g["pts_y"], g["pts_x"], order=order))
+
+
+def test_g11_perspective_order3_as_demo_07(hip, orc):
+    g = golden("g11_spline45x60")
+    img = noise(g["seed"], g["shape"])
+    coef = list(g["list_coef"])
+    for mode in MODES:
+        out = pp.correct_perspective_image(img, coef, order=3, mode=mode)
+        assert spline_close(out, g["persp_o3_%s" % mode]), mode
+        assert np.array_equal(out, orc.correct_perspective_image(img, coef, order=3, mode=mode)), mode
+    ymap, xmap = pp._generate_perspective_map(img, coef)
+    assert np.array_equal(pp.correct_perspective_image(img, coef, order=3, map_index=(ymap, xmap)),
+                          pp.correct_perspective_image(img, coef, order=3))
+
+
+def test_spline_orders_on_ragged_and_large_inputs(hip, orc):
+    for shape in [(2, 2), (3, 17), (40, 1), (129, 300)]:
+        img = (noise(shape[1], shape) * 100).astype(np.float32)
+        for order, mode in [(3, "reflect"), (2, "mirror"), (5, "nearest"), (4, "grid-wrap"), (3, "constant")]:
+            want = orc.unwarp_image_backward(img, 0.4 * shape[1], 0.6 * shape[0], [1.0, 2e-3], order=order, mode=mode,
+                                             poly=orc.POLY_KERNEL)
+            got = pp.unwarp_image_backward(img, 0.4 * shape[1], 0.6 * shape[0], [1.0, 2e-3], order=order, mode=mode)
+            assert np.array_equal(got, want), (shape, order, mode)
+    rgb = noise(9, (50, 70, 3))                                   # strided channel view, as demo_07 loops
+    for ch in range(3):
+        want = orc.correct_perspective_image(np.ascontiguousarray(rgb[:, :, ch]), [0.98, 0.01, 1.0, -0.01, 0.97, 2.0, 1e-4, -1e-4],
+                                             order=3)
+        assert np.array_equal(pp.correct_perspective_image(rgb[:, :, ch], [0.98, 0.01, 1.0, -0.01, 0.97, 2.0, 1e-4, -1e-4], order=3), want)
+    c = configs.cfg2()                                            # a full 4096^2 frame, cubic
+    img = noise(c["seed"], (1024, 4096))
+    got = pp.unwarp_image_backward(img, c["xcenter"], 500.0, c["list_fact"], order=3)
+    want = orc.unwarp_image_backward(img, c["xcenter"], 500.0, c["list_fact"], order=3, poly=orc.POLY_KERNEL)
+    assert np.array_equal(got, want)
+
+
 # --------------------------------------------------------------------------- (b) oracle, seeded inputs
 
 SHAPES = [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (16, 64), (17, 65), (63, 257), (300, 517), (129, 1031)]

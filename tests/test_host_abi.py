@@ -75,6 +75,8 @@ def test_abi_rejects_bad_arguments_before_any_gpu_work():
     assert L.dcp_unwarp_image_f32(p, p, 4, 4, 4, 1, 0.0, 0.0, fa, n, 3, 1, 0, F.MEM_HOST, -1, None) == F.ERR_UNSUPPORTED
     with pytest.raises(NotImplementedError, match="order 3"):
         F.check(F.ERR_UNSUPPORTED)
+    assert L.dcp_unwarp_image_spline_f32(p, p, 4, 4, 4, 1, 0.0, 0.0, fa, n, 1, 0, F.MEM_HOST, -1, None) == F.ERR_INVALID_ARG
+    assert L.dcp_unwarp_image_spline_f32(p, p, 4, 4, 4, 1, 0.0, 0.0, fa, n, 3, 9, F.MEM_HOST, -1, None) == F.ERR_INVALID_ARG
 
 
 # ---- reference error behaviour, raised on the host before the device is needed
@@ -110,8 +112,10 @@ def test_image_shape_errors_surface_like_the_reference():
 
 def test_unsupported_inputs_fail_loudly_instead_of_falling_back():
     img = np.zeros((4, 4), np.float32)
-    with pytest.raises(NotImplementedError, match="order 3"):
-        pp.unwarp_image_backward(img, 1, 1, [1.0], order=3)
+    with pytest.raises(RuntimeError, match="spline order not supported"):
+        pp.unwarp_image_backward(img, 1, 1, [1.0], order=6)
+    with pytest.raises(NotImplementedError, match="fused one-pass"):
+        pp.unwarp_perspective_fused(img, 1, 1, [1.0], [1, 0, 0, 0, 1, 0, 0, 0], order=3)
     with pytest.raises(NotImplementedError, match="float32"):
         pp.unwarp_image_backward(img.astype(np.float64), 1, 1, [1.0])
     with pytest.raises(NotImplementedError, match="float32"):
