@@ -66,6 +66,7 @@ enum SplineFilterKind : int { kSplMirror = 0, kSplReflect = 1, kSplWrap = 2 };
 struct SplineArgs {
   const float* src;
   double* coef;            // (Hp x Wp) float64 workspace: padded image -> B-spline coefficients
+  double* scratch;         // second plane of the same size (out-of-place filter passes, transposes)
   int32_t H, W, src_stride, src_cstride;
   int32_t Hp, Wp, pad;     // pad = 12 for 'nearest' / 'grid-constant', else 0
   int32_t order, mode, filter_kind, npoles;

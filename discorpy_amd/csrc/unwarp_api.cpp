@@ -567,7 +567,9 @@ int run_spline(int map_kind, const float* src, float* dst, int64_t H, int64_t W,
     for (int p = 0; p < a.npoles; ++p)
       a.zpow[axis][p] = std::pow(a.poles[p], a.filter_kind == dcp::kSplMirror ? n - 1.0 : n);
   }
-  DCP_HIP(g_spline_ws.get((size_t)a.Hp * (size_t)a.Wp * sizeof(double), st, &a.coef));
+  const size_t plane = (size_t)a.Hp * (size_t)a.Wp * sizeof(double);
+  DCP_HIP(g_spline_ws.get(2 * plane, st, &a.coef));
+  a.scratch = a.coef + (size_t)a.Hp * (size_t)a.Wp;
   dcp::CoordArgs ca;
   memset(&ca, 0, sizeof(ca));
   ca.npts = npts;

@@ -403,6 +403,12 @@ static int spline_filter_kind(int mode)
     return SPL_MIRROR;
 }
 
+/* The exact initial sums run over the whole line in scipy; their terms decay like |z|^i with
+   |z| <= 0.431, so everything past SPL_HORIZON terms is below 4e-24 of the leading ones and cannot be
+   seen in float64.  The sums stop there (here and in spline_kernels.hip), which bounds the serial
+   part of a line. */
+#define SPL_HORIZON 64
+
 /* in-place recursive filter of n samples with stride s */
 static void spline_filter_line(double *c, int64_t n, int64_t s, const double *poles, int npoles, int kind)
 {
@@ -417,7 +423,8 @@ static void spline_filter_line(double *c, int64_t n, int64_t s, const double *po
             const double z_n = pow(z, (double)n);
             const double c0 = c[0];
             double acc = c[0] + z_n * c[(n - 1) * s];
-            for (int64_t i = 1; i < n; ++i) {
+            const int64_t m = n - 1 < SPL_HORIZON ? n - 1 : SPL_HORIZON;
+            for (int64_t i = 1; i <= m; ++i) {
                 acc += z_i * (c[i * s] + z_n * c[(n - 1 - i) * s]);
                 z_i *= z;
             }
@@ -429,7 +436,8 @@ static void spline_filter_line(double *c, int64_t n, int64_t s, const double *po
             double z_i = z;
             const double z_n_1 = pow(z, (double)(n - 1));
             double acc = c[0] + z_n_1 * c[(n - 1) * s];
-            for (int64_t i = 1; i < n - 1; ++i) {
+            const int64_t m = n - 2 < SPL_HORIZON ? n - 2 : SPL_HORIZON;
+            for (int64_t i = 1; i <= m; ++i) {
                 acc += z_i * (c[i * s] + z_n_1 * c[(n - 1 - i) * s]);
                 z_i *= z;
             }
@@ -439,15 +447,16 @@ static void spline_filter_line(double *c, int64_t n, int64_t s, const double *po
             for (int64_t i = n - 2; i >= 0; --i) c[i * s] = z * (c[(i + 1) * s] - c[i * s]);
         } else {
             double z_i = z, acc = c[0];
-            for (int64_t i = n - 1; i > 0; --i) {
-                acc += z_i * c[i * s];
+            const int64_t m = n - 1 < SPL_HORIZON ? n - 1 : SPL_HORIZON;
+            for (int64_t k = 0; k < m; ++k) {
+                acc += z_i * c[(n - 1 - k) * s];
                 z_i *= z;
             }
             c[0] = acc / (1.0 - z_i);
             for (int64_t i = 1; i < n; ++i) c[i * s] += z * c[(i - 1) * s];
             z_i = z;
             acc = c[(n - 1) * s];
-            for (int64_t i = 0; i < n - 1; ++i) {
+            for (int64_t i = 0; i < m; ++i) {
                 acc += z_i * c[i * s];
                 z_i *= z;
             }
