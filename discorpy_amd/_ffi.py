@@ -16,6 +16,9 @@ BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
 COORD_F32, COORD_F64 = 0, 1
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
 MAP_RADIAL, MAP_PERSPECTIVE, MAP_FUSED = 0, 1, 2
+# DCP_DTYPE_* by NumPy / torch dtype name
+DTYPE_BY_NAME = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7}
+DTYPE_F32 = 0
 MAX_FACT = 32
 
 BLEND_BY_NAME = {"scipy": BLEND_SCIPY, "exact": BLEND_SCIPY, "f64": BLEND_F64LERP,
@@ -55,6 +58,15 @@ SIGNATURES = {
     "dcp_perspective_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),
     "dcp_remap_coords_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _i64, _int, _int, _int,
                                            _int, _vp]),
+    "dcp_unwarp_image_typed": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int, _int,
+                                      _int, _vp]),
+    "dcp_perspective_image_typed": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),
+    "dcp_unwarp_fused_typed": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dp, _int, _int,
+                                      _int, _int, _vp]),
+    "dcp_remap_coords_typed": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _vp, _vp, _int, _i64, _int, _int, _int,
+                                      _int, _vp]),
+    "dcp_unwarp_stack_rows_typed": (_int, [_vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int,
+                                           _dbl, _i64, _int, _int, _int, _vp]),
     "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),

@@ -5,6 +5,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <limits>
+#include <type_traits>
+#include "dcp_internal.h"
 
 namespace dcp {
 
@@ -116,6 +119,98 @@ __device__ __forceinline__ void div2_rn(double nx, double ny, double den, double
   q = ny * r;
   t = __builtin_fma(-den, q, ny);
   *qy = __builtin_fma(t, r, q);
+}
+
+// ------------------------------------------------------------------ one pixel of a coordinate map
+
+// Source coordinate (float64, unclipped) of output pixel (x, y): the radial map of
+// postprocessing.py:138-145, the homography of :448-455, or the homography's float32-rounded
+// result fed to the radial map (the fused map).  Same operations as map_coord() of
+// unwarp_kernels.hip without the per-row / per-column hoisting -- for the kernels that are not
+// the float32 hot path (spline orders, other element types).
+template <int KIND>
+__device__ __forceinline__ void pixel_coord(const MapArgs& map, double X, double Y, float wmaxf, float hmaxf,
+                                            double* xd_out, double* yd_out) {
+  double xu, yu;
+  if constexpr (KIND == kRadial) {
+    xu = X - map.xc;
+    yu = Y - map.yc;
+  } else {
+    const double den = (map.coef[6] * X + map.coef[7] * Y) + 1.0;
+    const double nx = (map.coef[0] * X + map.coef[1] * Y) + map.coef[2];
+    const double ny = (map.coef[3] * X + map.coef[4] * Y) + map.coef[5];
+    double xd, yd;
+    if (map.fast_div) {
+      div2_rn(nx, ny, den, &xd, &yd);
+    } else {
+      xd = nx / den;
+      yd = ny / den;
+    }
+    if constexpr (KIND == kPersp) {
+      *xd_out = xd;
+      *yd_out = yd;
+      return;
+    }
+    xu = (double)round_clip_f32(xd, wmaxf) - map.xc;
+    yu = (double)round_clip_f32(yd, hmaxf) - map.yc;
+  }
+  const double xx = xu * xu, yy = yu * yu;
+  const double r2 = xx + yy;
+  const double ru = sqrt_rn(r2);
+  const double f = poly_lds(map.fact, map.nfact, r2, ru);
+  *xd_out = __builtin_fma(f, xu, map.xc);
+  *yd_out = __builtin_fma(f, yu, map.yc);
+}
+
+// ------------------------------------------------------------------ element types
+
+// scipy reads every element as a double and converts the double result on the way out
+// (ni_interpolation.c CASE_INTERP_OUT*): floats by a C cast; unsigned integers t > 0 ? t + 0.5 : 0,
+// clamped to the maximum, truncated; signed integers rounded half away from zero, clamped, truncated.
+template <typename T>
+__device__ __forceinline__ T to_elem(double t) {
+  if constexpr (std::is_same<T, float>::value) {
+    return (float)t;
+  } else if constexpr (std::is_same<T, double>::value) {
+    return t;
+  } else if constexpr (std::is_unsigned<T>::value) {
+    constexpr double hi = (double)std::numeric_limits<T>::max();
+    t = t > 0.0 ? t + 0.5 : 0.0;
+    t = t > hi ? hi : t;
+    return (T)(uint32_t)t;
+  } else {
+    constexpr double lo = (double)std::numeric_limits<T>::min(), hi = (double)std::numeric_limits<T>::max();
+    t = t > 0.0 ? t + 0.5 : t - 0.5;
+    t = t > hi ? hi : t;
+    t = t < lo ? lo : t;
+    return (T)(int32_t)t;
+  }
+}
+
+// runtime-typed access for the kernels where the element type is not worth a template parameter
+__device__ __forceinline__ double load_any(const void* p, int dtype, size_t i) {
+  switch (dtype) {
+    case kF32: return (double)((const float*)p)[i];
+    case kF64: return ((const double*)p)[i];
+    case kU8: return (double)((const uint8_t*)p)[i];
+    case kI8: return (double)((const int8_t*)p)[i];
+    case kU16: return (double)((const uint16_t*)p)[i];
+    case kI16: return (double)((const int16_t*)p)[i];
+    case kU32: return (double)((const uint32_t*)p)[i];
+    default: return (double)((const int32_t*)p)[i];
+  }
+}
+__device__ __forceinline__ void store_any(void* p, int dtype, size_t i, double t) {
+  switch (dtype) {
+    case kF32: ((float*)p)[i] = to_elem<float>(t); break;
+    case kF64: ((double*)p)[i] = t; break;
+    case kU8: ((uint8_t*)p)[i] = to_elem<uint8_t>(t); break;
+    case kI8: ((int8_t*)p)[i] = to_elem<int8_t>(t); break;
+    case kU16: ((uint16_t*)p)[i] = to_elem<uint16_t>(t); break;
+    case kI16: ((int16_t*)p)[i] = to_elem<int16_t>(t); break;
+    case kU32: ((uint32_t*)p)[i] = to_elem<uint32_t>(t); break;
+    default: ((int32_t*)p)[i] = to_elem<int32_t>(t); break;
+  }
 }
 
 }  // namespace dcp

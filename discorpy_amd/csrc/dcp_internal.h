@@ -63,8 +63,37 @@ enum BoundaryMode : int { kModeReflect = 0, kModeGridMirror, kModeConstant, kMod
                           kModeGridWrap, kModeWrap };
 enum SplineFilterKind : int { kSplMirror = 0, kSplReflect = 1, kSplWrap = 2 };
 
+// element types of the *_typed entry points (DCP_DTYPE_* of include/discorpy_hip.h)
+enum ElemType : int { kF32 = 0, kF64, kU8, kI8, kU16, kI16, kU32, kI32, kNumElemTypes };
+__host__ __device__ inline int elem_size(int dtype) {
+  return dtype == kF64 ? 8 : (dtype == kF32 || dtype == kU32 || dtype == kI32) ? 4 : (dtype == kU16 || dtype == kI16) ? 2 : 1;
+}
+
+// orders 0 / 1 on any element type (typed_kernels.hip); strides in elements
+struct TypedImageArgs {
+  const void* src;
+  void* dst;
+  int64_t src_stride, src_cstride;
+  int32_t H, W;
+  int32_t order;           // 0 or 1
+  int32_t dtype;
+};
+
+struct TypedStackArgs {
+  const void* vol;
+  void* out;
+  int64_t proj_stride, row_stride;
+  int32_t D, H, W;
+  int32_t nrows, d_chunk;
+  int32_t dtype;
+  int32_t out_f32;         // 1: out is float32 holding the value already converted to `dtype` (unwarp_slice_backward)
+  int32_t round_f32;       // 1: coordinates rounded to float32 (unwarp_chunk_slices_backward)
+  double row_start;
+};
+
 struct SplineArgs {
-  const float* src;
+  const void* src;
+  int32_t src_dtype, dst_dtype;
   double* coef;            // (Hp x Wp) float64 workspace: padded image -> B-spline coefficients
   double* scratch;         // second plane of the same size (out-of-place filter passes, transposes)
   int32_t H, W, src_stride, src_cstride;
@@ -94,7 +123,11 @@ hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bo
 
 hipError_t read_lds_stats(unsigned long long* out, bool reset);
 // spline_kernels.hip: map_kind 0 radial, 1 perspective, 2 explicit coordinates
-hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, float* dst,
+hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream);
+// typed_kernels.hip: map_kind 0 radial, 1 perspective, 2 fused, 3 explicit coordinates
+hipError_t launch_typed_image(int map_kind, const TypedImageArgs& img, const MapArgs& map, const CoordArgs& ca,
+                              hipStream_t stream);
+hipError_t launch_typed_stack(const TypedStackArgs& st, const MapArgs& map, hipStream_t stream);
 
 }  // namespace dcp

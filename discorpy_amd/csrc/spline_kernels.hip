@@ -3,7 +3,7 @@
 // `order` argument of unwarp_image_backward / correct_perspective_image
 // (discorpy/post/postprocessing.py:111,147,462,491; order=3 in examples/readthedocs_demo/demo_07.py:60).
 //
-//   spline_expand_kernel   float32 image -> float64 plane, padded by 12 for 'nearest' / 'grid-constant'
+//   spline_expand_kernel   image (any element type) -> float64 plane, padded by 12 for 'nearest' / 'grid-constant'
 //   spline_causal_kernel / spline_anticausal_kernel / spline_transpose_kernel
 //                          recursive B-spline prefilter, chunked along the line (see below)
 //   spline_remap_kernel    (order+1)^2-tap gather at the radial / perspective / explicit coordinates
@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(kSplBlock) spline_expand_kernel(const SplineAr
   } else {
     sy = sy < 0 ? 0 : (sy > a.H - 1 ? a.H - 1 : sy);
     sx = sx < 0 ? 0 : (sx > a.W - 1 ? a.W - 1 : sx);
-    v = (double)a.src[(size_t)sy * a.src_stride + (size_t)sx * a.src_cstride];
+    v = load_any(a.src, a.src_dtype, (size_t)sy * a.src_stride + (size_t)sx * a.src_cstride);
   }
   a.coef[i] = v;
 }
@@ -246,7 +246,7 @@ __device__ __forceinline__ int spline_fold(int i, int n, int mode) {
 // MAPKIND 0 radial, 1 perspective, 2 explicit coordinates (dst[i] for point i)
 template <int MAPKIND, int ORDER>
 __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArgs a, const MapArgs map, const CoordArgs ca,
-                                                                float* dst) {
+                                                                void* dst) {
   const int64_t i = (int64_t)blockIdx.x * kSplBlock + threadIdx.x;
   const int64_t total = MAPKIND == 2 ? ca.npts : (int64_t)a.H * a.W;
   if (i >= total) return;
@@ -265,22 +265,7 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
     const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
     const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
     double xd, yd;
-    if constexpr (MAPKIND == 0) {
-      const double xu = (double)x - map.xc, yu = (double)y - map.yc;
-      const double xx = xu * xu, yy = yu * yu;
-      const double r2 = xx + yy;
-      const double ru = sqrt_rn(r2);
-      const double f = poly_lds(map.fact, map.nfact, r2, ru);
-      xd = __builtin_fma(f, xu, map.xc);
-      yd = __builtin_fma(f, yu, map.yc);
-    } else {
-      const double X = (double)x, Y = (double)y;
-      const double den = (map.coef[6] * X + map.coef[7] * Y) + 1.0;
-      const double nx = (map.coef[0] * X + map.coef[1] * Y) + map.coef[2];
-      const double ny = (map.coef[3] * X + map.coef[4] * Y) + map.coef[5];
-      xd = nx / den;
-      yd = ny / den;
-    }
+    pixel_coord<MAPKIND == 0 ? kRadial : kPersp>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
     xc = (double)round_clip_f32(xd, wmaxf);
     yc = (double)round_clip_f32(yd, hmaxf);
   }
@@ -297,11 +282,11 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
 #pragma unroll
     for (int k = 0; k <= ORDER; ++k) t += (row[ix[k]] * wy[j]) * wx[k];
   }
-  dst[i] = (float)t;
+  store_any(dst, a.dst_dtype, (size_t)i, t);
 }
 
 template <int MAPKIND>
-static hipError_t launch_remap_order(const SplineArgs& a, const MapArgs& map, const CoordArgs& ca, float* dst,
+static hipError_t launch_remap_order(const SplineArgs& a, const MapArgs& map, const CoordArgs& ca, void* dst,
                                      int64_t total, hipStream_t stream) {
   const dim3 grid((unsigned)((total + kSplBlock - 1) / kSplBlock));
   switch (a.order) {
@@ -313,7 +298,7 @@ static hipError_t launch_remap_order(const SplineArgs& a, const MapArgs& map, co
   return hipGetLastError();
 }
 
-hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, float* dst,
+hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream) {
   const int64_t plane = (int64_t)a.Hp * a.Wp;
   hipLaunchKernelGGL(spline_expand_kernel, dim3((unsigned)((plane + kSplBlock - 1) / kSplBlock)), dim3(kSplBlock), 0,

@@ -533,11 +533,25 @@ int spline_poles(int order, double* z) {
   }
 }
 
-int run_spline(int map_kind, const float* src, float* dst, int64_t H, int64_t W, int64_t rs, int64_t cs,
+int check_image_typed(const void* src, const void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs) {
+  if (dtype < 0 || dtype >= dcp::kNumElemTypes) return fail(DCP_ERR_INVALID_ARG, "unknown element type %d", dtype);
+  if (!src || !dst) return fail(DCP_ERR_INVALID_ARG, "null image pointer");
+  if (H <= 0 || W <= 0) return fail(DCP_ERR_INVALID_ARG, "image must be non-empty (got %lld x %lld)", (long long)H, (long long)W);
+  if (cs < 1 || rs < 1) return fail(DCP_ERR_INVALID_ARG, "strides must be positive (row %lld, col %lld)", (long long)rs, (long long)cs);
+  if (rs < (W - 1) * cs + 1 && H > 1) return fail(DCP_ERR_INVALID_ARG, "row stride %lld overlaps rows of width %lld", (long long)rs, (long long)W);
+  if (H > 1073741823LL || W > 1073741823LL) return fail(DCP_ERR_UNSUPPORTED, "image too large");
+  return DCP_OK;
+}
+
+size_t extent_bytes_typed(int64_t H, int64_t W, int64_t rs, int64_t cs, int dtype) {
+  return (size_t)((H - 1) * rs + (W - 1) * cs + 1) * (size_t)dcp::elem_size(dtype);
+}
+
+int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
                const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
                int mode, int mem_kind, int device, void* stream) {
   int rc;
-  if ((rc = check_image(src, dst, H, W, rs, cs)) != DCP_OK) return rc;
+  if ((rc = check_image_typed(src, dst, dtype, H, W, rs, cs)) != DCP_OK) return rc;
   if (order < 2 || order > 5) return fail(DCP_ERR_INVALID_ARG, "spline order %d outside [2, 5]", order);
   if (mode < 0 || mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
   if (map_kind == 2) {
@@ -553,6 +567,7 @@ int run_spline(int map_kind, const float* src, float* dst, int64_t H, int64_t W,
   memset(&a, 0, sizeof(a));
   a.H = (int32_t)H;
   a.W = (int32_t)W;
+  a.src_dtype = a.dst_dtype = dtype;
   a.order = order;
   a.mode = mode;
   a.pad = (mode == dcp::kModeNearest || mode == dcp::kModeGridConstant) ? 12 : 0;
@@ -586,9 +601,9 @@ int run_spline(int map_kind, const float* src, float* dst, int64_t H, int64_t W,
   }
   if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
   void *dsrc, *ddst, *dy = nullptr, *dx = nullptr;
-  const size_t ext = extent_bytes(H, W, rs, cs);
+  const size_t ext = extent_bytes_typed(H, W, rs, cs, dtype), esz = (size_t)dcp::elem_size(dtype);
   DCP_HIP(g_staging.get(0, ext, &dsrc));
-  DCP_HIP(g_staging.get(1, (size_t)(nout > 0 ? nout : 1) * 4, &ddst));
+  DCP_HIP(g_staging.get(1, (size_t)(nout > 0 ? nout : 1) * esz, &ddst));
   DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
   if (map_kind == 2 && npts > 0) {
     const size_t csz = (size_t)npts * (ca.is_f64 ? 8 : 4);
@@ -597,13 +612,13 @@ int run_spline(int map_kind, const float* src, float* dst, int64_t H, int64_t W,
     DCP_HIP(hipMemcpyAsync(dy, ycoord, csz, hipMemcpyHostToDevice, st));
     DCP_HIP(hipMemcpyAsync(dx, xcoord, csz, hipMemcpyHostToDevice, st));
   }
-  a.src = (const float*)dsrc;
+  a.src = dsrc;
   a.src_stride = (int32_t)rs;
   a.src_cstride = (int32_t)cs;
   ca.ycoord = dy;
   ca.xcoord = dx;
-  DCP_HIP(dcp::launch_spline(a, map_kind, map, ca, (float*)ddst, st));
-  if (nout > 0) DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)nout * 4, hipMemcpyDeviceToHost, st));
+  DCP_HIP(dcp::launch_spline(a, map_kind, map, ca, ddst, st));
+  if (nout > 0) DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)nout * esz, hipMemcpyDeviceToHost, st));
   DCP_HIP(hipStreamSynchronize(st));
   return DCP_OK;
 }
@@ -618,7 +633,7 @@ int dcp_unwarp_image_spline_f32(const float* src, float* dst, int64_t height, in
   int rc;
   dcp::MapArgs map;
   if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
-  return run_spline(0, src, dst, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+  return run_spline(0, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
                     boundary_mode, mem_kind, device, stream);
 }
 
@@ -629,7 +644,7 @@ int dcp_perspective_image_spline_f32(const float* src, float* dst, int64_t heigh
   if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
   dcp::MapArgs map;
   if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
-  return run_spline(1, src, dst, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+  return run_spline(1, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
                     boundary_mode, mem_kind, device, stream);
 }
 
@@ -639,8 +654,198 @@ int dcp_remap_coords_spline_f32(const float* src, float* dst, int64_t height, in
   dcp::MapArgs map;
   memset(&map, 0, sizeof(map));
   if (npts == 0) return (order < 2 || order > 5) ? fail(DCP_ERR_INVALID_ARG, "spline order %d outside [2, 5]", order) : DCP_OK;
-  return run_spline(2, src, dst, height, width, src_row_stride, src_col_stride, map, ycoord, xcoord, coord_dtype, npts,
+  return run_spline(2, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, ycoord, xcoord, coord_dtype, npts,
                     order, boundary_mode, mem_kind, device, stream);
+}
+
+}  // extern "C"
+
+namespace {
+
+// Orders 0..5 on any element type: 0/1 through typed_kernels.hip, 2..5 through the spline path.
+// map_kind 0 radial, 1 perspective, 2 fused, 3 explicit coordinates.
+int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
+              const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
+              int mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if (order < 0 || order > 5) return fail(DCP_ERR_INVALID_ARG, "spline order %d outside [0, 5]", order);
+  if (mode < 0 || mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
+  if (order >= 2) {
+    if (map_kind == 2) return fail(DCP_ERR_UNSUPPORTED, "the fused map is implemented for orders 0 and 1");
+    return run_spline(map_kind == 3 ? 2 : map_kind, src, dst, dtype, H, W, rs, cs, map, ycoord, xcoord, coord_dtype, npts,
+                      order, mode, mem_kind, device, stream);
+  }
+  if ((rc = check_image_typed(src, dst, dtype, H, W, rs, cs)) != DCP_OK) return rc;
+  if (map_kind == 3) {
+    if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
+    if (npts > 0 && (!ycoord || !xcoord)) return fail(DCP_ERR_INVALID_ARG, "null coordinate pointer");
+    if (coord_dtype != DCP_COORD_F32 && coord_dtype != DCP_COORD_F64) return fail(DCP_ERR_INVALID_ARG, "unknown coord_dtype %d", coord_dtype);
+    if (npts > 2147483647LL * 256) return fail(DCP_ERR_UNSUPPORTED, "too many points");
+    if (npts == 0) return DCP_OK;
+  }
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipStream_t st = (hipStream_t)stream;
+  dcp::TypedImageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H = (int32_t)H;
+  a.W = (int32_t)W;
+  a.src_stride = rs;
+  a.src_cstride = cs;
+  a.order = order;
+  a.dtype = dtype;
+  dcp::CoordArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.npts = npts;
+  ca.is_f64 = coord_dtype == DCP_COORD_F64;
+  const int64_t nout = map_kind == 3 ? npts : H * W;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    a.src = src;
+    a.dst = dst;
+    ca.ycoord = ycoord;
+    ca.xcoord = xcoord;
+    DCP_HIP(dcp::launch_typed_image(map_kind, a, map, ca, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *dsrc, *ddst, *dy = nullptr, *dx = nullptr;
+  const size_t ext = extent_bytes_typed(H, W, rs, cs, dtype), esz = (size_t)dcp::elem_size(dtype);
+  DCP_HIP(g_staging.get(0, ext, &dsrc));
+  DCP_HIP(g_staging.get(1, (size_t)nout * esz, &ddst));
+  DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
+  if (map_kind == 3) {
+    const size_t csz = (size_t)npts * (ca.is_f64 ? 8 : 4);
+    DCP_HIP(g_staging.get(2, csz, &dy));
+    DCP_HIP(g_staging.get(3, csz, &dx));
+    DCP_HIP(hipMemcpyAsync(dy, ycoord, csz, hipMemcpyHostToDevice, st));
+    DCP_HIP(hipMemcpyAsync(dx, xcoord, csz, hipMemcpyHostToDevice, st));
+  }
+  a.src = dsrc;
+  a.dst = ddst;
+  ca.ycoord = dy;
+  ca.xcoord = dx;
+  DCP_HIP(dcp::launch_typed_image(map_kind, a, map, ca, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)nout * esz, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcp_unwarp_image_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width, int64_t src_row_stride,
+                           int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact, int nfact,
+                           int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  return run_typed(0, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                   boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_perspective_image_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width,
+                                int64_t src_row_stride, int64_t src_col_stride, const double* list_coef, int order,
+                                int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
+  if (height > 0 && width > 0) map.fast_div = homography_is_tame(list_coef, height, width);
+  return run_typed(1, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                   boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_unwarp_fused_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width, int64_t src_row_stride,
+                           int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact, int nfact,
+                           const double* list_coef, int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, list_coef)) != DCP_OK) return rc;
+  if (height > 0 && width > 0) map.fast_div = homography_is_tame(list_coef, height, width);
+  return run_typed(2, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                   boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_remap_coords_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width, int64_t src_row_stride,
+                           int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts,
+                           int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  dcp::MapArgs map;
+  memset(&map, 0, sizeof(map));
+  return run_typed(3, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, ycoord, xcoord, coord_dtype,
+                   npts, order, boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_float32, int64_t depth, int64_t height,
+                                int64_t width, int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
+                                int mem_kind, int device, void* stream) {
+  int rc;
+  if (dtype < 0 || dtype >= dcp::kNumElemTypes) return fail(DCP_ERR_INVALID_ARG, "unknown element type %d", dtype);
+  if (depth < 0 || nrows < 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows");
+  if (height <= 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "projections must be non-empty");
+  if (depth > 0 && nrows > 0 && (!vol || !out)) return fail(DCP_ERR_INVALID_ARG, "null volume pointer");
+  if (row_stride < width || proj_stride < (height - 1) * row_stride + width)
+    return fail(DCP_ERR_INVALID_ARG, "strides overlap (row %lld, projection %lld)", (long long)row_stride, (long long)proj_stride);
+  if (height > 1073741823LL || width > 1073741823LL || depth > 2147483647LL) return fail(DCP_ERR_UNSUPPORTED, "stack too large");
+  if (nrows > 65535) return fail(DCP_ERR_UNSUPPORTED, "nrows > 65535 in one call");
+  if (!std::isfinite(row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  if (depth == 0 || nrows == 0) return DCP_OK;
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::LaunchOpts opts = current_opts();
+  if ((depth + opts.d_chunk - 1) / opts.d_chunk > 65535) opts.d_chunk = (int)((depth + 65534) / 65535);
+  dcp::TypedStackArgs st;
+  memset(&st, 0, sizeof(st));
+  st.D = (int32_t)depth;
+  st.H = (int32_t)height;
+  st.W = (int32_t)width;
+  st.row_start = row_start;
+  st.nrows = (int32_t)nrows;
+  st.d_chunk = opts.d_chunk;
+  st.dtype = dtype;
+  st.out_f32 = out_float32 != 0;
+  st.round_f32 = coord_round_f32 != 0;
+  hipStream_t hs = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    st.vol = vol;
+    st.out = out;
+    st.proj_stride = proj_stride;
+    st.row_stride = row_stride;
+    DCP_HIP(dcp::launch_typed_stack(st, map, hs));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  // as dcp_unwarp_stack_rows_f32: ship only the row band the requested rows can reach
+  int64_t band0 = 0, band1 = height;
+  host_row_band(map, height, width, row_start, nrows, &band0, &band1);
+  const int64_t bh = band1 - band0;
+  const size_t esz = (size_t)dcp::elem_size(dtype), osz = out_float32 ? 4 : esz;
+  const size_t pbytes = (size_t)bh * (size_t)width * esz, obytes = (size_t)depth * (size_t)nrows * (size_t)width * osz;
+  void *dvol, *dout;
+  DCP_HIP(g_staging.get(0, pbytes * (size_t)depth, &dvol));
+  DCP_HIP(g_staging.get(1, obytes, &dout));
+  for (int64_t d = 0; d < depth; ++d) {
+    const char* hsrc = (const char*)vol + (size_t)(d * proj_stride + band0 * row_stride) * esz;
+    char* ddst = (char*)dvol + (size_t)d * pbytes;
+    if (row_stride == width) {
+      DCP_HIP(hipMemcpyAsync(ddst, hsrc, pbytes, hipMemcpyHostToDevice, hs));
+    } else {
+      DCP_HIP(hipMemcpy2DAsync(ddst, (size_t)width * esz, hsrc, (size_t)row_stride * esz, (size_t)width * esz, (size_t)bh,
+                               hipMemcpyHostToDevice, hs));
+    }
+  }
+  st.vol = (const char*)dvol - (size_t)(band0 * width) * esz;   // absolute row indexing, never dereferenced below the band
+  st.out = dout;
+  st.proj_stride = bh * width;
+  st.row_stride = width;
+  DCP_HIP(dcp::launch_typed_stack(st, map, hs));
+  DCP_HIP(hipMemcpyAsync(out, dout, obytes, hipMemcpyDeviceToHost, hs));
+  DCP_HIP(hipStreamSynchronize(hs));
+  return DCP_OK;
 }
 
 int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t width, int map_kind, double xcenter,

@@ -22,8 +22,10 @@ Inputs may be
 
 What differs from the reference, on purpose:
 
-* data must be float32 (what ``discorpy.losa.load_image`` / ``load_hdf_file`` produce); other
-  dtypes raise ``NotImplementedError`` instead of silently taking another code path;
+* float32 data (what ``discorpy.losa.load_image`` / ``load_hdf_file`` produce) takes the tuned kernels;
+  float64, (u)int8, (u)int16 and (u)int32 data run the generic kernels with scipy's exact arithmetic and
+  its integer rounding, output dtype = input dtype as in the reference; other dtypes (64-bit
+  integers, bool, complex, float16) raise ``NotImplementedError``;
 * for spline ``order`` 0 and 1 ``mode`` cannot influence the result because every coordinate is
   clipped into the image first; it is validated and otherwise ignored.
   Orders 2..5 run scipy's prefiltered B-spline interpolation on the GPU with all eight modes
@@ -74,8 +76,17 @@ def _check_order_mode(order, mode):
     return order
 
 
+def _dtype_code(dtype):
+    name = str(dtype).replace("torch.", "")
+    try:
+        return F.DTYPE_BY_NAME[name]
+    except KeyError:
+        raise NotImplementedError("element type %s is not implemented on the GPU path (supported: %s)"
+                                  % (dtype, ", ".join(sorted(F.DTYPE_BY_NAME))))
+
+
 class _Image:
-    """A float32 2-D / 3-D array handed to the C ABI: pointer, element strides, memory kind."""
+    """A 2-D / 3-D array handed to the C ABI: pointer, element type, element strides, memory kind."""
 
     def __init__(self, a, ndim):
         self.torch = _is_torch(a)
@@ -85,8 +96,8 @@ class _Image:
                 self.torch = False
         if self.torch:
             import torch
-            if a.dtype != torch.float32:
-                raise NotImplementedError("only float32 data is implemented on the GPU path (got %s)" % a.dtype)
+            self.code = _dtype_code(a.dtype)
+            self.dtype = a.dtype
             self.shape = tuple(a.shape)
             self.strides = tuple(a.stride())
             self.ptr = a.data_ptr()
@@ -96,12 +107,14 @@ class _Image:
             self.keep = a
         else:
             a = np.asarray(a)
-            if a.dtype != np.float32:
-                raise NotImplementedError("only float32 data is implemented on the GPU path (got %s)" % a.dtype)
-            if any(s < 0 for s in a.strides) or any(s % 4 for s in a.strides):
+            self.code = _dtype_code(a.dtype)
+            self.dtype = a.dtype
+            if not a.dtype.isnative:
+                a = a.astype(a.dtype.newbyteorder("="))
+            if any(s < 0 for s in a.strides) or any(s % a.itemsize for s in a.strides):
                 a = np.ascontiguousarray(a)
             self.shape = a.shape
-            self.strides = tuple(s // 4 for s in a.strides)
+            self.strides = tuple(s // a.itemsize for s in a.strides)
             self.ptr = a.ctypes.data
             self.mem = F.MEM_HOST
             self.device = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
@@ -110,13 +123,18 @@ class _Image:
         if len(self.shape) != ndim:
             raise ValueError("expected a %d-D array" % ndim)
 
-    def empty(self, shape):
-        """Fresh float32 output of the same kind (device tensor / NumPy array) as the input."""
+    @property
+    def f32(self):
+        return self.code == F.DTYPE_F32
+
+    def empty(self, shape, float32=False):
+        """Fresh output of the same kind (device tensor / NumPy array) and element type as the input
+        (float32 if asked)."""
         if self.torch:
             import torch
-            out = torch.empty(shape, dtype=torch.float32, device=self.keep.device)
+            out = torch.empty(shape, dtype=torch.float32 if float32 else self.dtype, device=self.keep.device)
             return out, out.data_ptr()
-        out = np.empty(shape, np.float32)
+        out = np.empty(shape, np.float32 if float32 else self.dtype)
         return out, out.ctypes.data
 
     def dense_rows(self):
@@ -148,7 +166,7 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     Parameters
     ----------
     mat : array_like
-        2D float32 array (NumPy array or ROCm torch tensor).
+        2D array (NumPy array or ROCm torch tensor).
     xcenter : float
         Center of distortion in x-direction.
     ycenter : float
@@ -156,10 +174,10 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     list_fact : list of float
         Polynomial coefficients of the backward model.
     order : int, optional.
-        The order of the spline interpolation (0 or 1).
+        The order of the spline interpolation (0..5).
     mode : {'reflect', 'grid-mirror', 'constant', 'grid-constant', 'nearest',
            'mirror', 'grid-wrap', 'wrap'}, optional
-        Accepted for compatibility; inert for order <= 1.
+        Boundary mode of scipy's spline interpolation; inert for order <= 1.
 
     Returns
     -------
@@ -174,6 +192,11 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     fa, nf = F.fact_array(fact)
     out, optr = img.empty((height, width))
     F.require_device()
+    if not img.f32:
+        F.check(F.lib().dcp_unwarp_image_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
+                                               float(xcenter), float(ycenter), fa, nf, order, _MODES.index(mode),
+                                               img.mem, img.device, img.stream))
+        return out
     if order >= 2:
         F.check(F.lib().dcp_unwarp_image_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
                                                     float(xcenter), float(ycenter), fa, nf, order, _MODES.index(mode),
@@ -194,7 +217,7 @@ def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=No
     if len(mat3D.shape) < 3:
         raise ValueError("Input must be a 3D data")
     (depth, height, width) = mat3D.shape
-    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend)[:, 0, :]
+    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True)[:, 0, :]
 
 
 def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *, blend=None):
@@ -219,19 +242,25 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
     return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend)
 
 
-def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend):
+def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32=False):
     bcode = _blend_code(blend)
     vol = _Image(mat3D, 3)
     depth, height, width = vol.shape
     if depth == 0:
-        return vol.empty((0, nrows, width))[0]
+        return vol.empty((0, nrows, width), out_float32)[0]
     ps, rs, cs = vol.strides
     if cs != 1 or rs < width or (depth > 1 and ps < (height - 1) * rs + width):
         vol = _Image(vol.keep.contiguous() if vol.torch else np.ascontiguousarray(vol.keep), 3)
         ps, rs, cs = vol.strides
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
-    out, optr = vol.empty((depth, nrows, width))
+    out, optr = vol.empty((depth, nrows, width), out_float32)
     F.require_device()
+    if not vol.f32:
+        F.check(F.lib().dcp_unwarp_stack_rows_typed(vol.ptr, optr, vol.code, int(out_float32), depth, height, width,
+                                                    ps if depth > 1 else height * rs, rs, float(xcenter),
+                                                    float(ycenter), fa, nf, float(row_start), nrows, int(round_f32),
+                                                    vol.mem, vol.device, vol.stream))
+        return out
     F.check(F.lib().dcp_unwarp_stack_rows_f32(vol.ptr, optr, depth, height, width, ps if depth > 1 else height * rs,
                                               rs, float(xcenter), float(ycenter), fa, nf, float(row_start), nrows,
                                               int(round_f32), bcode, vol.mem, vol.device, vol.stream))
@@ -245,13 +274,13 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     Parameters
     ----------
     mat : array_like
-        2D float32 array. Image for correction.
+        2D array. Image for correction.
     list_coef : list of floats
         Coefficients of the backward-mapping matrix (c1..c8, (x, y) convention).
     order : int, optional.
-        The order of the spline interpolation (0 or 1).
+        The order of the spline interpolation (0..5).
     mode : str, optional
-        Accepted for compatibility; inert for order <= 1.
+        Boundary mode of scipy's spline interpolation; inert for order <= 1.
     map_index : array_like
         Indices for mapping, (ycoords, xcoords) with height*width points. Generated if None.
 
@@ -272,6 +301,11 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
     out, optr = img.empty((height, width))
     F.require_device()
+    if not img.f32:
+        F.check(F.lib().dcp_perspective_image_typed(img.ptr, optr, img.code, height, width, img.strides[0],
+                                                    img.strides[1], ca, order, _MODES.index(mode), img.mem, img.device,
+                                                    img.stream))
+        return out
     if order >= 2:
         F.check(F.lib().dcp_perspective_image_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
                                                          ca, order, _MODES.index(mode), img.mem, img.device, img.stream))
@@ -355,6 +389,11 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
     ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
     out, optr = img.empty((height, width))
     F.require_device()
+    if not img.f32:
+        F.check(F.lib().dcp_unwarp_fused_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
+                                               float(xcenter), float(ycenter), fa, nf, ca, order, 0, img.mem,
+                                               img.device, img.stream))
+        return out
     F.check(F.lib().dcp_unwarp_fused_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
                                          float(xcenter), float(ycenter), fa, nf, ca, order, bcode,
                                          img.mem, img.device, img.stream))
@@ -394,6 +433,11 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
         npts, yptr, xptr, shape = yc.size, yc.ctypes.data, xc.ctypes.data, yc.shape
     out, optr = img.empty(shape)
     F.require_device()
+    if not img.f32:
+        F.check(F.lib().dcp_remap_coords_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
+                                               yptr, xptr, cdt, npts, order, _MODES.index(mode), img.mem, img.device,
+                                               img.stream))
+        return out
     if order >= 2:
         F.check(F.lib().dcp_remap_coords_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], yptr,
                                                     xptr, cdt, npts, order, _MODES.index(mode), img.mem, img.device,

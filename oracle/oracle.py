@@ -3,7 +3,8 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module (see the header of oracle/unwarp_oracle.c).  The functions mirror
 the reference signatures of discorpy/post/postprocessing.py (:111, :188, :255,
-:462) for float32 data and spline order 0/1.
+:462); float32 data has dedicated entry points, the other element types go through
+map_coordinates().
 """
 import ctypes as C
 import os
@@ -53,6 +54,7 @@ def lib():
         L.orc_spline_coefficients_f32.argtypes = [fp, i64, i64, i64, i32, i32, dp]
         L.orc_remap_spline_f32.argtypes = [fp, fp, i64, i64, i64, i32, dbl, dbl, dp, i32, dp, vp, vp, i32, i64, i32, i32,
                                            i32, dp]
+        L.orc_map_coordinates_typed.argtypes = [vp, vp, i32, i64, i64, i64, vp, vp, i32, i64, i32, i32, dp]
         _lib = L
     return _lib
 
@@ -94,6 +96,33 @@ def spline_coefficients(mat, order, mode):
     work = np.empty((height + 2 * pad, width + 2 * pad), np.float64)
     _check(lib().orc_spline_coefficients_f32(_fp(mat), height, width, _row_stride(mat), int(order), m, _dp(work)))
     return work
+
+
+# element types of the typed path (codes shared with DCP_DTYPE_* of include/discorpy_hip.h)
+DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.int8): 3,
+          np.dtype(np.uint16): 4, np.dtype(np.int16): 5, np.dtype(np.uint32): 6, np.dtype(np.int32): 7}
+
+
+def map_coordinates(mat, ycoord, xcoord, order=1, mode="reflect"):
+    """scipy.ndimage.map_coordinates(mat, (ycoord, xcoord), order, mode) for a 2-D `mat` of any of the
+    DTYPES and coordinates clamped into the image; output has mat's dtype and ycoord's shape."""
+    mat = np.asarray(mat)
+    if mat.dtype not in DTYPES:
+        raise TypeError("oracle does not handle dtype %s" % mat.dtype)
+    if mat.ndim != 2 or mat.strides[1] != mat.itemsize or mat.strides[0] % mat.itemsize:
+        mat = np.ascontiguousarray(mat)
+    ycoord, xcoord = np.ascontiguousarray(ycoord), np.ascontiguousarray(xcoord)
+    if ycoord.dtype != xcoord.dtype or ycoord.dtype not in (np.float32, np.float64):
+        raise TypeError("coordinates must both be float32 or both float64")
+    (height, width) = mat.shape
+    m = MODES.index(mode)
+    pad = lib().orc_spline_pad(m)
+    work = np.empty((height + 2 * pad, width + 2 * pad) if int(order) >= 2 else (1,), np.float64)
+    out = np.empty(ycoord.shape, mat.dtype)
+    _check(lib().orc_map_coordinates_typed(mat.ctypes.data, out.ctypes.data, DTYPES[mat.dtype], height, width,
+                                           mat.strides[0] // mat.itemsize, ycoord.ctypes.data, xcoord.ctypes.data,
+                                           int(ycoord.dtype == np.float64), ycoord.size, int(order), m, _dp(work)))
+    return out
 
 
 def set_threads(n):
@@ -155,6 +184,10 @@ def perspective_coords(height, width, list_coef, round_f32=True):
 def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *,
                           poly=POLY_NUMPY, blend=BLEND_SCIPY, coord_round_f32=True):
     """postprocessing.py:111-148 for float32 `mat`, order 0/1 (mode is inert there)."""
+    if np.asarray(mat).dtype != np.float32:
+        (height, width) = np.shape(mat)
+        yd, xd = radial_coords(height, width, xcenter, ycenter, list_fact, poly=poly, round_f32=coord_round_f32)
+        return map_coordinates(mat, yd, xd, order, mode)
     if int(order) >= 2:
         return _spline(mat, 0, order, mode, xcenter, ycenter, list_fact, poly=poly)
     mat = _f32c(mat)
@@ -172,6 +205,13 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     """postprocessing.py:462-492."""
     if len(list_coef) != 8:
         raise ValueError("!!! Eight coefficients are required !!!")
+    if np.asarray(mat).dtype != np.float32:
+        (height, width) = np.shape(mat)
+        if map_index is None:
+            yd, xd = perspective_coords(height, width, list_coef)
+        else:
+            yd, xd = (np.ascontiguousarray(np.asarray(m).reshape(-1)) for m in map_index)
+        return map_coordinates(mat, yd, xd, order, mode).reshape(height, width)
     mat = _f32c(mat)
     (height, width) = mat.shape
     if int(order) >= 2:
@@ -191,6 +231,8 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
 
 def remap_coords(mat, ycoord, xcoord, order=1, *, blend=BLEND_SCIPY, mode="reflect"):
     """map_coordinates(mat, (ycoord, xcoord), order) for in-range coordinates."""
+    if np.asarray(mat).dtype != np.float32:
+        return map_coordinates(mat, ycoord, xcoord, order, mode)
     if int(order) >= 2:
         return _spline(mat, 2, order, mode, ycoord=ycoord, xcoord=xcoord)
     mat = _f32c(mat)
@@ -222,6 +264,18 @@ def unwarp_fused(mat, xcenter, ycenter, list_fact, list_coef, order=1, *, poly=P
 
 def unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, *, coord_round_f32,
                       poly=POLY_NUMPY, blend=BLEND_SCIPY):
+    if np.asarray(mat3D).dtype != np.float32:
+        # any other element type: the coordinates of the requested rows once (x runs fastest, as :216-225 /
+        # :303-309 build them), then one map_coordinates per projection in the input's dtype (:226-228, :310-312)
+        mat3D = np.asarray(mat3D)
+        (depth, height, width) = mat3D.shape
+        yd, xd = radial_coords(height, width, xcenter, ycenter, list_fact, poly=poly, round_f32=coord_round_f32)
+        r0 = int(row_start)
+        yd, xd = yd[r0:r0 + nrows], xd[r0:r0 + nrows]
+        out = np.empty((depth, nrows, width), mat3D.dtype)
+        for d in range(depth):
+            out[d] = map_coordinates(mat3D[d], yd, xd, 1)
+        return out
     mat3D = np.ascontiguousarray(_f32c(mat3D))
     (depth, height, width) = mat3D.shape
     f = _facts(list_fact)
@@ -237,8 +291,10 @@ def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, poly=POL
     """postprocessing.py:188-229 (float64 coordinates, float32 output)."""
     if len(np.shape(mat3D)) < 3:
         raise ValueError("Input must be a 3D data")
+    # :224 allocates the sinogram as float32 whatever the input dtype; each row is first produced in the
+    # input's dtype by map_coordinates (:227) and converted by the assignment
     return unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, index, 1, coord_round_f32=False,
-                             poly=poly, blend=blend)[:, 0, :]
+                             poly=poly, blend=blend)[:, 0, :].astype(np.float32, copy=False)
 
 
 def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *,

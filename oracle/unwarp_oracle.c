@@ -468,9 +468,57 @@ static void spline_filter_line(double *c, int64_t n, int64_t s, const double *po
 
 int orc_spline_pad(int mode) { return (mode == ORC_MODE_NEAREST || mode == ORC_MODE_GRID_CONSTANT) ? 12 : 0; }
 
+/* ---- element types other than float32 ("output dtype = input dtype") ----
+ * scipy reads every input element as a double (ni_interpolation.c CASE_INTERP / the line buffers of
+ * spline_filter) and converts the double result on the way out (CASE_INTERP_OUT*):
+ *   float32 / float64: C cast;
+ *   unsigned: t = t > 0 ? t + 0.5 : 0, clamped to the type's maximum, truncated;
+ *   signed:   t = t > 0 ? t + 0.5 : t - 0.5 (round half away from zero), clamped, truncated.
+ * Pinned by tests/golden/g12_* (reference outputs for uint8 .. float64 inputs). */
+static inline double load_typed(const void *src, int dtype, int64_t i)
+{
+    switch (dtype) {
+    case ORC_DT_F32: return (double)((const float *)src)[i];
+    case ORC_DT_F64: return ((const double *)src)[i];
+    case ORC_DT_U8: return (double)((const uint8_t *)src)[i];
+    case ORC_DT_I8: return (double)((const int8_t *)src)[i];
+    case ORC_DT_U16: return (double)((const uint16_t *)src)[i];
+    case ORC_DT_I16: return (double)((const int16_t *)src)[i];
+    case ORC_DT_U32: return (double)((const uint32_t *)src)[i];
+    default: return (double)((const int32_t *)src)[i];
+    }
+}
+
+static inline double round_unsigned(double t, double hi)
+{
+    t = t > 0 ? t + 0.5 : 0.0;
+    return t > hi ? hi : t;
+}
+
+static inline double round_signed(double t, double lo, double hi)
+{
+    t = t > 0 ? t + 0.5 : t - 0.5;
+    t = t > hi ? hi : t;
+    return t < lo ? lo : t;
+}
+
+static inline void store_typed(void *dst, int dtype, int64_t i, double t)
+{
+    switch (dtype) {
+    case ORC_DT_F32: ((float *)dst)[i] = (float)t; break;
+    case ORC_DT_F64: ((double *)dst)[i] = t; break;
+    case ORC_DT_U8: ((uint8_t *)dst)[i] = (uint8_t)round_unsigned(t, 255.0); break;
+    case ORC_DT_I8: ((int8_t *)dst)[i] = (int8_t)round_signed(t, -128.0, 127.0); break;
+    case ORC_DT_U16: ((uint16_t *)dst)[i] = (uint16_t)round_unsigned(t, 65535.0); break;
+    case ORC_DT_I16: ((int16_t *)dst)[i] = (int16_t)round_signed(t, -32768.0, 32767.0); break;
+    case ORC_DT_U32: ((uint32_t *)dst)[i] = (uint32_t)round_unsigned(t, 4294967295.0); break;
+    default: ((int32_t *)dst)[i] = (int32_t)round_signed(t, -2147483648.0, 2147483647.0); break;
+    }
+}
+
 /* coefficients of the (padded) image: coef is (H + 2 pad) x (W + 2 pad) doubles */
-int orc_spline_coefficients_f32(const float *src, int64_t H, int64_t W, int64_t src_row_stride, int order,
-                                int mode, double *coef)
+static int spline_coefficients_any(const void *src, int dtype, int64_t H, int64_t W, int64_t src_row_stride, int order,
+                                   int mode, double *coef)
 {
     double poles[2];
     const int np = spline_poles(order, poles);
@@ -485,7 +533,7 @@ int orc_spline_coefficients_f32(const float *src, int64_t H, int64_t W, int64_t 
             else {
                 sy = sy < 0 ? 0 : (sy > H - 1 ? H - 1 : sy);
                 sx = sx < 0 ? 0 : (sx > W - 1 ? W - 1 : sx);
-                v = (double)src[sy * src_row_stride + sx];
+                v = load_typed(src, dtype, sy * src_row_stride + sx);
             }
             coef[y * Wp + x] = v;
         }
@@ -495,6 +543,12 @@ int orc_spline_coefficients_f32(const float *src, int64_t H, int64_t W, int64_t 
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int64_t y = 0; y < Hp; ++y) spline_filter_line(coef + y * Wp, Wp, 1, poles, np, kind); /* axis 1 */
     return 0;
+}
+
+int orc_spline_coefficients_f32(const float *src, int64_t H, int64_t W, int64_t src_row_stride, int order,
+                                int mode, double *coef)
+{
+    return spline_coefficients_any(src, ORC_DT_F32, H, W, src_row_stride, order, mode, coef);
 }
 
 /* centred B-spline weights; returns the first tap index */
@@ -571,8 +625,8 @@ static inline int64_t spline_fold(int64_t i, int64_t n, int mode)
 }
 
 /* one point of the padded coefficient array; (y, x) are coordinates in the UNPADDED image */
-static inline float spline_sample(const double *coef, int64_t Hp, int64_t Wp, int pad, double y, double x,
-                                  int order, int mode)
+static inline double spline_sample_d(const double *coef, int64_t Hp, int64_t Wp, int pad, double y, double x,
+                                     int order, int mode)
 {
     double wy[6], wx[6];
     const int64_t sy = spline_weights(order, y + (double)pad, wy);
@@ -585,7 +639,13 @@ static inline float spline_sample(const double *coef, int64_t Hp, int64_t Wp, in
             t += (coef[iy * Wp + ix] * wy[j]) * wx[i];
         }
     }
-    return (float)t;
+    return t;
+}
+
+static inline float spline_sample(const double *coef, int64_t Hp, int64_t Wp, int pad, double y, double x,
+                                  int order, int mode)
+{
+    return (float)spline_sample_d(coef, Hp, Wp, pad, y, x, order, mode);
 }
 
 /* map_kind: 0 radial (unwarp_image_backward), 1 perspective (correct_perspective_image), 2 explicit
@@ -621,5 +681,48 @@ int orc_remap_spline_f32(const float *src, float *dst, int64_t H, int64_t W, int
                 persp_coord((double)x, (double)y, coef8, (double)(W - 1), (double)(H - 1), 1, &xd, &yd);
             dst[y * W + x] = spline_sample(workspace, Hp, Wp, pad, yd, xd, order, mode);
         }
+    return 0;
+}
+
+/* scipy.ndimage.map_coordinates(src, (ycoord, xcoord), order, mode) for a 2-D `src` of any of the
+ * element types above and npts coordinates clamped into the image, output of the same type --
+ * what the reference's four functions reduce to once the coordinates exist
+ * (postprocessing.py:146-147, 226-228, 250-251, 490-491).  Orders 0..5; `workspace` holds
+ * (H + 2 pad) x (W + 2 pad) doubles for order >= 2. */
+int orc_map_coordinates_typed(const void *src, void *dst, int dtype, int64_t H, int64_t W, int64_t src_row_stride,
+                              const void *ycoord, const void *xcoord, int coord_is_f64, int64_t npts, int order,
+                              int mode, double *workspace)
+{
+    if (H <= 0 || W <= 0 || npts < 0 || order < 0 || order > 5 || mode < 0 || mode > 7) return -1;
+    if (dtype < ORC_DT_F32 || dtype > ORC_DT_I32) return -1;
+    const int pad = orc_spline_pad(mode);
+    const int64_t Hp = H + 2 * pad, Wp = W + 2 * pad;
+    if (order >= 2 && spline_coefficients_any(src, dtype, H, W, src_row_stride, order, mode, workspace) != 0) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int64_t i = 0; i < npts; ++i) {
+        double y = coord_is_f64 ? ((const double *)ycoord)[i] : (double)((const float *)ycoord)[i];
+        double x = coord_is_f64 ? ((const double *)xcoord)[i] : (double)((const float *)xcoord)[i];
+        y = clipd(y, 0.0, (double)(H - 1));
+        x = clipd(x, 0.0, (double)(W - 1));
+        double t;
+        if (order >= 2) {
+            t = spline_sample_d(workspace, Hp, Wp, pad, y, x, order, mode);
+        } else if (order == 0) {
+            const int64_t iy = fold_edge((int64_t)floor(y + 0.5), H), ix = fold_edge((int64_t)floor(x + 0.5), W);
+            t = load_typed(src, dtype, iy * src_row_stride + ix);
+        } else {
+            const double y0 = floor(y), x0 = floor(x);
+            const double wy0 = 1.0 - (y - y0), wy1 = 1.0 - wy0;
+            const double wx0 = 1.0 - (x - x0), wx1 = 1.0 - wx0;
+            const int64_t iy0 = fold_edge((int64_t)y0, H), ix0 = fold_edge((int64_t)x0, W);
+            const int64_t iy1 = fold_edge((int64_t)y0 + 1, H), ix1 = fold_edge((int64_t)x0 + 1, W);
+            t = 0.0;
+            t += (load_typed(src, dtype, iy0 * src_row_stride + ix0) * wy0) * wx0;
+            t += (load_typed(src, dtype, iy0 * src_row_stride + ix1) * wy0) * wx1;
+            t += (load_typed(src, dtype, iy1 * src_row_stride + ix0) * wy1) * wx0;
+            t += (load_typed(src, dtype, iy1 * src_row_stride + ix1) * wy1) * wx1;
+        }
+        store_typed(dst, dtype, i, t);
+    }
     return 0;
 }

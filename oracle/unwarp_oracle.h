@@ -23,6 +23,16 @@ extern "C" {
 #define ORC_MODE_GRID_WRAP 6
 #define ORC_MODE_WRAP 7
 
+/* element types of orc_map_coordinates_typed (same codes as DCP_DTYPE_* in include/discorpy_hip.h) */
+#define ORC_DT_F32 0
+#define ORC_DT_F64 1
+#define ORC_DT_U8 2
+#define ORC_DT_I8 3
+#define ORC_DT_U16 4
+#define ORC_DT_I16 5
+#define ORC_DT_U32 6
+#define ORC_DT_I32 7
+
 void orc_set_threads(int n);
 int orc_get_threads(void);
 int orc_max_threads(void);
@@ -51,6 +61,9 @@ int orc_remap_spline_f32(const float *src, float *dst, int64_t H, int64_t W, int
                          double xc, double yc, const double *fact, int nfact, const double *coef8,
                          const void *ycoord, const void *xcoord, int coord_is_f64, int64_t npts, int order,
                          int mode, int poly_mode, double *workspace);
+int orc_map_coordinates_typed(const void *src, void *dst, int dtype, int64_t H, int64_t W, int64_t src_row_stride,
+                              const void *ycoord, const void *xcoord, int coord_is_f64, int64_t npts, int order,
+                              int mode, double *workspace);
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,29 @@ def noise(seed, shape):
     return np.random.default_rng(int(seed)).random(tuple(int(v) for v in shape), dtype=np.float32)
 
 
+def typed_image(dt, shape, seed):
+    """The inputs of golden G12 (tools/gen_golden.py): full-range integers / floats in [-700, 1300)."""
+    rng = np.random.default_rng(int(seed))
+    dt = np.dtype(dt)
+    shape = tuple(int(v) for v in shape)
+    if dt.kind == "f":
+        return (rng.random(shape) * 2000.0 - 700.0).astype(dt)
+    info = np.iinfo(dt)
+    return rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=np.int64).astype(dt)
+
+
+def g12_inputs(g, dt):
+    """(image, volume) of golden G12 for element type `dt`."""
+    names = ("uint8", "int8", "uint16", "int16", "uint32", "int32", "float64")
+    k = names.index(dt)
+    im = typed_image(dt, g["shape"], 800 + k)
+    im[:8, :5] = np.arange(40).reshape(8, 5).astype(im.dtype) - (20 if np.dtype(dt).kind != "u" else 0)
+    return im, typed_image(dt, g["vol_shape"], 900 + k)
+
+
+G12_DTYPES = ("uint8", "int8", "uint16", "int16", "uint32", "int32", "float64")
+
+
 def ulp_diff(a, b):
     """Distance in float32 ulps between two float32 arrays (finite values)."""
     ia = np.ascontiguousarray(a, dtype=np.float32).view(np.int32).astype(np.int64)

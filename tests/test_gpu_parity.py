@@ -8,7 +8,7 @@ scipy's arithmetic by at most one float32 ulp (and in these vectors does not dif
 import numpy as np
 import pytest
 
-from conftest import golden, noise, ulp_diff
+from conftest import G12_DTYPES, g12_inputs, golden, noise, typed_image, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -426,6 +426,97 @@ def test_device_resident_tensors_take_the_same_path(hip, orc):
     assert got.is_cuda and np.array_equal(
         got.cpu().numpy(), orc.unwarp_chunk_slices_backward(vol.cpu().numpy(), 70.0, 50.0, [1.0, 2e-3], 20, 40,
                                                             **kernel_oracle(orc, "scipy")))
+
+
+# --------------------------------------------------------------------------- element types other than float32
+
+def typed_close(out, ref, order):
+    """Orders 0 / 1 bit-exact; a spline order may land one unit apart where the double result sits on a
+    rounding boundary (integers) or differ in the last places (float64)."""
+    assert out.dtype == ref.dtype and out.shape == ref.shape, (out.dtype, ref.dtype, out.shape, ref.shape)
+    if order <= 1:
+        return np.array_equal(out, ref)
+    if out.dtype.kind == "f":
+        return np.allclose(out, ref, rtol=1e-12, atol=1e-9)
+    d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+    return d.max() <= 1 and np.count_nonzero(d) <= 3
+
+
+@pytest.mark.parametrize("dt", G12_DTYPES)
+def test_g12_element_types_against_the_reference(hip, dt):
+    """Output dtype = input dtype, scipy's integer rounding and saturation; the slice function returns float32."""
+    g = golden("g12_dtypes40x52")
+    im, vol = g12_inputs(g, dt)
+    xc, yc, fact, coef = float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]), list(g["list_coef"])
+    for order in (0, 1, 3):
+        assert typed_close(pp.unwarp_image_backward(im, xc, yc, fact, order=order), g["radial_o%d_%s" % (order, dt)], order)
+        assert typed_close(pp.remap_coordinates(im, g["pts_y"], g["pts_x"], order=order), g["points_o%d_%s" % (order, dt)], order)
+    assert typed_close(pp.unwarp_image_backward(im, xc, yc, fact, order=2, mode="nearest"), g["radial_o2_nearest_" + dt], 2)
+    assert typed_close(pp.correct_perspective_image(im, coef), g["persp_o1_" + dt], 1)
+    assert typed_close(pp.correct_perspective_image(im, coef, order=5, mode="grid-wrap"), g["persp_o5_wrap_" + dt], 5)
+    sl = pp.unwarp_slice_backward(vol, xc, yc, fact, int(g["index"]))
+    assert sl.dtype == np.float32 and np.array_equal(sl, g["slice_" + dt])
+    assert typed_close(pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, int(g["start"]), int(g["stop"])), g["chunk_" + dt], 1)
+
+
+@pytest.mark.parametrize("dt", ["uint8", "uint16", "int32", "float64", "float32"])
+def test_element_types_match_oracle_on_ragged_shapes(hip, orc, dt):
+    L = hip.lib()
+    for k, (h, w) in enumerate([(1, 1), (1, 9), (7, 1), (63, 257), (300, 421)]):
+        im = typed_image(dt, (h, w), 40 + k)
+        a = (0.45 * w, 0.55 * h, [1.0, 2e-3 * 300 / max(h, w), 1e-6])
+        for order in (0, 1):
+            want = orc.map_coordinates(im, *orc.radial_coords(h, w, *a, poly=orc.POLY_KERNEL), order)
+            if dt == "float32":     # the typed entry point also takes float32 (exact scipy blend)
+                out = np.empty_like(im)
+                fa, nf = hip.fact_array(a[2])
+                hip.check(L.dcp_unwarp_image_typed(im.ctypes.data, out.ctypes.data, 0, h, w, w, 1, a[0], a[1], fa, nf,
+                                                   order, 0, hip.MEM_HOST, -1, None))
+            else:
+                out = pp.unwarp_image_backward(im, *a, order=order)
+            assert typed_close(out, want, order), (dt, h, w, order)
+    # one channel of an interleaved colour image, and the whole image through the colour helper
+    from discorpy_amd.util import utility as util
+    if dt != "float32":
+        rgb = typed_image(dt, (50, 70, 3), 77)
+        a = (33.0, 26.0, [1.0, 3e-3])
+        yd, xd = orc.radial_coords(50, 70, *a, poly=orc.POLY_KERNEL)
+        got = util.unwarp_color_image_backward(rgb, *a)
+        assert got.dtype == rgb.dtype and got.shape == rgb.shape
+        for c in range(3):
+            want = orc.map_coordinates(np.ascontiguousarray(rgb[:, :, c]), yd, xd, 1)
+            assert np.array_equal(pp.unwarp_image_backward(rgb[:, :, c], *a), want)
+            assert np.array_equal(got[:, :, c], want)
+        f = orc.map_coordinates(rgb[:, :, 0].copy(), *orc.radial_coords(50, 70, *a, poly=orc.POLY_KERNEL), 1)
+        coef = [0.97, 0.01, 1.0, -0.02, 0.98, 0.5, 1e-4, -2e-4]
+        py, px = pp.generate_fused_map((50, 70), *a, coef)
+        fused = pp.unwarp_perspective_fused(rgb[:, :, 0], *a, coef)
+        assert fused.dtype == rgb.dtype and np.array_equal(fused, orc.map_coordinates(rgb[:, :, 0].copy(), py, px, 1))
+
+
+def test_element_types_on_device_tensors_and_stacks(hip, orc):
+    torch = pytest.importorskip("torch")
+    a = (70.0, 50.0, [1.0, 2e-3])
+    for dt in ("uint8", "int16", "float64"):
+        vol = typed_image(dt, (6, 100, 140), 5)
+        tv = torch.from_numpy(vol).cuda()
+        got = pp.unwarp_chunk_slices_backward(tv, *a, 20, 40)
+        assert got.is_cuda and str(got.dtype) == "torch." + dt
+        assert np.array_equal(got.cpu().numpy(), orc.unwarp_chunk_slices_backward(vol, *a, 20, 40, poly=orc.POLY_KERNEL))
+        sl = pp.unwarp_slice_backward(tv, *a, 33)
+        assert sl.dtype == torch.float32
+        assert np.array_equal(sl.cpu().numpy(), orc.unwarp_slice_backward(vol, *a, 33, poly=orc.POLY_KERNEL))
+        im = torch.from_numpy(vol[0]).cuda()
+        for order in (1, 3):
+            out = pp.unwarp_image_backward(im, *a, order=order, mode="mirror")
+            want = orc.map_coordinates(vol[0], *orc.radial_coords(100, 140, *a, poly=orc.POLY_KERNEL), order, "mirror")
+            assert str(out.dtype) == "torch." + dt and typed_close(out.cpu().numpy(), want, order)
+    # a host stack with padded rows / projections (the row-band staging of the typed path)
+    big = typed_image("uint16", (4, 90, 130), 6)
+    view = big[:, 5:85, 7:120]
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(view, 50.0, 40.0, [1.0, 1e-3], 10, 70),
+                          orc.unwarp_chunk_slices_backward(np.ascontiguousarray(view), 50.0, 40.0, [1.0, 1e-3], 10, 70,
+                                                           poly=orc.POLY_KERNEL))
 
 
 # --------------------------------------------------------------------------- (c) BASELINE sizes

@@ -116,10 +116,11 @@ def test_unsupported_inputs_fail_loudly_instead_of_falling_back():
         pp.unwarp_image_backward(img, 1, 1, [1.0], order=6)
     with pytest.raises(NotImplementedError, match="fused one-pass"):
         pp.unwarp_perspective_fused(img, 1, 1, [1.0], [1, 0, 0, 0, 1, 0, 0, 0], order=3)
-    with pytest.raises(NotImplementedError, match="float32"):
-        pp.unwarp_image_backward(img.astype(np.float64), 1, 1, [1.0])
-    with pytest.raises(NotImplementedError, match="float32"):
-        pp.unwarp_image_backward(img.astype(np.uint8), 1, 1, [1.0])
+    for dt in (np.int64, np.uint64, np.float16, np.bool_, np.complex64):
+        with pytest.raises(NotImplementedError, match="element type"):
+            pp.unwarp_image_backward(img.astype(dt), 1, 1, [1.0])
+        with pytest.raises(NotImplementedError, match="element type"):
+            pp.unwarp_chunk_slices_backward(np.zeros((2, 4, 4), dt), 1, 1, [1.0], 0, 1)
     with pytest.raises(RuntimeError, match="boundary mode not supported"):
         pp.unwarp_image_backward(img, 1, 1, [1.0], mode="bogus")
     with pytest.raises(ValueError, match="unknown blend"):

@@ -8,7 +8,7 @@ on the same float32 coordinates.
 import numpy as np
 import pytest
 
-from conftest import golden, noise, ulp_diff
+from conftest import G12_DTYPES, g12_inputs, golden, noise, ulp_diff
 
 POLYS = ["numpy", "kernel"]
 
@@ -189,3 +189,33 @@ def test_g11_perspective_order3_every_mode(orc):
     for mode in MODES:
         assert spline_close(orc.correct_perspective_image(img, g["list_coef"], order=3, mode=mode),
                             g["persp_o3_%s" % mode]), mode
+
+
+def typed_close(out, ref, order):
+    """Orders 0/1 are bit-exact; a spline order may flip a rounding where the double result sits on .5
+    (integers) or differ in the last place (float64), as spline_close allows for float32."""
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    if order <= 1:
+        return np.array_equal(out, ref)
+    if out.dtype.kind == "f":
+        return np.allclose(out, ref, rtol=1e-12, atol=1e-9)
+    d = np.abs(out.astype(np.int64) - ref.astype(np.int64))
+    # a full-range 32-bit image: one unit in the last place of the double result is ~1e-6 of an integer step
+    return d.max() <= 1 and np.count_nonzero(d) <= 3
+
+
+@pytest.mark.parametrize("dt", G12_DTYPES)
+def test_g12_element_types(orc, dt):
+    g = golden("g12_dtypes40x52")
+    im, vol = g12_inputs(g, dt)
+    xc, yc, fact, coef = g["xcenter"], g["ycenter"], g["list_fact"], g["list_coef"]
+    for order in (0, 1, 3):
+        assert typed_close(orc.unwarp_image_backward(im, xc, yc, fact, order=order), g["radial_o%d_%s" % (order, dt)], order)
+        assert typed_close(orc.map_coordinates(im, g["pts_y"], g["pts_x"], order), g["points_o%d_%s" % (order, dt)], order)
+    assert typed_close(orc.unwarp_image_backward(im, xc, yc, fact, order=2, mode="nearest"), g["radial_o2_nearest_" + dt], 2)
+    assert typed_close(orc.correct_perspective_image(im, coef), g["persp_o1_" + dt], 1)
+    assert typed_close(orc.correct_perspective_image(im, coef, order=5, mode="grid-wrap"), g["persp_o5_wrap_" + dt], 5)
+    sl = orc.unwarp_slice_backward(vol, xc, yc, fact, int(g["index"]))
+    assert sl.dtype == np.float32 and np.array_equal(sl, g["slice_" + dt])
+    ch = orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, int(g["start"]), int(g["stop"]))
+    assert typed_close(ch, g["chunk_" + dt], 1)

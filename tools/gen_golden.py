@@ -28,6 +28,13 @@ os.makedirs(OUT, exist_ok=True)
 
 def save(name, **arrays):
     path = os.path.join(OUT, name + ".npz")
+    if os.path.exists(path):
+        old = np.load(path)
+        if sorted(old.files) == sorted(arrays) and all(
+                np.asarray(arrays[k]).dtype == old[k].dtype and np.array_equal(old[k], arrays[k], equal_nan=True)
+                for k in arrays):
+            print("%-28s unchanged" % (name + ".npz"))
+            return
     np.savez_compressed(path, **arrays)
     print("%-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024.0))
 
@@ -213,4 +220,39 @@ g11["pts_y"], g11["pts_x"] = pts_y, pts_x
 for order in (2, 3, 4, 5):
     g11["points_o%d_reflect" % order] = map_coordinates(im, (pts_y, pts_x), order=order, mode="reflect")
 save("g11_spline45x60", **g11)
+# ---- G12: element types other than float32 (output dtype = input dtype; unwarp_slice_backward -> float32)
+def typed_image(dt, shape, seed):
+    rng = np.random.default_rng(seed)
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        return (rng.random(shape) * 2000.0 - 700.0).astype(dt)
+    info = np.iinfo(dt)
+    return rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=np.int64).astype(dt)
+
+
+g12 = dict(shape=np.array([40, 52]), xcenter=f64(24.6), ycenter=f64(20.3), list_fact=f64([1.0, 5e-3, 3e-5]),
+           list_coef=f64([0.96, -0.03, 1.5, 0.02, 0.97, 1.0, -3e-4, 2e-4]), vol_shape=np.array([5, 40, 52]),
+           index=np.int64(17), start=np.int64(8), stop=np.int64(21))
+pts_y = (np.random.default_rng(82).random(400) * 39).astype(np.float32)
+pts_x = (np.random.default_rng(83).random(400) * 51).astype(np.float32)
+# exact halves between neighbouring integers: the integer stores round half away from zero
+pts_y[:40] = np.repeat(np.arange(8, dtype=np.float32), 5)
+pts_x[:40] = np.tile(np.array([0.5, 1.5, 2.5, 3.5, 4.0], dtype=np.float32), 8)
+g12["pts_y"], g12["pts_x"] = pts_y, pts_x
+for k, dt in enumerate(("uint8", "int8", "uint16", "int16", "uint32", "int32", "float64")):
+    im = typed_image(dt, (40, 52), 800 + k)
+    im[:8, :5] = np.arange(40).reshape(8, 5).astype(im.dtype) - (20 if np.dtype(dt).kind != "u" else 0)
+    g12["seed_" + dt] = np.int64(800 + k)
+    for order in (0, 1, 3):
+        g12["radial_o%d_%s" % (order, dt)] = post.unwarp_image_backward(im, 24.6, 20.3, g12["list_fact"], order=order)
+        g12["points_o%d_%s" % (order, dt)] = map_coordinates(im, (pts_y, pts_x), order=order, mode="reflect")
+    g12["radial_o2_nearest_" + dt] = post.unwarp_image_backward(im, 24.6, 20.3, g12["list_fact"], order=2, mode="nearest")
+    g12["persp_o1_" + dt] = post.correct_perspective_image(im, g12["list_coef"])
+    g12["persp_o5_wrap_" + dt] = post.correct_perspective_image(im, g12["list_coef"], order=5, mode="grid-wrap")
+    vol = typed_image(dt, (5, 40, 52), 900 + k)
+    g12["slice_" + dt] = post.unwarp_slice_backward(vol, 24.6, 20.3, g12["list_fact"], 17)
+    g12["chunk_" + dt] = post.unwarp_chunk_slices_backward(vol, 24.6, 20.3, g12["list_fact"], 8, 21)
+    assert g12["radial_o1_" + dt].dtype == np.dtype(dt) and g12["chunk_" + dt].dtype == np.dtype(dt)
+    assert g12["slice_" + dt].dtype == np.float32
+save("g12_dtypes40x52", **g12)
 print("done")
