@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
 
 namespace {
 
@@ -472,6 +475,46 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
   DCP_HIP(dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs));
   DCP_HIP(hipMemcpyAsync(out, dout, (size_t)depth * (size_t)nrows * (size_t)width * 4, hipMemcpyDeviceToHost, hs));
   DCP_HIP(hipStreamSynchronize(hs));
+  return DCP_OK;
+}
+
+int dcp_unwarp_stack_rows_multi_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
+                                    int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                    const double* list_fact, int nfact, double row_start, int64_t nrows,
+                                    int coord_round_f32, int blend_mode, const int* devices, int ndev) {
+  if (ndev < 1 || !devices) return fail(DCP_ERR_INVALID_ARG, "need at least one device");
+  if (ndev > 64) return fail(DCP_ERR_INVALID_ARG, "ndev = %d > 64", ndev);
+  const int have = dcp_device_count();
+  for (int i = 0; i < ndev; ++i)
+    if (devices[i] < 0 || devices[i] >= have)
+      return have == 0 ? fail(DCP_ERR_NO_DEVICE, "no HIP device visible")
+                       : fail(DCP_ERR_INVALID_ARG, "devices[%d] = %d outside [0, %d)", i, devices[i], have);
+  if (depth < 0 || nrows < 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows or empty projections");
+  // shard i = projections [d0, d1) with the sizes of numpy.array_split(range(depth), ndev); every worker
+  // stages its own shard, runs K4 on its device and copies its block of `out` back -- the blocks are
+  // disjoint, contiguous along depth, so the "gather" is the D2H copies themselves
+  std::vector<int> rcs((size_t)ndev, DCP_OK);
+  std::vector<std::string> msgs((size_t)ndev);
+  std::vector<std::thread> workers;
+  const int64_t base = depth / ndev, extra = depth % ndev;
+  int64_t d0 = 0;
+  for (int i = 0; i < ndev; ++i) {
+    const int64_t n = base + (i < extra ? 1 : 0);
+    const float* v = vol ? vol + d0 * proj_stride : vol;
+    float* o = out ? out + d0 * nrows * width : out;
+    const int dev = devices[i];
+    workers.emplace_back([=, &rcs, &msgs]() {
+      rcs[(size_t)i] = dcp_unwarp_stack_rows_f32(v, o, n, height, width, proj_stride, row_stride, xcenter, ycenter, list_fact,
+                                                 nfact, row_start, nrows, coord_round_f32, blend_mode, DCP_MEM_HOST, dev,
+                                                 nullptr);
+      if (rcs[(size_t)i] != DCP_OK) msgs[(size_t)i] = dcp_last_error();
+      g_staging.release();   // the worker's scratch lives on `dev`; free it before the thread ends
+    });
+    d0 += n;
+  }
+  for (auto& w : workers) w.join();
+  for (int i = 0; i < ndev; ++i)
+    if (rcs[(size_t)i] != DCP_OK) return fail(rcs[(size_t)i], "shard %d on device %d: %s", i, devices[i], msgs[(size_t)i].c_str());
   return DCP_OK;
 }
 

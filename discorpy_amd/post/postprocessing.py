@@ -208,24 +208,28 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     return out
 
 
-def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=None):
+def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=None, devices=None):
     """
     Generate an unwarped slice [:,index.:] of a 3D dataset, i.e. one unwarped sinogram of a 3D
     tomographic data (reference ``postprocessing.py:188-229``).  Coordinates stay float64, the
-    result is float32 of shape (depth, width).
+    result is float32 of shape (depth, width).  ``devices=[0, 1, ...]`` shards a host (NumPy) float32
+    stack along depth over those GPUs of this process.
     """
     if len(mat3D.shape) < 3:
         raise ValueError("Input must be a 3D data")
     (depth, height, width) = mat3D.shape
-    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True)[:, 0, :]
+    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True,
+                       devices=devices)[:, 0, :]
 
 
-def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *, blend=None):
+def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *, blend=None,
+                                 devices=None):
     """
     Generate a chunk of unwarped slices [:,start_index: stop_index, :] used for tomographic data
     (reference ``postprocessing.py:255-313``).  Rows ``start_index .. stop_index`` INCLUSIVE;
     coordinates are rounded to float32 as the reference does; ``stop_index=-1`` raises, as it
-    does in the reference (:285-288).
+    does in the reference (:285-288).  ``devices=[0, 1, ...]`` shards a host (NumPy) float32 stack along
+    depth over those GPUs of this process (projections are independent, :310-312).
     """
     if (len(mat3D.shape) < 3):
         raise ValueError("Input must be a 3D data")
@@ -239,10 +243,11 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
     if nrows < 1:
         # np.arange(start, stop + 1) is empty in the reference and map_coordinates then fails
         raise ValueError("Selected index is out of the range")
-    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend)
+    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices)
 
 
-def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32=False):
+def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32=False,
+                devices=None):
     bcode = _blend_code(blend)
     vol = _Image(mat3D, 3)
     depth, height, width = vol.shape
@@ -260,6 +265,17 @@ def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32,
                                                     ps if depth > 1 else height * rs, rs, float(xcenter),
                                                     float(ycenter), fa, nf, float(row_start), nrows, int(round_f32),
                                                     vol.mem, vol.device, vol.stream))
+        return out
+    if devices is not None:
+        if vol.torch:
+            raise ValueError("devices= shards a host (NumPy) stack; a device tensor already lives on one GPU "
+                             "(see discorpy_amd.stack for one process per GPU)")
+        devs = [int(d) for d in devices]
+        arr = (C.c_int * max(len(devs), 1))(*devs)
+        F.check(F.lib().dcp_unwarp_stack_rows_multi_f32(vol.ptr, optr, depth, height, width,
+                                                        ps if depth > 1 else height * rs, rs, float(xcenter),
+                                                        float(ycenter), fa, nf, float(row_start), nrows, int(round_f32),
+                                                        bcode, arr, len(devs)))
         return out
     F.check(F.lib().dcp_unwarp_stack_rows_f32(vol.ptr, optr, depth, height, width, ps if depth > 1 else height * rs,
                                               rs, float(xcenter), float(ycenter), fa, nf, float(row_start), nrows,

@@ -104,6 +104,16 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
                               const double* list_fact, int nfact, double row_start, int64_t nrows,
                               int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream);
 
+/* The same over a HOST-resident stack sharded across `ndev` GPUs of this process (SURVEY.md section
+ * 8(e): projections are independent).  devices[i] takes the i-th contiguous depth shard (sizes as
+ * numpy.array_split), stages it, runs the kernel and copies its block of `out` (depth x nrows x width,
+ * host) back; the shards run concurrently on one host thread each.  For DEVICE-resident shards use one
+ * process per GPU and an RCCL all-gather (discorpy_amd/stack.py). */
+int dcp_unwarp_stack_rows_multi_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
+                                    int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                    const double* list_fact, int nfact, double row_start, int64_t nrows,
+                                    int coord_round_f32, int blend_mode, const int* devices, int ndev);
+
 /* ---- spline orders 2..5 (scipy.ndimage.map_coordinates with its B-spline prefilter) ----
  * The same maps as dcp_unwarp_image_f32 / dcp_perspective_image_f32 / dcp_remap_coords_f32 for
  * `order` in 2..5 -- what the reference computes when a caller passes order >= 2

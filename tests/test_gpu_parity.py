@@ -389,6 +389,22 @@ def test_stack_rows_match_oracle(hip, orc):
                           orc.unwarp_slice_backward(np.ascontiguousarray(vol[::2]), *a, 59, **kernel_oracle(orc, "scipy")))
 
 
+def test_host_stack_sharded_over_devices_of_one_process(hip, orc):
+    """dcp_unwarp_stack_rows_multi_f32: depth shards on one worker thread per entry of `devices` (here the one GPU of
+    the box, several times) give the same sinograms as one call; ragged and empty shards included."""
+    vol = noise(31, (7, 120, 160))
+    a = (83.0, 55.0, list(configs.COEF_DOT_05))
+    want = orc.unwarp_chunk_slices_backward(vol, *a, 30, 90, **kernel_oracle(orc, "f64lerp"))
+    for devs in ([0], [0, 0], [0, 0, 0], [0] * 9):
+        assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, 30, 90, devices=devs), want), devs
+    assert np.array_equal(pp.unwarp_slice_backward(vol, *a, 44, devices=[0, 0]),
+                          orc.unwarp_slice_backward(vol, *a, 44, **kernel_oracle(orc, "f64lerp")))
+    with pytest.raises(ValueError, match="outside"):
+        pp.unwarp_chunk_slices_backward(vol, *a, 30, 90, devices=[0, 99])
+    with pytest.raises(ValueError, match="at least one device"):
+        pp.unwarp_chunk_slices_backward(vol, *a, 30, 90, devices=[])
+
+
 def test_explicit_coordinates_match_oracle(hip, orc):
     img = noise(3, (70, 90))
     rng = np.random.default_rng(5)
