@@ -236,7 +236,12 @@ int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_
   const size_t frame = (size_t)H * (size_t)W * sizeof(float);
   DCP_HIP(g_staging.get(0, frame, &dsrc));
   DCP_HIP(g_staging.get(1, frame, &ddst));
-  if (cs == 1) {
+  if (cs == 1 && rs == W) {
+    DCP_HIP(hipMemcpyAsync(dsrc, src, frame, hipMemcpyHostToDevice, st));
+    img.src_stride = (int32_t)W;
+    img.src_col_stride = 1;
+    img.src_bytes = (uint32_t)frame;
+  } else if (cs == 1) {
     DCP_HIP(hipMemcpy2DAsync(dsrc, (size_t)W * 4, src, (size_t)rs * 4, (size_t)W * 4, (size_t)H, hipMemcpyHostToDevice, st));
     img.src_stride = (int32_t)W;
     img.src_col_stride = 1;

@@ -373,7 +373,10 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
 // [1] containment vote failed.  Read through dcp_debug_counters().
 __device__ unsigned long long g_lds_stats[2];
 
-constexpr int kLdsTW = 64, kLdsTH = 16;
+#ifndef DCP_LDS_TH
+#define DCP_LDS_TH 16
+#endif
+constexpr int kLdsTW = 64, kLdsTH = DCP_LDS_TH;
 #ifndef DCP_BOXW
 #define DCP_BOXW 80
 #endif
@@ -386,13 +389,17 @@ constexpr int kLdsTW = 64, kLdsTH = 16;
 #ifndef DCP_LDS_WAVES
 #define DCP_LDS_WAVES 5
 #endif
+#ifndef DCP_LDS_BLOCK_WAVES
+#define DCP_LDS_BLOCK_WAVES 4   // wave tiles (64 x 16 pixels, stacked vertically) per workgroup
+#endif
 constexpr int kBoxW = DCP_BOXW, kBoxH = DCP_BOXH;
+constexpr int kLdsBW = DCP_LDS_BLOCK_WAVES;
 
 template <int KIND, int NF, int SAMPLER>
-__global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
+__global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
   // 4 x 7680 B slabs + row table + coefficients <= 32 KB: five workgroups (20 waves) per CU
-  __shared__ float s_box[4][kBoxH * kBoxW];
-  __shared__ double s_row[4 * kLdsTH][KIND == kRadial ? 2 : 4];
+  __shared__ float s_box[kLdsBW][kBoxH * kBoxW];
+  __shared__ double s_row[kLdsBW * kLdsTH][KIND == kRadial ? 2 : 4];
   __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
   using FetchT = Fetch<SAMPLER, true, float>;
 
@@ -414,11 +421,11 @@ __global__ void __launch_bounds__(kBlock, DCP_LDS_WAVES) remap_lds_kernel(const 
   } else {
     logical_tile(img.xcd_remap, img.tiles_x, &tx, &ty);
   }
-  const int yblk = ty * (4 * kLdsTH);
+  const int yblk = ty * (kLdsBW * kLdsTH);
   const int y0 = yblk + wave * kLdsTH;            // first row of this wave's tile
   const int x = tx * kLdsTW + lane;
 
-  if ((int)threadIdx.x < 4 * kLdsTH)
+  if ((int)threadIdx.x < kLdsBW * kLdsTH)
     fill_row<KIND, (KIND == kRadial ? 2 : 4)>(map, s_row, threadIdx.x, (double)min(yblk + (int)threadIdx.x, img.H - 1));
   if constexpr (NF < 0 && KIND != kPersp) {
     if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
@@ -745,10 +752,10 @@ template <int KIND, int NF, int SAMPLER>
 static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {
   ImageArgs img = img_in;
   img.tiles_x = (img.W + kLdsTW - 1) / kLdsTW;
-  img.tiles_y = (img.H + 4 * kLdsTH - 1) / (4 * kLdsTH);
+  img.tiles_y = (img.H + kLdsBW * kLdsTH - 1) / (kLdsBW * kLdsTH);
   dim3 grid(img.tiles_x * img.tiles_y);
   if (img.xcd_remap == 2) grid = dim3(8 * ((img.tiles_x + 7) / 8), img.tiles_y);   // see the kernel's tile order
-  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER>), grid, dim3(kBlock), 0, stream, img, map);
+  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER>), grid, dim3(64 * kLdsBW), 0, stream, img, map);
   return hipGetLastError();
 }
 

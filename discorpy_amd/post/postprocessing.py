@@ -30,7 +30,9 @@ What differs from the reference, on purpose:
   clipped into the image first; it is validated and otherwise ignored.
   Orders 2..5 run scipy's prefiltered B-spline interpolation on the GPU with all eight modes
   (within one float32 ulp of scipy);
-* keyword-only extras: ``blend`` selects the bilinear arithmetic (``"f64lerp"`` default: float64
+* keyword-only extras: ``out=`` writes into a caller-supplied array / tensor of the right shape and
+  dtype; without it NumPy outputs are leased from a recycling pool (``discorpy_amd/_pool.py``) so that
+  a loop does not pay 4 ms of page faults per 4096 x 4096 frame; ``blend`` selects the bilinear arithmetic (``"f64lerp"`` default: float64
   factorised lerp, within one float32 ulp of scipy and bit-equal in practice; ``"scipy"``:
   scipy's exact float64 operation order; ``"f32"``: float32 lerp, opt-in).
 """
@@ -40,6 +42,7 @@ import os
 import numpy as np
 
 from .. import _ffi as F
+from .. import _pool
 
 __all__ = ["unwarp_image_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
            "correct_perspective_image", "unwarp_perspective_fused", "remap_coordinates",
@@ -127,14 +130,26 @@ class _Image:
     def f32(self):
         return self.code == F.DTYPE_F32
 
-    def empty(self, shape, float32=False):
+    def empty(self, shape, float32=False, out=None):
         """Fresh output of the same kind (device tensor / NumPy array) and element type as the input
-        (float32 if asked)."""
+        (float32 if asked) -- or the caller's ``out`` after checking that it is exactly that."""
         if self.torch:
             import torch
-            out = torch.empty(shape, dtype=torch.float32 if float32 else self.dtype, device=self.keep.device)
+            dt = torch.float32 if float32 else self.dtype
+            if out is not None:
+                if not (_is_torch(out) and out.is_cuda and out.device == self.keep.device and out.dtype == dt
+                        and tuple(out.shape) == tuple(shape) and out.is_contiguous()):
+                    raise ValueError("out must be a contiguous %s tensor of shape %s on %s" % (dt, tuple(shape), self.keep.device))
+                return out, out.data_ptr()
+            out = torch.empty(shape, dtype=dt, device=self.keep.device)
             return out, out.data_ptr()
-        out = np.empty(shape, np.float32 if float32 else self.dtype)
+        dt = np.dtype(np.float32) if float32 else np.dtype(self.dtype)
+        if out is not None:
+            if not (isinstance(out, np.ndarray) and out.dtype == dt and out.shape == tuple(shape)
+                    and out.flags.c_contiguous and out.flags.writeable):
+                raise ValueError("out must be a writeable C-contiguous %s array of shape %s" % (dt, tuple(shape)))
+            return out, out.ctypes.data
+        out = _pool.empty(shape, dt)      # recycled once the caller drops it (discorpy_amd/_pool.py)
         return out, out.ctypes.data
 
     def dense_rows(self):
@@ -159,7 +174,7 @@ def _coefs(values, what):
 
 # --------------------------------------------------------------------------- public functions
 
-def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *, blend=None):
+def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *, blend=None, out=None):
     """
     Unwarp an image using a backward model (reference ``postprocessing.py:111-148``).
 
@@ -190,7 +205,7 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     img = _Image(mat, 2).dense_rows()
     fact = _coefs(list_fact, "list_fact")
     fa, nf = F.fact_array(fact)
-    out, optr = img.empty((height, width))
+    out, optr = img.empty((height, width), out=out)
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_unwarp_image_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
@@ -208,7 +223,7 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     return out
 
 
-def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=None, devices=None):
+def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=None, devices=None, out=None):
     """
     Generate an unwarped slice [:,index.:] of a 3D dataset, i.e. one unwarped sinogram of a 3D
     tomographic data (reference ``postprocessing.py:188-229``).  Coordinates stay float64, the
@@ -218,12 +233,16 @@ def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=No
     if len(mat3D.shape) < 3:
         raise ValueError("Input must be a 3D data")
     (depth, height, width) = mat3D.shape
+    if out is not None:
+        if tuple(out.shape) != (depth, width):
+            raise ValueError("out must have shape (depth, width)")
+        out = out.reshape((depth, 1, width))
     return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True,
-                       devices=devices)[:, 0, :]
+                       devices=devices, out=out)[:, 0, :]
 
 
 def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *, blend=None,
-                                 devices=None):
+                                 devices=None, out=None):
     """
     Generate a chunk of unwarped slices [:,start_index: stop_index, :] used for tomographic data
     (reference ``postprocessing.py:255-313``).  Rows ``start_index .. stop_index`` INCLUSIVE;
@@ -243,22 +262,23 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
     if nrows < 1:
         # np.arange(start, stop + 1) is empty in the reference and map_coordinates then fails
         raise ValueError("Selected index is out of the range")
-    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices)
+    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices,
+                       out=out)
 
 
 def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32=False,
-                devices=None):
+                devices=None, out=None):
     bcode = _blend_code(blend)
     vol = _Image(mat3D, 3)
     depth, height, width = vol.shape
     if depth == 0:
-        return vol.empty((0, nrows, width), out_float32)[0]
+        return vol.empty((0, nrows, width), out_float32, out=out)[0]
     ps, rs, cs = vol.strides
     if cs != 1 or rs < width or (depth > 1 and ps < (height - 1) * rs + width):
         vol = _Image(vol.keep.contiguous() if vol.torch else np.ascontiguousarray(vol.keep), 3)
         ps, rs, cs = vol.strides
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
-    out, optr = vol.empty((depth, nrows, width), out_float32)
+    out, optr = vol.empty((depth, nrows, width), out_float32, out=out)
     F.require_device()
     if not vol.f32:
         F.check(F.lib().dcp_unwarp_stack_rows_typed(vol.ptr, optr, vol.code, int(out_float32), depth, height, width,
@@ -283,7 +303,7 @@ def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32,
     return out
 
 
-def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index=None, *, blend=None):
+def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index=None, *, blend=None, out=None):
     """
     Apply perspective correction to an image (reference ``postprocessing.py:462-492``).
 
@@ -313,9 +333,13 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     img = _Image(mat, 2).dense_rows()
     if map_index is not None:
         ymap, xmap = map_index[0], map_index[1]
-        return remap_coordinates(mat, ymap, xmap, order=order, mode=mode, blend=blend).reshape((height, width))
+        res = remap_coordinates(mat, ymap, xmap, order=order, mode=mode, blend=blend).reshape((height, width))
+        if out is not None:
+            out[...] = res
+            return out
+        return res
     ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
-    out, optr = img.empty((height, width))
+    out, optr = img.empty((height, width), out=out)
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_perspective_image_typed(img.ptr, optr, img.code, height, width, img.strides[0],
@@ -381,7 +405,8 @@ def generate_fused_map(shape, xcenter, ycenter, list_fact, list_coef, *, like=No
     return _coordinate_map(tuple(shape), F.MAP_FUSED, xcenter, ycenter, list_fact, list_coef, like)
 
 
-def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=1, mode="reflect", *, blend=None):
+def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=1, mode="reflect", *, blend=None,
+                             out=None):
     """
     Perspective and radial correction in ONE resampling (BASELINE config 3).
 
@@ -403,7 +428,7 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
     img = _Image(mat, 2).dense_rows()
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
     ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
-    out, optr = img.empty((height, width))
+    out, optr = img.empty((height, width), out=out)
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_unwarp_fused_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],

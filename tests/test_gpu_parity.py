@@ -405,6 +405,32 @@ def test_host_stack_sharded_over_devices_of_one_process(hip, orc):
         pp.unwarp_chunk_slices_backward(vol, *a, 30, 90, devices=[])
 
 
+def test_out_argument_and_recycled_outputs(hip, orc):
+    from discorpy_amd import _pool
+    img = noise(71, (600, 700))                                   # 1.6 MiB: above the pool's threshold
+    a = (333.0, 290.0, list(configs.COEF_DOT_05))
+    want = orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp"))
+    out = np.full(img.shape, -1.0, np.float32)
+    assert pp.unwarp_image_backward(img, *a, out=out) is out and np.array_equal(out, want)
+    _pool.clear()
+    r1 = pp.unwarp_image_backward(img, *a)
+    addr = r1.ctypes.data
+    keep = r1.copy()
+    del r1
+    r2 = pp.unwarp_image_backward(img[::-1].copy(), *a)           # reuses the block r1 gave back
+    assert r2.ctypes.data == addr and np.array_equal(keep, want) and not np.array_equal(r2, want)
+    r3 = pp.unwarp_image_backward(img, *a)                        # r2 is alive: a different block
+    assert r3.ctypes.data != addr and np.array_equal(r3, want)
+    vol = noise(72, (4, 200, 300))
+    sl = np.empty((4, 300), np.float32)
+    assert np.array_equal(pp.unwarp_slice_backward(vol, 150.0, 100.0, [1.0, 1e-3], 77, out=sl),
+                          orc.unwarp_slice_backward(vol, 150.0, 100.0, [1.0, 1e-3], 77, **kernel_oracle(orc, "f64lerp")))
+    ch = np.empty((4, 11, 300), np.float32)
+    assert pp.unwarp_chunk_slices_backward(vol, 150.0, 100.0, [1.0, 1e-3], 50, 60, out=ch) is ch
+    assert np.array_equal(ch, orc.unwarp_chunk_slices_backward(vol, 150.0, 100.0, [1.0, 1e-3], 50, 60,
+                                                               **kernel_oracle(orc, "f64lerp")))
+
+
 def test_explicit_coordinates_match_oracle(hip, orc):
     img = noise(3, (70, 90))
     rng = np.random.default_rng(5)

@@ -156,3 +156,42 @@ def test_coefficient_file_of_the_reference_parses():
     vals = [float(line.split()[-1]) for line in text.splitlines()]
     assert vals[0] == configs.XCENTER_DOT_05 and vals[1] == configs.YCENTER_DOT_05
     assert tuple(vals[2:]) == configs.COEF_DOT_05
+
+
+def test_host_output_pool_recycles_only_unreachable_blocks():
+    """discorpy_amd/_pool.py: a block returns to the pool when the caller has dropped the array and every view of it,
+    never earlier; small outputs and a disabled pool are plain np.empty."""
+    from discorpy_amd import _pool
+    _pool.clear()
+    a = _pool.empty((512, 1024), np.float32)
+    assert a.shape == (512, 1024) and a.dtype == np.float32 and a.flags.writeable and a.flags.c_contiguous
+    a[:] = 3.0
+    addr = a.ctypes.data
+    view = a[100:200, ::2]
+    del a
+    assert _pool.stats()["idle_bytes"] == 0                  # the view keeps the block alive
+    b = _pool.empty((512, 1024), np.float32)
+    assert b.ctypes.data != addr
+    assert float(view[0, 0]) == 3.0
+    del view
+    assert _pool.stats()["idle_bytes"] == 512 * 1024 * 4
+    c = _pool.empty((1024, 512), np.float32)                 # same byte count, other shape: reused
+    assert c.ctypes.data == addr and _pool.stats()["idle_bytes"] == 0
+    d = _pool.empty((512, 1024), np.uint16)                  # other size: a new block
+    assert d.ctypes.data not in (addr, b.ctypes.data)
+    small = _pool.empty((10, 10), np.float32)
+    assert small.flags.owndata
+    off = _pool.HostPool(0).empty((512, 1024), np.float32)
+    assert off.flags.owndata
+    del b, c, d
+    _pool.clear()
+    assert _pool.stats()["idle_bytes"] == 0
+
+
+def test_out_argument_is_validated_on_the_host(monkeypatch):
+    img = np.zeros((8, 8), np.float32)
+    for bad in (np.zeros((8, 9), np.float32), np.zeros((8, 8), np.float64), np.zeros((8, 16), np.float32)[:, ::2], [[0.0]]):
+        with pytest.raises(ValueError, match="out must be"):
+            pp.unwarp_image_backward(img, 4, 4, [1.0], out=bad)
+    with pytest.raises(ValueError, match="out must"):
+        pp.unwarp_slice_backward(np.zeros((2, 8, 8), np.float32), 4, 4, [1.0], 3, out=np.zeros((2, 9), np.float32))
