@@ -5,6 +5,8 @@
 #include "dcp_internal.h"
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -32,7 +34,7 @@ int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -99,6 +101,34 @@ struct Staging {
   }
 };
 thread_local Staging g_staging;
+
+// Two non-blocking streams per host thread for the streamed DCP_MEM_HOST stack path (uploads + kernels,
+// downloads).  The legacy null stream would serialise the two directions.
+struct HostStreams {
+  hipStream_t up = nullptr, down = nullptr;
+  int device = -1;
+  ~HostStreams() { release(); }
+  void release() {
+    if (up) (void)hipStreamDestroy(up);
+    if (down) (void)hipStreamDestroy(down);
+    up = down = nullptr;
+  }
+  hipError_t get(hipStream_t* u, hipStream_t* d) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != device) {
+      release();
+      device = dev;
+    }
+    if (!up && (e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking)) != hipSuccess) return e;
+    if (!down && (e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking)) != hipSuccess) return e;
+    *u = up;
+    *d = down;
+    return hipSuccess;
+  }
+};
+thread_local HostStreams g_host_streams;
 
 int sampler_of(int order, int blend_mode, int* sampler) {
   if (order == 0) {
@@ -169,36 +199,57 @@ uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs) {
 }
 
 // Rows of a projection that the radial map of output rows row_start .. row_start+nrows-1 can
-// touch: [*b0, *b1).  Evaluated in double on the host with the kernels' operation order and
-// widened by one row on each side, so a 1-ulp difference from the device cannot matter.
+// touch: [*b0, *b1).  yd = yc + yu * B(r) is bilinear in (yu, B), so its range over the rows is spanned
+// by the corners of [yu_min, yu_max] x [B_min, B_max], with B's range taken over every radius the rows
+// reach.  B is sampled every 1/4 pixel of radius (a few thousand evaluations, instead of one per output
+// pixel) and the range is widened by twice the largest step between neighbouring samples; the hull is
+// then grown by a safety row on each side.  A non-finite model gets the whole projection.
 void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0,
                    int64_t* b1) {
-  double ymin = 1e300, ymax = -1e300;
+  *b0 = 0;
+  *b1 = H;
   const int n = m.nfact, ne = (n + 1) / 2, no = n / 2;
-  for (int64_t r = 0; r < nrows; ++r) {
-    const double yu = (row_start + (double)r) - m.yc;
-    for (int64_t x = 0; x < W; ++x) {
-      const double xu = (double)x - m.xc;
-      const double r2 = xu * xu + yu * yu;
-      const double ru = std::sqrt(r2);
-      double f = 0.0;
-      if (n > 0) {
-        double E = m.fact[2 * (ne - 1)];
-        for (int k = ne - 2; k >= 0; --k) E = std::fma(r2, E, m.fact[2 * k]);
-        f = E;
-        if (no > 0) {
-          double O = m.fact[2 * (no - 1) + 1];
-          for (int k = no - 2; k >= 0; --k) O = std::fma(r2, O, m.fact[2 * k + 1]);
-          f = std::fma(ru, O, E);
-        }
-      }
-      double yd = std::fma(f, yu, m.yc);
+  auto B = [&](double ru) {
+    if (n <= 0) return 0.0;
+    const double r2 = ru * ru;
+    double E = m.fact[2 * (ne - 1)];
+    for (int k = ne - 2; k >= 0; --k) E = E * r2 + m.fact[2 * k];
+    if (no == 0) return E;
+    double O = m.fact[2 * (no - 1) + 1];
+    for (int k = no - 2; k >= 0; --k) O = O * r2 + m.fact[2 * k + 1];
+    return ru * O + E;
+  };
+  const double yu0 = row_start - m.yc, yu1 = (row_start + (double)(nrows - 1)) - m.yc;
+  const double ya = std::fmin(std::fabs(yu0), std::fabs(yu1));
+  const double ay_min = (yu0 <= 0.0 && yu1 >= 0.0) ? 0.0 : ya;                    // smallest |yu| over the rows
+  const double ay_max = std::fmax(std::fabs(yu0), std::fabs(yu1));
+  const double xl = 0.0 - m.xc, xr = (double)(W - 1) - m.xc;
+  const double ax_min = (xl <= 0.0 && xr >= 0.0) ? 0.0 : std::fmin(std::fabs(xl), std::fabs(xr));
+  const double ax_max = std::fmax(std::fabs(xl), std::fabs(xr));
+  const double rlo = std::sqrt(ax_min * ax_min + ay_min * ay_min), rhi = std::sqrt(ax_max * ax_max + ay_max * ay_max);
+  if (!std::isfinite(rlo) || !std::isfinite(rhi) || rhi > 1e9) return;
+  const int64_t ns = (int64_t)std::ceil((rhi - rlo) * 4.0) + 1;
+  double bmin = 1e300, bmax = -1e300, step = 0.0, prev = 0.0;
+  for (int64_t i = 0; i <= ns; ++i) {
+    const double r = i == ns ? rhi : rlo + 0.25 * (double)i;
+    const double v = B(r < rhi ? r : rhi);
+    if (!std::isfinite(v)) return;
+    if (i > 0) step = std::fmax(step, std::fabs(v - prev));
+    prev = v;
+    bmin = std::fmin(bmin, v);
+    bmax = std::fmax(bmax, v);
+  }
+  bmin -= 2.0 * step;
+  bmax += 2.0 * step;
+  double ymin = 1e300, ymax = -1e300;
+  for (double yu : {yu0, yu1})
+    for (double bv : {bmin, bmax}) {
+      double yd = m.yc + yu * bv;
       if (!(yd >= 0.0)) yd = 0.0;               // also catches NaN
       if (yd > (double)(H - 1)) yd = (double)(H - 1);
-      if (yd < ymin) ymin = yd;
-      if (yd > ymax) ymax = yd;
+      ymin = std::fmin(ymin, yd);
+      ymax = std::fmax(ymax, yd);
     }
-  }
   int64_t lo = (int64_t)std::floor(ymin) - 1, hi = (int64_t)std::floor(ymax) + 3;
   if (lo < 0) lo = 0;
   if (hi > H) hi = H;
@@ -296,6 +347,9 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "d_chunk")) {
     if (value < 1) return fail(DCP_ERR_INVALID_ARG, "d_chunk must be >= 1");
     g_d_chunk = value;
+  } else if (!strcmp(key, "stack_chunk_kb")) {
+    if (value < 1) return fail(DCP_ERR_INVALID_ARG, "stack_chunk_kb must be >= 1");
+    g_stack_chunk_kb = value;
   } else {
     return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   }
@@ -310,6 +364,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "d_chunk")) *value = g_d_chunk;
   else if (!strcmp(key, "pipe_depth")) *value = g_pipe_depth;
   else if (!strcmp(key, "lds_gather")) *value = g_lds_gather;
+  else if (!strcmp(key, "stack_chunk_kb")) *value = g_stack_chunk_kb;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }
@@ -457,29 +512,101 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
   int64_t band0 = 0, band1 = height;
   host_row_band(map, height, width, row_start, nrows, &band0, &band1);
   const int64_t bh = band1 - band0;
-  void *dvol, *dout;
-  const size_t pbytes = (size_t)bh * (size_t)width * 4;
-  DCP_HIP(g_staging.get(0, pbytes * (size_t)depth, &dvol));
-  DCP_HIP(g_staging.get(1, (size_t)depth * (size_t)nrows * (size_t)width * 4, &dout));
-  for (int64_t d = 0; d < depth; ++d) {
-    const float* hsrc = vol + d * proj_stride + band0 * row_stride;
-    char* ddst = (char*)dvol + (size_t)d * pbytes;
-    if (row_stride == width) {
-      DCP_HIP(hipMemcpyAsync(ddst, hsrc, pbytes, hipMemcpyHostToDevice, hs));
-    } else {
-      DCP_HIP(hipMemcpy2DAsync(ddst, (size_t)width * 4, hsrc, (size_t)row_stride * 4, (size_t)width * 4,
-                               (size_t)bh, hipMemcpyHostToDevice, hs));
-    }
+  // Projections are independent (postprocessing.py:226-228, 310-312), so the stack streams through the
+  // GPU in depth chunks: while chunk k is copied back by a second host thread, chunk k+1 is uploaded
+  // and computed (PCIe is full duplex; pageable copies block their calling thread, hence two threads
+  // rather than two streams -- tools/ubench_pcie.hip).  Device scratch: two band buffers and two
+  // output buffers of one chunk each, instead of the whole stack.
+  const size_t pbytes = (size_t)bh * (size_t)width * 4;                 // one projection's band
+  const size_t obytes = (size_t)nrows * (size_t)width * 4;              // one projection's output rows
+  int64_t dc = (int64_t)(((size_t)g_stack_chunk_kb.load() << 10) / (pbytes > obytes ? pbytes : obytes));
+  dc = dc < 1 ? 1 : (dc > depth ? depth : dc);
+  const int64_t nchunks = (depth + dc - 1) / dc;
+  void *din[2], *dout[2];
+  for (int b = 0; b < 2; ++b) {
+    DCP_HIP(g_staging.get(b, pbytes * (size_t)dc, &din[b]));
+    DCP_HIP(g_staging.get(2 + b, obytes * (size_t)dc, &dout[b]));
   }
-  // absolute row indexing: shift the base up by band0 rows (never dereferenced below the band)
-  st.vol = (const float*)dvol - band0 * width;
-  st.out = (float*)dout;
+  int cur_dev = 0;
+  DCP_HIP(hipGetDevice(&cur_dev));
+  hipStream_t s_down = nullptr;
+  DCP_HIP(g_host_streams.get(&hs, &s_down));   // host memory: nothing to order against the caller's stream
   st.proj_stride = bh * width;
   st.row_stride = (int32_t)width;
   st.proj_bytes = (uint32_t)((size_t)band1 * (size_t)width * 4);
-  DCP_HIP(dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs));
-  DCP_HIP(hipMemcpyAsync(out, dout, (size_t)depth * (size_t)nrows * (size_t)width * 4, hipMemcpyDeviceToHost, hs));
-  DCP_HIP(hipStreamSynchronize(hs));
+
+  const bool trace = getenv("DISCORPY_AMD_TRACE") != nullptr;   // per-chunk timeline on stderr
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+  std::mutex mu;
+  std::condition_variable cv;
+  int64_t computed = 0, downloaded = 0;     // chunks whose kernel has finished / whose D2H has finished
+  hipError_t down_err = hipSuccess;
+  bool abort_down = false;
+  std::thread downloader([&]() {
+    hipError_t e = hipSetDevice(cur_dev);
+    for (int64_t k = 0; k < nchunks && e == hipSuccess; ++k) {
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return computed > k || abort_down; });
+        if (abort_down) break;
+      }
+      const int64_t d0 = k * dc, n = (d0 + dc > depth ? depth - d0 : dc);
+      const double td0 = ms();
+      e = hipMemcpyAsync(out + (size_t)d0 * (size_t)nrows * (size_t)width, dout[k & 1], obytes * (size_t)n,
+                         hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+      if (trace) fprintf(stderr, "down %lld: %.3f -> %.3f\n", (long long)k, td0, ms());
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        downloaded = k + 1;
+      }
+      cv.notify_all();
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    down_err = e;
+    downloaded = nchunks;      // never leave the uploader waiting
+    cv.notify_all();
+  });
+  hipError_t up_err = hipSuccess;
+  for (int64_t k = 0; k < nchunks && up_err == hipSuccess; ++k) {
+    const int64_t d0 = k * dc, n = (d0 + dc > depth ? depth - d0 : dc);
+    if (k >= 2) {   // output buffer k & 1 is free once chunk k-2 has been copied back
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&] { return downloaded >= k - 1; });
+    }
+    const float* hsrc = vol + d0 * proj_stride + band0 * row_stride;
+    const double tu0 = ms();
+    if (row_stride == width) {   // the bands of n projections: n runs of pbytes, proj_stride apart
+      up_err = hipMemcpy2DAsync(din[k & 1], pbytes, hsrc, (size_t)proj_stride * 4, pbytes, (size_t)n, hipMemcpyHostToDevice, hs);
+    } else {
+      for (int64_t d = 0; d < n && up_err == hipSuccess; ++d)
+        up_err = hipMemcpy2DAsync((char*)din[k & 1] + (size_t)d * pbytes, (size_t)width * 4, hsrc + d * proj_stride,
+                                  (size_t)row_stride * 4, (size_t)width * 4, (size_t)bh, hipMemcpyHostToDevice, hs);
+    }
+    if (up_err != hipSuccess) break;
+    const double tu1 = ms();
+    st.D = (int32_t)n;
+    st.vol = (const float*)din[k & 1] - band0 * width;   // absolute row indexing (never dereferenced below the band)
+    st.out = (float*)dout[k & 1];
+    up_err = dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs);
+    if (up_err == hipSuccess) up_err = hipStreamSynchronize(hs);
+    if (trace) fprintf(stderr, "up %lld: issue %.3f -> %.3f, done %.3f\n", (long long)k, tu0, tu1, ms());
+    if (up_err != hipSuccess) break;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      computed = k + 1;
+    }
+    cv.notify_all();
+  }
+  if (up_err != hipSuccess) {
+    std::lock_guard<std::mutex> lock(mu);
+    abort_down = true;
+    cv.notify_all();
+  }
+  downloader.join();
+  if (up_err != hipSuccess) return fail(DCP_ERR_HIP, "stack upload / kernel failed: %s", hipGetErrorString(up_err));
+  if (down_err != hipSuccess) return fail(DCP_ERR_HIP, "stack download failed: %s", hipGetErrorString(down_err));
   return DCP_OK;
 }
 
@@ -514,6 +641,7 @@ int dcp_unwarp_stack_rows_multi_f32(const float* vol, float* out, int64_t depth,
                                                  nullptr);
       if (rcs[(size_t)i] != DCP_OK) msgs[(size_t)i] = dcp_last_error();
       g_staging.release();   // the worker's scratch lives on `dev`; free it before the thread ends
+      g_host_streams.release();
     });
     d0 += n;
   }

@@ -405,6 +405,27 @@ def test_host_stack_sharded_over_devices_of_one_process(hip, orc):
         pp.unwarp_chunk_slices_backward(vol, *a, 30, 90, devices=[])
 
 
+def test_host_stack_streams_in_depth_chunks(hip, orc):
+    """DCP_MEM_HOST stacks go through the GPU chunk by chunk (upload k+1 while chunk k is copied back); the result
+    must not depend on the chunking, including a ragged last chunk and chunks of a single projection."""
+    vol = noise(91, (11, 90, 130))
+    a = (66.0, 41.0, [1.0, 2e-3, 1e-6])
+    want_c = orc.unwarp_chunk_slices_backward(vol, *a, 20, 70, **kernel_oracle(orc, "f64lerp"))
+    want_s = orc.unwarp_slice_backward(vol, *a, 45, **kernel_oracle(orc, "f64lerp"))
+    old = hip.get_option("stack_chunk_kb")
+    try:
+        for kb in (1, 64, 110, 24576):
+            hip.set_option("stack_chunk_kb", kb)
+            assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, 20, 70), want_c), kb
+            assert np.array_equal(pp.unwarp_slice_backward(vol, *a, 45), want_s), kb
+            padded = np.zeros((11, 95, 140), np.float32)
+            padded[:, :90, :130] = vol
+            assert np.array_equal(pp.unwarp_chunk_slices_backward(padded[:, :90, :130], *a, 20, 70), want_c), kb
+            assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, 20, 70, devices=[0, 0, 0]), want_c), kb
+    finally:
+        hip.set_option("stack_chunk_kb", old)
+
+
 def test_out_argument_and_recycled_outputs(hip, orc):
     from discorpy_amd import _pool
     img = noise(71, (600, 700))                                   # 1.6 MiB: above the pool's threshold

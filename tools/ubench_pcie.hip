@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 #define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("%s: %s\n", #e, hipGetErrorString(r_)); exit(1); } } while (0)
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main() {
@@ -51,6 +52,56 @@ int main() {
         CK(hipEventRecord(ev[c & 1], s0));
       }
       CK(hipEventDestroy(ev[0])); CK(hipEventDestroy(ev[1]));
+    });
+  }
+  // a chunk of a (D, H, W) stack: 33 bands of 70 rows x 2560 floats, one projection (2560 x 2560 floats) apart
+  {
+    const size_t wbytes = 70u * 2560u * 4u, pitch = 2560u * 2560u * 4u, hgt = 33;
+    char* big = (char*)aligned_alloc(4096, pitch * hgt); memset(big, 7, pitch * hgt);
+    auto rep2 = [&](const char* name, auto&& f) {
+      f(); CK(hipDeviceSynchronize());
+      double best = 1e9;
+      for (int r = 0; r < 5; ++r) { double t = now(); f(); CK(hipDeviceSynchronize()); t = now() - t; if (t < best) best = t; }
+      printf("%-52s %8.3f ms  %6.1f GB/s (%.1f MB)\n", name, best * 1e3, wbytes * hgt / best / 1e9, wbytes * hgt / 1e6);
+    };
+    rep2("H2D pageable hipMemcpy2DAsync 33 x 717 KB bands", [&] { CK(hipMemcpy2DAsync(d0, wbytes, big, pitch, wbytes, hgt, hipMemcpyHostToDevice, s0)); });
+    rep2("H2D pageable 33 x hipMemcpyAsync of 717 KB", [&] { for (size_t i = 0; i < hgt; ++i) CK(hipMemcpyAsync((char*)d0 + i * wbytes, big + i * pitch, wbytes, hipMemcpyHostToDevice, s0)); });
+    rep2("H2D pageable one hipMemcpyAsync of the same bytes", [&] { CK(hipMemcpyAsync(d0, big, wbytes * hgt, hipMemcpyHostToDevice, s0)); });
+    // the streamed stack path: 8 chunks up (2-D) in this thread while another thread copies 8 chunks down
+    char* dn = (char*)aligned_alloc(4096, wbytes * hgt * 8); memset(dn, 1, wbytes * hgt * 8);
+    for (int it = 0; it < 9; ++it) { const int mode = it % 3;
+      double t = now();
+      std::thread th([&] { for (int c = 0; c < 8; ++c) { CK(hipMemcpyAsync(dn + c * wbytes * hgt, d1, wbytes * hgt, hipMemcpyDeviceToHost, s1)); CK(hipStreamSynchronize(s1)); } });
+      for (int c = 0; c < 8; ++c) {
+        if (mode == 0) CK(hipMemcpy2DAsync(d0, wbytes, big, pitch, wbytes, hgt, hipMemcpyHostToDevice, s0));
+        else if (mode == 1) CK(hipMemcpyAsync(d0, big, wbytes * hgt, hipMemcpyHostToDevice, s0));
+        else for (size_t i = 0; i < hgt; ++i) CK(hipMemcpyAsync((char*)d0 + i * wbytes, big + i * pitch, wbytes, hipMemcpyHostToDevice, s0));
+        CK(hipStreamSynchronize(s0));
+      }
+      th.join();
+      t = now() - t;
+      printf("8 chunks up (%s) || 8 chunks down, two threads: %.3f ms (%.1f MB each way)\n", mode == 0 ? "2-D" : mode == 1 ? "1-D" : "33 x 1-D", t * 1e3, wbytes * hgt * 8 / 1e6);
+    }
+    free(dn);
+    free(big);
+  }
+  // first-time registration of buffers never seen by the runtime, and unregistration
+  for (int k = 0; k < 4; ++k) {
+    char* f = (char*)aligned_alloc(4096, n); memset(f, k, n);
+    double t0 = now(); CK(hipHostRegister(f, n, hipHostRegisterDefault)); double t1 = now();
+    CK(hipMemcpyAsync(d0, f, n, hipMemcpyHostToDevice, s0)); CK(hipStreamSynchronize(s0)); double t2 = now();
+    CK(hipHostUnregister(f)); double t3 = now();
+    printf("fresh buffer %d: register %.3f ms, H2D %.3f ms, unregister %.3f ms\n", k, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3);
+    free(f);
+  }
+  // two host threads, blocking pageable copies in opposite directions
+  {
+    char* a = (char*)aligned_alloc(4096, n); memset(a, 5, n);
+    char* b = (char*)aligned_alloc(4096, n); memset(b, 6, n);
+    rep("H2D + D2H pageable, two host threads", [&] {
+      std::thread t([&] { CK(hipMemcpyAsync(b, d1, n, hipMemcpyDeviceToHost, s1)); CK(hipStreamSynchronize(s1)); });
+      CK(hipMemcpyAsync(d0, a, n, hipMemcpyHostToDevice, s0)); CK(hipStreamSynchronize(s0));
+      t.join();
     });
   }
   return 0;
