@@ -244,6 +244,25 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
 
+    copy_gbps = None
+    if rank == 0:
+        # context for roofline.frac: what a plain device-to-device copy of the same frames reaches on this box
+        # (hipMemcpyAsync D2D over the ring, outside the timed region)
+        try:
+            nbytes = H * W * 4
+            for s, d in zip(srcs, dsts):
+                F.check(L.dcp_memcpy(d.ptr, s.ptr, nbytes, F.COPY_D2D, dev, None))
+            c0, c1 = F.Event(dev), F.Event(dev)
+            c0.record()
+            for _ in range(4):
+                for s, d in zip(srcs, dsts):
+                    F.check(L.dcp_memcpy(d.ptr, s.ptr, nbytes, F.COPY_D2D, dev, None))
+            c1.record()
+            c1.synchronize()
+            copy_gbps = round(2.0 * nbytes * 4 * len(srcs) / (c0.elapsed_ms(c1) * 1e-3) / 1e9, 1)
+        except Exception:
+            copy_gbps = None
+
     if rank == 0:
         launches = a.steps * a.batch
         pix_per_launch = H * W
@@ -271,7 +290,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": ("remap_lds_kernel<Radial,NF=5>" if F.get_option("lds_gather") and a.order == 1
                                     else "remap_tile_kernel<Radial,NF=5>"), "launch_us": round(launch_us, 3),
-                         "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch)},
+                         "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch),
+                         "d2d_copy_same_frames_GBps": copy_gbps},
         }
         if n_gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, img0, blend, a.cpu_threads)

@@ -582,6 +582,23 @@ def test_element_types_on_device_tensors_and_stacks(hip, orc):
                                                            poly=orc.POLY_KERNEL))
 
 
+def test_randomised_differential_campaign(hip, orc):
+    """600 seeded random cases of tools/fuzz_parity.py (shapes, centres, models from mild to folding, homographies,
+    strides, blends, stacks, coordinates, element types, spline orders and modes): HIP == oracle, bit for bit at
+    orders 0/1.  profiles/r01c_fuzz_parity.txt holds a 32 000-case run."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(777)
+    kinds = set()
+    for k in range(600):
+        kinds.add(fz.one_case(rng, k))
+    assert kinds == {"radial", "persp", "fused", "stack", "coords", "spline", "color"}
+
+
 # --------------------------------------------------------------------------- (c) BASELINE sizes
 
 def test_cfg2_full_frame_against_oracle_and_properties(hip, orc):

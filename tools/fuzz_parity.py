@@ -1,0 +1,195 @@
+"""Randomised differential test: HIP path (through the Python front end and the C ABI) against the CPU oracle in the
+kernels' evaluation order -- bit for bit for orders 0/1, within one ulp on a few pixels for spline orders.
+
+    python tools/fuzz_parity.py [cases] [seed]
+
+Shapes from 1 x 1 to ~1500 x 1500, centres inside and far outside the image, polynomial lengths 0..12 from mild to
+folding maps (which exercise the LDS kernel's "box does not fit" / "vote failed" fallbacks), strong homographies,
+strided sources, every blend mode, stacks, explicit coordinates, element types, spline orders and boundary modes.
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from oracle import oracle as orc                      # noqa: E402  (checker only)
+from discorpy_amd import _ffi as F                    # noqa: E402
+from discorpy_amd.post import postprocessing as pp    # noqa: E402
+
+MODES = orc.MODES
+BLENDS = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32": orc.BLEND_F32LERP}
+DTYPES = ["float32"] * 6 + ["float64", "uint8", "int8", "uint16", "int16", "uint32", "int32"]
+
+
+def rand_shape(rng):
+    kind = rng.integers(0, 10)
+    if kind == 0:
+        return int(rng.integers(1, 4)), int(rng.integers(1, 80))
+    if kind == 1:
+        return int(rng.integers(1, 80)), int(rng.integers(1, 4))
+    if kind == 2:
+        return int(rng.integers(600, 1500)), int(rng.integers(600, 1500))
+    return int(rng.integers(2, 420)), int(rng.integers(2, 420))
+
+
+def rand_image(rng, shape, dt):
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        return (rng.random(shape) * 400.0 - 100.0).astype(dt)
+    info = np.iinfo(dt)
+    return rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=np.int64).astype(dt)
+
+
+def rand_fact(rng, h, w):
+    n = int(rng.integers(0, 13))
+    R = float(np.hypot(h, w))
+    style = rng.integers(0, 6)
+    f = []
+    for i in range(n):
+        if i == 0:
+            f.append({0: 1.0, 1: float(rng.uniform(0.7, 1.3)), 2: float(rng.uniform(0.9, 1.1)), 3: 0.0,
+                      4: float(rng.uniform(-2, 3)), 5: 1.0}[int(style)])
+        else:
+            amp = {0: 0.05, 1: 0.2, 2: 0.02, 3: 0.5, 4: 1.5, 5: 0.0}[int(style)]
+            f.append(float(rng.uniform(-amp, amp)) / R ** i)
+    return f
+
+
+def rand_coef(rng, h, w):
+    style = rng.integers(0, 4)
+    s = {0: 0.02, 1: 0.15, 2: 0.5, 3: 0.0}[int(style)]
+    p = {0: 1e-5, 1: 2e-4, 2: 2e-3, 3: 0.0}[int(style)]
+    return [1.0 + rng.uniform(-s, s), rng.uniform(-s, s), rng.uniform(-0.2, 0.2) * w,
+            rng.uniform(-s, s), 1.0 + rng.uniform(-s, s), rng.uniform(-0.2, 0.2) * h,
+            rng.uniform(-p, p), rng.uniform(-p, p)]
+
+
+def same(a, b, order, what):
+    assert a.dtype == b.dtype and a.shape == b.shape, (what, a.dtype, b.dtype, a.shape, b.shape)
+    if order <= 1:
+        if not np.array_equal(a, b, equal_nan=True):
+            bad = np.argwhere(~((a == b) | (np.isnan(a.astype(np.float64)) & np.isnan(b.astype(np.float64)))))
+            raise AssertionError("%s: %d pixels differ, first at %s: %r vs %r" % (what, len(bad), bad[0], a[tuple(bad[0])], b[tuple(bad[0])]))
+        return
+    if a.dtype.kind == "f":
+        tol = 2e-6 if a.dtype == np.float32 else 1e-11
+        scale = max(1.0, float(np.max(np.abs(b))))
+        assert np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) <= tol * scale, what
+    else:
+        d = np.abs(a.astype(np.int64) - b.astype(np.int64))
+        assert d.max() <= 1 and np.count_nonzero(d) <= max(3, a.size // 2000), what
+
+
+def one_case(rng, k):
+    kind = ["radial"] * 5 + ["persp", "fused", "stack", "coords", "spline", "color"]
+    kind = kind[int(rng.integers(0, len(kind)))]
+    h, w = rand_shape(rng)
+    dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
+    order = int(rng.integers(0, 2))
+    blend = list(BLENDS)[int(rng.integers(0, 3))]
+    xc, yc = float(rng.uniform(-0.3, 1.3) * w), float(rng.uniform(-0.3, 1.3) * h)
+    if rng.integers(0, 5) == 0:
+        xc, yc = float(round(xc)), float(round(yc))
+    fact = rand_fact(rng, h, w)
+    okw = dict(poly=orc.POLY_KERNEL)
+    tag = "case %d %s %dx%d %s order %d blend %s xc=%r yc=%r fact=%r" % (k, kind, h, w, dt, order, blend, xc, yc, fact)
+    f32 = dt == "float32"
+    kw = dict(blend=blend) if f32 else {}
+    if f32:
+        okw["blend"] = BLENDS[blend]
+    if kind == "radial":
+        img = rand_image(rng, (h, w), dt)
+        if rng.integers(0, 4) == 0 and h > 2 and w > 2:       # strided / padded view
+            big = rand_image(rng, (h + 3, 2 * w + 5), dt)
+            img = big[1:h + 1, 2:2 * w + 2:2] if rng.integers(0, 2) else big[2:h + 2, 3:w + 3]
+        want = orc.unwarp_image_backward(np.ascontiguousarray(img), xc, yc, fact, order=order, **okw)
+        same(pp.unwarp_image_backward(img, xc, yc, fact, order=order, **kw), want, order, tag)
+    elif kind == "persp":
+        img = rand_image(rng, (h, w), dt)
+        coef = rand_coef(rng, h, w)
+        ok2 = {k_: v for k_, v in okw.items() if k_ != "poly"}
+        want = orc.correct_perspective_image(img, coef, order=order, **ok2)
+        same(pp.correct_perspective_image(img, coef, order=order, **kw), want, order, tag + " coef=%r" % coef)
+    elif kind == "fused":
+        img = rand_image(rng, (h, w), dt)
+        coef = rand_coef(rng, h, w)
+        got = pp.unwarp_perspective_fused(img, xc, yc, fact, coef, order=order, **kw)
+        if f32:
+            want = orc.unwarp_fused(img, xc, yc, fact, coef, order=order, **okw)
+        else:
+            py, px = pp.generate_fused_map((h, w), xc, yc, fact, coef)
+            want = orc.map_coordinates(img, py, px, order)
+        same(got, want, order, tag + " coef=%r" % coef)
+    elif kind == "stack":
+        h, w = max(h, 2), max(w, 2)
+        if h * w > 250000:
+            h, w = h // 3 + 2, w // 3 + 2
+        d = int(rng.integers(1, 6))
+        vol = rand_image(rng, (d, h, w), dt)
+        r0 = int(rng.integers(0, h))
+        r1 = int(rng.integers(r0, min(h, r0 + 40)))
+        xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
+        fact = rand_fact(rng, h, w)[:8]
+        tag += " rows %d..%d depth %d xc=%r yc=%r fact=%r" % (r0, r1, d, xc, yc, fact)
+        same(pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **kw),
+             orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **okw), 1, tag + " chunk")
+        same(pp.unwarp_slice_backward(vol, xc, yc, fact, r0, **kw),
+             orc.unwarp_slice_backward(vol, xc, yc, fact, r0, **okw), 1, tag + " slice")
+    elif kind == "coords":
+        img = rand_image(rng, (h, w), dt)
+        n = int(rng.integers(0, 5000))
+        cdt = np.float32 if rng.integers(0, 2) else np.float64
+        ys = (rng.uniform(-0.1, 1.1, n) * (h - 1)).astype(cdt)
+        xs = (rng.uniform(-0.1, 1.1, n) * (w - 1)).astype(cdt)
+        if n > 10:
+            ys[:5] = [0, h - 1, 0.5, h - 1.5 if h > 1 else 0, (h - 1) / 2.0]
+            xs[:5] = [w - 1, 0, 0.5, w - 1.5 if w > 1 else 0, (w - 1) / 2.0]
+        ok2 = {k_: v for k_, v in okw.items() if k_ != "poly"}
+        same(pp.remap_coordinates(img, ys, xs, order=order, **kw), orc.remap_coords(img, ys, xs, order=order, **ok2), order, tag)
+    elif kind == "spline":
+        h, w = min(h, 300), min(w, 300)
+        img = rand_image(rng, (h, w), dt)
+        so = int(rng.integers(2, 6))
+        mode = MODES[int(rng.integers(0, 8))]
+        xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
+        fact = [1.0] + [float(rng.uniform(-0.05, 0.05)) / float(np.hypot(h, w)) ** i for i in range(1, int(rng.integers(1, 5)))]
+        tag = "case %d spline %dx%d %s order %d mode %s xc=%r yc=%r fact=%r" % (k, h, w, dt, so, mode, xc, yc, fact)
+        same(pp.unwarp_image_backward(img, xc, yc, fact, order=so, mode=mode),
+             orc.unwarp_image_backward(img, xc, yc, fact, order=so, mode=mode, poly=orc.POLY_KERNEL), so, tag)
+    else:
+        from discorpy_amd.util import utility as util
+        h, w = min(max(h, 2), 300), min(max(w, 2), 300)
+        c = int(rng.integers(1, 5))
+        rgb = rand_image(rng, (h, w, c), dt)
+        pad = int(rng.integers(0, 6))
+        xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
+        fact = rand_fact(rng, h, w)[:6]
+        got = util.unwarp_color_image_backward(rgb, xc, yc, fact, order=order, pad=pad, pad_mode="edge", **kw)
+        padded = np.pad(rgb, [(pad, pad), (pad, pad), (0, 0)], mode="edge")
+        for ch in range(c):
+            want = orc.unwarp_image_backward(np.ascontiguousarray(padded[:, :, ch]), xc + pad, yc + pad, fact, order=order, **okw)
+            same(np.ascontiguousarray(got[:, :, ch]), want, order, tag + " colour pad %d channel %d" % (pad, ch))
+    return kind
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260928
+    orc.build()
+    orc.set_threads(min(32, orc.max_threads()))
+    F.lib()
+    F.require_device()
+    rng = np.random.default_rng(seed)
+    counts, t0 = {}, time.time()
+    F.debug_counters()
+    for k in range(cases):
+        kind = one_case(rng, k)
+        counts[kind] = counts.get(kind, 0) + 1
+    nofit, vote = F.debug_counters()
+    print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; LDS-kernel fallbacks exercised: %d tiles did not fit, "
+          "%d tiles failed the vote" % (cases, seed, time.time() - t0, dict(sorted(counts.items())), nofit, vote))
+
+
+if __name__ == "__main__":
+    main()
