@@ -69,6 +69,9 @@ SIGNATURES = {
                                       _int, _vp]),
     "dcp_unwarp_stack_rows_typed": (_int, [_vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int,
                                            _dbl, _i64, _int, _int, _int, _vp]),
+    "dcp_stack_row_band": (_int, [_i64, _i64, _dbl, _dbl, _dp, _int, _dbl, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
+    "dcp_unwarp_stack_band": (_int, [_vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp,
+                                     _int, _dbl, _i64, _int, _int, _int, _int, _vp]),
     "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
@@ -169,6 +172,15 @@ def debug_counters(reset=True):
     out = (C.c_uint64 * 2)()
     check(lib().dcp_debug_counters(out, 2, int(reset)))
     return int(out[0]), int(out[1])
+
+
+def stack_row_band(height, width, xcenter, ycenter, list_fact, row_start, nrows):
+    """(band_start, band_rows): source rows of a projection that output rows row_start .. row_start+nrows-1 can reach."""
+    fa, nf = fact_array(list_fact)
+    b0, bn = C.c_int64(0), C.c_int64(0)
+    check(lib().dcp_stack_row_band(int(height), int(width), float(xcenter), float(ycenter), fa, nf, float(row_start),
+                                   int(nrows), C.byref(b0), C.byref(bn)))
+    return int(b0.value), int(bn.value)
 
 
 def fact_array(list_fact):

@@ -464,61 +464,112 @@ int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t w
   return DCP_OK;
 }
 
-int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
-                              int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
-                              const double* list_fact, int nfact, double row_start, int64_t nrows,
-                              int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
-  int rc, sampler;
-  if (depth < 0 || nrows < 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows");
-  if (height <= 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "projections must be non-empty");
-  if (depth > 0 && nrows > 0 && (!vol || !out)) return fail(DCP_ERR_INVALID_ARG, "null volume pointer");
-  if (height < 2 || width < 2) return fail(DCP_ERR_UNSUPPORTED, "stack path needs projections of at least 2 x 2");
-  if (row_stride < width || proj_stride < (height - 1) * row_stride + width)
-    return fail(DCP_ERR_INVALID_ARG, "strides overlap (row %lld, projection %lld)", (long long)row_stride, (long long)proj_stride);
-  if ((double)height * (double)row_stride * 4.0 > 4294967040.0)
-    return fail(DCP_ERR_UNSUPPORTED, "one projection exceeds the 4 GiB the 32-bit gather offsets address");
-  if (nrows > 65535) return fail(DCP_ERR_UNSUPPORTED, "nrows > 65535 in one call");
-  if (!std::isfinite(row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
-  if ((rc = sampler_of(1, blend_mode, &sampler)) != DCP_OK) return rc;
+}  // extern "C"
+
+namespace {
+
+// One description of every stack call: rows row_start .. row_start+nrows-1 of the corrected stack from
+// `vol`, which holds rows [band_start, band_start + band_rows) of each of `depth` projections
+// (band_start = 0, band_rows = height for a whole stack).
+struct StackCall {
+  const void* vol;
+  void* out;
+  int dtype, out_f32;
+  int64_t depth, height, width, band_start, band_rows, proj_stride, row_stride;
   dcp::MapArgs map;
-  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
-  if (depth == 0 || nrows == 0) return DCP_OK;
-  DeviceScope scope(device);
-  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
-  dcp::LaunchOpts opts = current_opts();
-  if ((depth + opts.d_chunk - 1) / opts.d_chunk > 65535) opts.d_chunk = (int)((depth + 65534) / 65535);
-  dcp::StackArgs st;
-  memset(&st, 0, sizeof(st));
-  st.D = (int32_t)depth;
-  st.H = (int32_t)height;
-  st.W = (int32_t)width;
-  st.row_start = row_start;
-  st.nrows = (int32_t)nrows;
-  hipStream_t hs = (hipStream_t)stream;
-  if (mem_kind == DCP_MEM_DEVICE) {
-    st.vol = vol;
-    st.out = out;
+  double row_start;
+  int64_t nrows;
+  int round_f32, sampler;      // sampler: float32 data only (the other element types use scipy's exact blend)
+  int mem_kind, device;
+  void* stream;
+};
+
+// base = address of (projection 0, row 0) -- possibly before the buffer when the band starts later; the
+// kernels only touch rows inside the band
+hipError_t launch_stack_any(const StackCall& c, const void* base, void* out, int64_t n, int64_t proj_stride,
+                            int64_t row_stride, int64_t rows_end, const dcp::LaunchOpts& opts, hipStream_t hs) {
+  if (c.dtype == dcp::kF32 && !c.out_f32) {
+    dcp::StackArgs st;
+    memset(&st, 0, sizeof(st));
+    st.D = (int32_t)n;
+    st.H = (int32_t)c.height;
+    st.W = (int32_t)c.width;
+    st.row_start = c.row_start;
+    st.nrows = (int32_t)c.nrows;
+    st.vol = (const float*)base;
+    st.out = (float*)out;
     st.proj_stride = proj_stride;
     st.row_stride = (int32_t)row_stride;
-    st.proj_bytes = (uint32_t)(((height - 1) * row_stride + width) * 4);
-    DCP_HIP(dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs));
+    st.proj_bytes = (uint32_t)(((rows_end - 1) * row_stride + c.width) * 4);
+    return dcp::launch_stack(st, c.map, c.sampler, c.round_f32 != 0, opts, hs);
+  }
+  dcp::TypedStackArgs st;
+  memset(&st, 0, sizeof(st));
+  st.D = (int32_t)n;
+  st.H = (int32_t)c.height;
+  st.W = (int32_t)c.width;
+  st.row_start = c.row_start;
+  st.nrows = (int32_t)c.nrows;
+  st.d_chunk = opts.d_chunk;
+  st.dtype = c.dtype;
+  st.out_f32 = c.out_f32;
+  st.round_f32 = c.round_f32 != 0;
+  st.vol = base;
+  st.out = out;
+  st.proj_stride = proj_stride;
+  st.row_stride = row_stride;
+  return dcp::launch_typed_stack(st, c.map, hs);
+}
+
+int run_stack(const StackCall& c) {
+  const int64_t depth = c.depth, height = c.height, width = c.width, nrows = c.nrows;
+  if (c.dtype < 0 || c.dtype >= dcp::kNumElemTypes) return fail(DCP_ERR_INVALID_ARG, "unknown element type %d", c.dtype);
+  if (depth < 0 || nrows < 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows");
+  if (height <= 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "projections must be non-empty");
+  if (depth > 0 && nrows > 0 && (!c.vol || !c.out)) return fail(DCP_ERR_INVALID_ARG, "null volume pointer");
+  if (c.band_start < 0 || c.band_rows < 1 || c.band_start + c.band_rows > height)
+    return fail(DCP_ERR_INVALID_ARG, "band rows [%lld, %lld) outside the projection height %lld", (long long)c.band_start,
+                (long long)(c.band_start + c.band_rows), (long long)height);
+  if (c.row_stride < width || c.proj_stride < (c.band_rows - 1) * c.row_stride + width)
+    return fail(DCP_ERR_INVALID_ARG, "strides overlap (row %lld, projection %lld)", (long long)c.row_stride, (long long)c.proj_stride);
+  const bool fast = c.dtype == dcp::kF32 && !c.out_f32;
+  if (fast) {
+    if (height < 2 || width < 2) return fail(DCP_ERR_UNSUPPORTED, "stack path needs projections of at least 2 x 2");
+    if ((double)height * (double)c.row_stride * 4.0 > 4294967040.0)
+      return fail(DCP_ERR_UNSUPPORTED, "one projection exceeds the 4 GiB the 32-bit gather offsets address");
+  }
+  if (height > 1073741823LL || width > 1073741823LL || depth > 2147483647LL) return fail(DCP_ERR_UNSUPPORTED, "stack too large");
+  if (nrows > 65535) return fail(DCP_ERR_UNSUPPORTED, "nrows > 65535 in one call");
+  if (!std::isfinite(c.row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
+  // rows of a projection the requested rows can reach (the reference slices mat3D[i, yd_min:yd_max, :] for
+  // the same reason, postprocessing.py:221-228)
+  int64_t band0 = 0, band1 = height;
+  host_row_band(c.map, height, width, c.row_start, nrows, &band0, &band1);
+  const bool partial = c.band_start != 0 || c.band_rows != height;
+  if (partial && (band0 < c.band_start || band1 > c.band_start + c.band_rows))
+    return fail(DCP_ERR_INVALID_ARG, "the rows need source rows [%lld, %lld) but the band holds [%lld, %lld) (see dcp_stack_row_band)",
+                (long long)band0, (long long)band1, (long long)c.band_start, (long long)(c.band_start + c.band_rows));
+  if (depth == 0 || nrows == 0) return DCP_OK;
+  DeviceScope scope(c.device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", c.device, hipGetErrorString(scope.status));
+  dcp::LaunchOpts opts = current_opts();
+  if ((depth + opts.d_chunk - 1) / opts.d_chunk > 65535) opts.d_chunk = (int)((depth + 65534) / 65535);
+  const size_t esz = (size_t)dcp::elem_size(c.dtype), osz = c.out_f32 ? 4 : esz;
+  hipStream_t hs = (hipStream_t)c.stream;
+  if (c.mem_kind == DCP_MEM_DEVICE) {
+    const char* base = (const char*)c.vol - (size_t)(c.band_start * c.row_stride) * esz;
+    DCP_HIP(launch_stack_any(c, base, c.out, depth, c.proj_stride, c.row_stride, c.band_start + c.band_rows, opts, hs));
     return DCP_OK;
   }
-  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
-  // Host volume: only the row band the requested rows can reach is shipped (the reference slices
-  // mat3D[i, yd_min:yd_max, :] for the same reason, postprocessing.py:221-228).  The band is the
-  // hull of the source rows evaluated on the host, grown by a safety row on each side; the
-  // kernel keeps addressing rows by their absolute index.
-  int64_t band0 = 0, band1 = height;
-  host_row_band(map, height, width, row_start, nrows, &band0, &band1);
+  if (c.mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", c.mem_kind);
+  // Host stack.  Only the reachable row band is shipped, and projections are independent
+  // (postprocessing.py:226-228, 310-312), so the stack streams through the GPU in depth chunks: while
+  // chunk k is copied back by a second host thread, chunk k+1 is uploaded and computed (PCIe is full
+  // duplex; pageable copies block their calling thread, hence two threads rather than two streams --
+  // tools/ubench_pcie.hip).  Device scratch: two band buffers and two output buffers of one chunk each.
   const int64_t bh = band1 - band0;
-  // Projections are independent (postprocessing.py:226-228, 310-312), so the stack streams through the
-  // GPU in depth chunks: while chunk k is copied back by a second host thread, chunk k+1 is uploaded
-  // and computed (PCIe is full duplex; pageable copies block their calling thread, hence two threads
-  // rather than two streams -- tools/ubench_pcie.hip).  Device scratch: two band buffers and two
-  // output buffers of one chunk each, instead of the whole stack.
-  const size_t pbytes = (size_t)bh * (size_t)width * 4;                 // one projection's band
-  const size_t obytes = (size_t)nrows * (size_t)width * 4;              // one projection's output rows
+  const size_t pbytes = (size_t)bh * (size_t)width * esz;               // one projection's band
+  const size_t obytes = (size_t)nrows * (size_t)width * osz;            // one projection's output rows
   int64_t dc = (int64_t)(((size_t)g_stack_chunk_kb.load() << 10) / (pbytes > obytes ? pbytes : obytes));
   dc = dc < 1 ? 1 : (dc > depth ? depth : dc);
   const int64_t nchunks = (depth + dc - 1) / dc;
@@ -531,9 +582,6 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
   DCP_HIP(hipGetDevice(&cur_dev));
   hipStream_t s_down = nullptr;
   DCP_HIP(g_host_streams.get(&hs, &s_down));   // host memory: nothing to order against the caller's stream
-  st.proj_stride = bh * width;
-  st.row_stride = (int32_t)width;
-  st.proj_bytes = (uint32_t)((size_t)band1 * (size_t)width * 4);
 
   const bool trace = getenv("DISCORPY_AMD_TRACE") != nullptr;   // per-chunk timeline on stderr
   const auto t_begin = std::chrono::steady_clock::now();
@@ -553,8 +601,7 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
       }
       const int64_t d0 = k * dc, n = (d0 + dc > depth ? depth - d0 : dc);
       const double td0 = ms();
-      e = hipMemcpyAsync(out + (size_t)d0 * (size_t)nrows * (size_t)width, dout[k & 1], obytes * (size_t)n,
-                         hipMemcpyDeviceToHost, s_down);
+      e = hipMemcpyAsync((char*)c.out + (size_t)d0 * obytes, dout[k & 1], obytes * (size_t)n, hipMemcpyDeviceToHost, s_down);
       if (e == hipSuccess) e = hipStreamSynchronize(s_down);
       if (trace) fprintf(stderr, "down %lld: %.3f -> %.3f\n", (long long)k, td0, ms());
       {
@@ -575,21 +622,21 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
       std::unique_lock<std::mutex> lock(mu);
       cv.wait(lock, [&] { return downloaded >= k - 1; });
     }
-    const float* hsrc = vol + d0 * proj_stride + band0 * row_stride;
+    const char* hsrc = (const char*)c.vol + (size_t)(d0 * c.proj_stride + (band0 - c.band_start) * c.row_stride) * esz;
     const double tu0 = ms();
-    if (row_stride == width) {   // the bands of n projections: n runs of pbytes, proj_stride apart
-      up_err = hipMemcpy2DAsync(din[k & 1], pbytes, hsrc, (size_t)proj_stride * 4, pbytes, (size_t)n, hipMemcpyHostToDevice, hs);
+    if (c.row_stride == width) {   // the bands of n projections: n runs of pbytes, proj_stride apart
+      up_err = hipMemcpy2DAsync(din[k & 1], pbytes, hsrc, (size_t)c.proj_stride * esz, pbytes, (size_t)n, hipMemcpyHostToDevice, hs);
     } else {
       for (int64_t d = 0; d < n && up_err == hipSuccess; ++d)
-        up_err = hipMemcpy2DAsync((char*)din[k & 1] + (size_t)d * pbytes, (size_t)width * 4, hsrc + d * proj_stride,
-                                  (size_t)row_stride * 4, (size_t)width * 4, (size_t)bh, hipMemcpyHostToDevice, hs);
+        up_err = hipMemcpy2DAsync((char*)din[k & 1] + (size_t)d * pbytes, (size_t)width * esz,
+                                  hsrc + (size_t)(d * c.proj_stride) * esz, (size_t)c.row_stride * esz, (size_t)width * esz,
+                                  (size_t)bh, hipMemcpyHostToDevice, hs);
     }
     if (up_err != hipSuccess) break;
     const double tu1 = ms();
-    st.D = (int32_t)n;
-    st.vol = (const float*)din[k & 1] - band0 * width;   // absolute row indexing (never dereferenced below the band)
-    st.out = (float*)dout[k & 1];
-    up_err = dcp::launch_stack(st, map, sampler, coord_round_f32 != 0, opts, hs);
+    // absolute row indexing: the staged band starts at row band0 (never dereferenced below it)
+    const char* base = (const char*)din[k & 1] - (size_t)(band0 * width) * esz;
+    up_err = launch_stack_any(c, base, dout[k & 1], n, bh * width, width, band1, opts, hs);
     if (up_err == hipSuccess) up_err = hipStreamSynchronize(hs);
     if (trace) fprintf(stderr, "up %lld: issue %.3f -> %.3f, done %.3f\n", (long long)k, tu0, tu1, ms());
     if (up_err != hipSuccess) break;
@@ -608,6 +655,91 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
   if (up_err != hipSuccess) return fail(DCP_ERR_HIP, "stack upload / kernel failed: %s", hipGetErrorString(up_err));
   if (down_err != hipSuccess) return fail(DCP_ERR_HIP, "stack download failed: %s", hipGetErrorString(down_err));
   return DCP_OK;
+}
+
+int make_stack_call(StackCall* c, const void* vol, void* out, int dtype, int out_f32, int64_t depth, int64_t height,
+                    int64_t width, int64_t band_start, int64_t band_rows, int64_t proj_stride, int64_t row_stride,
+                    double xcenter, double ycenter, const double* list_fact, int nfact, double row_start, int64_t nrows,
+                    int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  c->vol = vol;
+  c->out = out;
+  c->dtype = dtype;
+  c->out_f32 = out_f32 != 0;
+  c->depth = depth;
+  c->height = height;
+  c->width = width;
+  c->band_start = band_start;
+  c->band_rows = band_rows;
+  c->proj_stride = proj_stride;
+  c->row_stride = row_stride;
+  c->row_start = row_start;
+  c->nrows = nrows;
+  c->round_f32 = coord_round_f32;
+  c->mem_kind = mem_kind;
+  c->device = device;
+  c->stream = stream;
+  c->sampler = dcp::kScipy;
+  if (dtype == dcp::kF32 && !out_f32 && (rc = sampler_of(1, blend_mode, &c->sampler)) != DCP_OK) return rc;
+  return fill_map(&c->map, xcenter, ycenter, list_fact, nfact, nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
+                              int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                              const double* list_fact, int nfact, double row_start, int64_t nrows,
+                              int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  StackCall c;
+  if ((rc = make_stack_call(&c, vol, out, dcp::kF32, 0, depth, height, width, 0, height, proj_stride, row_stride, xcenter,
+                            ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode, mem_kind, device,
+                            stream)) != DCP_OK)
+    return rc;
+  return run_stack(c);
+}
+
+int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_float32, int64_t depth, int64_t height,
+                                int64_t width, int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
+                                int mem_kind, int device, void* stream) {
+  int rc;
+  StackCall c;
+  if ((rc = make_stack_call(&c, vol, out, dtype, out_float32, depth, height, width, 0, height, proj_stride, row_stride,
+                            xcenter, ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, DCP_BLEND_SCIPY, mem_kind,
+                            device, stream)) != DCP_OK)
+    return rc;
+  return run_stack(c);
+}
+
+int dcp_stack_row_band(int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact, int nfact,
+                       double row_start, int64_t nrows, int64_t* band_start, int64_t* band_rows) {
+  int rc;
+  if (!band_start || !band_rows) return fail(DCP_ERR_INVALID_ARG, "null out pointer");
+  if (height <= 0 || width <= 0 || nrows < 1) return fail(DCP_ERR_INVALID_ARG, "empty projection or no rows");
+  if (!std::isfinite(row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  int64_t b0 = 0, b1 = height;
+  host_row_band(map, height, width, row_start, nrows, &b0, &b1);
+  *band_start = b0;
+  *band_rows = b1 - b0;
+  return DCP_OK;
+}
+
+int dcp_unwarp_stack_band(const void* band, void* out, int dtype, int out_float32, int64_t depth, int64_t height,
+                          int64_t width, int64_t band_start, int64_t band_rows, int64_t proj_stride, int64_t row_stride,
+                          double xcenter, double ycenter, const double* list_fact, int nfact, double row_start,
+                          int64_t nrows, int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  StackCall c;
+  if ((rc = make_stack_call(&c, band, out, dtype, out_float32, depth, height, width, band_start, band_rows, proj_stride,
+                            row_stride, xcenter, ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode,
+                            mem_kind, device, stream)) != DCP_OK)
+    return rc;
+  return run_stack(c);
 }
 
 int dcp_unwarp_stack_rows_multi_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
@@ -951,77 +1083,6 @@ int dcp_remap_coords_typed(const void* src, void* dst, int dtype, int64_t height
   memset(&map, 0, sizeof(map));
   return run_typed(3, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, ycoord, xcoord, coord_dtype,
                    npts, order, boundary_mode, mem_kind, device, stream);
-}
-
-int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_float32, int64_t depth, int64_t height,
-                                int64_t width, int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
-                                const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
-                                int mem_kind, int device, void* stream) {
-  int rc;
-  if (dtype < 0 || dtype >= dcp::kNumElemTypes) return fail(DCP_ERR_INVALID_ARG, "unknown element type %d", dtype);
-  if (depth < 0 || nrows < 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows");
-  if (height <= 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "projections must be non-empty");
-  if (depth > 0 && nrows > 0 && (!vol || !out)) return fail(DCP_ERR_INVALID_ARG, "null volume pointer");
-  if (row_stride < width || proj_stride < (height - 1) * row_stride + width)
-    return fail(DCP_ERR_INVALID_ARG, "strides overlap (row %lld, projection %lld)", (long long)row_stride, (long long)proj_stride);
-  if (height > 1073741823LL || width > 1073741823LL || depth > 2147483647LL) return fail(DCP_ERR_UNSUPPORTED, "stack too large");
-  if (nrows > 65535) return fail(DCP_ERR_UNSUPPORTED, "nrows > 65535 in one call");
-  if (!std::isfinite(row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
-  dcp::MapArgs map;
-  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
-  if (depth == 0 || nrows == 0) return DCP_OK;
-  DeviceScope scope(device);
-  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
-  dcp::LaunchOpts opts = current_opts();
-  if ((depth + opts.d_chunk - 1) / opts.d_chunk > 65535) opts.d_chunk = (int)((depth + 65534) / 65535);
-  dcp::TypedStackArgs st;
-  memset(&st, 0, sizeof(st));
-  st.D = (int32_t)depth;
-  st.H = (int32_t)height;
-  st.W = (int32_t)width;
-  st.row_start = row_start;
-  st.nrows = (int32_t)nrows;
-  st.d_chunk = opts.d_chunk;
-  st.dtype = dtype;
-  st.out_f32 = out_float32 != 0;
-  st.round_f32 = coord_round_f32 != 0;
-  hipStream_t hs = (hipStream_t)stream;
-  if (mem_kind == DCP_MEM_DEVICE) {
-    st.vol = vol;
-    st.out = out;
-    st.proj_stride = proj_stride;
-    st.row_stride = row_stride;
-    DCP_HIP(dcp::launch_typed_stack(st, map, hs));
-    return DCP_OK;
-  }
-  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
-  // as dcp_unwarp_stack_rows_f32: ship only the row band the requested rows can reach
-  int64_t band0 = 0, band1 = height;
-  host_row_band(map, height, width, row_start, nrows, &band0, &band1);
-  const int64_t bh = band1 - band0;
-  const size_t esz = (size_t)dcp::elem_size(dtype), osz = out_float32 ? 4 : esz;
-  const size_t pbytes = (size_t)bh * (size_t)width * esz, obytes = (size_t)depth * (size_t)nrows * (size_t)width * osz;
-  void *dvol, *dout;
-  DCP_HIP(g_staging.get(0, pbytes * (size_t)depth, &dvol));
-  DCP_HIP(g_staging.get(1, obytes, &dout));
-  for (int64_t d = 0; d < depth; ++d) {
-    const char* hsrc = (const char*)vol + (size_t)(d * proj_stride + band0 * row_stride) * esz;
-    char* ddst = (char*)dvol + (size_t)d * pbytes;
-    if (row_stride == width) {
-      DCP_HIP(hipMemcpyAsync(ddst, hsrc, pbytes, hipMemcpyHostToDevice, hs));
-    } else {
-      DCP_HIP(hipMemcpy2DAsync(ddst, (size_t)width * esz, hsrc, (size_t)row_stride * esz, (size_t)width * esz, (size_t)bh,
-                               hipMemcpyHostToDevice, hs));
-    }
-  }
-  st.vol = (const char*)dvol - (size_t)(band0 * width) * esz;   // absolute row indexing, never dereferenced below the band
-  st.out = dout;
-  st.proj_stride = bh * width;
-  st.row_stride = width;
-  DCP_HIP(dcp::launch_typed_stack(st, map, hs));
-  DCP_HIP(hipMemcpyAsync(out, dout, obytes, hipMemcpyDeviceToHost, hs));
-  DCP_HIP(hipStreamSynchronize(hs));
-  return DCP_OK;
 }
 
 int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t width, int map_kind, double xcenter,

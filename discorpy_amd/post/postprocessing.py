@@ -266,8 +266,61 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
                        out=out)
 
 
+def _is_lazy_stack(a):
+    """An h5py-style dataset: has shape / dtype / slicing but is neither a NumPy array nor a tensor."""
+    return (not isinstance(a, np.ndarray) and not _is_torch(a) and hasattr(a, "shape") and hasattr(a, "dtype")
+            and hasattr(a, "__getitem__") and not isinstance(a, (list, tuple)))
+
+
+def _stack_rows_lazy(src, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32, out):
+    """Out-of-core stack (e.g. the h5py dataset ``losa.load_hdf_object`` returns): like the reference
+    (``:221-228``, ``:295-301``) only the row band the requested rows can reach is read from each projection --
+    ``src[d0:d1, band, :]`` per depth chunk, the next chunk being read while this one is on the GPU."""
+    from concurrent.futures import ThreadPoolExecutor
+    bcode = _blend_code(blend)
+    (depth, height, width) = src.shape
+    dtype = np.dtype(src.dtype)
+    code = _dtype_code(dtype)
+    fact = _coefs(list_fact, "list_fact")
+    fa, nf = F.fact_array(fact)
+    odt = np.dtype(np.float32) if out_float32 else dtype
+    if out is None:
+        out = _pool.empty((depth, nrows, width), odt)
+    elif not (isinstance(out, np.ndarray) and out.dtype == odt and out.shape == (depth, nrows, width)
+              and out.flags.c_contiguous and out.flags.writeable):
+        raise ValueError("out must be a writeable C-contiguous %s array of shape %s" % (odt, (depth, nrows, width)))
+    if depth == 0:
+        return out
+    F.require_device()
+    b0, bn = F.stack_row_band(height, width, xcenter, ycenter, fact, row_start, nrows)
+    per = max(bn * width * dtype.itemsize, 1)
+    chunk = int(max(1, min(depth, int(float(os.environ.get("DISCORPY_AMD_READ_CHUNK_MB", "64")) * (1 << 20)) // per)))
+    device = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
+
+    def read(d0):
+        a = np.asarray(src[d0:min(depth, d0 + chunk), b0:b0 + bn, :])
+        return np.ascontiguousarray(a, dtype=dtype)
+
+    with ThreadPoolExecutor(max_workers=1) as reader:
+        nxt = reader.submit(read, 0)
+        for d0 in range(0, depth, chunk):
+            band = nxt.result()
+            if d0 + chunk < depth:
+                nxt = reader.submit(read, d0 + chunk)
+            n = band.shape[0]
+            F.check(F.lib().dcp_unwarp_stack_band(band.ctypes.data, out[d0:d0 + n].ctypes.data, code, int(out_float32), n,
+                                                  height, width, b0, bn, bn * width, width, float(xcenter),
+                                                  float(ycenter), fa, nf, float(row_start), nrows, int(round_f32), bcode,
+                                                  F.MEM_HOST, device, None))
+    return out
+
+
 def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32=False,
                 devices=None, out=None):
+    if _is_lazy_stack(mat3D):
+        if devices is not None:
+            raise ValueError("devices= needs a NumPy stack in memory")
+        return _stack_rows_lazy(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32, out)
     bcode = _blend_code(blend)
     vol = _Image(mat3D, 3)
     depth, height, width = vol.shape

@@ -177,6 +177,23 @@ int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_f
                                 const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
                                 int mem_kind, int device, void* stream);
 
+/* ---- out-of-core stacks ----
+ * The reference never touches more of a projection than mat3D[i, yd_min:yd_max, :]
+ * (discorpy/post/postprocessing.py:221-228, 295-301), which is what lets it run on an HDF5 dataset
+ * larger than memory.  dcp_stack_row_band reports that band for a request (rows row_start ..
+ * row_start + nrows - 1): source rows [band_start, band_start + band_rows).  dcp_unwarp_stack_band is
+ * dcp_unwarp_stack_rows_f32 / _typed for a buffer that holds ONLY the rows [band_start, band_start +
+ * band_rows) of each of `depth` projections (row_stride / proj_stride: element strides inside that
+ * buffer); it fails with DCP_ERR_INVALID_ARG if the request needs rows outside the band.  dtype
+ * DCP_DTYPE_F32 with out_float32 = 0 runs the tuned kernel with `blend_mode`; every other combination
+ * uses scipy's exact blend. */
+int dcp_stack_row_band(int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact, int nfact,
+                       double row_start, int64_t nrows, int64_t* band_start, int64_t* band_rows);
+int dcp_unwarp_stack_band(const void* band, void* out, int dtype, int out_float32, int64_t depth, int64_t height,
+                          int64_t width, int64_t band_start, int64_t band_rows, int64_t proj_stride, int64_t row_stride,
+                          double xcenter, double ycenter, const double* list_fact, int nfact, double row_start,
+                          int64_t nrows, int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream);
+
 /* The float32 source-coordinate planes themselves, ymap / xmap of height*width floats each:
  * DCP_MAP_RADIAL       yd_mat / xd_mat of unwarp_image_backward, discorpy/post/postprocessing.py:141-145
  * DCP_MAP_PERSPECTIVE  _generate_perspective_map, :444-459 (list_fact ignored)

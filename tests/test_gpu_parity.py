@@ -426,6 +426,70 @@ def test_host_stack_streams_in_depth_chunks(hip, orc):
         hip.set_option("stack_chunk_kb", old)
 
 
+class LazyStack:
+    """Stands in for the h5py dataset losa.load_hdf_object returns: shape, dtype, slicing -- and a log of what was read."""
+
+    def __init__(self, data):
+        self._data = data
+        self.shape = data.shape
+        self.dtype = data.dtype
+        self.reads = []
+
+    def __getitem__(self, key):
+        self.reads.append(key)
+        return self._data[key]
+
+    def __len__(self):
+        return self.shape[0]
+
+
+@pytest.mark.parametrize("dt", ["float32", "uint16"])
+def test_out_of_core_stack_reads_only_the_row_band(hip, orc, dt, monkeypatch, tmp_path):
+    """A dataset that is not an in-memory array is read like the reference reads it (:221-228): per depth chunk,
+    only the rows the request can reach; results equal the in-memory path."""
+    vol = typed_image(dt, (9, 300, 400), 12) if dt != "float32" else noise(12, (9, 300, 400))
+    a = (190.0, 140.0, [1.0, 1.5e-3, 1e-6])
+    want_c = pp.unwarp_chunk_slices_backward(vol, *a, 100, 139)
+    want_s = pp.unwarp_slice_backward(vol, *a, 222)
+    assert np.array_equal(want_c, orc.unwarp_chunk_slices_backward(vol, *a, 100, 139, poly=orc.POLY_KERNEL,
+                                                                   **({"blend": orc.BLEND_F64LERP} if dt == "float32" else {})))
+    monkeypatch.setenv("DISCORPY_AMD_READ_CHUNK_MB", "0.2")
+    lazy = LazyStack(vol)
+    got = pp.unwarp_chunk_slices_backward(lazy, *a, 100, 139)
+    assert got.dtype == vol.dtype and np.array_equal(got, want_c)
+    b0, bn = hip.stack_row_band(300, 400, *a, 100, 40)
+    assert 0 < b0 and bn < 80 and len(lazy.reads) >= 3
+    covered = []
+    for (ds, rs, cs) in lazy.reads:
+        assert (rs.start, rs.stop) == (b0, b0 + bn) and cs == slice(None)
+        covered += list(range(ds.start, ds.stop))
+    assert covered == list(range(9))
+    lazy = LazyStack(vol)
+    sl = pp.unwarp_slice_backward(lazy, *a, 222)
+    assert sl.dtype == np.float32 and np.array_equal(sl, want_s)
+    sb0, sbn = hip.stack_row_band(300, 400, *a, 222, 1)
+    assert sbn < 60 and all((r[1].start, r[1].stop) == (sb0, sb0 + sbn) for r in lazy.reads)
+    # a memory-mapped .npy file is an ndarray: the library itself copies only the band
+    path = tmp_path / "stack.npy"
+    np.save(path, vol)
+    mm = np.load(path, mmap_mode="r")
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(mm, *a, 100, 139), want_c)
+    # the C ABI on a device-resident band, and its refusal of a band that is too small
+    torch = pytest.importorskip("torch")
+    if dt == "float32":
+        L = hip.lib()
+        fa, nf = hip.fact_array(a[2])
+        band = torch.from_numpy(np.ascontiguousarray(vol[:, b0:b0 + bn, :])).cuda()
+        out = torch.empty((9, 40, 400), dtype=torch.float32, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        hip.check(L.dcp_unwarp_stack_band(band.data_ptr(), out.data_ptr(), 0, 0, 9, 300, 400, b0, bn, bn * 400, 400, a[0], a[1],
+                                          fa, nf, 100.0, 40, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE, 0, st))
+        assert np.array_equal(out.cpu().numpy(), want_c)
+        rc = L.dcp_unwarp_stack_band(band.data_ptr(), out.data_ptr(), 0, 0, 9, 300, 400, b0 + 3, bn - 3, bn * 400, 400, a[0],
+                                     a[1], fa, nf, 100.0, 40, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE, 0, st)
+        assert rc == hip.ERR_INVALID_ARG and "band holds" in hip.last_error()
+
+
 def test_out_argument_and_recycled_outputs(hip, orc):
     from discorpy_amd import _pool
     img = noise(71, (600, 700))                                   # 1.6 MiB: above the pool's threshold

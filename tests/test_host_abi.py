@@ -195,3 +195,30 @@ def test_out_argument_is_validated_on_the_host(monkeypatch):
             pp.unwarp_image_backward(img, 4, 4, [1.0], out=bad)
     with pytest.raises(ValueError, match="out must"):
         pp.unwarp_slice_backward(np.zeros((2, 8, 8), np.float32), 4, 4, [1.0], 3, out=np.zeros((2, 9), np.float32))
+
+
+def test_stack_row_band_and_band_validation_need_no_gpu():
+    """dcp_stack_row_band is host arithmetic; dcp_unwarp_stack_band rejects a band that does not cover the request
+    before any device work."""
+    from discorpy_amd import configs
+    H, W = 800, 1280
+    a = (configs.XCENTER_DOT_05, configs.YCENTER_DOT_05, list(configs.COEF_DOT_05))
+    b0, bn = F.stack_row_band(H, W, *a, 400, 1)
+    assert 380 <= b0 <= 400 and 2 <= bn <= 12
+    b0c, bnc = F.stack_row_band(H, W, *a, 14, 7)                      # examples/example_04.py:92-96
+    assert 0 <= b0c <= 14 and b0c + bnc >= 21 and bnc < 40
+    assert F.stack_row_band(H, W, a[0], a[1], [], 10, 5) == (max(int(a[1]) - 1, 0), 4)   # B = 0: every row maps to yc
+    full = F.stack_row_band(H, W, a[0], a[1], [float("nan")], 10, 5)
+    assert full == (0, H)
+    L = F.lib()
+    fa, n = F.fact_array(a[2])
+    buf = np.zeros((2, bn, W), np.float32)
+    out = np.zeros((2, 1, W), np.float32)
+    rc = L.dcp_unwarp_stack_band(buf.ctypes.data, out.ctypes.data, 0, 0, 2, H, W, b0 + 1, bn - 1, bn * W, W, a[0], a[1], fa, n,
+                                 400.0, 1, 0, 1, F.MEM_HOST, -1, None)
+    assert rc == F.ERR_INVALID_ARG and "band holds" in F.last_error()
+    rc = L.dcp_unwarp_stack_band(buf.ctypes.data, out.ctypes.data, 0, 0, 2, H, W, 790, 20, bn * W, W, a[0], a[1], fa, n,
+                                 400.0, 1, 0, 1, F.MEM_HOST, -1, None)
+    assert rc == F.ERR_INVALID_ARG and "outside the projection" in F.last_error()
+    with pytest.raises(ValueError):
+        F.stack_row_band(H, W, *a, float("inf"), 1)
