@@ -80,6 +80,48 @@ __global__ void __launch_bounds__(kTypedBlock) typed_image_kernel(const TypedIma
   ((T*)a.dst)[i] = to_elem<T>(t);
 }
 
+// Interleaved (H, W, C) image, every channel sampled at the SAME coordinate -- what
+// util.unwarp_color_image_backward does channel by channel (discorpy/util/utility.py:327-341): one
+// coordinate evaluation and C blends per pixel, taps of a pixel's C channels contiguous in memory.
+template <typename T>
+__global__ void __launch_bounds__(kTypedBlock) typed_channels_kernel(const TypedImageArgs a, const MapArgs map, int C) {
+  const int64_t i = (int64_t)blockIdx.x * kTypedBlock + threadIdx.x;
+  if (i >= (int64_t)a.H * a.W) return;
+  const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
+  const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
+  double xd, yd;
+  pixel_coord<kRadial>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
+  const double xc = (double)round_clip_f32(xd, wmaxf), yc = (double)round_clip_f32(yd, hmaxf);
+  const T* src = (const T*)a.src;
+  T* dst = (T*)a.dst + i * C;
+  const int64_t rs = a.src_stride, cs = a.src_cstride;
+  if (a.order == 0) {
+    int iy = (int)__builtin_floor(yc + 0.5), ix = (int)__builtin_floor(xc + 0.5);
+    iy = min(max(iy, 0), a.H - 1);
+    ix = min(max(ix, 0), a.W - 1);
+    const T* p = src + (int64_t)iy * rs + (int64_t)ix * cs;
+    for (int c = 0; c < C; ++c) dst[c] = to_elem<T>((double)p[c]);
+    return;
+  }
+  const double y0 = __builtin_floor(yc), x0 = __builtin_floor(xc);
+  const double wy0 = 1.0 - (yc - y0), wy1 = 1.0 - wy0;
+  const double wx0 = 1.0 - (xc - x0), wx1 = 1.0 - wx0;
+  const int iy0 = min((int)y0, a.H - 1), ix0 = min((int)x0, a.W - 1);
+  const int iy1 = min(iy0 + 1, a.H - 1), ix1 = min(ix0 + 1, a.W - 1);
+  const T* p00 = src + (int64_t)iy0 * rs + (int64_t)ix0 * cs;
+  const T* p01 = src + (int64_t)iy0 * rs + (int64_t)ix1 * cs;
+  const T* p10 = src + (int64_t)iy1 * rs + (int64_t)ix0 * cs;
+  const T* p11 = src + (int64_t)iy1 * rs + (int64_t)ix1 * cs;
+  for (int c = 0; c < C; ++c) {
+    double t = 0.0;
+    t += ((double)p00[c] * wy0) * wx0;
+    t += ((double)p01[c] * wy0) * wx1;
+    t += ((double)p10[c] * wy1) * wx0;
+    t += ((double)p11[c] * wy1) * wx1;
+    dst[c] = to_elem<T>(t);
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(kTypedBlock) typed_stack_kernel(const TypedStackArgs st, const MapArgs map) {
   const int x = blockIdx.x * kTypedBlock + (int)threadIdx.x;
@@ -143,6 +185,20 @@ static hipError_t launch_image_t(int map_kind, const TypedImageArgs& a, const Ma
 hipError_t launch_typed_image(int map_kind, const TypedImageArgs& a, const MapArgs& map, const CoordArgs& ca,
                               hipStream_t stream) {
 #define DCP_CALL(T) launch_image_t<T>(map_kind, a, map, ca, stream)
+  DCP_TYPED_DISPATCH(a.dtype, DCP_CALL)
+#undef DCP_CALL
+}
+
+template <typename T>
+static hipError_t launch_channels_t(const TypedImageArgs& a, const MapArgs& map, int channels, hipStream_t stream) {
+  const int64_t total = (int64_t)a.H * a.W;
+  hipLaunchKernelGGL((typed_channels_kernel<T>), dim3((unsigned)((total + kTypedBlock - 1) / kTypedBlock)), dim3(kTypedBlock), 0,
+                     stream, a, map, channels);
+  return hipGetLastError();
+}
+
+hipError_t launch_typed_channels(const TypedImageArgs& a, const MapArgs& map, int channels, hipStream_t stream) {
+#define DCP_CALL(T) launch_channels_t<T>(a, map, channels, stream)
   DCP_TYPED_DISPATCH(a.dtype, DCP_CALL)
 #undef DCP_CALL
 }

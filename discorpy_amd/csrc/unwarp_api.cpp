@@ -130,6 +130,8 @@ struct HostStreams {
 };
 thread_local HostStreams g_host_streams;
 
+int check_image_typed(const void* src, const void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs);
+
 int sampler_of(int order, int blend_mode, int* sampler) {
   if (order == 0) {
     *sampler = dcp::kNearest;
@@ -712,6 +714,51 @@ int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_f
                             device, stream)) != DCP_OK)
     return rc;
   return run_stack(c);
+}
+
+int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t height, int64_t width, int channels,
+                              int64_t src_row_stride, int64_t src_pixel_stride, double xcenter, double ycenter,
+                              const double* list_fact, int nfact, int order, int mem_kind, int device, void* stream) {
+  int rc;
+  if (channels < 1 || channels > 64) return fail(DCP_ERR_INVALID_ARG, "channels = %d outside [1, 64]", channels);
+  if (order < 0 || order > 1) return fail(DCP_ERR_UNSUPPORTED, "the interleaved-channel kernel takes orders 0 and 1 (got %d)", order);
+  if (src_pixel_stride < channels) return fail(DCP_ERR_INVALID_ARG, "pixel stride %lld smaller than %d channels", (long long)src_pixel_stride, channels);
+  if ((rc = check_image_typed(src, dst, dtype, height, width, src_row_stride, src_pixel_stride)) != DCP_OK) return rc;
+  if (src_row_stride < (width - 1) * src_pixel_stride + channels && height > 1)
+    return fail(DCP_ERR_INVALID_ARG, "row stride %lld overlaps rows of %lld pixels", (long long)src_row_stride, (long long)width);
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipStream_t st = (hipStream_t)stream;
+  dcp::TypedImageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H = (int32_t)height;
+  a.W = (int32_t)width;
+  a.src_stride = src_row_stride;
+  a.src_cstride = src_pixel_stride;
+  a.order = order;
+  a.dtype = dtype;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    a.src = src;
+    a.dst = dst;
+    DCP_HIP(dcp::launch_typed_channels(a, map, channels, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  const size_t esz = (size_t)dcp::elem_size(dtype);
+  const size_t ext = (size_t)((height - 1) * src_row_stride + (width - 1) * src_pixel_stride + channels) * esz;
+  const size_t obytes = (size_t)height * (size_t)width * (size_t)channels * esz;
+  void *dsrc, *ddst;
+  DCP_HIP(g_staging.get(0, ext, &dsrc));
+  DCP_HIP(g_staging.get(1, obytes, &ddst));
+  DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
+  a.src = dsrc;
+  a.dst = ddst;
+  DCP_HIP(dcp::launch_typed_channels(a, map, channels, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, obytes, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
 }
 
 int dcp_stack_row_band(int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact, int nfact,

@@ -93,6 +93,24 @@ def _pad_device(t, pad_width, mode):
     return t
 
 
+def _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order):
+    """(H, W, C) interleaved image in one launch of dcp_unwarp_image_channels: one coordinate per pixel, C blends in
+    scipy's exact arithmetic, no per-channel planes on the host."""
+    F = _pp.F
+    img = _pp._Image(mat_pad, 3)
+    h, w, c = img.shape
+    rs, ps, cs = img.strides
+    if cs != 1 or ps < c or (h > 1 and rs < (w - 1) * ps + c):
+        img = _pp._Image(img.keep.contiguous() if img.torch else np.ascontiguousarray(img.keep), 3)
+        rs, ps, cs = img.strides
+    fa, nf = F.fact_array(_pp._coefs(list_fact, "list_fact"))
+    out, optr = img.empty((h, w, c))
+    F.require_device()
+    F.check(F.lib().dcp_unwarp_image_channels(img.ptr, optr, img.code, h, w, c, rs, ps, float(xcenter), float(ycenter),
+                                              fa, nf, order, img.mem, img.device, img.stream))
+    return out
+
+
 def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", pad=False,
                                 pad_mode='constant', *, blend=None):
     """
@@ -130,12 +148,17 @@ def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode=
     is_torch = _pp._is_torch(mat) and mat.is_cuda
     if is_torch:
         mat_pad = _pad_device(mat, pad_width, pad_mode)
+    elif t_pad == b_pad == l_pad == r_pad == 0:
+        mat_pad = np.asarray(mat)                     # np.pad would copy the image for nothing
     else:
         mat_pad = np.pad(np.asarray(mat), pad_width, mode=pad_mode)
     xcenter = xcenter + l_pad
     ycenter = ycenter + t_pad
     if num_dim == 2:
         return _pp.unwarp_image_backward(mat_pad, xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
+    order = _pp._check_order_mode(order, mode)
+    if order <= 1 and blend in (None, "scipy", "exact", "f64lerp", "f64") and 1 <= mat_pad.shape[2] <= 64:
+        return _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order)
     # channels as dense planes: one coordinate map, C gathers
     if is_torch:
         import torch

@@ -177,6 +177,15 @@ int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_f
                                 const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
                                 int mem_kind, int device, void* stream);
 
+/* discorpy/util/utility.py:278-342 (unwarp_color_image_backward), the part after np.pad: an interleaved
+ * (height, width, channels) image of `dtype`, every channel sampled at the same radial coordinate
+ * (:320-341 loops map_coordinates over mat_pad[:, :, i]) -- one coordinate evaluation and `channels`
+ * blends per pixel, scipy's exact arithmetic, orders 0 / 1.  src_pixel_stride = elements between
+ * pixels (>= channels); dst is dense (height, width, channels). */
+int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t height, int64_t width, int channels,
+                              int64_t src_row_stride, int64_t src_pixel_stride, double xcenter, double ycenter,
+                              const double* list_fact, int nfact, int order, int mem_kind, int device, void* stream);
+
 /* ---- out-of-core stacks ----
  * The reference never touches more of a projection than mat3D[i, yd_min:yd_max, :]
  * (discorpy/post/postprocessing.py:221-228, 295-301), which is what lets it run on an HDF5 dataset
