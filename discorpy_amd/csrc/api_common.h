@@ -1,0 +1,124 @@
+// api_common.h -- shared by the C-ABI translation units (api_*.cpp): error reporting, device selection,
+// per-thread device scratch and streams for DCP_MEM_HOST callers, tuning knobs, argument checks.
+// Not installed; the public surface is include/discorpy_hip.h.
+#pragma once
+#include "../../include/discorpy_hip.h"
+#include "dcp_internal.h"
+
+#include <atomic>
+#include <cstddef>
+#include <cstdint>
+
+namespace dcpapi {
+
+// sets the calling thread's last-error message and returns `code`
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+const char* last_error();
+
+#define DCP_HIP(expr)                                                                                      \
+  do {                                                                                                     \
+    hipError_t e_ = (expr);                                                                                \
+    if (e_ != hipSuccess) return dcpapi::fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb;
+dcp::LaunchOpts current_opts();
+
+// Selects `device` for the calling thread for the lifetime of the object (no-op for device < 0).
+struct DeviceScope {
+  int prev = -1;
+  bool switched = false;
+  hipError_t status = hipSuccess;
+  explicit DeviceScope(int device) {
+    if (device < 0) return;
+    status = hipGetDevice(&prev);
+    if (status != hipSuccess) return;
+    if (prev != device) {
+      status = hipSetDevice(device);
+      switched = status == hipSuccess;
+    }
+  }
+  ~DeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
+
+// Grow-only device scratch used for DCP_MEM_HOST calls; one set per host thread.
+struct Staging {
+  void* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[4] = {0, 0, 0, 0};
+  int device = -1;
+  ~Staging() { release(); }
+  void release() {
+    for (int i = 0; i < 4; ++i) {
+      if (buf[i]) (void)hipFree(buf[i]);
+      buf[i] = nullptr;
+      cap[i] = 0;
+    }
+  }
+  hipError_t get(int slot, size_t bytes, void** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != device) {
+      release();
+      device = dev;
+    }
+    if (bytes == 0) bytes = 4;
+    if (cap[slot] < bytes) {
+      if (buf[slot]) (void)hipFree(buf[slot]);
+      buf[slot] = nullptr;
+      cap[slot] = 0;
+      e = hipMalloc(&buf[slot], bytes);
+      if (e != hipSuccess) return e;
+      cap[slot] = bytes;
+    }
+    *out = buf[slot];
+    return hipSuccess;
+  }
+};
+extern thread_local Staging g_staging;
+
+// Two non-blocking streams per host thread for the streamed DCP_MEM_HOST stack path (uploads + kernels,
+// downloads).  The legacy null stream would serialise the two directions.
+struct HostStreams {
+  hipStream_t up = nullptr, down = nullptr;
+  int device = -1;
+  ~HostStreams() { release(); }
+  void release() {
+    if (up) (void)hipStreamDestroy(up);
+    if (down) (void)hipStreamDestroy(down);
+    up = down = nullptr;
+  }
+  hipError_t get(hipStream_t* u, hipStream_t* d) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != device) {
+      release();
+      device = dev;
+    }
+    if (!up && (e = hipStreamCreateWithFlags(&up, hipStreamNonBlocking)) != hipSuccess) return e;
+    if (!down && (e = hipStreamCreateWithFlags(&down, hipStreamNonBlocking)) != hipSuccess) return e;
+    *u = up;
+    *d = down;
+    return hipSuccess;
+  }
+};
+extern thread_local HostStreams g_host_streams;
+
+int sampler_of(int order, int blend_mode, int* sampler);
+int check_image(const void* src, const void* dst, int64_t H, int64_t W, int64_t rs, int64_t cs);
+int check_image_typed(const void* src, const void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs);
+uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs);
+size_t extent_bytes_typed(int64_t H, int64_t W, int64_t rs, int64_t cs, int dtype);
+int fill_map(dcp::MapArgs* m, double xc, double yc, const double* fact, int nfact, const double* coef);
+int homography_is_tame(const double* c, int64_t H, int64_t W);
+void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0, int64_t* b1);
+
+// api_spline.cpp: orders 2..5 on any element type; map_kind 0 radial, 1 perspective, 2 explicit coordinates
+int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
+               const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
+               int mode, int mem_kind, int device, void* stream);
+
+}  // namespace dcpapi

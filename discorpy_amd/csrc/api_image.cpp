@@ -1,0 +1,362 @@
+// api_image.cpp -- whole-image entry points of the C ABI: radial / perspective / fused remaps, explicit
+// coordinates and coordinate maps for float32 (tuned kernels, unwarp_kernels.hip), the same for the other
+// element types and interleaved channels (typed_kernels.hip; orders >= 2 go to api_spline.cpp).
+#include "api_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+using namespace dcpapi;
+
+namespace {
+
+// Shared driver of the three whole-image entry points.
+int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_t W, int64_t rs, int64_t cs,
+              const dcp::MapArgs& map, int sampler, bool round_f32, int mem_kind, int device, void* stream) {
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::ImageArgs img;
+  memset(&img, 0, sizeof(img));
+  img.H = (int32_t)H;
+  img.W = (int32_t)W;
+  const dcp::LaunchOpts opts = current_opts();
+  if (mem_kind == DCP_MEM_DEVICE) {
+    img.src = src;
+    img.dst = dst;
+    img.src_stride = (int32_t)rs;
+    img.src_col_stride = (int32_t)cs;
+    img.src_bytes = extent_bytes(H, W, rs, cs);
+    DCP_HIP(dcp::launch_image(kind, img, map, sampler, round_f32, opts, (hipStream_t)stream));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  // host memory: pack rows densely on the way in, run on the stream, copy back, synchronise
+  hipStream_t st = (hipStream_t)stream;
+  void *dsrc = nullptr, *ddst = nullptr;
+  const size_t frame = (size_t)H * (size_t)W * sizeof(float);
+  DCP_HIP(g_staging.get(0, frame, &dsrc));
+  DCP_HIP(g_staging.get(1, frame, &ddst));
+  if (cs == 1 && rs == W) {
+    DCP_HIP(hipMemcpyAsync(dsrc, src, frame, hipMemcpyHostToDevice, st));
+    img.src_stride = (int32_t)W;
+    img.src_col_stride = 1;
+    img.src_bytes = (uint32_t)frame;
+  } else if (cs == 1) {
+    DCP_HIP(hipMemcpy2DAsync(dsrc, (size_t)W * 4, src, (size_t)rs * 4, (size_t)W * 4, (size_t)H, hipMemcpyHostToDevice, st));
+    img.src_stride = (int32_t)W;
+    img.src_col_stride = 1;
+    img.src_bytes = (uint32_t)frame;
+  } else {
+    // column-strided host view (e.g. one channel of an interleaved HxWxC image): ship the
+    // enclosing extent and let the kernel's strided gather pick the channel
+    const size_t ext = extent_bytes(H, W, rs, cs);
+    DCP_HIP(g_staging.get(0, ext, &dsrc));
+    DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
+    img.src_stride = (int32_t)rs;
+    img.src_col_stride = (int32_t)cs;
+    img.src_bytes = (uint32_t)ext;
+  }
+  img.src = (const float*)dsrc;
+  img.dst = (float*)ddst;
+  DCP_HIP(dcp::launch_image(kind, img, map, sampler, round_f32, opts, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, frame, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+// Orders 0..5 on any element type: 0/1 through typed_kernels.hip, 2..5 through the spline path.
+// map_kind 0 radial, 1 perspective, 2 fused, 3 explicit coordinates.
+int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
+              const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
+              int mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if (order < 0 || order > 5) return fail(DCP_ERR_INVALID_ARG, "spline order %d outside [0, 5]", order);
+  if (mode < 0 || mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
+  if (order >= 2) {
+    if (map_kind == 2) return fail(DCP_ERR_UNSUPPORTED, "the fused map is implemented for orders 0 and 1");
+    return run_spline(map_kind == 3 ? 2 : map_kind, src, dst, dtype, H, W, rs, cs, map, ycoord, xcoord, coord_dtype, npts,
+                      order, mode, mem_kind, device, stream);
+  }
+  if ((rc = check_image_typed(src, dst, dtype, H, W, rs, cs)) != DCP_OK) return rc;
+  if (map_kind == 3) {
+    if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
+    if (npts > 0 && (!ycoord || !xcoord)) return fail(DCP_ERR_INVALID_ARG, "null coordinate pointer");
+    if (coord_dtype != DCP_COORD_F32 && coord_dtype != DCP_COORD_F64) return fail(DCP_ERR_INVALID_ARG, "unknown coord_dtype %d", coord_dtype);
+    if (npts > 2147483647LL * 256) return fail(DCP_ERR_UNSUPPORTED, "too many points");
+    if (npts == 0) return DCP_OK;
+  }
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipStream_t st = (hipStream_t)stream;
+  dcp::TypedImageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H = (int32_t)H;
+  a.W = (int32_t)W;
+  a.src_stride = rs;
+  a.src_cstride = cs;
+  a.order = order;
+  a.dtype = dtype;
+  dcp::CoordArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.npts = npts;
+  ca.is_f64 = coord_dtype == DCP_COORD_F64;
+  const int64_t nout = map_kind == 3 ? npts : H * W;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    a.src = src;
+    a.dst = dst;
+    ca.ycoord = ycoord;
+    ca.xcoord = xcoord;
+    DCP_HIP(dcp::launch_typed_image(map_kind, a, map, ca, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *dsrc, *ddst, *dy = nullptr, *dx = nullptr;
+  const size_t ext = extent_bytes_typed(H, W, rs, cs, dtype), esz = (size_t)dcp::elem_size(dtype);
+  DCP_HIP(g_staging.get(0, ext, &dsrc));
+  DCP_HIP(g_staging.get(1, (size_t)nout * esz, &ddst));
+  DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
+  if (map_kind == 3) {
+    const size_t csz = (size_t)npts * (ca.is_f64 ? 8 : 4);
+    DCP_HIP(g_staging.get(2, csz, &dy));
+    DCP_HIP(g_staging.get(3, csz, &dx));
+    DCP_HIP(hipMemcpyAsync(dy, ycoord, csz, hipMemcpyHostToDevice, st));
+    DCP_HIP(hipMemcpyAsync(dx, xcoord, csz, hipMemcpyHostToDevice, st));
+  }
+  a.src = dsrc;
+  a.dst = ddst;
+  ca.ycoord = dy;
+  ca.xcoord = dx;
+  DCP_HIP(dcp::launch_typed_image(map_kind, a, map, ca, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)nout * esz, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcp_unwarp_image_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                         int nfact, int order, int coord_round_f32, int blend_mode, int mem_kind, int device,
+                         void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  return run_image(dcp::kRadial, src, dst, height, width, src_row_stride, src_col_stride, map, sampler,
+                   coord_round_f32 != 0, mem_kind, device, stream);
+}
+
+int dcp_perspective_image_f32(const float* src, float* dst, int64_t height, int64_t width,
+                              int64_t src_row_stride, int64_t src_col_stride, const double* list_coef,
+                              int order, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
+  map.fast_div = homography_is_tame(list_coef, height, width);
+  return run_image(dcp::kPersp, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
+                   mem_kind, device, stream);
+}
+
+int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                         int nfact, const double* list_coef, int order, int blend_mode, int mem_kind,
+                         int device, void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, list_coef)) != DCP_OK) return rc;
+  map.fast_div = homography_is_tame(list_coef, height, width);
+  return run_image(dcp::kFused, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
+                   mem_kind, device, stream);
+}
+
+int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                         int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
+                         int64_t npts, int order, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc, sampler;
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
+  if (npts > 0 && (!ycoord || !xcoord)) return fail(DCP_ERR_INVALID_ARG, "null coordinate pointer");
+  if (coord_dtype != DCP_COORD_F32 && coord_dtype != DCP_COORD_F64)
+    return fail(DCP_ERR_INVALID_ARG, "unknown coord_dtype %d", coord_dtype);
+  if (npts > 2147483647LL * 256) return fail(DCP_ERR_UNSUPPORTED, "too many points");
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  if (npts == 0) return DCP_OK;
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::ImageArgs img;
+  memset(&img, 0, sizeof(img));
+  img.H = (int32_t)height;
+  img.W = (int32_t)width;
+  img.src_stride = (int32_t)src_row_stride;
+  img.src_col_stride = (int32_t)src_col_stride;
+  img.src_bytes = extent_bytes(height, width, src_row_stride, src_col_stride);
+  dcp::CoordArgs ca;
+  ca.npts = npts;
+  ca.is_f64 = coord_dtype == DCP_COORD_F64;
+  hipStream_t st = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    img.src = src;
+    img.dst = dst;
+    ca.ycoord = ycoord;
+    ca.xcoord = xcoord;
+    DCP_HIP(dcp::launch_coords(img, ca, sampler, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *dsrc, *ddst, *dy, *dx;
+  const size_t csz = (size_t)npts * (ca.is_f64 ? 8 : 4);
+  DCP_HIP(g_staging.get(0, img.src_bytes, &dsrc));
+  DCP_HIP(g_staging.get(1, (size_t)npts * 4, &ddst));
+  DCP_HIP(g_staging.get(2, csz, &dy));
+  DCP_HIP(g_staging.get(3, csz, &dx));
+  DCP_HIP(hipMemcpyAsync(dsrc, src, img.src_bytes, hipMemcpyHostToDevice, st));
+  DCP_HIP(hipMemcpyAsync(dy, ycoord, csz, hipMemcpyHostToDevice, st));
+  DCP_HIP(hipMemcpyAsync(dx, xcoord, csz, hipMemcpyHostToDevice, st));
+  img.src = (const float*)dsrc;
+  img.dst = (float*)ddst;
+  ca.ycoord = dy;
+  ca.xcoord = dx;
+  DCP_HIP(dcp::launch_coords(img, ca, sampler, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)npts * 4, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+int dcp_unwarp_image_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width, int64_t src_row_stride,
+                           int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact, int nfact,
+                           int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  return run_typed(0, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                   boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_perspective_image_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width,
+                                int64_t src_row_stride, int64_t src_col_stride, const double* list_coef, int order,
+                                int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
+  if (height > 0 && width > 0) map.fast_div = homography_is_tame(list_coef, height, width);
+  return run_typed(1, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                   boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_unwarp_fused_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width, int64_t src_row_stride,
+                           int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact, int nfact,
+                           const double* list_coef, int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, list_coef)) != DCP_OK) return rc;
+  if (height > 0 && width > 0) map.fast_div = homography_is_tame(list_coef, height, width);
+  return run_typed(2, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                   boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_remap_coords_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width, int64_t src_row_stride,
+                           int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts,
+                           int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  dcp::MapArgs map;
+  memset(&map, 0, sizeof(map));
+  return run_typed(3, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, ycoord, xcoord, coord_dtype,
+                   npts, order, boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t height, int64_t width, int channels,
+                              int64_t src_row_stride, int64_t src_pixel_stride, double xcenter, double ycenter,
+                              const double* list_fact, int nfact, int order, int mem_kind, int device, void* stream) {
+  int rc;
+  if (channels < 1 || channels > 64) return fail(DCP_ERR_INVALID_ARG, "channels = %d outside [1, 64]", channels);
+  if (order < 0 || order > 1) return fail(DCP_ERR_UNSUPPORTED, "the interleaved-channel kernel takes orders 0 and 1 (got %d)", order);
+  if (src_pixel_stride < channels) return fail(DCP_ERR_INVALID_ARG, "pixel stride %lld smaller than %d channels", (long long)src_pixel_stride, channels);
+  if ((rc = check_image_typed(src, dst, dtype, height, width, src_row_stride, src_pixel_stride)) != DCP_OK) return rc;
+  if (src_row_stride < (width - 1) * src_pixel_stride + channels && height > 1)
+    return fail(DCP_ERR_INVALID_ARG, "row stride %lld overlaps rows of %lld pixels", (long long)src_row_stride, (long long)width);
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipStream_t st = (hipStream_t)stream;
+  dcp::TypedImageArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H = (int32_t)height;
+  a.W = (int32_t)width;
+  a.src_stride = src_row_stride;
+  a.src_cstride = src_pixel_stride;
+  a.order = order;
+  a.dtype = dtype;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    a.src = src;
+    a.dst = dst;
+    DCP_HIP(dcp::launch_typed_channels(a, map, channels, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  const size_t esz = (size_t)dcp::elem_size(dtype);
+  const size_t ext = (size_t)((height - 1) * src_row_stride + (width - 1) * src_pixel_stride + channels) * esz;
+  const size_t obytes = (size_t)height * (size_t)width * (size_t)channels * esz;
+  void *dsrc, *ddst;
+  DCP_HIP(g_staging.get(0, ext, &dsrc));
+  DCP_HIP(g_staging.get(1, obytes, &ddst));
+  DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
+  a.src = dsrc;
+  a.dst = ddst;
+  DCP_HIP(dcp::launch_typed_channels(a, map, channels, st));
+  DCP_HIP(hipMemcpyAsync(dst, ddst, obytes, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t width, int map_kind, double xcenter,
+                           double ycenter, const double* list_fact, int nfact, const double* list_coef, int mem_kind,
+                           int device, void* stream) {
+  int rc;
+  if (!ymap || !xmap) return fail(DCP_ERR_INVALID_ARG, "null map pointer");
+  if (height <= 0 || width <= 0 || height > 1073741823LL || width > 1073741823LL)
+    return fail(DCP_ERR_INVALID_ARG, "map must be non-empty (got %lld x %lld)", (long long)height, (long long)width);
+  if (map_kind < DCP_MAP_RADIAL || map_kind > DCP_MAP_FUSED) return fail(DCP_ERR_INVALID_ARG, "unknown map_kind %d", map_kind);
+  if (map_kind != DCP_MAP_RADIAL && !list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, map_kind == DCP_MAP_PERSPECTIVE ? nullptr : list_fact,
+                     map_kind == DCP_MAP_PERSPECTIVE ? 0 : nfact, map_kind == DCP_MAP_RADIAL ? nullptr : list_coef)) != DCP_OK)
+    return rc;
+  if (map_kind != DCP_MAP_RADIAL) map.fast_div = homography_is_tame(list_coef, height, width);
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::ImageArgs img;
+  memset(&img, 0, sizeof(img));
+  img.H = (int32_t)height;
+  img.W = (int32_t)width;
+  const dcp::MapKind kind = map_kind == DCP_MAP_RADIAL ? dcp::kRadial : map_kind == DCP_MAP_PERSPECTIVE ? dcp::kPersp : dcp::kFused;
+  hipStream_t st = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    DCP_HIP(dcp::launch_coord_map(kind, img, map, ymap, xmap, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *dy, *dx;
+  const size_t plane = (size_t)height * (size_t)width * 4;
+  DCP_HIP(g_staging.get(2, plane, &dy));
+  DCP_HIP(g_staging.get(3, plane, &dx));
+  DCP_HIP(dcp::launch_coord_map(kind, img, map, (float*)dy, (float*)dx, st));
+  DCP_HIP(hipMemcpyAsync(ymap, dy, plane, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipMemcpyAsync(xmap, dx, plane, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+}  // extern "C"

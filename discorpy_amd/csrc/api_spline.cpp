@@ -1,0 +1,183 @@
+// api_spline.cpp -- spline orders 2..5 (scipy's prefiltered B-spline interpolation, spline_kernels.hip): the
+// per-device coefficient workspace, host staging, and the *_spline_f32 entry points of the C ABI.
+#include "api_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include <mutex>
+
+using namespace dcpapi;
+
+namespace {
+
+// Per-device float64 coefficient workspace (grow-only).  Reused across calls; a call on a stream
+// other than the previous one first waits for the device so that the old user is done.
+struct SplineWorkspace {
+  std::mutex mu;
+  void* buf[64] = {};
+  size_t cap[64] = {};
+  hipStream_t last[64] = {};
+  hipError_t get(size_t bytes, hipStream_t stream, double** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (buf[dev] && last[dev] != stream) {
+      e = hipDeviceSynchronize();
+      if (e != hipSuccess) return e;
+    }
+    if (cap[dev] < bytes) {
+      if (buf[dev]) {
+        e = hipDeviceSynchronize();
+        if (e != hipSuccess) return e;
+        (void)hipFree(buf[dev]);
+        buf[dev] = nullptr;
+        cap[dev] = 0;
+      }
+      e = hipMalloc(&buf[dev], bytes);
+      if (e != hipSuccess) return e;
+      cap[dev] = bytes;
+    }
+    last[dev] = stream;
+    *out = (double*)buf[dev];
+    return hipSuccess;
+  }
+};
+SplineWorkspace g_spline_ws;
+
+int spline_poles(int order, double* z) {
+  switch (order) {
+    case 2: z[0] = std::sqrt(8.0) - 3.0; return 1;
+    case 3: z[0] = std::sqrt(3.0) - 2.0; return 1;
+    case 4:
+      z[0] = std::sqrt(664.0 - std::sqrt(438976.0)) + std::sqrt(304.0) - 19.0;
+      z[1] = std::sqrt(664.0 + std::sqrt(438976.0)) - std::sqrt(304.0) - 19.0;
+      return 2;
+    case 5:
+      z[0] = std::sqrt(67.5 - std::sqrt(4436.25)) + std::sqrt(26.25) - 6.5;
+      z[1] = std::sqrt(67.5 + std::sqrt(4436.25)) - std::sqrt(26.25) - 6.5;
+      return 2;
+    default: return 0;
+  }
+}
+
+}  // namespace
+
+namespace dcpapi {
+
+int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
+               const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
+               int mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if ((rc = check_image_typed(src, dst, dtype, H, W, rs, cs)) != DCP_OK) return rc;
+  if (order < 2 || order > 5) return fail(DCP_ERR_INVALID_ARG, "spline order %d outside [2, 5]", order);
+  if (mode < 0 || mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
+  if (map_kind == 2) {
+    if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
+    if (npts > 0 && (!ycoord || !xcoord)) return fail(DCP_ERR_INVALID_ARG, "null coordinate pointer");
+    if (coord_dtype != DCP_COORD_F32 && coord_dtype != DCP_COORD_F64) return fail(DCP_ERR_INVALID_ARG, "unknown coord_dtype %d", coord_dtype);
+  }
+  if (H > 1000000 || W > 1000000) return fail(DCP_ERR_UNSUPPORTED, "image too large for the spline path");
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipStream_t st = (hipStream_t)stream;
+  dcp::SplineArgs a;
+  memset(&a, 0, sizeof(a));
+  a.H = (int32_t)H;
+  a.W = (int32_t)W;
+  a.src_dtype = a.dst_dtype = dtype;
+  a.order = order;
+  a.mode = mode;
+  a.pad = (mode == dcp::kModeNearest || mode == dcp::kModeGridConstant) ? 12 : 0;
+  a.Hp = a.H + 2 * a.pad;
+  a.Wp = a.W + 2 * a.pad;
+  a.filter_kind = (mode == dcp::kModeReflect || mode == dcp::kModeGridMirror) ? dcp::kSplReflect
+                  : mode == dcp::kModeGridWrap                                 ? dcp::kSplWrap
+                                                                               : dcp::kSplMirror;
+  a.npoles = spline_poles(order, a.poles);
+  for (int axis = 0; axis < 2; ++axis) {
+    const double n = axis == 0 ? (double)a.Hp : (double)a.Wp;
+    for (int p = 0; p < a.npoles; ++p)
+      a.zpow[axis][p] = std::pow(a.poles[p], a.filter_kind == dcp::kSplMirror ? n - 1.0 : n);
+  }
+  const size_t plane = (size_t)a.Hp * (size_t)a.Wp * sizeof(double);
+  DCP_HIP(g_spline_ws.get(2 * plane, st, &a.coef));
+  a.scratch = a.coef + (size_t)a.Hp * (size_t)a.Wp;
+  dcp::CoordArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  ca.npts = npts;
+  ca.is_f64 = coord_dtype == DCP_COORD_F64;
+  const int64_t nout = map_kind == 2 ? npts : H * W;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    a.src = src;
+    a.src_stride = (int32_t)rs;
+    a.src_cstride = (int32_t)cs;
+    ca.ycoord = ycoord;
+    ca.xcoord = xcoord;
+    DCP_HIP(dcp::launch_spline(a, map_kind, map, ca, dst, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *dsrc, *ddst, *dy = nullptr, *dx = nullptr;
+  const size_t ext = extent_bytes_typed(H, W, rs, cs, dtype), esz = (size_t)dcp::elem_size(dtype);
+  DCP_HIP(g_staging.get(0, ext, &dsrc));
+  DCP_HIP(g_staging.get(1, (size_t)(nout > 0 ? nout : 1) * esz, &ddst));
+  DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
+  if (map_kind == 2 && npts > 0) {
+    const size_t csz = (size_t)npts * (ca.is_f64 ? 8 : 4);
+    DCP_HIP(g_staging.get(2, csz, &dy));
+    DCP_HIP(g_staging.get(3, csz, &dx));
+    DCP_HIP(hipMemcpyAsync(dy, ycoord, csz, hipMemcpyHostToDevice, st));
+    DCP_HIP(hipMemcpyAsync(dx, xcoord, csz, hipMemcpyHostToDevice, st));
+  }
+  a.src = dsrc;
+  a.src_stride = (int32_t)rs;
+  a.src_cstride = (int32_t)cs;
+  ca.ycoord = dy;
+  ca.xcoord = dx;
+  DCP_HIP(dcp::launch_spline(a, map_kind, map, ca, ddst, st));
+  if (nout > 0) DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)nout * esz, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
+}  // namespace dcpapi
+
+extern "C" {
+
+int dcp_unwarp_image_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                                int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                                int nfact, int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  return run_spline(0, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                    boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_perspective_image_spline_f32(const float* src, float* dst, int64_t height, int64_t width,
+                                     int64_t src_row_stride, int64_t src_col_stride, const double* list_coef, int order,
+                                     int boundary_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
+  return run_spline(1, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                    boundary_mode, mem_kind, device, stream);
+}
+
+int dcp_remap_coords_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                                int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
+                                int64_t npts, int order, int boundary_mode, int mem_kind, int device, void* stream) {
+  dcp::MapArgs map;
+  memset(&map, 0, sizeof(map));
+  if (npts == 0) return (order < 2 || order > 5) ? fail(DCP_ERR_INVALID_ARG, "spline order %d outside [2, 5]", order) : DCP_OK;
+  return run_spline(2, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, ycoord, xcoord, coord_dtype, npts,
+                    order, boundary_mode, mem_kind, device, stream);
+}
+
+}  // extern "C"

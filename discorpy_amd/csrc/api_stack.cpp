@@ -1,0 +1,337 @@
+// api_stack.cpp -- stack entry points of the C ABI (unwarp_slice_backward / unwarp_chunk_slices_backward over a
+// (depth, height, width) stack): device-resident stacks, host stacks streamed through the GPU in depth chunks,
+// buffers that hold only the reachable row band (out-of-core callers), host stacks sharded over several GPUs.
+#include "api_common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+using namespace dcpapi;
+
+namespace {
+
+// One description of every stack call: rows row_start .. row_start+nrows-1 of the corrected stack from
+// `vol`, which holds rows [band_start, band_start + band_rows) of each of `depth` projections
+// (band_start = 0, band_rows = height for a whole stack).
+struct StackCall {
+  const void* vol;
+  void* out;
+  int dtype, out_f32;
+  int64_t depth, height, width, band_start, band_rows, proj_stride, row_stride;
+  dcp::MapArgs map;
+  double row_start;
+  int64_t nrows;
+  int round_f32, sampler;      // sampler: float32 data only (the other element types use scipy's exact blend)
+  int mem_kind, device;
+  void* stream;
+};
+
+// base = address of (projection 0, row 0) -- possibly before the buffer when the band starts later; the
+// kernels only touch rows inside the band
+hipError_t launch_stack_any(const StackCall& c, const void* base, void* out, int64_t n, int64_t proj_stride,
+                            int64_t row_stride, int64_t rows_end, const dcp::LaunchOpts& opts, hipStream_t hs) {
+  if (c.dtype == dcp::kF32 && !c.out_f32) {
+    dcp::StackArgs st;
+    memset(&st, 0, sizeof(st));
+    st.D = (int32_t)n;
+    st.H = (int32_t)c.height;
+    st.W = (int32_t)c.width;
+    st.row_start = c.row_start;
+    st.nrows = (int32_t)c.nrows;
+    st.vol = (const float*)base;
+    st.out = (float*)out;
+    st.proj_stride = proj_stride;
+    st.row_stride = (int32_t)row_stride;
+    st.proj_bytes = (uint32_t)(((rows_end - 1) * row_stride + c.width) * 4);
+    return dcp::launch_stack(st, c.map, c.sampler, c.round_f32 != 0, opts, hs);
+  }
+  dcp::TypedStackArgs st;
+  memset(&st, 0, sizeof(st));
+  st.D = (int32_t)n;
+  st.H = (int32_t)c.height;
+  st.W = (int32_t)c.width;
+  st.row_start = c.row_start;
+  st.nrows = (int32_t)c.nrows;
+  st.d_chunk = opts.d_chunk;
+  st.dtype = c.dtype;
+  st.out_f32 = c.out_f32;
+  st.round_f32 = c.round_f32 != 0;
+  st.vol = base;
+  st.out = out;
+  st.proj_stride = proj_stride;
+  st.row_stride = row_stride;
+  return dcp::launch_typed_stack(st, c.map, hs);
+}
+
+int run_stack(const StackCall& c) {
+  const int64_t depth = c.depth, height = c.height, width = c.width, nrows = c.nrows;
+  if (c.dtype < 0 || c.dtype >= dcp::kNumElemTypes) return fail(DCP_ERR_INVALID_ARG, "unknown element type %d", c.dtype);
+  if (depth < 0 || nrows < 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows");
+  if (height <= 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "projections must be non-empty");
+  if (depth > 0 && nrows > 0 && (!c.vol || !c.out)) return fail(DCP_ERR_INVALID_ARG, "null volume pointer");
+  if (c.band_start < 0 || c.band_rows < 1 || c.band_start + c.band_rows > height)
+    return fail(DCP_ERR_INVALID_ARG, "band rows [%lld, %lld) outside the projection height %lld", (long long)c.band_start,
+                (long long)(c.band_start + c.band_rows), (long long)height);
+  if (c.row_stride < width || c.proj_stride < (c.band_rows - 1) * c.row_stride + width)
+    return fail(DCP_ERR_INVALID_ARG, "strides overlap (row %lld, projection %lld)", (long long)c.row_stride, (long long)c.proj_stride);
+  const bool fast = c.dtype == dcp::kF32 && !c.out_f32;
+  if (fast) {
+    if (height < 2 || width < 2) return fail(DCP_ERR_UNSUPPORTED, "stack path needs projections of at least 2 x 2");
+    if ((double)height * (double)c.row_stride * 4.0 > 4294967040.0)
+      return fail(DCP_ERR_UNSUPPORTED, "one projection exceeds the 4 GiB the 32-bit gather offsets address");
+  }
+  if (height > 1073741823LL || width > 1073741823LL || depth > 2147483647LL) return fail(DCP_ERR_UNSUPPORTED, "stack too large");
+  if (nrows > 65535) return fail(DCP_ERR_UNSUPPORTED, "nrows > 65535 in one call");
+  if (!std::isfinite(c.row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
+  // rows of a projection the requested rows can reach (the reference slices mat3D[i, yd_min:yd_max, :] for
+  // the same reason, postprocessing.py:221-228)
+  int64_t band0 = 0, band1 = height;
+  host_row_band(c.map, height, width, c.row_start, nrows, &band0, &band1);
+  const bool partial = c.band_start != 0 || c.band_rows != height;
+  if (partial && (band0 < c.band_start || band1 > c.band_start + c.band_rows))
+    return fail(DCP_ERR_INVALID_ARG, "the rows need source rows [%lld, %lld) but the band holds [%lld, %lld) (see dcp_stack_row_band)",
+                (long long)band0, (long long)band1, (long long)c.band_start, (long long)(c.band_start + c.band_rows));
+  if (depth == 0 || nrows == 0) return DCP_OK;
+  DeviceScope scope(c.device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", c.device, hipGetErrorString(scope.status));
+  dcp::LaunchOpts opts = current_opts();
+  if ((depth + opts.d_chunk - 1) / opts.d_chunk > 65535) opts.d_chunk = (int)((depth + 65534) / 65535);
+  const size_t esz = (size_t)dcp::elem_size(c.dtype), osz = c.out_f32 ? 4 : esz;
+  hipStream_t hs = (hipStream_t)c.stream;
+  if (c.mem_kind == DCP_MEM_DEVICE) {
+    const char* base = (const char*)c.vol - (size_t)(c.band_start * c.row_stride) * esz;
+    DCP_HIP(launch_stack_any(c, base, c.out, depth, c.proj_stride, c.row_stride, c.band_start + c.band_rows, opts, hs));
+    return DCP_OK;
+  }
+  if (c.mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", c.mem_kind);
+  // Host stack.  Only the reachable row band is shipped, and projections are independent
+  // (postprocessing.py:226-228, 310-312), so the stack streams through the GPU in depth chunks: while
+  // chunk k is copied back by a second host thread, chunk k+1 is uploaded and computed (PCIe is full
+  // duplex; pageable copies block their calling thread, hence two threads rather than two streams --
+  // tools/ubench_pcie.hip).  Device scratch: two band buffers and two output buffers of one chunk each.
+  const int64_t bh = band1 - band0;
+  const size_t pbytes = (size_t)bh * (size_t)width * esz;               // one projection's band
+  const size_t obytes = (size_t)nrows * (size_t)width * osz;            // one projection's output rows
+  int64_t dc = (int64_t)(((size_t)g_stack_chunk_kb.load() << 10) / (pbytes > obytes ? pbytes : obytes));
+  dc = dc < 1 ? 1 : (dc > depth ? depth : dc);
+  const int64_t nchunks = (depth + dc - 1) / dc;
+  void *din[2], *dout[2];
+  for (int b = 0; b < 2; ++b) {
+    DCP_HIP(g_staging.get(b, pbytes * (size_t)dc, &din[b]));
+    DCP_HIP(g_staging.get(2 + b, obytes * (size_t)dc, &dout[b]));
+  }
+  int cur_dev = 0;
+  DCP_HIP(hipGetDevice(&cur_dev));
+  hipStream_t s_down = nullptr;
+  DCP_HIP(g_host_streams.get(&hs, &s_down));   // host memory: nothing to order against the caller's stream
+
+  const bool trace = getenv("DISCORPY_AMD_TRACE") != nullptr;   // per-chunk timeline on stderr
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+  std::mutex mu;
+  std::condition_variable cv;
+  int64_t computed = 0, downloaded = 0;     // chunks whose kernel has finished / whose D2H has finished
+  hipError_t down_err = hipSuccess;
+  bool abort_down = false;
+  std::thread downloader([&]() {
+    hipError_t e = hipSetDevice(cur_dev);
+    for (int64_t k = 0; k < nchunks && e == hipSuccess; ++k) {
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return computed > k || abort_down; });
+        if (abort_down) break;
+      }
+      const int64_t d0 = k * dc, n = (d0 + dc > depth ? depth - d0 : dc);
+      const double td0 = ms();
+      e = hipMemcpyAsync((char*)c.out + (size_t)d0 * obytes, dout[k & 1], obytes * (size_t)n, hipMemcpyDeviceToHost, s_down);
+      if (e == hipSuccess) e = hipStreamSynchronize(s_down);
+      if (trace) fprintf(stderr, "down %lld: %.3f -> %.3f\n", (long long)k, td0, ms());
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        downloaded = k + 1;
+      }
+      cv.notify_all();
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    down_err = e;
+    downloaded = nchunks;      // never leave the uploader waiting
+    cv.notify_all();
+  });
+  hipError_t up_err = hipSuccess;
+  for (int64_t k = 0; k < nchunks && up_err == hipSuccess; ++k) {
+    const int64_t d0 = k * dc, n = (d0 + dc > depth ? depth - d0 : dc);
+    if (k >= 2) {   // output buffer k & 1 is free once chunk k-2 has been copied back
+      std::unique_lock<std::mutex> lock(mu);
+      cv.wait(lock, [&] { return downloaded >= k - 1; });
+    }
+    const char* hsrc = (const char*)c.vol + (size_t)(d0 * c.proj_stride + (band0 - c.band_start) * c.row_stride) * esz;
+    const double tu0 = ms();
+    if (c.row_stride == width) {   // the bands of n projections: n runs of pbytes, proj_stride apart
+      up_err = hipMemcpy2DAsync(din[k & 1], pbytes, hsrc, (size_t)c.proj_stride * esz, pbytes, (size_t)n, hipMemcpyHostToDevice, hs);
+    } else {
+      for (int64_t d = 0; d < n && up_err == hipSuccess; ++d)
+        up_err = hipMemcpy2DAsync((char*)din[k & 1] + (size_t)d * pbytes, (size_t)width * esz,
+                                  hsrc + (size_t)(d * c.proj_stride) * esz, (size_t)c.row_stride * esz, (size_t)width * esz,
+                                  (size_t)bh, hipMemcpyHostToDevice, hs);
+    }
+    if (up_err != hipSuccess) break;
+    const double tu1 = ms();
+    // absolute row indexing: the staged band starts at row band0 (never dereferenced below it)
+    const char* base = (const char*)din[k & 1] - (size_t)(band0 * width) * esz;
+    up_err = launch_stack_any(c, base, dout[k & 1], n, bh * width, width, band1, opts, hs);
+    if (up_err == hipSuccess) up_err = hipStreamSynchronize(hs);
+    if (trace) fprintf(stderr, "up %lld: issue %.3f -> %.3f, done %.3f\n", (long long)k, tu0, tu1, ms());
+    if (up_err != hipSuccess) break;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      computed = k + 1;
+    }
+    cv.notify_all();
+  }
+  if (up_err != hipSuccess) {
+    std::lock_guard<std::mutex> lock(mu);
+    abort_down = true;
+    cv.notify_all();
+  }
+  downloader.join();
+  if (up_err != hipSuccess) return fail(DCP_ERR_HIP, "stack upload / kernel failed: %s", hipGetErrorString(up_err));
+  if (down_err != hipSuccess) return fail(DCP_ERR_HIP, "stack download failed: %s", hipGetErrorString(down_err));
+  return DCP_OK;
+}
+
+int make_stack_call(StackCall* c, const void* vol, void* out, int dtype, int out_f32, int64_t depth, int64_t height,
+                    int64_t width, int64_t band_start, int64_t band_rows, int64_t proj_stride, int64_t row_stride,
+                    double xcenter, double ycenter, const double* list_fact, int nfact, double row_start, int64_t nrows,
+                    int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  c->vol = vol;
+  c->out = out;
+  c->dtype = dtype;
+  c->out_f32 = out_f32 != 0;
+  c->depth = depth;
+  c->height = height;
+  c->width = width;
+  c->band_start = band_start;
+  c->band_rows = band_rows;
+  c->proj_stride = proj_stride;
+  c->row_stride = row_stride;
+  c->row_start = row_start;
+  c->nrows = nrows;
+  c->round_f32 = coord_round_f32;
+  c->mem_kind = mem_kind;
+  c->device = device;
+  c->stream = stream;
+  c->sampler = dcp::kScipy;
+  if (dtype == dcp::kF32 && !out_f32 && (rc = sampler_of(1, blend_mode, &c->sampler)) != DCP_OK) return rc;
+  return fill_map(&c->map, xcenter, ycenter, list_fact, nfact, nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
+                              int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                              const double* list_fact, int nfact, double row_start, int64_t nrows,
+                              int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  StackCall c;
+  if ((rc = make_stack_call(&c, vol, out, dcp::kF32, 0, depth, height, width, 0, height, proj_stride, row_stride, xcenter,
+                            ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode, mem_kind, device,
+                            stream)) != DCP_OK)
+    return rc;
+  return run_stack(c);
+}
+
+int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_float32, int64_t depth, int64_t height,
+                                int64_t width, int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
+                                int mem_kind, int device, void* stream) {
+  int rc;
+  StackCall c;
+  if ((rc = make_stack_call(&c, vol, out, dtype, out_float32, depth, height, width, 0, height, proj_stride, row_stride,
+                            xcenter, ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, DCP_BLEND_SCIPY, mem_kind,
+                            device, stream)) != DCP_OK)
+    return rc;
+  return run_stack(c);
+}
+
+int dcp_stack_row_band(int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact, int nfact,
+                       double row_start, int64_t nrows, int64_t* band_start, int64_t* band_rows) {
+  int rc;
+  if (!band_start || !band_rows) return fail(DCP_ERR_INVALID_ARG, "null out pointer");
+  if (height <= 0 || width <= 0 || nrows < 1) return fail(DCP_ERR_INVALID_ARG, "empty projection or no rows");
+  if (!std::isfinite(row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  int64_t b0 = 0, b1 = height;
+  host_row_band(map, height, width, row_start, nrows, &b0, &b1);
+  *band_start = b0;
+  *band_rows = b1 - b0;
+  return DCP_OK;
+}
+
+int dcp_unwarp_stack_band(const void* band, void* out, int dtype, int out_float32, int64_t depth, int64_t height,
+                          int64_t width, int64_t band_start, int64_t band_rows, int64_t proj_stride, int64_t row_stride,
+                          double xcenter, double ycenter, const double* list_fact, int nfact, double row_start,
+                          int64_t nrows, int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream) {
+  int rc;
+  StackCall c;
+  if ((rc = make_stack_call(&c, band, out, dtype, out_float32, depth, height, width, band_start, band_rows, proj_stride,
+                            row_stride, xcenter, ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode,
+                            mem_kind, device, stream)) != DCP_OK)
+    return rc;
+  return run_stack(c);
+}
+
+int dcp_unwarp_stack_rows_multi_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
+                                    int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                    const double* list_fact, int nfact, double row_start, int64_t nrows,
+                                    int coord_round_f32, int blend_mode, const int* devices, int ndev) {
+  if (ndev < 1 || !devices) return fail(DCP_ERR_INVALID_ARG, "need at least one device");
+  if (ndev > 64) return fail(DCP_ERR_INVALID_ARG, "ndev = %d > 64", ndev);
+  const int have = dcp_device_count();
+  for (int i = 0; i < ndev; ++i)
+    if (devices[i] < 0 || devices[i] >= have)
+      return have == 0 ? fail(DCP_ERR_NO_DEVICE, "no HIP device visible")
+                       : fail(DCP_ERR_INVALID_ARG, "devices[%d] = %d outside [0, %d)", i, devices[i], have);
+  if (depth < 0 || nrows < 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows or empty projections");
+  // shard i = projections [d0, d1) with the sizes of numpy.array_split(range(depth), ndev); every worker
+  // stages its own shard, runs K4 on its device and copies its block of `out` back -- the blocks are
+  // disjoint, contiguous along depth, so the "gather" is the D2H copies themselves
+  std::vector<int> rcs((size_t)ndev, DCP_OK);
+  std::vector<std::string> msgs((size_t)ndev);
+  std::vector<std::thread> workers;
+  const int64_t base = depth / ndev, extra = depth % ndev;
+  int64_t d0 = 0;
+  for (int i = 0; i < ndev; ++i) {
+    const int64_t n = base + (i < extra ? 1 : 0);
+    const float* v = vol ? vol + d0 * proj_stride : vol;
+    float* o = out ? out + d0 * nrows * width : out;
+    const int dev = devices[i];
+    workers.emplace_back([=, &rcs, &msgs]() {
+      rcs[(size_t)i] = dcp_unwarp_stack_rows_f32(v, o, n, height, width, proj_stride, row_stride, xcenter, ycenter, list_fact,
+                                                 nfact, row_start, nrows, coord_round_f32, blend_mode, DCP_MEM_HOST, dev,
+                                                 nullptr);
+      if (rcs[(size_t)i] != DCP_OK) msgs[(size_t)i] = dcp_last_error();
+      g_staging.release();   // the worker's scratch lives on `dev`; free it before the thread ends
+      g_host_streams.release();
+    });
+    d0 += n;
+  }
+  for (auto& w : workers) w.join();
+  for (int i = 0; i < ndev; ++i)
+    if (rcs[(size_t)i] != DCP_OK) return fail(rcs[(size_t)i], "shard %d on device %d: %s", i, devices[i], msgs[(size_t)i].c_str());
+  return DCP_OK;
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
 // dcp_internal.h -- shared between the HIP kernels (unwarp_kernels.hip) and the
-// C-ABI layer (unwarp_api.cpp).  Not installed; the public surface is
+// C-ABI layer (api_*.cpp).  Not installed; the public surface is
 // include/discorpy_hip.h.
 #pragma once
 #include <hip/hip_runtime.h>

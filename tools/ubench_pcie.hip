@@ -1,5 +1,5 @@
 // Host<->device transfer rates for one 4096^2 float32 frame (64 MiB): pageable, registered, pinned,
-// chunked, and both directions at once.  Informs the DCP_MEM_HOST staging of unwarp_api.cpp.
+// chunked, and both directions at once.  Informs the DCP_MEM_HOST staging of api_image.cpp / api_stack.cpp.
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench_pcie.hip -o /tmp/ubench_pcie && /tmp/ubench_pcie
 #include <hip/hip_runtime.h>
 #include <chrono>
