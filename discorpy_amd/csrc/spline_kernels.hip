@@ -3,7 +3,8 @@
 // `order` argument of unwarp_image_backward / correct_perspective_image
 // (discorpy/post/postprocessing.py:111,147,462,491; order=3 in examples/readthedocs_demo/demo_07.py:60).
 //
-//   spline_expand_kernel   image (any element type) -> float64 plane, padded by 12 for 'nearest' / 'grid-constant'
+//   spline_expand_kernel   image -> float64 plane, padded by 12 for 'nearest' / 'grid-constant' (an unpadded
+//                          float32 image is read by the first causal pass directly instead)
 //   spline_causal_kernel / spline_anticausal_kernel / spline_transpose_kernel
 //                          recursive B-spline prefilter, chunked along the line (see below)
 //   spline_remap_kernel    (order+1)^2-tap gather at the radial / perspective / explicit coordinates
@@ -48,7 +49,11 @@ __global__ void __launch_bounds__(kSplBlock) spline_expand_kernel(const SplineAr
 // columns and every access is coalesced; the row pass is a column pass on the transposed plane.
 constexpr int kChunk = 256;
 constexpr int kWarm = 64;
-constexpr int kHorizon = 64;     // terms kept of the exact initial sums (SPL_HORIZON in the oracle)
+constexpr int kHorizon = 64;
+#ifndef DCP_SPL_BATCH
+#define DCP_SPL_BATCH 16
+#endif
+constexpr int kBatch = DCP_SPL_BATCH;   // loads issued ahead of the recursion     // terms kept of the exact initial sums (SPL_HORIZON in the oracle)
 
 struct FilterPass {
   const double* in;
@@ -60,42 +65,52 @@ struct FilterPass {
   double lam;            // gain applied to the input of the first causal pass, 1.0 afterwards
 };
 
-__global__ void __launch_bounds__(kSplBlock) spline_causal_kernel(const FilterPass f) {
+// FROM_SRC: the first causal pass (axis 0, first pole) reads the caller's float32 image directly instead of
+// a float64 copy of it (no expansion pass).  Other element types and the two padded modes are expanded first.
+template <bool FROM_SRC>
+__global__ void __launch_bounds__(kSplBlock) spline_causal_kernel(const FilterPass f, const SplineArgs a) {
   const int line = blockIdx.x * kSplBlock + threadIdx.x;
   if (line >= f.nlines) return;
   const int64_t s = f.nlines;                         // stride between samples of a line
-  const double* in = f.in + line;
-  double* out = f.out + line;
+  const double* __restrict__ in = f.in + line;
+  double* __restrict__ out = f.out + line;
+  // sample i of this line; FROM_SRC is used for unpadded modes only, so image row i is sample i
+  const float* __restrict__ col = FROM_SRC ? (const float*)a.src + (size_t)line * a.src_cstride : nullptr;
+  const int64_t cstep = a.src_stride;
+  auto ld = [&](int i) -> double {
+    if constexpr (FROM_SRC) return (double)col[(int64_t)i * cstep];
+    else return in[(int64_t)i * s];
+  };
   const int n = f.n;
   const int c0 = blockIdx.y * kChunk;                 // first sample this thread writes
   const int c1 = min(n, c0 + kChunk);
   const double z = f.z, lam = f.lam;
   if (n < 2) {                                        // scipy leaves a 1-sample line untouched
-    if (c0 == 0 && n == 1) out[0] = in[0];
+    if (c0 == 0 && n == 1) out[0] = ld(0);
     return;
   }
   double t;
   int i;
   if (c0 - kWarm <= 0) {
     // exact start of the line (the expressions of spline_filter_line() in the oracle)
-    const double x0 = in[0] * lam;
+    const double x0 = ld(0) * lam;
     if (f.kind == kSplReflect) {
       double z_i = z;
       const double z_n = f.zpow;
-      double acc = x0 + z_n * (in[(int64_t)(n - 1) * s] * lam);
+      double acc = x0 + z_n * (ld(n - 1) * lam);
       const int m = min(n - 1, kHorizon);
       for (int k = 1; k <= m; ++k) {
-        acc += z_i * (in[(int64_t)k * s] * lam + z_n * (in[(int64_t)(n - 1 - k) * s] * lam));
+        acc += z_i * (ld(k) * lam + z_n * (ld(n - 1 - k) * lam));
         z_i *= z;
       }
       t = acc * z / (1.0 - z_i * z_i) + x0;
     } else if (f.kind == kSplMirror) {
       double z_i = z;
       const double z_n_1 = f.zpow;
-      double acc = x0 + z_n_1 * (in[(int64_t)(n - 1) * s] * lam);
+      double acc = x0 + z_n_1 * (ld(n - 1) * lam);
       const int m = min(n - 2, kHorizon);
       for (int k = 1; k <= m; ++k) {
-        acc += z_i * (in[(int64_t)k * s] * lam + z_n_1 * (in[(int64_t)(n - 1 - k) * s] * lam));
+        acc += z_i * (ld(k) * lam + z_n_1 * (ld(n - 1 - k) * lam));
         z_i *= z;
       }
       t = acc / (1.0 - z_n_1 * z_n_1);
@@ -103,7 +118,7 @@ __global__ void __launch_bounds__(kSplBlock) spline_causal_kernel(const FilterPa
       double z_i = z, acc = x0;
       const int m = min(n - 1, kHorizon);
       for (int k = 0; k < m; ++k) {
-        acc += z_i * (in[(int64_t)(n - 1 - k) * s] * lam);
+        acc += z_i * (ld(n - 1 - k) * lam);
         z_i *= z;
       }
       t = acc / (1.0 - z_i);
@@ -114,9 +129,21 @@ __global__ void __launch_bounds__(kSplBlock) spline_causal_kernel(const FilterPa
     t = 0.0;
     i = c0 - kWarm;
   }
-  for (; i < c0; ++i) t = in[(int64_t)i * s] * lam + z * t;          // warm-up, nothing stored
+  for (; i < c0; ++i) t = ld(i) * lam + z * t;          // warm-up, nothing stored
+  // kBatch loads in flight per thread: one wave per SIMD is all the parallelism a 4096 x 4096 plane
+  // offers (lines x chunks), so the latency has to be covered inside the thread
+  for (; i + kBatch <= c1; i += kBatch) {
+    double v[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) v[j] = ld(i + j);
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      t = v[j] * lam + z * t;
+      out[(int64_t)(i + j) * s] = t;
+    }
+  }
   for (; i < c1; ++i) {
-    t = in[(int64_t)i * s] * lam + z * t;
+    t = ld(i) * lam + z * t;
     out[(int64_t)i * s] = t;
   }
 }
@@ -125,8 +152,8 @@ __global__ void __launch_bounds__(kSplBlock) spline_anticausal_kernel(const Filt
   const int line = blockIdx.x * kSplBlock + threadIdx.x;
   if (line >= f.nlines) return;
   const int64_t s = f.nlines;
-  const double* in = f.in + line;                     // output of the causal pass
-  double* out = f.out + line;
+  const double* __restrict__ in = f.in + line;        // output of the causal pass
+  double* __restrict__ out = f.out + line;
   const int n = f.n;
   const int c0 = blockIdx.y * kChunk;
   const int c1 = min(n, c0 + kChunk);                 // this thread writes samples c1-1 down to c0
@@ -159,6 +186,16 @@ __global__ void __launch_bounds__(kSplBlock) spline_anticausal_kernel(const Filt
     i = c1 + kWarm - 1;
   }
   for (; i >= c1; --i) t = z * (t - in[(int64_t)i * s]);              // warm-up
+  for (; i - kBatch + 1 >= c0; i -= kBatch) {
+    double v[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) v[j] = in[(int64_t)(i - j) * s];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      t = z * (t - v[j]);
+      out[(int64_t)(i - j) * s] = t;
+    }
+  }
   for (; i >= c0; --i) {
     t = z * (t - in[(int64_t)i * s]);
     out[(int64_t)i * s] = t;
@@ -300,14 +337,17 @@ static hipError_t launch_remap_order(const SplineArgs& a, const MapArgs& map, co
 
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream) {
-  const int64_t plane = (int64_t)a.Hp * a.Wp;
-  hipLaunchKernelGGL(spline_expand_kernel, dim3((unsigned)((plane + kSplBlock - 1) / kSplBlock)), dim3(kSplBlock), 0,
-                     stream, a);
   // prefilter: axis 0 on the (Hp x Wp) plane, transpose, axis 1 as axis 0 of the (Wp x Hp) plane,
   // transpose back.  Two planes ping-pong: a.coef (A) and a.scratch (B); the result ends in A.
   double lam = 1.0;
   for (int p = 0; p < a.npoles; ++p) lam *= (1.0 - a.poles[p]) * (1.0 - 1.0 / a.poles[p]);
-  auto filter_axis = [&](double* A, double* B, int n, int nlines, int axis) {
+  const bool direct = a.src_dtype == kF32 && a.pad == 0;
+  if (!direct) {
+    const int64_t plane = (int64_t)a.Hp * a.Wp;
+    hipLaunchKernelGGL(spline_expand_kernel, dim3((unsigned)((plane + kSplBlock - 1) / kSplBlock)), dim3(kSplBlock), 0,
+                       stream, a);
+  }
+  auto filter_axis = [&](double* A, double* B, int n, int nlines, int axis, bool from_src) {
     const dim3 grid((unsigned)((nlines + kSplBlock - 1) / kSplBlock), (unsigned)((n + kChunk - 1) / kChunk));
     for (int p = 0; p < a.npoles; ++p) {
       FilterPass f;
@@ -319,17 +359,18 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       f.lam = p == 0 ? lam : 1.0;
       f.in = A;
       f.out = B;
-      hipLaunchKernelGGL(spline_causal_kernel, grid, dim3(kSplBlock), 0, stream, f);
+      if (from_src && p == 0) hipLaunchKernelGGL(spline_causal_kernel<true>, grid, dim3(kSplBlock), 0, stream, f, a);
+      else hipLaunchKernelGGL(spline_causal_kernel<false>, grid, dim3(kSplBlock), 0, stream, f, a);
       f.in = B;
       f.out = A;
       f.lam = 1.0;
       hipLaunchKernelGGL(spline_anticausal_kernel, grid, dim3(kSplBlock), 0, stream, f);
     }
   };
-  filter_axis(a.coef, a.scratch, a.Hp, a.Wp, 0);
+  filter_axis(a.coef, a.scratch, a.Hp, a.Wp, 0, direct);   // float32: the first pass reads the image itself
   hipLaunchKernelGGL(spline_transpose_kernel, dim3((unsigned)((a.Wp + 31) / 32), (unsigned)((a.Hp + 31) / 32)),
                      dim3(kSplBlock), 0, stream, (const double*)a.coef, a.scratch, a.Hp, a.Wp);
-  filter_axis(a.scratch, a.coef, a.Wp, a.Hp, 1);
+  filter_axis(a.scratch, a.coef, a.Wp, a.Hp, 1, false);
   hipLaunchKernelGGL(spline_transpose_kernel, dim3((unsigned)((a.Hp + 31) / 32), (unsigned)((a.Wp + 31) / 32)),
                      dim3(kSplBlock), 0, stream, (const double*)a.scratch, a.coef, a.Wp, a.Hp);
   hipError_t e = hipGetLastError();
