@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--blend", default="f64lerp", choices=sorted(BLEND_NAMES))
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 64)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the CPUs this process may use (affinity, cgroup quota)")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (dcp_set_option)")
     ap.add_argument("--workload", default="frame", choices=["frame", "stack"],
                     help="frame: BASELINE config 2 (default, the headline metric); stack: config 4, the "
@@ -51,11 +51,36 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """CPUs this process may really use: the smaller of the affinity mask and the cgroup quota (the GPU boxes
+    show 256 logical CPUs but grant 16; running 64 threads there is slower than running 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            quota = None
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    return max(1, n)
+
+
 def cpu_baseline(cfg, img, blend, threads):
     """Time the oracle (a C port of the reference arithmetic) on the host: whole 4096^2 frames."""
     from oracle import oracle as orc
     ncores = orc.max_threads()
-    t = threads if threads > 0 else min(ncores, 64)
+    t = threads if threads > 0 else min(ncores, usable_cpus())
     orc.set_threads(t)
     kw = dict(order=cfg["order"], poly=orc.POLY_NUMPY, blend=orc.BLEND_SCIPY)
     orc.unwarp_image_backward(img, cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], **kw)  # warm
@@ -69,8 +94,9 @@ def cpu_baseline(cfg, img, blend, threads):
     mpix = frames * img.size / dt / 1e6
     return {"value": round(mpix, 2), "unit": "Mpixels/s", "cores": t, "kind": "port",
             "sample": "%d full %dx%d frames of the bench workload, reference arithmetic order "
-                      "(numpy-order polynomial, scipy blend), %d OpenMP threads of %d host cores, %.2f s wall"
-                      % (frames, img.shape[0], img.shape[1], t, ncores, dt)}
+                      "(numpy-order polynomial, scipy blend), %d OpenMP threads (%d logical CPUs visible, %d usable "
+                      "under the affinity mask / cgroup quota), %.2f s wall"
+                      % (frames, img.shape[0], img.shape[1], t, ncores, usable_cpus(), dt)}
 
 
 def stack_main(a, world, rank, dev, dist, backend):
