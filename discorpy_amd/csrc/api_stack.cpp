@@ -95,8 +95,9 @@ int run_stack(const StackCall& c) {
   // rows of a projection the requested rows can reach (the reference slices mat3D[i, yd_min:yd_max, :] for
   // the same reason, postprocessing.py:221-228)
   int64_t band0 = 0, band1 = height;
-  host_row_band(c.map, height, width, c.row_start, nrows, &band0, &band1);
   const bool partial = c.band_start != 0 || c.band_rows != height;
+  if (partial || c.mem_kind == DCP_MEM_HOST)    // (a whole device-resident stack needs no band: skip the host arithmetic)
+    host_row_band(c.map, height, width, c.row_start, nrows, &band0, &band1);
   if (partial && (band0 < c.band_start || band1 > c.band_start + c.band_rows))
     return fail(DCP_ERR_INVALID_ARG, "the rows need source rows [%lld, %lld) but the band holds [%lld, %lld) (see dcp_stack_row_band)",
                 (long long)band0, (long long)band1, (long long)c.band_start, (long long)(c.band_start + c.band_rows));

@@ -10,8 +10,8 @@ for kv in sys.argv[1:]:
 
 
 def timed(fn, reps):
-    for _ in range(3):
-        fn(0)
+    for w in range(max(3, min(reps, 60))):      # warm-up long enough for the clocks to settle
+        fn(w)
     e0, e1 = F.Event(), F.Event(); e0.record()
     for r in range(reps):
         fn(r)
