@@ -2,8 +2,8 @@
 
 ``unwarp_color_image_backward`` has the signature and semantics of the reference
 (``/root/reference/discorpy/util/utility.py:278-342``): optional padding, then the backward radial
-unwarp of every channel at the SAME float32 coordinates.  Channels are processed as dense planes
-by the image kernel of :mod:`discorpy_amd.post.postprocessing`.
+unwarp of every channel at the SAME float32 coordinates -- one launch on the interleaved image for
+orders 0 / 1, plane by plane through :mod:`discorpy_amd.post.postprocessing` otherwise.
 
 ``find_point_to_point`` is the closed-form point mapping of ``utility.py:192-230`` (host, NumPy).
 """
@@ -16,60 +16,56 @@ __all__ = ["unwarp_color_image_backward", "find_point_to_point"]
 
 def find_point_to_point(points, xcenter, ycenter, list_fact, output_order="xy"):
     """
-    Corresponding point in the other space: ``centre + B(r) * (point - centre)`` with
-    ``B(r) = sum_i list_fact[i] * r**i`` (reference ``utility.py:192-230``).  ``points`` is
-    ``(row_index, column_index)``; the result is ``(x, y)`` or, with ``output_order="yx"``, ``(y, x)``.
+    The radial model applied to ONE point (reference ``utility.py:192-230``): the point moves along its ray
+    from the centre by the factor ``B(r) = sum_i list_fact[i] * r**i``.  With a forward model a distorted
+    point goes to the undistorted space, with a backward model the other way.  ``points`` is
+    ``(row_index, column_index)``; returns ``(x, y)``, or ``(y, x)`` for ``output_order="yx"``.
     """
-    xi, yi = points[1] - xcenter, points[0] - ycenter
-    ri = np.sqrt(xi * xi + yi * yi)
-    factor = np.float64(np.sum(list_fact * np.power(ri, np.arange(len(list_fact)))))
-    xo = xcenter + factor * xi
-    yo = ycenter + factor * yi
-    return (xo, yo) if output_order == "xy" else (yo, xo)
+    row, col = points[0], points[1]
+    dx = col - xcenter
+    dy = row - ycenter
+    radius = np.sqrt(dx * dx + dy * dy)
+    coefs = np.asarray(list_fact, dtype=np.float64)
+    scale = np.float64(np.sum(coefs * radius ** np.arange(coefs.size)))
+    moved = (xcenter + scale * dx, ycenter + scale * dy)
+    return moved if output_order == "xy" else moved[::-1]
+
+
+def _auto_pad(height, width, xcenter, ycenter, list_fact):
+    """pad=True: how far the four image corners land outside the frame once the forward model (fitted from the
+    backward one by discorpy's CPU routine, which is not part of this package) is applied to them."""
+    try:
+        import discorpy.proc.processing as proc
+    except ImportError:
+        raise NotImplementedError(
+            "pad=True needs discorpy.proc.transform_coef_backward_and_forward (the CPU model fit, "
+            "not part of this package); install discorpy or pass explicit pad widths")
+    grid = [[gy - ycenter, gx - xcenter] for gy in np.linspace(0, height, 40) for gx in np.linspace(0, width, 40)]
+    forward = proc.transform_coef_backward_and_forward(list_fact, ref_points=grid)
+    corners = {name: find_point_to_point(rc, xcenter, ycenter, forward)
+               for name, rc in (("tl", (0, 0)), ("tr", (0, width - 1)), ("br", (height - 1, width - 1)),
+                                ("bl", (height - 1, 0)))}
+    left = min(corners["tl"][0], corners["bl"][0])
+    right = max(corners["tr"][0], corners["br"][0])
+    top = min(corners["tl"][1], corners["tr"][1])
+    bottom = max(corners["bl"][1], corners["br"][1])
+    return (int(-top) if top < 0 else 0, int(bottom - height) if bottom > height else 0,
+            int(-left) if left < 0 else 0, int(right - width) if right > width else 0)
 
 
 def _calc_pad(pad, height, width, xcenter, ycenter, list_fact):
-    """Pad widths (top, bottom, left, right); reference ``utility.py:233-275``."""
-    t_pad, b_pad, l_pad, r_pad = 0, 0, 0, 0
+    """(top, bottom, left, right) pad widths from the ``pad`` argument of the reference (``utility.py:233-275``):
+    False -> none, True -> automatic, an int -> that width on every side, four values -> as given."""
     if isinstance(pad, bool):
-        if pad is True:
-            # automatic width: needs the forward model fitted from the backward one -- the one-off
-            # CPU fit of discorpy.proc (out of scope here); use it when discorpy is installed
-            try:
-                import discorpy.proc.processing as proc
-            except ImportError:
-                raise NotImplementedError(
-                    "pad=True needs discorpy.proc.transform_coef_backward_and_forward (the CPU model fit, "
-                    "not part of this package); install discorpy or pass explicit pad widths")
-            ref_points = [[i - ycenter, j - xcenter] for i in np.linspace(0, height, 40)
-                          for j in np.linspace(0, width, 40)]
-            list_tfact = proc.transform_coef_backward_and_forward(list_fact, ref_points=ref_points)
-            xu_tl, yu_tl = find_point_to_point((0, 0), xcenter, ycenter, list_tfact)
-            xu_tr, yu_tr = find_point_to_point((0, width - 1), xcenter, ycenter, list_tfact)
-            xu_br, yu_br = find_point_to_point((height - 1, width - 1), xcenter, ycenter, list_tfact)
-            xu_bl, yu_bl = find_point_to_point((height - 1, 0), xcenter, ycenter, list_tfact)
-            l_val = min(xu_tl, xu_bl)
-            if l_val < 0:
-                l_pad = int(-l_val)
-            r_val = max(xu_tr, xu_br)
-            if r_val > width:
-                r_pad = int(r_val - width)
-            t_val = min(yu_tl, yu_tr)
-            if t_val < 0:
-                t_pad = int(-t_val)
-            b_val = max(yu_bl, yu_br)
-            if b_val > height:
-                b_pad = int(b_val - height)
-    elif isinstance(pad, int):
-        t_pad = b_pad = l_pad = r_pad = pad
-    elif isinstance(pad, tuple) or isinstance(pad, list):
+        return _auto_pad(height, width, xcenter, ycenter, list_fact) if pad else (0, 0, 0, 0)
+    if isinstance(pad, int):
+        return (pad,) * 4
+    if isinstance(pad, (tuple, list)):
         if len(pad) != 4:
             raise ValueError("Incorrect format!!! Please use a tuple/list of "
                              "(top_pad, bottom_pad, left_pad, right_pad)")
-        t_pad, b_pad, l_pad, r_pad = pad
-    else:
-        raise ValueError("Invalid format of the 'pad' parameter!!!")
-    return t_pad, b_pad, l_pad, r_pad
+        return tuple(pad)
+    raise ValueError("Invalid format of the 'pad' parameter!!!")
 
 
 def _pad_device(t, pad_width, mode):
