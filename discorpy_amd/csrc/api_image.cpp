@@ -12,6 +12,19 @@ using namespace dcpapi;
 
 namespace {
 
+// The float32 kernels address their source with 32-bit byte offsets (buffer instructions).  A source that
+// needs more -- a 40 000 x 40 000 frame fits this GPU's memory many times over -- goes to the generic
+// kernels of typed_kernels.hip (64-bit addressing, scipy's exact blend) instead of being refused.
+bool beyond_32bit_offsets(int64_t H, int64_t W, int64_t rs, int64_t cs) {
+  if (H <= 0 || W <= 0 || rs < 1 || cs < 1) return false;
+  const double extent = ((double)(H - 1) * (double)rs + (double)(W - 1) * (double)cs + 1.0) * 4.0;
+  return extent > 4294967040.0 && H <= 1073741823LL && W <= 1073741823LL;
+}
+
+int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
+              const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
+              int mode, int mem_kind, int device, void* stream);
+
 // Shared driver of the three whole-image entry points.
 int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_t W, int64_t rs, int64_t cs,
               const dcp::MapArgs& map, int sampler, bool round_f32, int mem_kind, int device, void* stream) {
@@ -143,10 +156,13 @@ int dcp_unwarp_image_f32(const float* src, float* dst, int64_t height, int64_t w
                          int nfact, int order, int coord_round_f32, int blend_mode, int mem_kind, int device,
                          void* stream) {
   int rc, sampler;
-  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
   dcp::MapArgs map;
   if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  if (beyond_32bit_offsets(height, width, src_row_stride, src_col_stride) && coord_round_f32)
+    return run_typed(0, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                     0, mem_kind, device, stream);
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   return run_image(dcp::kRadial, src, dst, height, width, src_row_stride, src_col_stride, map, sampler,
                    coord_round_f32 != 0, mem_kind, device, stream);
 }
@@ -155,12 +171,15 @@ int dcp_perspective_image_f32(const float* src, float* dst, int64_t height, int6
                               int64_t src_row_stride, int64_t src_col_stride, const double* list_coef,
                               int order, int blend_mode, int mem_kind, int device, void* stream) {
   int rc, sampler;
-  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
   if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
   dcp::MapArgs map;
   if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
-  map.fast_div = homography_is_tame(list_coef, height, width);
+  if (height > 0 && width > 0) map.fast_div = homography_is_tame(list_coef, height, width);
+  if (beyond_32bit_offsets(height, width, src_row_stride, src_col_stride))
+    return run_typed(1, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                     0, mem_kind, device, stream);
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   return run_image(dcp::kPersp, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
                    mem_kind, device, stream);
 }
@@ -170,12 +189,15 @@ int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t w
                          int nfact, const double* list_coef, int order, int blend_mode, int mem_kind,
                          int device, void* stream) {
   int rc, sampler;
-  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
   if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
   dcp::MapArgs map;
   if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, list_coef)) != DCP_OK) return rc;
-  map.fast_div = homography_is_tame(list_coef, height, width);
+  if (height > 0 && width > 0) map.fast_div = homography_is_tame(list_coef, height, width);
+  if (beyond_32bit_offsets(height, width, src_row_stride, src_col_stride))
+    return run_typed(2, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
+                     0, mem_kind, device, stream);
+  if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   return run_image(dcp::kFused, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
                    mem_kind, device, stream);
 }
@@ -184,6 +206,13 @@ int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t w
                          int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
                          int64_t npts, int order, int blend_mode, int mem_kind, int device, void* stream) {
   int rc, sampler;
+  if (beyond_32bit_offsets(height, width, src_row_stride, src_col_stride)) {
+    dcp::MapArgs none;
+    memset(&none, 0, sizeof(none));
+    if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+    return run_typed(3, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, none, ycoord, xcoord, coord_dtype,
+                     npts, order, 0, mem_kind, device, stream);
+  }
   if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
   if (npts > 0 && (!ycoord || !xcoord)) return fail(DCP_ERR_INVALID_ARG, "null coordinate pointer");

@@ -37,9 +37,9 @@ struct StackCall {
 
 // base = address of (projection 0, row 0) -- possibly before the buffer when the band starts later; the
 // kernels only touch rows inside the band
-hipError_t launch_stack_any(const StackCall& c, const void* base, void* out, int64_t n, int64_t proj_stride,
+hipError_t launch_stack_any(const StackCall& c, bool fast, const void* base, void* out, int64_t n, int64_t proj_stride,
                             int64_t row_stride, int64_t rows_end, const dcp::LaunchOpts& opts, hipStream_t hs) {
-  if (c.dtype == dcp::kF32 && !c.out_f32) {
+  if (fast) {
     dcp::StackArgs st;
     memset(&st, 0, sizeof(st));
     st.D = (int32_t)n;
@@ -83,12 +83,10 @@ int run_stack(const StackCall& c) {
                 (long long)(c.band_start + c.band_rows), (long long)height);
   if (c.row_stride < width || c.proj_stride < (c.band_rows - 1) * c.row_stride + width)
     return fail(DCP_ERR_INVALID_ARG, "strides overlap (row %lld, projection %lld)", (long long)c.row_stride, (long long)c.proj_stride);
-  const bool fast = c.dtype == dcp::kF32 && !c.out_f32;
-  if (fast) {
-    if (height < 2 || width < 2) return fail(DCP_ERR_UNSUPPORTED, "stack path needs projections of at least 2 x 2");
-    if ((double)height * (double)c.row_stride * 4.0 > 4294967040.0)
-      return fail(DCP_ERR_UNSUPPORTED, "one projection exceeds the 4 GiB the 32-bit gather offsets address");
-  }
+  // the tuned float32 kernel gathers 8-byte pairs with 32-bit byte offsets inside a projection; tiny or
+  // huge (> 4 GiB) projections take the generic kernel (64-bit addressing, scipy's exact blend)
+  const bool fast = c.dtype == dcp::kF32 && !c.out_f32 && height >= 2 && width >= 2 &&
+                    (double)height * (double)c.row_stride * 4.0 <= 4294967040.0;
   if (height > 1073741823LL || width > 1073741823LL || depth > 2147483647LL) return fail(DCP_ERR_UNSUPPORTED, "stack too large");
   if (nrows > 65535) return fail(DCP_ERR_UNSUPPORTED, "nrows > 65535 in one call");
   if (!std::isfinite(c.row_start)) return fail(DCP_ERR_INVALID_ARG, "row_start is not finite");
@@ -110,7 +108,7 @@ int run_stack(const StackCall& c) {
   hipStream_t hs = (hipStream_t)c.stream;
   if (c.mem_kind == DCP_MEM_DEVICE) {
     const char* base = (const char*)c.vol - (size_t)(c.band_start * c.row_stride) * esz;
-    DCP_HIP(launch_stack_any(c, base, c.out, depth, c.proj_stride, c.row_stride, c.band_start + c.band_rows, opts, hs));
+    DCP_HIP(launch_stack_any(c, fast, base, c.out, depth, c.proj_stride, c.row_stride, c.band_start + c.band_rows, opts, hs));
     return DCP_OK;
   }
   if (c.mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", c.mem_kind);
@@ -188,7 +186,7 @@ int run_stack(const StackCall& c) {
     const double tu1 = ms();
     // absolute row indexing: the staged band starts at row band0 (never dereferenced below it)
     const char* base = (const char*)din[k & 1] - (size_t)(band0 * width) * esz;
-    up_err = launch_stack_any(c, base, dout[k & 1], n, bh * width, width, band1, opts, hs);
+    up_err = launch_stack_any(c, fast, base, dout[k & 1], n, bh * width, width, band1, opts, hs);
     if (up_err == hipSuccess) up_err = hipStreamSynchronize(hs);
     if (trace) fprintf(stderr, "up %lld: issue %.3f -> %.3f, done %.3f\n", (long long)k, tu0, tu1, ms());
     if (up_err != hipSuccess) break;

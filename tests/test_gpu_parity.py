@@ -646,6 +646,57 @@ def test_element_types_on_device_tensors_and_stacks(hip, orc):
                                                            poly=orc.POLY_KERNEL))
 
 
+def test_calls_from_several_python_threads(hip, orc):
+    """SURVEY 8(b) threading: the native layer is re-entrant -- per-thread staging, thread-local error text."""
+    import threading
+    imgs = [noise(200 + k, (300 + 7 * k, 400 - 5 * k)) for k in range(6)]
+    a = [(150.0 + k, 120.0 - k, [1.0, 1e-3 * (k + 1) / 6, 2e-6]) for k in range(6)]
+    want = [orc.unwarp_image_backward(im, *p, **kernel_oracle(orc, "f64lerp")) for im, p in zip(imgs, a)]
+    vol = noise(300, (5, 120, 160))
+    want_c = orc.unwarp_chunk_slices_backward(vol, 80.0, 60.0, [1.0, 2e-3], 30, 60, **kernel_oracle(orc, "f64lerp"))
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(8):
+                assert np.array_equal(pp.unwarp_image_backward(imgs[k], *a[k]), want[k])
+                assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, 80.0, 60.0, [1.0, 2e-3], 30, 60), want_c)
+                with pytest.raises(ValueError, match="nfact"):
+                    hip.check(hip.lib().dcp_unwarp_image_f32(imgs[k].ctypes.data, imgs[k].ctypes.data, 4, 4, 4, 1, 0.0, 0.0,
+                                                             hip.fact_array([1.0])[0], 99, 1, 1, 1, hip.MEM_HOST, -1, None))
+        except Exception as e:            # noqa: BLE001 -- reported below
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+def test_frame_larger_than_4_gib(hip, orc):
+    """A 33 000 x 33 000 float32 frame (4.36 GB) is beyond the 32-bit offsets of the tuned kernels; the C ABI sends it
+    to the generic kernels (64-bit addressing, exact blend) instead of refusing it.  Rows at the top, the middle and
+    the bottom are checked against the oracle."""
+    H = W = 33000
+    base = noise(5, (500, W))
+    img = np.tile(base, (H // 500, 1))
+    assert img.shape == (H, W) and img.nbytes > 2 ** 32
+    a = (W * 0.47, H * 0.52, [1.0, 2.0e-6, -1.5e-10, 2.0e-15])
+    out = pp.unwarp_image_backward(img, *a)
+    out0 = pp.unwarp_image_backward(img, *a, order=0)
+    for r0 in (0, 16490, H - 24):
+        want = orc.unwarp_stack_rows(img[None], *a, r0, 24, coord_round_f32=True, poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY)[0]
+        assert np.array_equal(out[r0:r0 + 24], want), r0
+    del out
+    # order 0 copies source pixels: every value of an output row is a value of the source rows its band reaches
+    assert out0.shape == (H, W)
+    for r0 in (3, 20000, H - 2):
+        b0, bn = hip.stack_row_band(H, W, *a, r0, 1)
+        assert np.isin(out0[r0], img[b0:b0 + bn]).all(), r0
+
+
 def test_randomised_differential_campaign(hip, orc):
     """600 seeded random cases of tools/fuzz_parity.py (shapes, centres, models from mild to folding, homographies,
     strides, blends, stacks, coordinates, element types, spline orders and modes): HIP == oracle, bit for bit at
