@@ -80,7 +80,8 @@ def _check_order_mode(order, mode):
 
 
 def _dtype_code(dtype):
-    name = str(dtype).replace("torch.", "")
+    # NumPy: the dtype's name ("uint16" also for a big-endian '>u2' read from HDF5); torch: "torch.uint16"
+    name = dtype.name if isinstance(dtype, np.dtype) else str(dtype).replace("torch.", "")
     try:
         return F.DTYPE_BY_NAME[name]
     except KeyError:
@@ -111,9 +112,9 @@ class _Image:
         else:
             a = np.asarray(a)
             self.code = _dtype_code(a.dtype)
-            self.dtype = a.dtype
             if not a.dtype.isnative:
                 a = a.astype(a.dtype.newbyteorder("="))
+            self.dtype = a.dtype          # native byte order, as scipy allocates its output
             if any(s < 0 for s in a.strides) or any(s % a.itemsize for s in a.strides):
                 a = np.ascontiguousarray(a)
             self.shape = a.shape
@@ -281,6 +282,7 @@ def _stack_rows_lazy(src, xcenter, ycenter, list_fact, row_start, nrows, round_f
     (depth, height, width) = src.shape
     dtype = np.dtype(src.dtype)
     code = _dtype_code(dtype)
+    dtype = dtype.newbyteorder("=")                   # chunks are converted to native byte order on the way in
     fact = _coefs(list_fact, "list_fact")
     fa, nf = F.fact_array(fact)
     odt = np.dtype(np.float32) if out_float32 else dtype

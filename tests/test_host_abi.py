@@ -222,3 +222,11 @@ def test_stack_row_band_and_band_validation_need_no_gpu():
     assert rc == F.ERR_INVALID_ARG and "outside the projection" in F.last_error()
     with pytest.raises(ValueError):
         F.stack_row_band(H, W, *a, float("inf"), 1)
+
+
+def test_non_native_byte_order_is_normalised():
+    """HDF5 files often hold big-endian integers; scipy returns native-endian output for them and so does this path."""
+    a = np.arange(12, dtype=">u2").reshape(3, 4)
+    im = pp._Image(a, 2)
+    assert im.code == F.DTYPE_BY_NAME["uint16"] and im.dtype == np.dtype("uint16") and im.dtype.isnative
+    assert np.array_equal(im.keep, a) and im.keep.dtype.isnative
