@@ -110,6 +110,7 @@ struct LaunchOpts {
   int lds_gather = 1;
   int coef_lds = 0;        // 1: force the LDS-staged coefficient path even for short vectors
   int d_chunk = 16;
+  int stack_lds = 1;       // LDS-staged stack kernel: 0 never, 1 when the launch has enough wave tiles, 2 always
 };
 
 // launchers (unwarp_kernels.hip)

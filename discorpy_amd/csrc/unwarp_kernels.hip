@@ -725,6 +725,153 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
   }
 }
 
+// K4 with the LDS-staged gather of K1: a wave owns a 64 x 16 tile of (x, row) positions; the coordinates, the
+// source box and the per-pixel LDS tap address and fractions are computed ONCE and kept in registers, then for
+// each of the d_chunk projections the box is filled by LDS-DMA from that projection and the 1024 pixels are
+// blended out of LDS.  Per voxel that leaves two ds_read2, the blend and a store (~15 VALU instructions against
+// ~42 for a single frame), and row-contiguous 16-byte fills instead of scattered 8-byte gathers.  A tile whose box
+// does not fit the slab, or whose containment vote fails, gathers directly as stack_rows_kernel does.
+// float32 coordinates only (unwarp_chunk_slices_backward); the slice path keeps stack_rows_kernel.
+template <int NF, int SAMPLER>
+__global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(const StackArgs st, const MapArgs map) {
+  __shared__ float s_box[kLdsBW][kBoxH * kBoxW];
+  __shared__ double s_row[kLdsBW * kLdsTH][2];
+  __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
+  using FetchT = Fetch<SAMPLER, true, float>;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int rblk = blockIdx.y * (kLdsBW * kLdsTH);
+  const int r0 = rblk + wave * kLdsTH;              // first output row (index into the requested rows) of this wave
+  const int x = blockIdx.x * kLdsTW + lane;
+  const int d0 = blockIdx.z * st.d_chunk, d1 = min(st.D, d0 + st.d_chunk);
+  if ((int)threadIdx.x < kLdsBW * kLdsTH)
+    fill_row<kRadial, 2>(map, s_row, threadIdx.x, st.row_start + (double)min(rblk + (int)threadIdx.x, st.nrows - 1));
+  if constexpr (NF < 0) {
+    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
+  }
+  __syncthreads();
+  if (r0 >= st.nrows) return;                       // wave-uniform
+  const int rows = min(kLdsTH, st.nrows - r0);
+  const float wmaxf = (float)(st.W - 1), hmaxf = (float)(st.H - 1);
+  const ColCtx col = make_col<kRadial, NF>(map, min(x, st.W - 1));
+  const auto* rowtab = s_row + wave * kLdsTH;
+
+  // ---- coordinates of the tile (once for all projections)
+  float xf[kLdsTH], yf[kLdsTH];
+#pragma unroll
+  for (int k = 0; k < kLdsTH; ++k) {
+    double xd, yd;
+    map_coord<kRadial, NF, 2>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+    xf[k] = round_clip_f32(xd, wmaxf);
+    yf[k] = round_clip_f32(yd, hmaxf);
+  }
+  // ---- source box: hull of the four corner pixels grown by one pixel, verified for every pixel of the tile
+  int cx0, cx1, cy0, cy1;
+  {
+    const int xa = (int)xf[0], xb = (int)xf[kLdsTH - 1], ya = (int)yf[0], yb = (int)yf[kLdsTH - 1];
+    const int xa0 = __builtin_amdgcn_readlane(xa, 0), xa1 = __builtin_amdgcn_readlane(xa, 63);
+    const int xb0 = __builtin_amdgcn_readlane(xb, 0), xb1 = __builtin_amdgcn_readlane(xb, 63);
+    const int ya0 = __builtin_amdgcn_readlane(ya, 0), ya1 = __builtin_amdgcn_readlane(ya, 63);
+    const int yb0 = __builtin_amdgcn_readlane(yb, 0), yb1 = __builtin_amdgcn_readlane(yb, 63);
+    cx0 = min(min(xa0, xa1), min(xb0, xb1));
+    cx1 = max(max(xa0, xa1), max(xb0, xb1));
+    cy0 = min(min(ya0, ya1), min(yb0, yb1));
+    cy1 = max(max(ya0, ya1), max(yb0, yb1));
+  }
+  const int bx0 = max(min(cx0 - DCP_LDS_MARGIN, st.W - 2), 0);
+  const int bx1 = min(cx1 + 1 + DCP_LDS_MARGIN, st.W - 1);
+  const int by0 = max(min(cy0 - DCP_LDS_MARGIN, st.H - 2), 0);
+  const int by1 = min(cy1 + 1 + DCP_LDS_MARGIN, st.H - 1);
+  const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+  const bool fits = bw <= kBoxW && bh <= kBoxH;
+  float xmn = xf[0], xmx = xf[0], ymn = yf[0], ymx = yf[0];
+#pragma unroll
+  for (int k = 1; k < kLdsTH; ++k) {
+    xmn = __builtin_fminf(xmn, xf[k]);
+    xmx = __builtin_fmaxf(xmx, xf[k]);
+    ymn = __builtin_fminf(ymn, yf[k]);
+    ymx = __builtin_fmaxf(ymx, yf[k]);
+  }
+  const bool inside = xmn >= (float)bx0 && (xmx < (float)bx1 || bx1 == st.W - 1) && ymn >= (float)by0 &&
+                      (ymx < (float)by1 || by1 == st.H - 1);
+  const bool staged = fits && __builtin_amdgcn_ballot_w64(!inside) == 0;
+  if (!staged && lane == 0) atomicAdd(&g_lds_stats[fits ? 1 : 0], 1ull);
+
+  // ---- per-pixel tap address in the slab and fractions (base tap held at x0 <= W-2, y0 <= H-2)
+  uint32_t addr[kLdsTH];
+  float fx[kLdsTH], fy[kLdsTH];
+#pragma unroll
+  for (int k = 0; k < kLdsTH; ++k) {
+    const int xi = min((int)xf[k], st.W - 2), yi = min((int)yf[k], st.H - 2);
+    fx[k] = xf[k] - (float)xi;
+    fy[k] = yf[k] - (float)yi;
+    // slab byte address when staged, byte offset inside the projection otherwise
+    addr[k] = staged ? (uint32_t)(((yi - by0) * kBoxW + (xi - bx0)) * 4) : (__umul24(yi, st.row_stride) + (uint32_t)xi) << 2;
+  }
+  const bool active = x < st.W;
+  float* box = s_box[wave];
+  const char* boxb = (const char*)box;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  static_assert(kBoxW == 80, "the fill maps 20 lanes of 16 bytes to one slab row");
+  const uint32_t org = ((uint32_t)by0 * (uint32_t)st.row_stride + (uint32_t)bx0) * 4u;
+  const uint32_t rstep = (uint32_t)st.row_stride * 4u;
+  const int lrow = (int)(__umul24((uint32_t)lane, 13u) >> 8);        // lane / 20 for lane < 64
+  const int lcol = lane - lrow * 20;
+  const uint32_t voff = __umul24((uint32_t)lrow, rstep) + (uint32_t)lcol * 16u;
+  const int row_bytes = st.row_stride * 4;
+  const float* base = st.vol + (size_t)d0 * (size_t)st.proj_stride;
+  float* out = st.out + ((size_t)d0 * (size_t)st.nrows + (size_t)r0) * (size_t)st.W;
+  const size_t out_step = (size_t)st.nrows * (size_t)st.W;
+  const uint32_t out_row = (uint32_t)st.W * 4u, xoff = (uint32_t)x * 4u;
+  for (int d = d0; d < d1; ++d) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)st.proj_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst =
+        __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((uint32_t)rows * out_row), 0x00020000);
+    if (staged) {
+      // the previous projection's taps have been consumed (their values fed the stores): refill the slab
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane < 60) {
+#pragma unroll 2
+        for (int r = 0; r < bh; r += 3) {
+          if (r + lrow < bh)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr)(box + r * kBoxW), 16, voff + (org + (uint32_t)r * rstep), 0,
+                                                     0, 0);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (active) {
+#pragma unroll
+        for (int k = 0; k < kLdsTH; ++k) {
+          FetchT f;
+          f.fx = fx[k];
+          f.fy = fy[k];
+          const float* t = (const float*)(boxb + addr[k]);
+          f.a.x = __float_as_uint(t[0]);
+          f.a.y = __float_as_uint(t[1]);
+          f.b.x = __float_as_uint(t[kBoxW]);
+          f.b.y = __float_as_uint(t[kBoxW + 1]);
+          const float v = finish<SAMPLER, true, float>(f);
+          if (k < rows) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+        }
+      }
+    } else if (active) {
+#pragma unroll
+      for (int k = 0; k < kLdsTH; ++k) {
+        FetchT f;
+        f.fx = fx[k];
+        f.fy = fy[k];
+        f.a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, addr[k], 0, 0);
+        f.b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, addr[k], row_bytes, 0);
+        const float v = finish<SAMPLER, true, float>(f);
+        if (k < rows) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+      }
+    }
+    base += st.proj_stride;
+    out += out_step;
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 
 template <int KIND, int NF, int SAMPLER, bool ROUND32, bool PAIR>
@@ -917,11 +1064,42 @@ hipError_t read_lds_stats(unsigned long long* out, bool reset) {
   return hipMemcpyToSymbol(HIP_SYMBOL(g_lds_stats), zero, sizeof(zero));
 }
 
+template <int NF>
+static hipError_t launch_stack_lds(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
+  const dim3 grid((unsigned)((st.W + kLdsTW - 1) / kLdsTW), (unsigned)((st.nrows + kLdsBW * kLdsTH - 1) / (kLdsBW * kLdsTH)),
+                  (unsigned)((st.D + st.d_chunk - 1) / st.d_chunk));
+  const dim3 block(64 * kLdsBW);
+  switch (sampler) {
+    case kScipy: hipLaunchKernelGGL((stack_lds_kernel<NF, kScipy>), grid, block, 0, stream, st, map); break;
+    case kF64Lerp: hipLaunchKernelGGL((stack_lds_kernel<NF, kF64Lerp>), grid, block, 0, stream, st, map); break;
+    default: hipLaunchKernelGGL((stack_lds_kernel<NF, kF32Lerp>), grid, block, 0, stream, st, map); break;
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream) {
   StackArgs st = st_in;
   st.d_chunk = opts.d_chunk < 1 ? 1 : opts.d_chunk;
   if (st.D == 0 || st.nrows == 0) return hipSuccess;
+  // chunks of rows (float32 coordinates): the LDS-staged kernel; a few rows only, or the float64-coordinate
+  // slice path: the direct gather
+  if (opts.lds_gather && opts.stack_lds && round_f32 && (st.nrows >= 8 || opts.stack_lds == 2) && !opts.coef_lds) {
+    // a wave walks its projections one after the other, so the launch needs enough wave tiles to fill the
+    // chip (256 CUs x 20 waves): shorten the depth chunk until it does; with too little work even at 4
+    // projections per wave the finer-grained direct kernel is the faster one (measured on cfg4: 64 rows of
+    // a depth-64 shard 21.8 us direct, 39 us staged; all 2560 rows 876 us direct, 740 us staged)
+    const int64_t tiles = (int64_t)((st.W + kLdsTW - 1) / kLdsTW) * ((st.nrows + kLdsTH - 1) / kLdsTH);
+    int dc = st.d_chunk;
+    auto waves = [&](int c) { return tiles * ((st.D + c - 1) / c); };
+    while (dc > 4 && waves(dc) < 8192 && opts.stack_lds == 1) dc >>= 1;
+    if (waves(dc) >= 4096 || opts.stack_lds == 2) {
+      st.d_chunk = dc;
+      if (map.nfact == 5) return launch_stack_lds<5>(st, map, sampler, stream);
+      if (map.nfact == 4) return launch_stack_lds<4>(st, map, sampler, stream);
+      return launch_stack_lds<-1>(st, map, sampler, stream);
+    }
+  }
   if (!opts.coef_lds) {
     if (map.nfact == 5)
       return round_f32 ? launch_stack_t<5, true>(st, map, sampler, stream)

@@ -58,7 +58,8 @@ const char* dcp_last_error(void);
 /* Tuning knobs (process-wide): "tile_rows" (1..64, rows walked by one workgroup), "xcd_remap"
  * (0..2), "coef_lds" (0/1: force LDS-staged polynomial coefficients), "d_chunk" (projections per
  * thread in the stack kernel), "pipe_depth" (1/2/4), "lds_gather" (0/1), "stack_chunk_kb" (KiB of one
- * projection chunk when a host stack is streamed through the GPU).  Returns DCP_ERR_INVALID_ARG for an
+ * projection chunk when a host stack is streamed through the GPU), "stack_lds" (LDS-staged stack kernel:
+ * 0 never, 1 when the launch has enough wave tiles, 2 always).  Returns DCP_ERR_INVALID_ARG for an
  * unknown key. */
 int dcp_set_option(const char* key, int value);
 int dcp_get_option(const char* key, int* value);

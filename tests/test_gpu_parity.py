@@ -389,6 +389,42 @@ def test_stack_rows_match_oracle(hip, orc):
                           orc.unwarp_slice_backward(np.ascontiguousarray(vol[::2]), *a, 59, **kernel_oracle(orc, "scipy")))
 
 
+def test_lds_staged_stack_kernel_and_its_fallbacks(hip, orc):
+    """stack_lds_kernel (chunks of rows, float32 coordinates) is chosen by launch size; forced here on small stacks:
+    ragged tiles, every polynomial path, all blends, a strong model whose boxes do not fit (direct-gather fallback),
+    odd depth chunks, padded projections."""
+    torch = pytest.importorskip("torch")
+    old = hip.get_option("stack_lds"), hip.get_option("d_chunk")
+    try:
+        for force in (2, 0):
+            hip.set_option("stack_lds", force)
+            for (d, h, w, r0, r1), fact in [((5, 100, 140, 20, 60), [1.0, 2e-3]), ((3, 77, 263, 0, 76), list(configs.COEF_DOT_05)),
+                                            ((4, 90, 130, 10, 17), [1.0, 1e-3, 1e-6, 1e-9, 1e-12, 1e-15]),
+                                            ((2, 200, 300, 50, 150), [0.4, 8e-3]), ((7, 64, 65, 3, 40), [1.0, -2e-3, 3e-5])]:
+                vol = noise(500 + d, (d, h, w))
+                a = (0.53 * w, 0.48 * h, fact)
+                for blend in ("scipy", "f64lerp", "f32"):
+                    want = orc.unwarp_chunk_slices_backward(vol, *a, r0, r1, **kernel_oracle(orc, blend))
+                    for dc in (1, 3, 16):
+                        hip.set_option("d_chunk", dc)
+                        got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *a, r0, r1, blend=blend)
+                        assert np.array_equal(got.cpu().numpy(), want), (force, d, h, w, blend, dc)
+                big = np.zeros((d, h + 4, w + 9), np.float32)
+                big[:, 2:h + 2, 5:w + 5] = vol
+                view = torch.from_numpy(big).cuda()[:, 2:h + 2, 5:w + 5]
+                assert np.array_equal(pp.unwarp_chunk_slices_backward(view, *a, r0, r1).cpu().numpy(),
+                                      orc.unwarp_chunk_slices_backward(vol, *a, r0, r1, **kernel_oracle(orc, "f64lerp")))
+        hip.debug_counters()
+        hip.set_option("stack_lds", 2)
+        vol = noise(9, (2, 200, 300))
+        pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), 150.0, 100.0, [0.4, 8e-3], 50, 150)
+        nofit, vote = hip.debug_counters()
+        assert nofit + vote > 0                      # that model really exercised the fallback
+    finally:
+        hip.set_option("stack_lds", old[0])
+        hip.set_option("d_chunk", old[1])
+
+
 def test_host_stack_sharded_over_devices_of_one_process(hip, orc):
     """dcp_unwarp_stack_rows_multi_f32: depth shards on one worker thread per entry of `devices` (here the one GPU of
     the box, several times) give the same sinograms as one call; ragged and empty shards included."""

@@ -184,9 +184,11 @@ def main():
     counts, t0 = {}, time.time()
     F.debug_counters()
     for k in range(cases):
+        F.set_option("stack_lds", (1, 2, 0)[k % 3])       # stack cases: automatic choice / forced staged kernel / direct
         kind = one_case(rng, k)
         counts[kind] = counts.get(kind, 0) + 1
     nofit, vote = F.debug_counters()
+    F.set_option("stack_lds", 1)
     print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; LDS-kernel fallbacks exercised: %d tiles did not fit, "
           "%d tiles failed the vote" % (cases, seed, time.time() - t0, dict(sorted(counts.items())), nofit, vote))
 
