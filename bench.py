@@ -181,7 +181,7 @@ def stack_main(a, world, rank, dev, dist, backend):
                                                             else "no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "stack_rows_kernel (per GPU, step time includes the all-gather when enabled)"}}),
+                         "kernel": "stack_lds_kernel / stack_rows_kernel by launch size (per GPU, step time includes the all-gather when enabled)"}}),
             flush=True)
 
 
@@ -289,6 +289,43 @@ def main():
         except Exception:
             copy_gbps = None
 
+    batched = None
+    if rank == 0 and n_gpus == 1 and a.order == 1:
+        # context, not the metric: the frames of a step share one calibration, so the whole batch can also go
+        # through ONE launch of the stack entry point (depth = batch, all rows) -- bit-identical output, the
+        # coordinates evaluated once per pixel position instead of once per frame
+        try:
+            nbytes = H * W * 4
+            vsrc, vdst = F.DeviceBuffer(nbytes * a.batch, dev), F.DeviceBuffer(nbytes * a.batch, dev)
+            for i, sbuf in enumerate(srcs):
+                F.check(L.dcp_memcpy(vsrc.ptr + i * nbytes, sbuf.ptr, nbytes, F.COPY_D2D, dev, None))
+
+            def stack_step():
+                F.check(L.dcp_unwarp_stack_rows_f32(vsrc.ptr, vdst.ptr, a.batch, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"],
+                                                    fa, nf, 0.0, H, 1, blend, F.MEM_DEVICE, dev, None))
+            stack_step()
+            b0, b1 = F.Event(dev), F.Event(dev)
+            b0.record()
+            for _ in range(max(4, a.steps // 4)):
+                stack_step()
+            b1.record()
+            b1.synchronize()
+            per_frame_us = b0.elapsed_ms(b1) * 1e3 / (max(4, a.steps // 4) * a.batch)
+            chk = np.empty((H, W), np.float32)
+            F.check(L.dcp_memcpy(chk.ctypes.data, vdst.ptr + (a.batch - 1) * nbytes, nbytes, F.COPY_D2H, dev, None))
+            ref = np.empty((H, W), np.float32)
+            F.check(L.dcp_unwarp_image_f32(srcs[a.batch - 1].ptr, dsts[a.batch - 1].ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"],
+                                           fa, nf, a.order, 1, blend, F.MEM_DEVICE, dev, None))
+            F.check(L.dcp_memcpy(ref.ctypes.data, dsts[a.batch - 1].ptr, nbytes, F.COPY_D2H, dev, None))
+            batched = {"what": "the %d frames of a step in one dcp_unwarp_stack_rows_f32 launch (same calibration)" % a.batch,
+                       "Mpixels_per_s": round(H * W / per_frame_us, 1), "us_per_frame": round(per_frame_us, 3),
+                       "frac_of_hbm_peak": round(configs.BYTES_PER_PIXEL * H * W / (per_frame_us * 1e-6) / 1e9 / configs.HBM_PEAK_GBPS, 4),
+                       "identical_to_per_frame_launches": bool(np.array_equal(chk, ref))}
+            vsrc.free()
+            vdst.free()
+        except Exception as e:      # noqa: BLE001 -- context only, never fails the bench
+            batched = {"error": repr(e)}
+
     if rank == 0:
         launches = a.steps * a.batch
         pix_per_launch = H * W
@@ -319,6 +356,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch),
                          "d2d_copy_same_frames_GBps": copy_gbps},
         }
+        if batched is not None:
+            out["batched_same_calibration"] = batched
         if n_gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, img0, blend, a.cpu_threads)
         print(json.dumps(out), flush=True)
