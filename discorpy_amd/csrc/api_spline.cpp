@@ -16,6 +16,8 @@ namespace {
 // Per-device float64 coefficient workspace (grow-only).  Reused across calls; a call on a stream
 // other than the previous one first waits for the device so that the old user is done.
 struct SplineWorkspace {
+  std::mutex use;          // held by run_spline from get() until its last kernel is enqueued (host callers: until the
+                           // result is back), so two host threads never interleave their passes over the shared planes
   std::mutex mu;
   void* buf[64] = {};
   size_t cap[64] = {};
@@ -105,6 +107,7 @@ int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, i
       a.zpow[axis][p] = std::pow(a.poles[p], a.filter_kind == dcp::kSplMirror ? n - 1.0 : n);
   }
   const size_t plane = (size_t)a.Hp * (size_t)a.Wp * sizeof(double);
+  std::lock_guard<std::mutex> exclusive(g_spline_ws.use);
   DCP_HIP(g_spline_ws.get(2 * plane, st, &a.coef));
   a.scratch = a.coef + (size_t)a.Hp * (size_t)a.Wp;
   dcp::CoordArgs ca;

@@ -688,6 +688,7 @@ def test_calls_from_several_python_threads(hip, orc):
     imgs = [noise(200 + k, (300 + 7 * k, 400 - 5 * k)) for k in range(6)]
     a = [(150.0 + k, 120.0 - k, [1.0, 1e-3 * (k + 1) / 6, 2e-6]) for k in range(6)]
     want = [orc.unwarp_image_backward(im, *p, **kernel_oracle(orc, "f64lerp")) for im, p in zip(imgs, a)]
+    want3 = [pp.unwarp_image_backward(im, *p, order=3, mode="mirror") for im, p in zip(imgs, a)]   # one shared spline workspace
     vol = noise(300, (5, 120, 160))
     want_c = orc.unwarp_chunk_slices_backward(vol, 80.0, 60.0, [1.0, 2e-3], 30, 60, **kernel_oracle(orc, "f64lerp"))
     errors = []
@@ -697,6 +698,7 @@ def test_calls_from_several_python_threads(hip, orc):
             for _ in range(8):
                 assert np.array_equal(pp.unwarp_image_backward(imgs[k], *a[k]), want[k])
                 assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, 80.0, 60.0, [1.0, 2e-3], 30, 60), want_c)
+                assert np.array_equal(pp.unwarp_image_backward(imgs[k], *a[k], order=3, mode="mirror"), want3[k])
                 with pytest.raises(ValueError, match="nfact"):
                     hip.check(hip.lib().dcp_unwarp_image_f32(imgs[k].ctypes.data, imgs[k].ctypes.data, 4, 4, 4, 1, 0.0, 0.0,
                                                              hip.fact_array([1.0])[0], 99, 1, 1, 1, hip.MEM_HOST, -1, None))
