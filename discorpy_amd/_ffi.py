@@ -58,6 +58,8 @@ SIGNATURES = {
     "dcp_unwarp_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int, _int,
                                            _int, _vp]),
     "dcp_perspective_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),
+    "dcp_unwarp_fused_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dp, _int, _int, _int,
+                                           _int, _vp]),
     "dcp_remap_coords_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _i64, _int, _int, _int,
                                            _int, _vp]),
     "dcp_unwarp_image_typed": (_int, [_vp, _vp, _int, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int, _int,

@@ -173,6 +173,19 @@ int dcp_perspective_image_spline_f32(const float* src, float* dst, int64_t heigh
                     boundary_mode, mem_kind, device, stream);
 }
 
+int dcp_unwarp_fused_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                                int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                                int nfact, const double* list_coef, int order, int boundary_mode, int mem_kind, int device,
+                                void* stream) {
+  int rc;
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, list_coef)) != DCP_OK) return rc;
+  if (height > 0 && width > 0) map.fast_div = homography_is_tame(list_coef, height, width);
+  return run_spline(3, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0,
+                    order, boundary_mode, mem_kind, device, stream);
+}
+
 int dcp_remap_coords_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
                                 int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
                                 int64_t npts, int order, int boundary_mode, int mem_kind, int device, void* stream) {

@@ -280,7 +280,7 @@ __device__ __forceinline__ int spline_fold(int i, int n, int mode) {
   return i < n ? i : s2 - i;
 }
 
-// MAPKIND 0 radial, 1 perspective, 2 explicit coordinates (dst[i] for point i)
+// MAPKIND 0 radial, 1 perspective, 2 explicit coordinates (dst[i] for point i), 3 fused perspective -> radial
 template <int MAPKIND, int ORDER>
 __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArgs a, const MapArgs map, const CoordArgs ca,
                                                                 void* dst) {
@@ -302,7 +302,7 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
     const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
     const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
     double xd, yd;
-    pixel_coord<MAPKIND == 0 ? kRadial : kPersp>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
+    pixel_coord<MAPKIND == 0 ? kRadial : MAPKIND == 1 ? kPersp : kFused>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
     xc = (double)round_clip_f32(xd, wmaxf);
     yc = (double)round_clip_f32(yd, hmaxf);
   }
@@ -379,6 +379,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
   if (total == 0) return hipSuccess;
   if (map_kind == 0) return launch_remap_order<0>(a, map, ca, dst, total, stream);
   if (map_kind == 1) return launch_remap_order<1>(a, map, ca, dst, total, stream);
+  if (map_kind == 3) return launch_remap_order<3>(a, map, ca, dst, total, stream);
   return launch_remap_order<2>(a, map, ca, dst, total, stream);
 }
 

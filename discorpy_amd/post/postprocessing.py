@@ -476,9 +476,6 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
         raise ValueError("!!! Eight coefficients are required !!!")
     (height, width) = mat.shape
     order = _check_order_mode(order, mode)
-    if order > 1:
-        raise NotImplementedError("the fused one-pass remap is implemented for orders 0 and 1 "
-                                  "(use remap_coordinates with generate_fused_map for a spline order)")
     bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
@@ -487,8 +484,13 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_unwarp_fused_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
-                                               float(xcenter), float(ycenter), fa, nf, ca, order, 0, img.mem,
-                                               img.device, img.stream))
+                                               float(xcenter), float(ycenter), fa, nf, ca, order, _MODES.index(mode),
+                                               img.mem, img.device, img.stream))
+        return out
+    if order >= 2:
+        F.check(F.lib().dcp_unwarp_fused_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
+                                                    float(xcenter), float(ycenter), fa, nf, ca, order, _MODES.index(mode),
+                                                    img.mem, img.device, img.stream))
         return out
     F.check(F.lib().dcp_unwarp_fused_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
                                          float(xcenter), float(ycenter), fa, nf, ca, order, bcode,

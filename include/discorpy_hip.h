@@ -142,14 +142,18 @@ int dcp_perspective_image_spline_f32(const float* src, float* dst, int64_t heigh
 int dcp_remap_coords_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
                                 int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
                                 int64_t npts, int order, int boundary_mode, int mem_kind, int device, void* stream);
+/* the one-pass perspective -> radial map of dcp_unwarp_fused_f32 at a spline order */
+int dcp_unwarp_fused_spline_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                                int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact,
+                                int nfact, const double* list_coef, int order, int boundary_mode, int mem_kind, int device,
+                                void* stream);
 
 /* ---- element types other than float32 ----
  * The reference hands `mat` to scipy.ndimage.map_coordinates whatever its dtype
  * (discorpy/post/postprocessing.py:147, 227, 251, 491): every element is read as a double, the blend
  * runs in double in scipy's operation order, and the result is converted to the INPUT's type -- a C
  * cast for floats; for integers round-half-away-from-zero and saturation.  The *_typed entry points
- * do that for `dtype` = DCP_DTYPE_*, orders 0..5 (`boundary_mode` matters for orders >= 2 only, the
- * fused map takes orders 0 / 1); `src` and `dst` hold elements of `dtype`, strides in elements.
+ * do that for `dtype` = DCP_DTYPE_*, orders 0..5 (`boundary_mode` matters for orders >= 2 only); `src` and `dst` hold elements of `dtype`, strides in elements.
  * DCP_DTYPE_F32 is accepted too (exact scipy blend; the *_f32 entry points are the fast path).
  * dcp_unwarp_stack_rows_typed: out_float32 = 1 stores float32 values of the result already converted
  * to `dtype`, as unwarp_slice_backward assigns into its float32 sinogram (:224-227). */

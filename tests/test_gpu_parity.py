@@ -201,6 +201,23 @@ def test_g11_perspective_order3_as_demo_07(hip, orc):
                           pp.correct_perspective_image(img, coef, order=3))
 
 
+def test_fused_map_at_spline_orders(hip, orc):
+    """The one-pass perspective -> radial remap at orders 2..5: equal to sampling the image at the fused coordinate
+    planes (which another test holds bit-equal to the reference's numpy planes), float32 and uint16."""
+    a = (61.0, 47.0, [1.0, 2e-3, -1e-6])
+    coef = [0.97, 0.02, 1.5, -0.01, 0.98, 0.8, 1e-4, -2e-4]
+    for img in (noise(33, (90, 120)), typed_image("uint16", (90, 120), 34)):
+        py, px = pp.generate_fused_map(img.shape, *a, coef)
+        for order, mode in ((2, "reflect"), (3, "mirror"), (3, "nearest"), (5, "grid-wrap")):
+            got = pp.unwarp_perspective_fused(img, *a, coef, order=order, mode=mode)
+            want = orc.map_coordinates(img, py, px, order, mode)
+            assert got.dtype == img.dtype
+            if img.dtype == np.float32:
+                assert spline_close(got, want), (order, mode)
+            else:
+                assert np.abs(got.astype(np.int64) - want.astype(np.int64)).max() <= 1, (order, mode)
+
+
 def test_spline_orders_on_ragged_and_large_inputs(hip, orc):
     for shape in [(2, 2), (3, 17), (40, 1), (129, 300)]:
         img = (noise(shape[1], shape) * 100).astype(np.float32)

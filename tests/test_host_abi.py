@@ -114,8 +114,6 @@ def test_unsupported_inputs_fail_loudly_instead_of_falling_back():
     img = np.zeros((4, 4), np.float32)
     with pytest.raises(RuntimeError, match="spline order not supported"):
         pp.unwarp_image_backward(img, 1, 1, [1.0], order=6)
-    with pytest.raises(NotImplementedError, match="fused one-pass"):
-        pp.unwarp_perspective_fused(img, 1, 1, [1.0], [1, 0, 0, 0, 1, 0, 0, 0], order=3)
     for dt in (np.int64, np.uint64, np.float16, np.bool_, np.complex64):
         with pytest.raises(NotImplementedError, match="element type"):
             pp.unwarp_image_backward(img.astype(dt), 1, 1, [1.0])
