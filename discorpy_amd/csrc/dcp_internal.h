@@ -130,6 +130,8 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
 hipError_t launch_typed_image(int map_kind, const TypedImageArgs& img, const MapArgs& map, const CoordArgs& ca,
                               hipStream_t stream);
 hipError_t launch_typed_stack(const TypedStackArgs& st, const MapArgs& map, hipStream_t stream);
+// n points (y, x) -> centre + B(r) (p - centre), float64
+hipError_t launch_map_points(const double* yx_in, double* yx_out, int64_t n, const MapArgs& map, hipStream_t stream);
 // interleaved (H, W, C) image, radial map, orders 0 / 1; src_cstride = elements between pixels
 hipError_t launch_typed_channels(const TypedImageArgs& img, const MapArgs& map, int channels, hipStream_t stream);
 

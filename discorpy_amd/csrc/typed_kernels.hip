@@ -152,6 +152,32 @@ __global__ void __launch_bounds__(kTypedBlock) typed_stack_kernel(const TypedSta
   }
 }
 
+// Closed-form radial mapping of a list of points (unwarp_line_forward, discorpy/post/postprocessing.py:36-64;
+// find_point_to_point, discorpy/util/utility.py:192-230): out = centre + B(r) (p - centre), float64 throughout,
+// B evaluated as the reference's sum a_i r^i accumulated left to right (powers by repeated multiplication).
+__global__ void __launch_bounds__(kTypedBlock) map_points_kernel(const double* __restrict__ yx_in, double* __restrict__ yx_out,
+                                                                int64_t n, const MapArgs map) {
+  const int64_t i = (int64_t)blockIdx.x * kTypedBlock + threadIdx.x;
+  if (i >= n) return;
+  const double y = yx_in[2 * i], x = yx_in[2 * i + 1];
+  const double xd = x - map.xc, yd = y - map.yc;
+  const double rd = sqrt_rn(xd * xd + yd * yd);
+  double factor = 0.0, p = 1.0;
+  for (int k = 0; k < map.nfact; ++k) {
+    factor += map.fact[k] * p;
+    p *= rd;
+  }
+  yx_out[2 * i] = map.yc + factor * yd;
+  yx_out[2 * i + 1] = map.xc + factor * xd;
+}
+
+hipError_t launch_map_points(const double* yx_in, double* yx_out, int64_t n, const MapArgs& map, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(map_points_kernel, dim3((unsigned)((n + kTypedBlock - 1) / kTypedBlock)), dim3(kTypedBlock), 0, stream,
+                     yx_in, yx_out, n, map);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ launchers
 
 template <typename T>

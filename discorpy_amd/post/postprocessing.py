@@ -44,7 +44,7 @@ import numpy as np
 from .. import _ffi as F
 from .. import _pool
 
-__all__ = ["unwarp_image_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
+__all__ = ["unwarp_line_forward", "unwarp_image_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
            "correct_perspective_image", "unwarp_perspective_fused", "remap_coordinates",
            "generate_radial_map", "generate_fused_map"]
 
@@ -174,6 +174,46 @@ def _coefs(values, what):
 
 
 # --------------------------------------------------------------------------- public functions
+
+def unwarp_line_forward(list_lines, xcenter, ycenter, list_fact):
+    """
+    Unwarp lines of dot-centroids using a forward model (reference ``postprocessing.py:36-64``).
+
+    Parameters
+    ----------
+    list_lines : list of 2D arrays
+        (y, x) coordinates of the dot-centroids of each line.
+    xcenter, ycenter : float
+        Center of distortion.
+    list_fact : list of floats
+        Polynomial coefficients of the forward model.
+
+    Returns
+    -------
+    list of 2D arrays
+        The unwarped (y, x) coordinates, line by line.  All points of all lines go through one launch
+        (``dcp_map_points_f64``).
+    """
+    lines = [np.asarray(line) for line in list_lines]
+    fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
+    sizes = [len(line) for line in lines]
+    if sum(sizes) == 0:
+        return [np.zeros_like(line) for line in lines]
+    pts = np.ascontiguousarray(np.concatenate([line[:, :2].reshape(-1, 2) for line in lines if len(line)]), dtype=np.float64)
+    out = np.empty_like(pts)
+    F.require_device()
+    F.check(F.lib().dcp_map_points_f64(pts.ctypes.data, out.ctypes.data, pts.shape[0], float(xcenter), float(ycenter), fa, nf,
+                                       F.MEM_HOST, int(os.environ.get("DISCORPY_AMD_DEVICE", "-1")), None))
+    res, pos = [], 0
+    for line, n in zip(lines, sizes):
+        uline = np.zeros_like(line)                  # the reference keeps the input's dtype (np.zeros_like)
+        if n:
+            uline[:, 0] = out[pos:pos + n, 0]
+            uline[:, 1] = out[pos:pos + n, 1]
+        pos += n
+        res.append(uline)
+    return res
+
 
 def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *, blend=None, out=None):
     """

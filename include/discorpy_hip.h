@@ -222,6 +222,13 @@ int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t wid
                            double ycenter, const double* list_fact, int nfact, const double* list_coef, int mem_kind,
                            int device, void* stream);
 
+/* discorpy/post/postprocessing.py:36-64 (unwarp_line_forward) and discorpy/util/utility.py:192-230
+ * (find_point_to_point): the radial model applied to npts points given as (y, x) pairs of doubles,
+ * out = centre + B(r) * (p - centre) with B(r) = sum_i list_fact[i] * r^i.  Float64; agrees with the
+ * reference's numpy/libm evaluation to a few units in the last place. */
+int dcp_map_points_f64(const double* yx_in, double* yx_out, int64_t npts, double xcenter, double ycenter,
+                       const double* list_fact, int nfact, int mem_kind, int device, void* stream);
+
 /* Diagnostics of the LDS-staged gather on the current device: out[0] = wave tiles whose source
  * box did not fit the LDS slab, out[1] = wave tiles whose containment vote failed (both fall back
  * to the direct gather).  Synchronises the device. */

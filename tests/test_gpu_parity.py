@@ -201,6 +201,18 @@ def test_g11_perspective_order3_as_demo_07(hip, orc):
                           pp.correct_perspective_image(img, coef, order=3))
 
 
+def test_g13_unwarp_line_forward(hip):
+    """Closed-form point mapping on the GPU (dcp_map_points_f64) against the reference's numpy/libm evaluation."""
+    g = golden("g13_lines_forward")
+    lines = [np.array(line) for line in g["lines"]]
+    out = pp.unwarp_line_forward(lines, float(g["xcenter"]), float(g["ycenter"]), g["list_fact"])
+    assert len(out) == 8 and all(o.shape == (12, 2) and o.dtype == np.float64 for o in out)
+    assert np.allclose(np.asarray(out), g["out"], rtol=1e-13, atol=1e-10)
+    assert pp.unwarp_line_forward([], 1.0, 2.0, [1.0]) == []
+    ints = pp.unwarp_line_forward([np.array([[10, 20], [30, 40]])], 25.0, 25.0, [1.0, 1e-3])   # integer lines stay integer
+    assert ints[0].dtype.kind == "i"
+
+
 def test_fused_map_at_spline_orders(hip, orc):
     """The one-pass perspective -> radial remap at orders 2..5: equal to sampling the image at the fused coordinate
     planes (which another test holds bit-equal to the reference's numpy planes), float32 and uint16."""

@@ -255,4 +255,11 @@ for k, dt in enumerate(("uint8", "int8", "uint16", "int16", "uint32", "int32", "
     assert g12["radial_o1_" + dt].dtype == np.dtype(dt) and g12["chunk_" + dt].dtype == np.dtype(dt)
     assert g12["slice_" + dt].dtype == np.float32
 save("g12_dtypes40x52", **g12)
+# ---- G13: unwarp_line_forward (postprocessing.py:36-64) on eight jittered dot lines of the 800 x 1280 pattern
+rng13 = np.random.default_rng(5)
+lines13 = [np.column_stack([np.full(12, 40.0 * k) + rng13.uniform(-2, 2, 12), np.linspace(5, 1270, 12) + rng13.uniform(-1, 1, 12)])
+           for k in range(1, 9)]
+fact13 = np.asarray([1.0, -2.9e-5, 8.9e-8, -1.5e-10, 8.0e-14])
+save("g13_lines_forward", lines=np.asarray(lines13), xcenter=f64(588.69), ycenter=f64(462.09), list_fact=fact13,
+     out=np.asarray(post.unwarp_line_forward(lines13, 588.69, 462.09, fact13)))
 print("done")
