@@ -555,6 +555,26 @@ def test_out_of_core_stack_reads_only_the_row_band(hip, orc, dt, monkeypatch, tm
         assert rc == hip.ERR_INVALID_ARG and "band holds" in hip.last_error()
 
 
+def test_out_of_core_full_stack_correction(hip, orc, tmp_path, monkeypatch):
+    """losa.stream.correct_stack: a stack on disk in, the corrected stack on disk out, pass by pass."""
+    from discorpy_amd.losa import stream
+    vol = typed_image("uint16", (7, 120, 200), 44)
+    a = (96.0, 57.0, [1.0, 1.2e-3, 2e-6])
+    np.save(tmp_path / "in.npy", vol)
+    src = LazyStack(np.load(tmp_path / "in.npy", mmap_mode="r"))
+    dst = np.lib.format.open_memmap(tmp_path / "out.npy", mode="w+", dtype=vol.dtype, shape=vol.shape)
+    monkeypatch.setenv("DISCORPY_AMD_READ_CHUNK_MB", "0.05")
+    assert stream.correct_stack(src, dst, *a, rows_per_pass=32) == 4
+    dst.flush()
+    got = np.load(tmp_path / "out.npy")
+    want = np.stack([orc.unwarp_image_backward(vol[d], *a, poly=orc.POLY_KERNEL) for d in range(7)])
+    assert got.dtype == vol.dtype and np.array_equal(got, want)          # corrected stack == every projection unwarped
+    part = np.zeros((7, 30, 200), vol.dtype)
+    assert stream.correct_stack(src, part, *a, row_range=(50, 80)) == 1 and np.array_equal(part, want[:, 50:80])
+    with pytest.raises(ValueError, match="dst must have shape"):
+        stream.correct_stack(src, np.zeros((7, 10, 200), vol.dtype), *a)
+
+
 def test_out_argument_and_recycled_outputs(hip, orc):
     from discorpy_amd import _pool
     img = noise(71, (600, 700))                                   # 1.6 MiB: above the pool's threshold
