@@ -166,6 +166,8 @@ def one_case(rng, k):
         xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
         fact = rand_fact(rng, h, w)[:6]
         got = util.unwarp_color_image_backward(rgb, xc, yc, fact, order=order, pad=pad, pad_mode="edge", **kw)
+        if f32 and blend != "f32":
+            okw["blend"] = BLENDS["scipy"]      # the interleaved kernel always blends in scipy's exact order
         padded = np.pad(rgb, [(pad, pad), (pad, pad), (0, 0)], mode="edge")
         for ch in range(c):
             want = orc.unwarp_image_backward(np.ascontiguousarray(padded[:, :, ch]), xc + pad, yc + pad, fact, order=order, **okw)
