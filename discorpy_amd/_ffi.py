@@ -255,3 +255,37 @@ class Event:
                 self.ptr = None
         except Exception:
             pass
+
+
+class DeviceArray:
+    """Result of a call whose input was a device array that is not a torch tensor (CuPy, Numba, ... -- anything
+    exposing ``__cuda_array_interface__``): owns a device allocation and exposes it through the same interface, so
+    ``cupy.asarray(result)`` / ``torch.as_tensor(result, device="cuda")`` wrap it without a copy."""
+
+    def __init__(self, shape, dtype, device=-1):
+        import numpy as np
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape, dtype=np.int64))
+        self.nbytes = self.size * self.dtype.itemsize
+        self._buf = DeviceBuffer(max(self.nbytes, 4), device)
+
+    @property
+    def ptr(self):
+        return self._buf.ptr
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self._buf.ptr, False), "version": 3,
+                "strides": None}
+
+    def copy_to_host(self):
+        return self._buf.download(self.shape, self.dtype)
+
+    def reshape(self, shape):
+        """A view with another shape (same allocation)."""
+        import numpy as np
+        view = DeviceArray.__new__(DeviceArray)
+        view.shape = tuple(int(s) for s in np.empty(self.shape, np.bool_).reshape(shape).shape)
+        view.dtype, view.size, view.nbytes, view._buf = self.dtype, self.size, self.nbytes, self._buf
+        return view

@@ -18,7 +18,10 @@ Inputs may be
 * ``numpy.ndarray`` (host): the library stages host<->device copies itself and a NumPy array is
   returned -- the plumbing-compatible mode, dominated by PCIe;
 * a ``torch.Tensor`` on a ROCm device: zero-copy, the kernel is enqueued on torch's current
-  stream and a tensor on the same device is returned -- the mode the throughput numbers are for.
+  stream and a tensor on the same device is returned -- the mode the throughput numbers are for;
+* any other device array exposing ``__cuda_array_interface__`` (CuPy, Numba): zero-copy on the current
+  device; the result is a :class:`discorpy_amd._ffi.DeviceArray` exposing the same interface
+  (``cupy.asarray(result)`` wraps it without a copy), or the caller's ``out=``.
 
 What differs from the reference, on purpose:
 
@@ -55,6 +58,11 @@ _MODES = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mir
 
 def _is_torch(a):
     return type(a).__module__.split(".")[0] == "torch" and hasattr(a, "data_ptr")
+
+
+def _is_cai(a):
+    """A device array that is not a torch tensor (CuPy, Numba, ...)."""
+    return hasattr(a, "__cuda_array_interface__") and not _is_torch(a)
 
 
 def _default_blend():
@@ -94,11 +102,35 @@ class _Image:
 
     def __init__(self, a, ndim):
         self.torch = _is_torch(a)
+        self.cai = False
         if self.torch:
             if not a.is_cuda:
                 a = a.detach().cpu().numpy()
                 self.torch = False
-        if self.torch:
+        if not self.torch and _is_cai(a):
+            # __cuda_array_interface__ v2/v3: pointer on the current device, byte strides (None = C order), optional stream
+            cai = a.__cuda_array_interface__
+            dt = np.dtype(cai["typestr"])
+            self.cai = True
+            self.code = _dtype_code(dt)
+            self.dtype = dt
+            self.shape = tuple(int(v) for v in cai["shape"])
+            st = cai.get("strides")
+            if st is None:
+                st, acc = [], dt.itemsize
+                for n in reversed(self.shape):
+                    st.insert(0, acc)
+                    acc *= max(int(n), 1)
+            if any(v % dt.itemsize or v < 0 for v in st):
+                raise ValueError("device array strides must be non-negative multiples of the item size")
+            self.strides = tuple(int(v) // dt.itemsize for v in st)
+            self.ptr = int(cai["data"][0])
+            self.mem = F.MEM_DEVICE
+            self.device = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
+            stream = cai.get("stream")
+            self.stream = None if stream in (None, 1, 2) else int(stream)
+            self.keep = a
+        elif self.torch:
             import torch
             self.code = _dtype_code(a.dtype)
             self.dtype = a.dtype
@@ -145,6 +177,15 @@ class _Image:
             out = torch.empty(shape, dtype=dt, device=self.keep.device)
             return out, out.data_ptr()
         dt = np.dtype(np.float32) if float32 else np.dtype(self.dtype)
+        if self.cai:
+            if out is not None:
+                cai = getattr(out, "__cuda_array_interface__", None)
+                if not (cai and np.dtype(cai["typestr"]) == dt and tuple(cai["shape"]) == tuple(shape)
+                        and cai.get("strides") is None and not cai["data"][1]):
+                    raise ValueError("out must be a writeable C-contiguous %s device array of shape %s" % (dt, tuple(shape)))
+                return out, int(cai["data"][0])
+            out = F.DeviceArray(shape, dt, self.device)
+            return out, out.ptr
         if out is not None:
             if not (isinstance(out, np.ndarray) and out.dtype == dt and out.shape == tuple(shape)
                     and out.flags.c_contiguous and out.flags.writeable):
@@ -160,6 +201,8 @@ class _Image:
         ok = cs >= 1 and rs >= 1 and (h == 1 or rs >= (w - 1) * cs + 1)
         if ok:
             return self
+        if self.cai:
+            raise ValueError("device arrays must have positive, non-overlapping strides")
         if self.torch:
             return _Image(self.keep.contiguous(), 2)
         return _Image(np.ascontiguousarray(self.keep), 2)
@@ -278,8 +321,9 @@ def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=No
         if tuple(out.shape) != (depth, width):
             raise ValueError("out must have shape (depth, width)")
         out = out.reshape((depth, 1, width))
-    return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True,
-                       devices=devices, out=out)[:, 0, :]
+    res = _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True,
+                      devices=devices, out=out)
+    return res.reshape((depth, width)) if isinstance(res, F.DeviceArray) else res[:, 0, :]
 
 
 def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index, stop_index, *, blend=None,
@@ -309,7 +353,7 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
 
 def _is_lazy_stack(a):
     """An h5py-style dataset: has shape / dtype / slicing but is neither a NumPy array nor a tensor."""
-    return (not isinstance(a, np.ndarray) and not _is_torch(a) and hasattr(a, "shape") and hasattr(a, "dtype")
+    return (not isinstance(a, np.ndarray) and not _is_torch(a) and not _is_cai(a) and hasattr(a, "shape") and hasattr(a, "dtype")
             and hasattr(a, "__getitem__") and not isinstance(a, (list, tuple)))
 
 
@@ -370,6 +414,8 @@ def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32,
         return vol.empty((0, nrows, width), out_float32, out=out)[0]
     ps, rs, cs = vol.strides
     if cs != 1 or rs < width or (depth > 1 and ps < (height - 1) * rs + width):
+        if vol.cai:
+            raise ValueError("a device stack must have unit column stride and non-overlapping rows / projections")
         vol = _Image(vol.keep.contiguous() if vol.torch else np.ascontiguousarray(vol.keep), 3)
         ps, rs, cs = vol.strides
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))

@@ -706,6 +706,45 @@ def test_element_types_match_oracle_on_ragged_shapes(hip, orc, dt):
         assert fused.dtype == rgb.dtype and np.array_equal(fused, orc.map_coordinates(rgb[:, :, 0].copy(), py, px, 1))
 
 
+class CudaArrayInterfaceOnly:
+    """What a CuPy / Numba device array looks like to this package: shape, dtype and __cuda_array_interface__."""
+
+    def __init__(self, tensor):
+        self._t = tensor
+        self.__cuda_array_interface__ = tensor.__cuda_array_interface__
+        self.shape = tuple(tensor.shape)
+        self.dtype = np.dtype(self.__cuda_array_interface__["typestr"])
+
+
+def test_cuda_array_interface_inputs(hip, orc):
+    torch = pytest.importorskip("torch")
+    img = noise(81, (150, 210))
+    a = (101.0, 77.0, [1.0, 1.5e-3])
+    want = orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp"))
+    t = torch.from_numpy(img).cuda()
+    res = pp.unwarp_image_backward(CudaArrayInterfaceOnly(t), *a)
+    assert isinstance(res, hip.DeviceArray) and res.shape == img.shape and res.dtype == np.float32
+    torch.cuda.synchronize()
+    assert np.array_equal(res.copy_to_host(), want)
+    assert np.array_equal(torch.as_tensor(res, device="cuda").cpu().numpy(), want)          # wrapped without a copy
+    strided = CudaArrayInterfaceOnly(torch.from_numpy(noise(82, (150, 210, 2))).cuda()[:, :, 1])
+    got = pp.unwarp_image_backward(strided, *a)
+    assert np.array_equal(got.copy_to_host(), orc.unwarp_image_backward(np.ascontiguousarray(strided._t.cpu().numpy()), *a,
+                                                                         **kernel_oracle(orc, "f64lerp")))
+    out = torch.empty((150, 210), dtype=torch.float32, device="cuda")
+    assert pp.unwarp_image_backward(CudaArrayInterfaceOnly(t), *a, out=CudaArrayInterfaceOnly(out)) is not None
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)
+    vol = typed_image("uint16", (4, 90, 120), 83)
+    v = CudaArrayInterfaceOnly(torch.from_numpy(vol).cuda())
+    ch = pp.unwarp_chunk_slices_backward(v, 60.0, 45.0, [1.0, 1e-3], 10, 40)
+    assert ch.dtype == np.uint16 and np.array_equal(ch.copy_to_host(), orc.unwarp_chunk_slices_backward(vol, 60.0, 45.0, [1.0, 1e-3], 10, 40,
+                                                                                                        poly=orc.POLY_KERNEL))
+    sl = pp.unwarp_slice_backward(v, 60.0, 45.0, [1.0, 1e-3], 33)
+    assert sl.shape == (4, 120) and sl.dtype == np.float32
+    assert np.array_equal(sl.copy_to_host(), orc.unwarp_slice_backward(vol, 60.0, 45.0, [1.0, 1e-3], 33, poly=orc.POLY_KERNEL))
+
+
 def test_element_types_on_device_tensors_and_stacks(hip, orc):
     torch = pytest.importorskip("torch")
     a = (70.0, 50.0, [1.0, 2e-3])
