@@ -706,6 +706,26 @@ def test_element_types_match_oracle_on_ragged_shapes(hip, orc, dt):
         assert fused.dtype == rgb.dtype and np.array_equal(fused, orc.map_coordinates(rgb[:, :, 0].copy(), py, px, 1))
 
 
+def test_integration_stub_of_the_docs_runs(hip, orc, monkeypatch):
+    """The ctypes stub INTEGRATION.md shows a discorpy maintainer is executed as written."""
+    import os
+    import re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = re.findall(r"```python\n(.*?)```", text, flags=re.S)
+    stub = next(b for b in blocks if "def unwarp_image(" in b and "dcp_unwarp_image_f32.argtypes" in b)
+    monkeypatch.setenv("DISCORPY_HIP_LIB", hip.LIB_PATH)
+    ns = {}
+    exec(compile(stub, "INTEGRATION.md", "exec"), ns)
+    img = noise(90, (120, 160))
+    a = (75.0, 61.0, [1.0, 2e-3, 1e-6])
+    assert ns["available"](img, 1)
+    got = ns["unwarp_image"](img, *a, 1)
+    assert np.array_equal(got, orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp")))
+    with pytest.raises(ValueError):
+        ns["_check"](ns["lib"]().dcp_unwarp_image_f32(None, None, 4, 4, 4, 1, 0.0, 0.0, None, 0, 1, 1, 1, 0, -1, None))
+
+
 class CudaArrayInterfaceOnly:
     """What a CuPy / Numba device array looks like to this package: shape, dtype and __cuda_array_interface__."""
 
