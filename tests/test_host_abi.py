@@ -1,7 +1,6 @@
 """CPU suite, part 2: the C ABI loads and exports what include/discorpy_hip.h declares; the Python
 front end validates like the reference (same exception types and messages) before touching a GPU.
 No compute call is made here."""
-import ctypes as C
 import os
 import re
 

@@ -1,5 +1,4 @@
 """Quick GPU-side parity + timing probe through the raw C ABI (no torch): run with gpurun."""
-import ctypes as C
 import sys
 import time
 

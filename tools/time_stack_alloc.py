@@ -1,5 +1,5 @@
 """Does the overlap of the streamed stack path depend on how the host arrays were allocated?"""
-import ctypes, mmap, sys, time
+import ctypes, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 from discorpy_amd import _ffi as F, configs

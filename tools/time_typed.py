@@ -1,6 +1,5 @@
 """Device-resident timings of the element-type kernels (typed_kernels.hip) next to the float32 hot path."""
 import sys, time
-import numpy as np
 import torch
 sys.path.insert(0, ".")
 from discorpy_amd import configs
