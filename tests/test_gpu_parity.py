@@ -726,6 +726,23 @@ def test_integration_stub_of_the_docs_runs(hip, orc, monkeypatch):
         ns["_check"](ns["lib"]().dcp_unwarp_image_f32(None, None, 4, 4, 4, 1, 0.0, 0.0, None, 0, 1, 1, 1, 0, -1, None))
 
 
+def test_c_abi_from_plain_c(hip, orc, tmp_path):
+    """tests/c/abi_smoke.c: the boundary used as a C library (gcc, no Python in the loop, no HIP headers) -- host and
+    device pointers, a uint16 stack, error codes -- checked against the oracle inside the C program."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "abi_smoke")
+    libdir, orcdir = os.path.dirname(hip.LIB_PATH), os.path.join(ROOT, "oracle")
+    cmd = ["gcc", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", orcdir, os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+           "-o", exe, "-L", libdir, "-ldiscorpy_hip", "-L", orcdir, "-lunwarp_oracle", "-lm",
+           "-Wl,-rpath," + libdir, "-Wl,-rpath," + orcdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    res = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+    assert res.returncode == 0 and "abi_smoke ok" in res.stdout, (res.returncode, res.stdout, res.stderr)
+
+
 class CudaArrayInterfaceOnly:
     """What a CuPy / Numba device array looks like to this package: shape, dtype and __cuda_array_interface__."""
 
