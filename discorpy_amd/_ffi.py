@@ -42,6 +42,7 @@ SIGNATURES = {
     "dcp_version": (_int, []),
     "dcp_device_count": (_int, []),
     "dcp_last_error": (C.c_char_p, []),
+    "dcp_release_scratch": (_int, []),
     "dcp_set_option": (_int, [C.c_char_p, _int]),
     "dcp_get_option": (_int, [C.c_char_p, C.POINTER(_int)]),
     "dcp_unwarp_image_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int,
@@ -160,6 +161,14 @@ def require_device():
         raise HipError("no HIP device visible: the discorpy_amd unwarp path runs on the GPU only "
                        "(no CPU fallback)")
     return n
+
+
+def release_scratch():
+    """Free the device scratch the library keeps between calls (this thread's staging, the spline planes) and the idle
+    blocks of the host output pool."""
+    from . import _pool
+    _pool.clear()
+    check(lib().dcp_release_scratch())
 
 
 def set_option(key, value):

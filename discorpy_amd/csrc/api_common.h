@@ -116,6 +116,9 @@ int fill_map(dcp::MapArgs* m, double xc, double yc, const double* fact, int nfac
 int homography_is_tame(const double* c, int64_t H, int64_t W);
 void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0, int64_t* b1);
 
+// api_spline.cpp: frees the coefficient planes of every device (waits for the devices first)
+int release_spline_workspace();
+
 // api_spline.cpp: orders 2..5 on any element type; map_kind 0 radial, 1 perspective, 2 explicit coordinates, 3 fused
 int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
                const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,

@@ -243,6 +243,13 @@ int dcp_get_option(const char* key, int* value) {
   return DCP_OK;
 }
 
+int dcp_release_scratch(void) {
+  // the calling thread's staging buffers and streams (DCP_MEM_HOST calls), and the spline planes of every device
+  g_staging.release();
+  g_host_streams.release();
+  return release_spline_workspace();
+}
+
 int dcp_debug_counters(uint64_t* out, int n, int reset) {
   if (!out || n < 2) return fail(DCP_ERR_INVALID_ARG, "need room for 2 counters");
   unsigned long long v[2];

@@ -71,6 +71,23 @@ int spline_poles(int order, double* z) {
 
 namespace dcpapi {
 
+int release_spline_workspace() {
+  std::lock_guard<std::mutex> exclusive(g_spline_ws.use);
+  std::lock_guard<std::mutex> lock(g_spline_ws.mu);
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess) return DCP_OK;      // no runtime / no device: nothing was ever allocated
+  for (int dev = 0; dev < 64; ++dev) {
+    if (!g_spline_ws.buf[dev]) continue;
+    DCP_HIP(hipSetDevice(dev));
+    DCP_HIP(hipDeviceSynchronize());
+    (void)hipFree(g_spline_ws.buf[dev]);
+    g_spline_ws.buf[dev] = nullptr;
+    g_spline_ws.cap[dev] = 0;
+  }
+  (void)hipSetDevice(prev);
+  return DCP_OK;
+}
+
 int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
                const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
                int mode, int mem_kind, int device, void* stream) {

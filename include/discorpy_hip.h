@@ -55,6 +55,11 @@ int dcp_version(void);                 /* major*10000 + minor*100 + patch */
 int dcp_device_count(void);            /* number of HIP devices, 0 if none / no driver */
 const char* dcp_last_error(void);
 
+/* Device scratch the library keeps between calls -- the calling thread's staging buffers and streams for
+ * DCP_MEM_HOST calls (grow-only, otherwise freed when the thread ends) and the per-device float64 planes of the
+ * spline path -- is released; the next call allocates again.  For long-running services. */
+int dcp_release_scratch(void);
+
 /* Tuning knobs (process-wide): "tile_rows" (1..64, rows walked by one workgroup), "xcd_remap"
  * (0..2), "coef_lds" (0/1: force LDS-staged polynomial coefficients), "d_chunk" (projections per
  * thread in the stack kernel), "pipe_depth" (1/2/4), "lds_gather" (0/1), "stack_chunk_kb" (KiB of one

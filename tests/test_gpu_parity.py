@@ -726,6 +726,17 @@ def test_integration_stub_of_the_docs_runs(hip, orc, monkeypatch):
         ns["_check"](ns["lib"]().dcp_unwarp_image_f32(None, None, 4, 4, 4, 1, 0.0, 0.0, None, 0, 1, 1, 1, 0, -1, None))
 
 
+def test_release_scratch_then_work_again(hip, orc):
+    img = noise(95, (300, 400))
+    a = (190.0, 140.0, [1.0, 1e-3])
+    before = pp.unwarp_image_backward(img, *a, order=3)
+    pp.unwarp_chunk_slices_backward(noise(96, (3, 100, 120)), 60.0, 50.0, [1.0, 1e-3], 10, 30)
+    hip.release_scratch()
+    hip.release_scratch()                                  # idempotent
+    assert np.array_equal(pp.unwarp_image_backward(img, *a, order=3), before)
+    assert np.array_equal(pp.unwarp_image_backward(img, *a), orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp")))
+
+
 def test_c_abi_from_plain_c(hip, orc, tmp_path):
     """tests/c/abi_smoke.c: the boundary used as a C library (gcc, no Python in the loop, no HIP headers) -- host and
     device pointers, a uint16 stack, error codes -- checked against the oracle inside the C program."""
