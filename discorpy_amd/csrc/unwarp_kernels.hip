@@ -1092,7 +1092,7 @@ hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler,
     const int64_t tiles = (int64_t)((st.W + kLdsTW - 1) / kLdsTW) * ((st.nrows + kLdsTH - 1) / kLdsTH);
     int dc = st.d_chunk;
     auto waves = [&](int c) { return tiles * ((st.D + c - 1) / c); };
-    while (dc > 4 && waves(dc) < 8192 && opts.stack_lds == 1) dc >>= 1;
+    while (dc > 4 && waves(dc) < 8192 && opts.stack_lds == 1 && (st.D + (dc >> 1) - 1) / (dc >> 1) <= 65535) dc >>= 1;
     if (waves(dc) >= 4096 || opts.stack_lds == 2) {
       st.d_chunk = dc;
       if (map.nfact == 5) return launch_stack_lds<5>(st, map, sampler, stream);
