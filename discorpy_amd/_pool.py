@@ -8,8 +8,10 @@ leased from a pool: the array handed to the caller owns its block like any other
 caller drops the last reference (including views) the block -- with its pages already faulted in --
 goes back to the pool for the next call of the same size.  Nothing is ever reused while reachable.
 
-``DISCORPY_AMD_HOST_POOL_MB`` caps the bytes kept idle (default 1024; 0 disables the pool).
+``DISCORPY_AMD_HOST_POOL_MB`` caps the bytes kept idle (default 1024; 0 disables the pool); beyond the cap the
+blocks that have been idle the longest are dropped.
 """
+import collections
 import os
 import threading
 
@@ -40,7 +42,8 @@ class _Lease:
 class HostPool:
     def __init__(self, cap_bytes):
         self.cap = int(cap_bytes)
-        self.idle = {}            # nbytes -> [uint8 blocks]
+        self.idle = {}            # nbytes -> [uint8 blocks], most recently returned last
+        self.age = collections.deque()   # nbytes of the idle blocks, oldest return first (eviction order)
         self.idle_bytes = 0
         self.lock = threading.Lock()
         self.hits = self.misses = 0
@@ -57,6 +60,7 @@ class HostPool:
             if stack:
                 block = stack.pop()
                 self.idle_bytes -= nbytes
+                self.age.remove(nbytes)
                 self.hits += 1
             else:
                 self.misses += 1
@@ -67,15 +71,22 @@ class HostPool:
     def _give_back(self, block):
         try:
             with self.lock:
-                if self.idle_bytes + block.nbytes <= self.cap:
-                    self.idle.setdefault(block.nbytes, []).append(block)
-                    self.idle_bytes += block.nbytes
+                if block.nbytes > self.cap:
+                    return
+                self.idle.setdefault(block.nbytes, []).append(block)
+                self.age.append(block.nbytes)
+                self.idle_bytes += block.nbytes
+                while self.idle_bytes > self.cap:        # evict the blocks that have been idle the longest
+                    old = self.age.popleft()
+                    self.idle[old].pop(0)
+                    self.idle_bytes -= old
         except Exception:      # interpreter shutdown: let the block go
             pass
 
     def clear(self):
         with self.lock:
             self.idle.clear()
+            self.age.clear()
             self.idle_bytes = 0
 
 

@@ -180,6 +180,13 @@ def test_host_output_pool_recycles_only_unreachable_blocks():
     assert small.flags.owndata
     off = _pool.HostPool(0).empty((512, 1024), np.float32)
     assert off.flags.owndata
+    small_pool = _pool.HostPool(10 << 20)                      # beyond the cap the longest-idle blocks go first
+    blocks = [small_pool.empty((1 << 20,), np.float32) for _ in range(4)]
+    addrs = [b_.ctypes.data for b_ in blocks]
+    del blocks, b_
+    assert small_pool.idle_bytes == 8 << 20 and len(small_pool.age) == 2
+    again = small_pool.empty((1 << 20,), np.float32)
+    assert again.ctypes.data in addrs[2:]
     del b, c, d
     _pool.clear()
     assert _pool.stats()["idle_bytes"] == 0
