@@ -182,8 +182,8 @@ def test_host_output_pool_recycles_only_unreachable_blocks():
     assert off.flags.owndata
     small_pool = _pool.HostPool(10 << 20)                      # beyond the cap the longest-idle blocks go first
     blocks = [small_pool.empty((1 << 20,), np.float32) for _ in range(4)]
-    addrs = [b_.ctypes.data for b_ in blocks]
-    del blocks, b_
+    addrs = [blk.ctypes.data for blk in blocks]
+    del blocks
     assert small_pool.idle_bytes == 8 << 20 and len(small_pool.age) == 2
     again = small_pool.empty((1 << 20,), np.float32)
     assert again.ctypes.data in addrs[2:]
