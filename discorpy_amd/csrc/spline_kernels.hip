@@ -284,9 +284,17 @@ __device__ __forceinline__ int spline_fold(int i, int n, int mode) {
 template <int MAPKIND, int ORDER>
 __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArgs a, const MapArgs map, const CoordArgs ca,
                                                                 void* dst) {
-  const int64_t i = (int64_t)blockIdx.x * kSplBlock + threadIdx.x;
-  const int64_t total = MAPKIND == 2 ? ca.npts : (int64_t)a.H * a.W;
-  if (i >= total) return;
+  int64_t i;
+  int x = 0, y = 0;
+  if constexpr (MAPKIND == 2) {
+    i = (int64_t)blockIdx.x * kSplBlock + threadIdx.x;
+    if (i >= ca.npts) return;
+  } else {       // blockIdx.y walks the rows (no 64-bit division)
+    x = blockIdx.x * kSplBlock + (int)threadIdx.x;
+    y = blockIdx.y + blockIdx.z * 65535;
+    if (x >= a.W || y >= a.H) return;
+    i = (int64_t)y * a.W + x;
+  }
   double yc, xc;   // float32-rounded (or caller-supplied) coordinates in the unpadded image
   if constexpr (MAPKIND == 2) {
     if (ca.is_f64) {
@@ -299,7 +307,6 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
     yc = clip_f64(yc, (double)(a.H - 1));
     xc = clip_f64(xc, (double)(a.W - 1));
   } else {
-    const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
     const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
     double xd, yd;
     pixel_coord<MAPKIND == 0 ? kRadial : MAPKIND == 1 ? kPersp : kFused>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
@@ -325,7 +332,9 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
 template <int MAPKIND>
 static hipError_t launch_remap_order(const SplineArgs& a, const MapArgs& map, const CoordArgs& ca, void* dst,
                                      int64_t total, hipStream_t stream) {
-  const dim3 grid((unsigned)((total + kSplBlock - 1) / kSplBlock));
+  const dim3 grid = MAPKIND == 2 ? dim3((unsigned)((total + kSplBlock - 1) / kSplBlock))
+                                 : dim3((unsigned)((a.W + kSplBlock - 1) / kSplBlock), (unsigned)(a.H < 65535 ? a.H : 65535),
+                                        (unsigned)((a.H + 65534) / 65535));
   switch (a.order) {
     case 2: hipLaunchKernelGGL((spline_remap_kernel<MAPKIND, 2>), grid, dim3(kSplBlock), 0, stream, a, map, ca, dst); break;
     case 3: hipLaunchKernelGGL((spline_remap_kernel<MAPKIND, 3>), grid, dim3(kSplBlock), 0, stream, a, map, ca, dst); break;

@@ -54,9 +54,18 @@ __device__ __forceinline__ double sample_typed(const T* __restrict__ src, int64_
 template <typename T, int KIND>
 __global__ void __launch_bounds__(kTypedBlock) typed_image_kernel(const TypedImageArgs a, const MapArgs map,
                                                                  const CoordArgs ca) {
-  const int64_t i = (int64_t)blockIdx.x * kTypedBlock + threadIdx.x;
-  const int64_t total = KIND == 3 ? ca.npts : (int64_t)a.H * a.W;
-  if (i >= total) return;
+  // explicit coordinates: a 1-D launch over the points; maps: blockIdx.y walks the rows (no 64-bit division)
+  int64_t i;
+  int x = 0, y = 0;
+  if constexpr (KIND == 3) {
+    i = (int64_t)blockIdx.x * kTypedBlock + threadIdx.x;
+    if (i >= ca.npts) return;
+  } else {
+    x = blockIdx.x * kTypedBlock + (int)threadIdx.x;
+    y = blockIdx.y + blockIdx.z * 65535;
+    if (x >= a.W || y >= a.H) return;
+    i = (int64_t)y * a.W + x;
+  }
   double yc, xc;
   if constexpr (KIND == 3) {
     if (ca.is_f64) {
@@ -69,7 +78,6 @@ __global__ void __launch_bounds__(kTypedBlock) typed_image_kernel(const TypedIma
     yc = clip_f64(yc, (double)(a.H - 1));
     xc = clip_f64(xc, (double)(a.W - 1));
   } else {
-    const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
     const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
     double xd, yd;
     pixel_coord<KIND>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
@@ -85,9 +93,10 @@ __global__ void __launch_bounds__(kTypedBlock) typed_image_kernel(const TypedIma
 // coordinate evaluation and C blends per pixel, taps of a pixel's C channels contiguous in memory.
 template <typename T>
 __global__ void __launch_bounds__(kTypedBlock) typed_channels_kernel(const TypedImageArgs a, const MapArgs map, int C) {
-  const int64_t i = (int64_t)blockIdx.x * kTypedBlock + threadIdx.x;
-  if (i >= (int64_t)a.H * a.W) return;
-  const int y = (int)(i / a.W), x = (int)(i - (int64_t)y * a.W);
+  const int x = blockIdx.x * kTypedBlock + (int)threadIdx.x;
+  const int y = blockIdx.y + blockIdx.z * 65535;
+  if (x >= a.W || y >= a.H) return;
+  const int64_t i = (int64_t)y * a.W + x;
   const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
   double xd, yd;
   pixel_coord<kRadial>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
@@ -180,12 +189,18 @@ hipError_t launch_map_points(const double* yx_in, double* yx_out, int64_t n, con
 
 // ------------------------------------------------------------------ launchers
 
+// x tiles of 256 pixels, one row per blockIdx.y (65535 per grid.z slice)
+static dim3 image_grid(int H, int W) {
+  return dim3((unsigned)((W + kTypedBlock - 1) / kTypedBlock), (unsigned)(H < 65535 ? H : 65535), (unsigned)((H + 65534) / 65535));
+}
+
 template <typename T>
 static hipError_t launch_image_t(int map_kind, const TypedImageArgs& a, const MapArgs& map, const CoordArgs& ca,
                                  hipStream_t stream) {
   const int64_t total = map_kind == 3 ? ca.npts : (int64_t)a.H * a.W;
   if (total == 0) return hipSuccess;
-  const dim3 grid((unsigned)((total + kTypedBlock - 1) / kTypedBlock)), block(kTypedBlock);
+  const dim3 block(kTypedBlock);
+  const dim3 grid = map_kind == 3 ? dim3((unsigned)((total + kTypedBlock - 1) / kTypedBlock)) : image_grid(a.H, a.W);
   switch (map_kind) {
     case 0: hipLaunchKernelGGL((typed_image_kernel<T, kRadial>), grid, block, 0, stream, a, map, ca); break;
     case 1: hipLaunchKernelGGL((typed_image_kernel<T, kPersp>), grid, block, 0, stream, a, map, ca); break;
@@ -217,9 +232,7 @@ hipError_t launch_typed_image(int map_kind, const TypedImageArgs& a, const MapAr
 
 template <typename T>
 static hipError_t launch_channels_t(const TypedImageArgs& a, const MapArgs& map, int channels, hipStream_t stream) {
-  const int64_t total = (int64_t)a.H * a.W;
-  hipLaunchKernelGGL((typed_channels_kernel<T>), dim3((unsigned)((total + kTypedBlock - 1) / kTypedBlock)), dim3(kTypedBlock), 0,
-                     stream, a, map, channels);
+  hipLaunchKernelGGL((typed_channels_kernel<T>), image_grid(a.H, a.W), dim3(kTypedBlock), 0, stream, a, map, channels);
   return hipGetLastError();
 }
 
