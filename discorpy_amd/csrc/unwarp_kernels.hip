@@ -484,7 +484,11 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
   // All rows are in flight at once and complete underneath phase 1b.  (The slab is filled to its
   // full 80-float pitch: up to 12 columns more than the box needs, from cache lines the
   // neighbouring tile fetches anyway.)
+#ifdef DCP_EXPERIMENT_NO_FILL
+  if (false) {
+#else
   if (fits) {
+#endif
     // 16 bytes per lane: 20 lanes cover one slab row (pitch 80 floats), so one instruction fills
     // three consecutive box rows (lanes 0-59) and the LDS image stays lane-linear as LDS-DMA needs
     const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
@@ -550,8 +554,10 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
                       ymn >= (float)by0 && (ymx < (float)by1 || (!unclipped && by1 == img.H - 1));
   const bool staged = fits && __builtin_amdgcn_ballot_w64(!inside) == 0;
   if (!staged && lane == 0) atomicAdd(&g_lds_stats[fits ? 1 : 0], 1ull);
+#ifndef DCP_EXPERIMENT_NO_FILL_WAIT      // timing experiment only (results are then garbage)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#endif
 
   // one descriptor for the rows of the tile that exist; the row offset goes through the scalar
   // offset (not bounds-checked, hence the explicit row and column predicates)
