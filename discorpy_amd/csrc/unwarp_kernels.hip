@@ -595,7 +595,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
         f.b.x = __float_as_uint(t[kBoxW]);
         f.b.y = __float_as_uint(t[kBoxW + 1]);
         const float v = finish<SAMPLER, true, float>(f);
-#ifdef DCP_EXPERIMENT_NO_STORE     // timing experiment only: the value is computed, the store (practically) never happens
+#if defined(DCP_EXPERIMENT_NO_STORE)     // timing experiment only: the value is computed, the store (practically) never happens
         if (__float_as_uint(v) == 0x7fc12345u)
 #else
         if (decltype(full)::value || k < rows)
