@@ -34,8 +34,11 @@ BLEND_NAMES = {"scipy": F.BLEND_SCIPY, "f64lerp": F.BLEND_F64LERP, "f32lerp": F.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="back-to-back launches for this long before the warm-up steps: the core clock needs ~100 ms under "
+                         "load to reach its sustained level (tools/time_ramp.py); 0 disables")
     ap.add_argument("--batch", type=int, default=24, help="distinct frames per step (ring size)")
     ap.add_argument("--blend", default="f64lerp", choices=sorted(BLEND_NAMES))
     ap.add_argument("--order", type=int, default=1)
@@ -246,6 +249,11 @@ def main():
             import torch
             torch.cuda.synchronize()
 
+    if a.settle_ms > 0:            # let the clocks reach their sustained level before anything is counted
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:
+            step()
+            sync()
     for _ in range(a.warmup):
         step()
     sync()
@@ -347,7 +355,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 coordinates / f32 pixels",
             "data": "synthetic (numpy default_rng uniform [0,1) float32 frames, device-resident)",
             "config": {"workload": cfg["name"], "frames_per_step_per_gpu": a.batch, "height": H, "width": W,
-                       "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True,
+                       "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True, "clock_settle_ms": a.settle_ms,
                        "parallelism": "independent frames per GPU (no collective)" if n_gpus > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
