@@ -83,6 +83,8 @@ SIGNATURES = {
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
     "dcp_free": (_int, [_vp, _int]),
     "dcp_memcpy": (_int, [_vp, _vp, _sz, _int, _int, _vp]),
+    "dcp_stream_create": (_int, [C.POINTER(_vp), _int]),
+    "dcp_stream_destroy": (_int, [_vp]),
     "dcp_stream_synchronize": (_int, [_int, _vp]),
     "dcp_event_create": (_int, [C.POINTER(_vp), _int]),
     "dcp_event_record": (_int, [_vp, _vp]),
@@ -263,6 +265,27 @@ class Event:
                 lib().dcp_event_destroy(self.ptr)
                 self.ptr = None
         except Exception:
+            pass
+
+
+class Stream:
+    """A non-blocking HIP stream owned by Python (dcp_stream_create / dcp_stream_destroy)."""
+
+    def __init__(self, device=-1):
+        self.device = device
+        p = C.c_void_p()
+        check(lib().dcp_stream_create(C.byref(p), device))
+        self.ptr = p.value
+
+    def synchronize(self):
+        check(lib().dcp_stream_synchronize(self.device, self.ptr))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().dcp_stream_destroy(self.ptr)
+                self.ptr = None
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
             pass
 
 

@@ -290,6 +290,21 @@ int dcp_memcpy(void* dst, const void* src, size_t bytes, int kind, int device, v
   return DCP_OK;
 }
 
+int dcp_stream_create(void** stream, int device) {
+  if (!stream) return fail(DCP_ERR_INVALID_ARG, "null out pointer");
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipStream_t s;
+  DCP_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (void*)s;
+  return DCP_OK;
+}
+
+int dcp_stream_destroy(void* stream) {
+  if (stream) DCP_HIP(hipStreamDestroy((hipStream_t)stream));
+  return DCP_OK;
+}
+
 int dcp_stream_synchronize(int device, void* stream) {
   DeviceScope scope(device);
   if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));

@@ -246,6 +246,8 @@ int dcp_free(void* ptr, int device);
 #define DCP_COPY_D2H 1
 #define DCP_COPY_D2D 2
 int dcp_memcpy(void* dst, const void* src, size_t bytes, int kind, int device, void* stream);
+int dcp_stream_create(void** stream, int device);   /* a non-blocking stream for DCP_MEM_DEVICE calls */
+int dcp_stream_destroy(void* stream);
 int dcp_stream_synchronize(int device, void* stream);
 int dcp_event_create(void** event, int device);
 int dcp_event_record(void* event, void* stream);
