@@ -7,6 +7,7 @@ Shapes from 1 x 1 to ~1500 x 1500, centres inside and far outside the image, pol
 folding maps (which exercise the LDS kernel's "box does not fit" / "vote failed" fallbacks), strong homographies,
 strided sources, every blend mode, stacks, explicit coordinates, element types, spline orders and boundary modes.
 """
+import os
 import sys
 import time
 
@@ -24,6 +25,8 @@ DTYPES = ["float32"] * 6 + ["float64", "uint8", "int8", "uint16", "int16", "uint
 
 def rand_shape(rng):
     kind = rng.integers(0, 10)
+    if os.environ.get("FUZZ_BIG") and kind >= 7:     # FUZZ_BIG=1: a third of the cases are 1500 .. 6000 pixels on a side
+        return int(rng.integers(1500, 6000)), int(rng.integers(1500, 6000))
     if kind == 0:
         return int(rng.integers(1, 4)), int(rng.integers(1, 80))
     if kind == 1:
