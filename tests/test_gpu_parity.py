@@ -575,6 +575,31 @@ def test_out_of_core_full_stack_correction(hip, orc, tmp_path, monkeypatch):
         stream.correct_stack(src, np.zeros((7, 10, 200), vol.dtype), *a)
 
 
+def test_host_frames_go_through_in_bands(hip, orc):
+    """A large NumPy frame (radial map, order 1) is processed in bands of rows with uploads and downloads overlapped;
+    the result must equal the one-shot path and the device-resident path, also when a band's source rows lie far away."""
+    torch = pytest.importorskip("torch")
+    old = hip.get_option("host_duplex")
+    try:
+        for k, (shape, a) in enumerate([((2100, 2048), (1000.0, 1100.0, list(configs.COEF_DOT_05))),
+                                        ((2304, 1900), (-300.0, 2500.0, [1.0, 1e-4])),          # centre outside the frame
+                                        ((2200, 2000), (900.0, 1000.0, [0.3, 9e-4])),           # strong: bands reach far rows
+                                        ((2200, 2000), (900.0, 1000.0, [-1.0, 0.0]))]):         # point reflection: rows reversed
+            img = noise(600 + k, shape)
+            padded = np.zeros((shape[0], shape[1] + 37), np.float32)
+            padded[:, :shape[1]] = img
+            dev = {b: pp.unwarp_image_backward(torch.from_numpy(img).cuda(), *a, blend=b).cpu().numpy() for b in ("f64lerp", "scipy")}
+            for mode in (2, 1, 0):       # forced banded path, probe-gated, one-shot
+                hip.set_option("host_duplex", mode)
+                assert np.array_equal(pp.unwarp_image_backward(img, *a), dev["f64lerp"]), (shape, mode)
+                assert np.array_equal(pp.unwarp_image_backward(img, *a, blend="scipy"), dev["scipy"]), (shape, mode)
+                assert np.array_equal(pp.unwarp_image_backward(padded[:, :shape[1]], *a), dev["f64lerp"]), (shape, mode)
+            if k == 0:
+                assert np.array_equal(dev["f64lerp"], orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp")))
+    finally:
+        hip.set_option("host_duplex", old)
+
+
 def test_out_argument_and_recycled_outputs(hip, orc):
     from discorpy_amd import _pool
     img = noise(71, (600, 700))                                   # 1.6 MiB: above the pool's threshold
