@@ -75,9 +75,13 @@ bool runtime_overlaps_directions() {
 // a chunk of rows of a one-projection stack, bit-identical to the image kernels) as soon as its source rows have
 // arrived, a second thread copies finished bands back.  With a runtime that overlaps the two directions (ROCm 7.2's)
 // a 4096 x 4096 frame takes ~1.5 ms instead of 2.45 ms; with one that serialises them it costs the same as before.
-int run_radial_host_banded(const float* src, float* dst, int64_t H, int64_t W, int64_t rs, const dcp::MapArgs& map,
-                           int sampler, const dcp::LaunchOpts& opts) {
-  const size_t frame = (size_t)H * (size_t)W * sizeof(float);
+// `pix` = bytes per pixel (all channels), `rs_bytes` = host row stride in bytes, launch_band(dsrc, dband, r0, n, stream)
+// enqueues the kernel for output rows [r0, r0 + n) reading the whole-frame device copy `dsrc`.
+template <typename LaunchBand>
+int run_radial_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix, size_t rs_bytes,
+                           const dcp::MapArgs& map, LaunchBand&& launch_band) {
+  const size_t row_bytes = (size_t)W * pix;
+  const size_t frame = (size_t)H * row_bytes;
   void *dsrc = nullptr, *ddst = nullptr;
   DCP_HIP(g_staging.get(0, frame, &dsrc));
   DCP_HIP(g_staging.get(1, frame, &ddst));
@@ -104,7 +108,7 @@ int run_radial_host_banded(const float* src, float* dst, int64_t H, int64_t W, i
         if (abort_down) break;
       }
       const int64_t r0 = k * rows_per, n = (r0 + rows_per > H ? H - r0 : rows_per);
-      e = hipMemcpyAsync(dst + (size_t)r0 * (size_t)W, (const float*)ddst + (size_t)r0 * (size_t)W, (size_t)n * (size_t)W * 4,
+      e = hipMemcpyAsync((char*)dst + (size_t)r0 * row_bytes, (const char*)ddst + (size_t)r0 * row_bytes, (size_t)n * row_bytes,
                          hipMemcpyDeviceToHost, s_down);
       if (e == hipSuccess) e = hipStreamSynchronize(s_down);
     }
@@ -121,25 +125,13 @@ int run_radial_host_banded(const float* src, float* dst, int64_t H, int64_t W, i
     // (for the last band everything is uploaded whatever the hull says)
     const int64_t need = (k == nb - 1) ? H : b1;
     if (need > uploaded) {
-      up_err = hipMemcpy2DAsync((char*)dsrc + (size_t)uploaded * (size_t)W * 4, (size_t)W * 4, src + uploaded * rs, (size_t)rs * 4,
-                                (size_t)W * 4, (size_t)(need - uploaded), hipMemcpyHostToDevice, s_up);
+      up_err = hipMemcpy2DAsync((char*)dsrc + (size_t)uploaded * row_bytes, row_bytes, (const char*)src + (size_t)uploaded * rs_bytes,
+                                rs_bytes, row_bytes, (size_t)(need - uploaded), hipMemcpyHostToDevice, s_up);
       uploaded = need;
       if (up_err != hipSuccess) break;
     }
     if (b0 < 0 || b1 > uploaded) { up_err = hipErrorInvalidValue; break; }   // cannot happen: need >= b1
-    dcp::StackArgs st;
-    memset(&st, 0, sizeof(st));
-    st.D = 1;
-    st.H = (int32_t)H;
-    st.W = (int32_t)W;
-    st.row_start = (double)r0;
-    st.nrows = (int32_t)n;
-    st.vol = (const float*)dsrc;
-    st.out = (float*)ddst + (size_t)r0 * (size_t)W;
-    st.proj_stride = H * W;
-    st.row_stride = (int32_t)W;
-    st.proj_bytes = (uint32_t)frame;
-    up_err = dcp::launch_stack(st, map, sampler, true, opts, s_up);
+    up_err = launch_band(dsrc, (char*)ddst + (size_t)r0 * row_bytes, r0, n, s_up);
     if (up_err == hipSuccess) up_err = hipStreamSynchronize(s_up);
     if (up_err != hipSuccess) break;
     {
@@ -182,7 +174,23 @@ int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_
   if (kind == dcp::kRadial && sampler != dcp::kNearest && round_f32 && cs == 1 && H >= 512 && W >= 2 && g_host_duplex.load() &&
       (double)H * (double)W * 4.0 >= 16.0 * 1048576.0 && (double)H * (double)W * 4.0 <= 4294967040.0 &&
       (g_host_duplex.load() == 2 || runtime_overlaps_directions()))
-    return run_radial_host_banded(src, dst, H, W, rs, map, sampler, opts);
+    return run_radial_host_banded(src, dst, H, W, sizeof(float), (size_t)rs * sizeof(float), map,
+                                  [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {
+                                    // a band of image rows = a chunk of rows of a one-projection stack
+                                    dcp::StackArgs st;
+                                    memset(&st, 0, sizeof(st));
+                                    st.D = 1;
+                                    st.H = (int32_t)H;
+                                    st.W = (int32_t)W;
+                                    st.row_start = (double)r0;
+                                    st.nrows = (int32_t)n;
+                                    st.vol = (const float*)dsrc;
+                                    st.out = (float*)dband;
+                                    st.proj_stride = H * W;
+                                    st.row_stride = (int32_t)W;
+                                    st.proj_bytes = (uint32_t)((size_t)H * (size_t)W * 4);
+                                    return dcp::launch_stack(st, map, sampler, true, opts, s);
+                                  });
   // host memory: pack rows densely on the way in, run on the stream, copy back, synchronise
   hipStream_t st = (hipStream_t)stream;
   void *dsrc = nullptr, *ddst = nullptr;
@@ -465,6 +473,8 @@ int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t hei
   a.src_cstride = src_pixel_stride;
   a.order = order;
   a.dtype = dtype;
+  a.y0 = 0;
+  a.rows = (int32_t)height;
   if (mem_kind == DCP_MEM_DEVICE) {
     a.src = src;
     a.dst = dst;
@@ -473,6 +483,21 @@ int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t hei
   }
   if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
   const size_t esz = (size_t)dcp::elem_size(dtype);
+  if (src_pixel_stride == channels && height >= 512 && (double)height * (double)width * (double)channels * (double)esz >= 16.0 * 1048576.0 &&
+      g_host_duplex.load() && (g_host_duplex.load() == 2 || runtime_overlaps_directions())) {
+    // dense interleaved frame: bands of rows, uploads and downloads overlapped (see run_radial_host_banded)
+    return run_radial_host_banded(src, dst, height, width, (size_t)channels * esz, (size_t)src_row_stride * esz, map,
+                                  [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {
+                                    dcp::TypedImageArgs b = a;
+                                    b.src = dsrc;
+                                    b.dst = dband;
+                                    b.src_stride = width * channels;
+                                    b.src_cstride = channels;
+                                    b.y0 = (int32_t)r0;
+                                    b.rows = (int32_t)n;
+                                    return dcp::launch_typed_channels(b, map, channels, s);
+                                  });
+  }
   const size_t ext = (size_t)((height - 1) * src_row_stride + (width - 1) * src_pixel_stride + channels) * esz;
   const size_t obytes = (size_t)height * (size_t)width * (size_t)channels * esz;
   void *dsrc, *ddst;

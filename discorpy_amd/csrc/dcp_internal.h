@@ -77,6 +77,7 @@ struct TypedImageArgs {
   int32_t H, W;
   int32_t order;           // 0 or 1
   int32_t dtype;
+  int32_t y0, rows;        // interleaved-channel kernel only: output rows [y0, y0 + rows), dst = first row of that band
 };
 
 struct TypedStackArgs {

@@ -94,9 +94,10 @@ __global__ void __launch_bounds__(kTypedBlock) typed_image_kernel(const TypedIma
 template <typename T>
 __global__ void __launch_bounds__(kTypedBlock) typed_channels_kernel(const TypedImageArgs a, const MapArgs map, int C) {
   const int x = blockIdx.x * kTypedBlock + (int)threadIdx.x;
-  const int y = blockIdx.y + blockIdx.z * 65535;
-  if (x >= a.W || y >= a.H) return;
-  const int64_t i = (int64_t)y * a.W + x;
+  const int yl = blockIdx.y + blockIdx.z * 65535;          // row inside the band [y0, y0 + rows)
+  if (x >= a.W || yl >= a.rows) return;
+  const int y = a.y0 + yl;
+  const int64_t i = (int64_t)yl * a.W + x;
   const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
   double xd, yd;
   pixel_coord<kRadial>(map, (double)x, (double)y, wmaxf, hmaxf, &xd, &yd);
@@ -232,7 +233,7 @@ hipError_t launch_typed_image(int map_kind, const TypedImageArgs& a, const MapAr
 
 template <typename T>
 static hipError_t launch_channels_t(const TypedImageArgs& a, const MapArgs& map, int channels, hipStream_t stream) {
-  hipLaunchKernelGGL((typed_channels_kernel<T>), image_grid(a.H, a.W), dim3(kTypedBlock), 0, stream, a, map, channels);
+  hipLaunchKernelGGL((typed_channels_kernel<T>), image_grid(a.rows, a.W), dim3(kTypedBlock), 0, stream, a, map, channels);
   return hipGetLastError();
 }
 

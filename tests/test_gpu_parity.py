@@ -596,6 +596,17 @@ def test_host_frames_go_through_in_bands(hip, orc):
                 assert np.array_equal(pp.unwarp_image_backward(padded[:, :shape[1]], *a), dev["f64lerp"]), (shape, mode)
             if k == 0:
                 assert np.array_equal(dev["f64lerp"], orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp")))
+        # interleaved colour frames take the same banded route (util.unwarp_color_image_backward)
+        from discorpy_amd.util import utility as util
+        rgb = typed_image("uint8", (2400, 2400, 3), 640)
+        a = (1150.0, 1260.0, [1.0, 3e-5, 2e-8])
+        got = {}
+        for mode in (2, 0):
+            hip.set_option("host_duplex", mode)
+            got[mode] = util.unwarp_color_image_backward(rgb, *a)
+        assert np.array_equal(got[2], got[0])
+        yd, xd = orc.radial_coords(2400, 2400, *a, poly=orc.POLY_KERNEL)
+        assert np.array_equal(got[2][:, :, 1], orc.map_coordinates(np.ascontiguousarray(rgb[:, :, 1]), yd, xd, 1))
     finally:
         hip.set_option("host_duplex", old)
 
