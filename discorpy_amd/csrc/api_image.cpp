@@ -411,6 +411,12 @@ int dcp_unwarp_image_typed(const void* src, void* dst, int dtype, int64_t height
                            int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact, int nfact,
                            int order, int boundary_mode, int mem_kind, int device, void* stream) {
   int rc;
+  // a large dense host frame, orders 0 / 1: the one-channel case of the interleaved entry point, whose host path moves
+  // the frame in bands of rows with uploads and downloads overlapped (same arithmetic: scipy's exact blend)
+  if (mem_kind == DCP_MEM_HOST && order >= 0 && order <= 1 && boundary_mode >= 0 && boundary_mode <= 7 && src_col_stride == 1 && height >= 512 && dtype >= 0 &&
+      dtype < dcp::kNumElemTypes && (double)height * (double)width * (double)dcp::elem_size(dtype) >= 16.0 * 1048576.0)
+    return dcp_unwarp_image_channels(src, dst, dtype, height, width, 1, src_row_stride, 1, xcenter, ycenter, list_fact, nfact,
+                                     order, mem_kind, device, stream);
   dcp::MapArgs map;
   if ((rc = fill_map(&map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
   return run_typed(0, src, dst, dtype, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,

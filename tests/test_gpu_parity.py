@@ -607,6 +607,16 @@ def test_host_frames_go_through_in_bands(hip, orc):
         assert np.array_equal(got[2], got[0])
         yd, xd = orc.radial_coords(2400, 2400, *a, poly=orc.POLY_KERNEL)
         assert np.array_equal(got[2][:, :, 1], orc.map_coordinates(np.ascontiguousarray(rgb[:, :, 1]), yd, xd, 1))
+        # ... and so do large single-channel frames of the other element types
+        u16 = typed_image("uint16", (3000, 3000), 641)
+        for order in (1, 0):
+            res = {}
+            for mode in (2, 0):
+                hip.set_option("host_duplex", mode)
+                res[mode] = pp.unwarp_image_backward(u16, 1400.0, 1600.0, [1.0, 2e-5], order=order)
+            assert res[2].dtype == np.uint16 and np.array_equal(res[2], res[0])
+            assert np.array_equal(res[2], pp.unwarp_image_backward(torch.from_numpy(u16).cuda(), 1400.0, 1600.0, [1.0, 2e-5],
+                                                                   order=order).cpu().numpy())
     finally:
         hip.set_option("host_duplex", old)
 
