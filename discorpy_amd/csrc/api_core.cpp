@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -223,6 +223,9 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "host_duplex")) {
     if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "host_duplex must be 0, 1 or 2");
     g_host_duplex = value;
+  } else if (!strcmp(key, "host_bands")) {
+    if (value < 1 || value > 256) return fail(DCP_ERR_INVALID_ARG, "host_bands must be in [1, 256]");
+    g_host_bands = value;
   } else if (!strcmp(key, "stack_chunk_kb")) {
     if (value < 1) return fail(DCP_ERR_INVALID_ARG, "stack_chunk_kb must be >= 1");
     g_stack_chunk_kb = value;
@@ -243,6 +246,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "stack_chunk_kb")) *value = g_stack_chunk_kb;
   else if (!strcmp(key, "stack_lds")) *value = g_stack_lds;
   else if (!strcmp(key, "host_duplex")) *value = g_host_duplex;
+  else if (!strcmp(key, "host_bands")) *value = g_host_bands;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }

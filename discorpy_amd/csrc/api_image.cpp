@@ -89,7 +89,7 @@ int run_radial_host_banded(const void* src, void* dst, int64_t H, int64_t W, siz
   DCP_HIP(g_host_streams.get(&s_up, &s_down));
   int cur_dev = 0;
   DCP_HIP(hipGetDevice(&cur_dev));
-  const int64_t nbands = 8;
+  const int64_t nbands = g_host_bands.load();
   int64_t rows_per = ((H + nbands - 1) / nbands + 63) / 64 * 64;
   if (rows_per > 65535) rows_per = 65535 / 64 * 64;
   const int64_t nb = (H + rows_per - 1) / rows_per;

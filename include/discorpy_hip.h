@@ -66,7 +66,7 @@ int dcp_release_scratch(void);
  * projection chunk when a host stack is streamed through the GPU), "stack_lds" (LDS-staged stack kernel:
  * 0 never, 1 when the launch has enough wave tiles, 2 always), "host_duplex" (host frames of the radial map
  * go through the GPU in bands of rows, uploads and downloads at the same time: 0 never, 1 when a one-off probe
- * finds that the HIP runtime overlaps the two directions, 2 always).  Returns DCP_ERR_INVALID_ARG for an
+ * finds that the HIP runtime overlaps the two directions, 2 always), "host_bands" (number of those bands, default 6).  Returns DCP_ERR_INVALID_ARG for an
  * unknown key. */
 int dcp_set_option(const char* key, int value);
 int dcp_get_option(const char* key, int* value);
