@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -75,11 +76,12 @@ bool runtime_overlaps_directions() {
 // a chunk of rows of a one-projection stack, bit-identical to the image kernels) as soon as its source rows have
 // arrived, a second thread copies finished bands back.  With a runtime that overlaps the two directions (ROCm 7.2's)
 // a 4096 x 4096 frame takes ~1.5 ms instead of 2.45 ms; with one that serialises them it costs the same as before.
-// `pix` = bytes per pixel (all channels), `rs_bytes` = host row stride in bytes, launch_band(dsrc, dband, r0, n, stream)
-// enqueues the kernel for output rows [r0, r0 + n) reading the whole-frame device copy `dsrc`.
-template <typename LaunchBand>
-int run_radial_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix, size_t rs_bytes,
-                           const dcp::MapArgs& map, LaunchBand&& launch_band) {
+// `pix` = bytes per pixel (all channels), `rs_bytes` = host row stride in bytes, source_rows(r0, n, &b0, &b1) = source rows
+// [b0, b1) that output rows [r0, r0 + n) can reach, launch_band(dsrc, dband, r0, n, stream) enqueues the kernel for
+// those output rows reading the whole-frame device copy `dsrc`.
+template <typename Hull, typename LaunchBand>
+int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix, size_t rs_bytes, Hull&& source_rows,
+                    LaunchBand&& launch_band) {
   const size_t row_bytes = (size_t)W * pix;
   const size_t frame = (size_t)H * row_bytes;
   void *dsrc = nullptr, *ddst = nullptr;
@@ -120,7 +122,7 @@ int run_radial_host_banded(const void* src, void* dst, int64_t H, int64_t W, siz
   for (int64_t k = 0; k < nb && up_err == hipSuccess; ++k) {
     const int64_t r0 = k * rows_per, n = (r0 + rows_per > H ? H - r0 : rows_per);
     int64_t b0 = 0, b1 = H;
-    host_row_band(map, H, W, (double)r0, n, &b0, &b1);
+    source_rows(r0, n, &b0, &b1);
     // the source arrives top to bottom; a band whose rows reach further down simply waits for more of it
     // (for the last band everything is uploaded whatever the hull says)
     const int64_t need = (k == nb - 1) ? H : b1;
@@ -171,10 +173,46 @@ int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_
     return DCP_OK;
   }
   if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  if (kind == dcp::kPersp && map.fast_div && cs == 1 && H >= 512 && W >= 2 && g_host_duplex.load() &&
+      (double)H * (double)W * 4.0 >= 16.0 * 1048576.0 && (double)H * (double)W * 4.0 <= 4294967040.0 &&
+      (g_host_duplex.load() == 2 || runtime_overlaps_directions())) {
+    // homography with a denominator of one sign over the frame ("tame", checked by the caller): yd is monotone along
+    // every segment, so over a band of output rows it takes its extremes at the band's four corners
+    auto band = [&](int64_t r0, int64_t n, int64_t* b0, int64_t* b1) {
+      double lo = 1e300, hi = -1e300;
+      for (double y : {(double)r0, (double)(r0 + n - 1)})
+        for (double x : {0.0, (double)(W - 1)}) {
+          const double den = (map.coef[6] * x + map.coef[7] * y) + 1.0;
+          double yd = ((map.coef[3] * x + map.coef[4] * y) + map.coef[5]) / den;
+          if (!(yd >= 0.0)) yd = 0.0;
+          if (yd > (double)(H - 1)) yd = (double)(H - 1);
+          lo = std::min(lo, yd);
+          hi = std::max(hi, yd);
+        }
+      *b0 = std::max<int64_t>(0, (int64_t)std::floor(lo) - 1);
+      *b1 = std::min<int64_t>(H, (int64_t)std::floor(hi) + 3);
+    };
+    return run_host_banded(src, dst, H, W, sizeof(float), (size_t)rs * sizeof(float), band,
+                           [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {
+                             dcp::ImageArgs b;
+                             memset(&b, 0, sizeof(b));
+                             b.H = (int32_t)H;
+                             b.W = (int32_t)W;
+                             b.src = (const float*)dsrc;
+                             b.dst = (float*)dband;
+                             b.src_stride = (int32_t)W;
+                             b.src_col_stride = 1;
+                             b.src_bytes = (uint32_t)((size_t)H * (size_t)W * 4);
+                             b.y_origin = (int32_t)r0;
+                             b.rows_out = (int32_t)n;
+                             return dcp::launch_image(kind, b, map, sampler, round_f32, opts, s);
+                           });
+  }
   if (kind == dcp::kRadial && sampler != dcp::kNearest && round_f32 && cs == 1 && H >= 512 && W >= 2 && g_host_duplex.load() &&
       (double)H * (double)W * 4.0 >= 16.0 * 1048576.0 && (double)H * (double)W * 4.0 <= 4294967040.0 &&
       (g_host_duplex.load() == 2 || runtime_overlaps_directions()))
-    return run_radial_host_banded(src, dst, H, W, sizeof(float), (size_t)rs * sizeof(float), map,
+    return run_host_banded(src, dst, H, W, sizeof(float), (size_t)rs * sizeof(float),
+                                  [&](int64_t r0, int64_t n, int64_t* b0, int64_t* b1) { host_row_band(map, H, W, (double)r0, n, b0, b1); },
                                   [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {
                                     // a band of image rows = a chunk of rows of a one-projection stack
                                     dcp::StackArgs st;
@@ -491,8 +529,9 @@ int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t hei
   const size_t esz = (size_t)dcp::elem_size(dtype);
   if (src_pixel_stride == channels && height >= 512 && (double)height * (double)width * (double)channels * (double)esz >= 16.0 * 1048576.0 &&
       g_host_duplex.load() && (g_host_duplex.load() == 2 || runtime_overlaps_directions())) {
-    // dense interleaved frame: bands of rows, uploads and downloads overlapped (see run_radial_host_banded)
-    return run_radial_host_banded(src, dst, height, width, (size_t)channels * esz, (size_t)src_row_stride * esz, map,
+    // dense interleaved frame: bands of rows, uploads and downloads overlapped (see run_host_banded)
+    return run_host_banded(src, dst, height, width, (size_t)channels * esz, (size_t)src_row_stride * esz,
+                                  [&](int64_t r0, int64_t n, int64_t* b0, int64_t* b1) { host_row_band(map, height, width, (double)r0, n, b0, b1); },
                                   [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {
                                     dcp::TypedImageArgs b = a;
                                     b.src = dsrc;

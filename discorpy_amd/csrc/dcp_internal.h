@@ -29,6 +29,8 @@ struct ImageArgs {
   int32_t xcd_remap;       // 1: contiguous band of tiles per XCD
   int32_t pipe_depth;      // rows of gathers in flight per thread (1, 2 or 4)
   int32_t lds_gather;      // 1: stage the source box of each wave tile in LDS (remap_lds_kernel)
+  int32_t y_origin;        // a launch may cover only output rows [y_origin, y_origin + rows_out) of the H x W map;
+  int32_t rows_out;        // dst then points at row y_origin (0 / 0 = the whole image)
 };
 
 struct MapArgs {

@@ -304,12 +304,12 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
   logical_tile(img.xcd_remap, img.tiles_x, &tx, &ty);
   const int y0 = ty * img.tile_rows;
   const int x = tx * kBlock + (int)threadIdx.x;
-  const int rows = min(img.tile_rows, img.H - y0);
+  const int rows = min(img.tile_rows, img.rows_out - y0);     // y0: row inside the launch's band of output rows
 
   // per-row invariants -> LDS.  PD rows past the tile are filled too: the pipeline below runs
   // ahead by PD rows and simply discards what it computed for them.
   if ((int)threadIdx.x < img.tile_rows + PD)
-    fill_row<KIND, 4>(map, s_row, threadIdx.x, (double)(y0 + (int)threadIdx.x));
+    fill_row<KIND, 4>(map, s_row, threadIdx.x, (double)(img.y_origin + y0 + (int)threadIdx.x));
   if constexpr (NF < 0 && KIND != kPersp) {
     if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
   }
@@ -426,13 +426,14 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
   const int x = tx * kLdsTW + lane;
 
   if ((int)threadIdx.x < kLdsBW * kLdsTH)
-    fill_row<KIND, (KIND == kRadial ? 2 : 4)>(map, s_row, threadIdx.x, (double)min(yblk + (int)threadIdx.x, img.H - 1));
+    fill_row<KIND, (KIND == kRadial ? 2 : 4)>(map, s_row, threadIdx.x,
+                                              (double)(img.y_origin + min(yblk + (int)threadIdx.x, img.rows_out - 1)));
   if constexpr (NF < 0 && KIND != kPersp) {
     if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
   }
   __syncthreads();
-  if (y0 >= img.H) return;                        // whole wave past the image (wave-uniform)
-  const int rows = min(kLdsTH, img.H - y0);
+  if (y0 >= img.rows_out) return;                 // whole wave past the band of output rows (wave-uniform)
+  const int rows = min(kLdsTH, img.rows_out - y0);
 
   const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
   const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
@@ -909,7 +910,7 @@ template <int KIND, int NF, int SAMPLER>
 static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {
   ImageArgs img = img_in;
   img.tiles_x = (img.W + kLdsTW - 1) / kLdsTW;
-  img.tiles_y = (img.H + kLdsBW * kLdsTH - 1) / (kLdsBW * kLdsTH);
+  img.tiles_y = (img.rows_out + kLdsBW * kLdsTH - 1) / (kLdsBW * kLdsTH);
   dim3 grid(img.tiles_x * img.tiles_y);
   if (img.xcd_remap == 2) grid = dim3(8 * ((img.tiles_x + 7) / 8), img.tiles_y);   // see the kernel's tile order
   hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER>), grid, dim3(64 * kLdsBW), 0, stream, img, map);
@@ -953,8 +954,12 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
   if (tr < 1) tr = 1;
   if (tr > kMaxTileRows) tr = kMaxTileRows;
   img.tile_rows = tr;
+  if (img.rows_out <= 0) {          // the whole image
+    img.y_origin = 0;
+    img.rows_out = img.H;
+  }
   img.tiles_x = (img.W + kBlock - 1) / kBlock;
-  img.tiles_y = (img.H + tr - 1) / tr;
+  img.tiles_y = (img.rows_out + tr - 1) / tr;
   img.xcd_remap = opts.xcd_remap;
   img.pipe_depth = opts.pipe_depth;
   img.lds_gather = opts.lds_gather;

@@ -596,6 +596,16 @@ def test_host_frames_go_through_in_bands(hip, orc):
                 assert np.array_equal(pp.unwarp_image_backward(padded[:, :shape[1]], *a), dev["f64lerp"]), (shape, mode)
             if k == 0:
                 assert np.array_equal(dev["f64lerp"], orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp")))
+        # perspective frames: the band's source rows come from its four corners
+        img = noise(650, (2300, 2000))
+        for coef in ([0.95, -0.02, 40.0, 0.03, 0.9, -25.0, 2e-5, -1e-5], [1.0, 0.0, 0.0, 0.0, -1.0, 2299.0, 0.0, 0.0],   # mild; rows flipped
+                     [0.7, 0.4, -300.0, -0.4, 0.7, 900.0, 1e-4, 8e-5]):                                                    # rotated, strong
+            devp = {o: pp.correct_perspective_image(torch.from_numpy(img).cuda(), coef, order=o).cpu().numpy() for o in (1, 0)}
+            for mode in (2, 0):
+                hip.set_option("host_duplex", mode)
+                for o in (1, 0):
+                    assert np.array_equal(pp.correct_perspective_image(img, coef, order=o), devp[o]), (coef, mode, o)
+            assert np.array_equal(devp[1], orc.correct_perspective_image(img, coef, blend=orc.BLEND_F64LERP))
         # interleaved colour frames take the same banded route (util.unwarp_color_image_backward)
         from discorpy_amd.util import utility as util
         rgb = typed_image("uint8", (2400, 2400, 3), 640)
