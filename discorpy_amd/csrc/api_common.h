@@ -115,6 +115,8 @@ size_t extent_bytes_typed(int64_t H, int64_t W, int64_t rs, int64_t cs, int dtyp
 int fill_map(dcp::MapArgs* m, double xc, double yc, const double* fact, int nfact, const double* coef);
 int homography_is_tame(const double* c, int64_t H, int64_t W);
 void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0, int64_t* b1);
+void host_row_band_rect(const dcp::MapArgs& m, int64_t H, double x_lo, double x_hi, double y_lo, double y_hi, int64_t* b0,
+                        int64_t* b1);
 
 // api_spline.cpp: frees the coefficient planes of every device (waits for the devices first)
 int release_spline_workspace();

@@ -114,6 +114,13 @@ uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs) {
 // then grown by a safety row on each side.  A non-finite model gets the whole projection.
 void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0,
                    int64_t* b1) {
+  host_row_band_rect(m, H, 0.0, (double)(W - 1), row_start, row_start + (double)(nrows - 1), b0, b1);
+}
+
+// The same for the radial map evaluated at any position of the rectangle [x_lo, x_hi] x [y_lo, y_hi] (the fused map
+// evaluates it at perspective-corrected positions rather than on the pixel grid).
+void host_row_band_rect(const dcp::MapArgs& m, int64_t H, double x_lo, double x_hi, double y_lo, double y_hi, int64_t* b0,
+                        int64_t* b1) {
   *b0 = 0;
   *b1 = H;
   const int n = m.nfact, ne = (n + 1) / 2, no = n / 2;
@@ -127,11 +134,11 @@ void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start
     for (int k = no - 2; k >= 0; --k) O = O * r2 + m.fact[2 * k + 1];
     return ru * O + E;
   };
-  const double yu0 = row_start - m.yc, yu1 = (row_start + (double)(nrows - 1)) - m.yc;
+  const double yu0 = y_lo - m.yc, yu1 = y_hi - m.yc;
   const double ya = std::fmin(std::fabs(yu0), std::fabs(yu1));
   const double ay_min = (yu0 <= 0.0 && yu1 >= 0.0) ? 0.0 : ya;                    // smallest |yu| over the rows
   const double ay_max = std::fmax(std::fabs(yu0), std::fabs(yu1));
-  const double xl = 0.0 - m.xc, xr = (double)(W - 1) - m.xc;
+  const double xl = x_lo - m.xc, xr = x_hi - m.xc;
   const double ax_min = (xl <= 0.0 && xr >= 0.0) ? 0.0 : std::fmin(std::fabs(xl), std::fabs(xr));
   const double ax_max = std::fmax(std::fabs(xl), std::fabs(xr));
   const double rlo = std::sqrt(ax_min * ax_min + ay_min * ay_min), rhi = std::sqrt(ax_max * ax_max + ay_max * ay_max);

@@ -173,24 +173,35 @@ int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_
     return DCP_OK;
   }
   if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
-  if (kind == dcp::kPersp && map.fast_div && cs == 1 && H >= 512 && W >= 2 && g_host_duplex.load() &&
+  if ((kind == dcp::kPersp || kind == dcp::kFused) && map.fast_div && cs == 1 && H >= 512 && W >= 2 && g_host_duplex.load() &&
       (double)H * (double)W * 4.0 >= 16.0 * 1048576.0 && (double)H * (double)W * 4.0 <= 4294967040.0 &&
       (g_host_duplex.load() == 2 || runtime_overlaps_directions())) {
     // homography with a denominator of one sign over the frame ("tame", checked by the caller): yd is monotone along
     // every segment, so over a band of output rows it takes its extremes at the band's four corners
+    // (the same holds for xd; the fused map then evaluates the radial model inside that clipped rectangle of positions)
     auto band = [&](int64_t r0, int64_t n, int64_t* b0, int64_t* b1) {
-      double lo = 1e300, hi = -1e300;
+      double ylo = 1e300, yhi = -1e300, xlo = 1e300, xhi = -1e300;
       for (double y : {(double)r0, (double)(r0 + n - 1)})
         for (double x : {0.0, (double)(W - 1)}) {
           const double den = (map.coef[6] * x + map.coef[7] * y) + 1.0;
           double yd = ((map.coef[3] * x + map.coef[4] * y) + map.coef[5]) / den;
+          double xd = ((map.coef[0] * x + map.coef[1] * y) + map.coef[2]) / den;
           if (!(yd >= 0.0)) yd = 0.0;
           if (yd > (double)(H - 1)) yd = (double)(H - 1);
-          lo = std::min(lo, yd);
-          hi = std::max(hi, yd);
+          if (!(xd >= 0.0)) xd = 0.0;
+          if (xd > (double)(W - 1)) xd = (double)(W - 1);
+          ylo = std::min(ylo, yd);
+          yhi = std::max(yhi, yd);
+          xlo = std::min(xlo, xd);
+          xhi = std::max(xhi, xd);
         }
-      *b0 = std::max<int64_t>(0, (int64_t)std::floor(lo) - 1);
-      *b1 = std::min<int64_t>(H, (int64_t)std::floor(hi) + 3);
+      if (kind == dcp::kFused) {
+        // float32 rounding of the perspective position moves it by < 1e-3 px: widen the rectangle a little
+        host_row_band_rect(map, H, xlo - 0.01, xhi + 0.01, ylo - 0.01, yhi + 0.01, b0, b1);
+        return;
+      }
+      *b0 = std::max<int64_t>(0, (int64_t)std::floor(ylo) - 1);
+      *b1 = std::min<int64_t>(H, (int64_t)std::floor(yhi) + 3);
     };
     return run_host_banded(src, dst, H, W, sizeof(float), (size_t)rs * sizeof(float), band,
                            [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {

@@ -606,6 +606,12 @@ def test_host_frames_go_through_in_bands(hip, orc):
                 for o in (1, 0):
                     assert np.array_equal(pp.correct_perspective_image(img, coef, order=o), devp[o]), (coef, mode, o)
             assert np.array_equal(devp[1], orc.correct_perspective_image(img, coef, blend=orc.BLEND_F64LERP))
+            # the fused perspective -> radial map: the radial model over the band's rectangle of perspective positions
+            for fact in ([1.0, 2e-5, -3e-9], [0.5, 6e-4]):
+                devf = pp.unwarp_perspective_fused(torch.from_numpy(img).cuda(), 1020.0, 1130.0, fact, coef).cpu().numpy()
+                for mode in (2, 0):
+                    hip.set_option("host_duplex", mode)
+                    assert np.array_equal(pp.unwarp_perspective_fused(img, 1020.0, 1130.0, fact, coef), devf), (coef, fact, mode)
         # interleaved colour frames take the same banded route (util.unwarp_color_image_backward)
         from discorpy_amd.util import utility as util
         rgb = typed_image("uint8", (2400, 2400, 3), 640)
