@@ -176,7 +176,7 @@ def stack_main(a, world, rank, dev, dist, backend):
             "metric": "Mpixels/s unwarp of a (depth, 2560, 2560) stack, rows of every projection (+ all-gather)",
             "value": round(vox / wall / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64 coordinates / f32 pixels",
+            "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (uniform [0,1) float32 projections, device-resident)",
             "config": {"workload": cfg["name"], "depth": D, "rows": nrows, "width": W, "depth_per_gpu": dl,
                        "all_gather": bool(gather), "blend": a.blend,
@@ -382,10 +382,11 @@ def main():
             "metric": "Mpixels/s backward unwarp (4096x4096, 5-term poly, bilinear)",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64 coordinates / f32 pixels",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (numpy default_rng uniform [0,1) float32 frames, device-resident)",
             "config": {"workload": cfg["name"], "frames_per_step_per_gpu": a.batch, "height": H, "width": W,
-                       "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True, "clock_settle_ms": a.settle_ms,
+                       "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True, "pixel_dtype": "f32",
+                       "arithmetic": "coordinates and blend in float64 (as numpy / scipy compute them), pixels float32", "clock_settle_ms": a.settle_ms,
                        "parallelism": "independent frames per GPU (no collective)" if n_gpus > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
