@@ -576,7 +576,13 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
       for (int k = 0; k < kLdsTH; ++k) {
         FetchT f;
         int xi, yi;
-        if constexpr (decltype(inner)::value) {
+        if constexpr (SAMPLER == kNearest) {
+          // order 0: index = floor(c + 0.5); it is one of the two bilinear tap indices, so it lies inside the box
+          xi = (int)xf[k];
+          yi = (int)yf[k];
+          xi += (xf[k] - (float)xi >= 0.5f) ? 1 : 0;
+          yi += (yf[k] - (float)yi >= 0.5f) ? 1 : 0;
+        } else if constexpr (decltype(inner)::value) {
           xi = (int)xf[k];
           yi = (int)yf[k];
           f.fx = __builtin_amdgcn_fractf(xf[k]);      // x - floor(x), exact
@@ -591,11 +597,16 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
         asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kBoxW * 4), "v"(xa));
         const float* t = (const float*)(boxb + addr);
-        f.a.x = __float_as_uint(t[0]);
-        f.a.y = __float_as_uint(t[1]);
-        f.b.x = __float_as_uint(t[kBoxW]);
-        f.b.y = __float_as_uint(t[kBoxW + 1]);
-        const float v = finish<SAMPLER, true, float>(f);
+        float v;
+        if constexpr (SAMPLER == kNearest) {
+          v = t[0];
+        } else {
+          f.a.x = __float_as_uint(t[0]);
+          f.a.y = __float_as_uint(t[1]);
+          f.b.x = __float_as_uint(t[kBoxW]);
+          f.b.y = __float_as_uint(t[kBoxW + 1]);
+          v = finish<SAMPLER, true, float>(f);
+        }
 #if defined(DCP_EXPERIMENT_NO_STORE)     // timing experiment only: the value is computed, the store (practically) never happens
         if (__float_as_uint(v) == 0x7fc12345u)
 #else
@@ -920,6 +931,7 @@ static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStr
 template <int KIND, int NF>
 static hipError_t launch_lds_any(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
   switch (sampler) {
+    case kNearest: return launch_lds<KIND, NF, kNearest>(img, map, stream);
     case kScipy: return launch_lds<KIND, NF, kScipy>(img, map, stream);
     case kF64Lerp: return launch_lds<KIND, NF, kF64Lerp>(img, map, stream);
     default: return launch_lds<KIND, NF, kF32Lerp>(img, map, stream);
@@ -928,7 +940,7 @@ static hipError_t launch_lds_any(const ImageArgs& img, const MapArgs& map, int s
 
 template <int KIND, int NF>
 static hipError_t launch_fast(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
-  if (img.lds_gather && sampler != kNearest) return launch_lds_any<KIND, NF>(img, map, sampler, stream);
+  if (img.lds_gather) return launch_lds_any<KIND, NF>(img, map, sampler, stream);
   switch (sampler) {
     case kNearest: return launch_one<KIND, NF, kNearest, true, true>(img, map, stream);
     case kScipy: return launch_one<KIND, NF, kScipy, true, true>(img, map, stream);
@@ -968,7 +980,7 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
   const int nf = map.nfact;
 
   // order-1 remaps of dense float32 images with float32 coordinates: LDS-staged gather
-  const bool lds = pair && round_f32 && opts.lds_gather && sampler != kNearest;
+  const bool lds = pair && round_f32 && opts.lds_gather;
   if (kind == kPersp) {
     if (lds) return launch_lds_any<kPersp, -1>(img, map, sampler, stream);
     if (pair) return launch_generic<kPersp, true, true>(img, map, sampler, stream);
