@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="stack workload: all-gather pipelined against the kernel in this many depth sub-blocks")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="back-to-back launches for this long before the warm-up steps: the core clock needs ~100 ms under "
                          "load to reach its sustained level (tools/time_ramp.py); 0 disables")
@@ -136,11 +138,27 @@ def stack_main(a, world, rank, dev, dist, backend):
     if gather and uneven:
         raise SystemExit("stack workload: depth must divide evenly over the ranks for the timed all-gather")
 
+    nsub = max(1, min(a.pipeline, dl)) if gather else 1
+
     def step():
-        F.check(L.dcp_unwarp_stack_rows_f32(vol_ptr, out_ptr, dl, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf,
-                                            0.0, nrows, 1, blend, F.MEM_DEVICE, dev, stream))
-        if gather:
-            dist.all_gather_into_tensor(full_t, out_t)
+        if nsub == 1:
+            F.check(L.dcp_unwarp_stack_rows_f32(vol_ptr, out_ptr, dl, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf,
+                                                0.0, nrows, 1, blend, F.MEM_DEVICE, dev, stream))
+            if gather:
+                dist.all_gather_into_tensor(full_t, out_t)
+            return
+        # the all-gather of sub-block s (asynchronous) runs while the kernel of sub-block s + 1 computes; every
+        # rank's piece lands directly in its place of the (depth, rows, W) result
+        pending = []
+        for s_ in range(nsub):
+            s0, s1 = st.shard_bounds(dl, nsub, s_)
+            F.check(L.dcp_unwarp_stack_rows_f32(vol_ptr + s0 * H * W * 4, out_ptr + s0 * nrows * W * 4, s1 - s0, H, W, H * W, W,
+                                                cfg["xcenter"], cfg["ycenter"], fa, nf, 0.0, nrows, 1, blend, F.MEM_DEVICE, dev,
+                                                stream))
+            pieces = [full_t[r * dl + s0:r * dl + s1] for r in range(world)]
+            pending.append(dist.all_gather(pieces, out_t[s0:s1], async_op=True))
+        for work in pending:
+            work.wait()
 
     def sync():
         F.check(L.dcp_stream_synchronize(dev, None))
@@ -179,7 +197,7 @@ def stack_main(a, world, rank, dev, dist, backend):
             "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (uniform [0,1) float32 projections, device-resident)",
             "config": {"workload": cfg["name"], "depth": D, "rows": nrows, "width": W, "depth_per_gpu": dl,
-                       "all_gather": bool(gather), "blend": a.blend,
+                       "all_gather": bool(gather), "gather_pipeline": nsub, "blend": a.blend,
                        "parallelism": "depth-sharded, %s" % ("RCCL all-gather of the (depth, rows, W) block" if gather
                                                             else "no collective")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS, "unit": "GB/s",

@@ -33,7 +33,7 @@ def _hip_rows(local_vol, xcenter, ycenter, list_fact, row_start, nrows, coord_ro
 
 
 def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_start, nrows, *,
-                         coord_round_f32=True, gather=True, group=None, blend=None, compute=None):
+                         coord_round_f32=True, gather=True, group=None, blend=None, compute=None, pipeline=1):
     """
     Rows ``row_start .. row_start+nrows-1`` of the corrected stack from a depth-sharded volume.
 
@@ -52,6 +52,10 @@ def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_star
     compute : callable, optional
         Replaces the HIP kernel call (signature of ``_hip_rows``); used by the CPU ``gloo`` tests to
         exercise the sharding and the collective without a GPU.
+    pipeline : int
+        > 1 (even shards only): the local shard is cut into that many depth sub-blocks; the all-gather of
+        sub-block ``s`` (asynchronous, on the collective's own stream) runs while the kernel of sub-block
+        ``s + 1`` is computing, every rank's piece landing directly in its place of the result.
     """
     import torch
     import torch.distributed as dist
@@ -63,13 +67,30 @@ def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_star
         raise ValueError("rank %d holds %d projections, its shard of depth %d is [%d, %d)"
                          % (rank, local_vol.shape[0], depth, d0, d1))
     fn = _hip_rows if compute is None else compute
+    counts = [shard_bounds(depth, world, r)[1] - shard_bounds(depth, world, r)[0] for r in range(world)]
+    dl = d1 - d0
+    if gather and world > 1 and int(pipeline) > 1 and len(set(counts)) == 1 and dl >= 2:
+        nsub = min(int(pipeline), dl)
+        out, pending = None, []
+        for s in range(nsub):
+            s0, s1 = shard_bounds(dl, nsub, s)
+            loc = fn(local_vol[s0:s1], xcenter, ycenter, list_fact, row_start, nrows, coord_round_f32, blend)
+            if not torch.is_tensor(loc):
+                loc = torch.from_numpy(np.ascontiguousarray(loc))
+            loc = loc.contiguous()
+            if out is None:
+                out = torch.empty((depth, nrows, loc.shape[2]), dtype=loc.dtype, device=loc.device)
+            pieces = [out[r * dl + s0:r * dl + s1] for r in range(world)]      # contiguous views: depth is the outer axis
+            pending.append((dist.all_gather(pieces, loc, group=group, async_op=True), loc))
+        for work, _keep in pending:
+            work.wait()
+        return out
     local = fn(local_vol, xcenter, ycenter, list_fact, row_start, nrows, coord_round_f32, blend)
     if not torch.is_tensor(local):
         local = torch.from_numpy(np.ascontiguousarray(local))
     if not gather or world == 1:
         return local
     width = local.shape[2]
-    counts = [shard_bounds(depth, world, r)[1] - shard_bounds(depth, world, r)[0] for r in range(world)]
     if len(set(counts)) == 1:
         out = torch.empty((depth, nrows, width), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(out, local.contiguous(), group=group)

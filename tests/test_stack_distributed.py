@@ -55,8 +55,11 @@ def _worker(rank, world, port, depth, result_dir):
         part = stack.unwarp_stack_sharded(local, depth, *args, 10, 6, coord_round_f32=True, gather=False,
                                           compute=cpu_rows)
         sl = stack.unwarp_stack_sharded(local, depth, *args, 21, 1, coord_round_f32=False, compute=cpu_rows)
+        # the all-gather pipelined against the per-shard work in depth sub-blocks (falls back for ragged shards)
+        piped = stack.unwarp_stack_sharded(local, depth, *args, 10, 6, coord_round_f32=True, compute=cpu_rows, pipeline=2)
+        piped9 = stack.unwarp_stack_sharded(local, depth, *args, 10, 6, coord_round_f32=True, compute=cpu_rows, pipeline=9)
         np.savez(os.path.join(result_dir, "rank%d.npz" % rank), full=full.numpy(), part=part.numpy(), sl=sl.numpy(),
-                 d0=d0, d1=d1)
+                 piped=piped.numpy(), piped9=piped9.numpy(), d0=d0, d1=d1)
     finally:
         dist.destroy_process_group()
 
@@ -77,3 +80,4 @@ def test_two_rank_gloo_all_gather_reassembles_the_stack(tmp_path, orc, depth):
         assert np.array_equal(z["full"], want)                       # every rank holds the whole block
         assert np.array_equal(z["part"], want[int(z["d0"]):int(z["d1"])])
         assert np.array_equal(z["sl"], want_sl)
+        assert np.array_equal(z["piped"], want) and np.array_equal(z["piped9"], want)
