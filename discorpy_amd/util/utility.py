@@ -5,13 +5,15 @@
 unwarp of every channel at the SAME float32 coordinates -- one launch on the interleaved image for
 orders 0 / 1, plane by plane through :mod:`discorpy_amd.post.postprocessing` otherwise.
 
-``find_point_to_point`` is the closed-form point mapping of ``utility.py:192-230`` (host, NumPy).
+``find_point_to_point`` is the closed-form point mapping of ``utility.py:192-230`` (host, NumPy);
+``transform_coef_backward_and_forward`` the small least-squares model reversal ``pad=True`` needs
+(``proc/processing.py:615-674``; host, NumPy -- the north star keeps the one-off fits on the CPU).
 """
 import numpy as np
 
 from ..post import postprocessing as _pp
 
-__all__ = ["unwarp_color_image_backward", "find_point_to_point"]
+__all__ = ["unwarp_color_image_backward", "find_point_to_point", "transform_coef_backward_and_forward"]
 
 
 def find_point_to_point(points, xcenter, ycenter, list_fact, output_order="xy"):
@@ -31,17 +33,40 @@ def find_point_to_point(points, xcenter, ycenter, list_fact, output_order="xy"):
     return moved if output_order == "xy" else moved[::-1]
 
 
+def transform_coef_backward_and_forward(list_fact, mapping="backward", ref_points=None):
+    """
+    Coefficients of the reversed radial model (reference ``proc/processing.py:615-674``, the one-off CPU fit the
+    north star leaves on the host).  A model maps a radius ``r`` to ``r * F(r)``, ``F(r) = sum_i list_fact[i] r**i``;
+    the reversed model ``G`` satisfies ``G(r F(r)) = 1 / F(r)``, and its coefficients are the least-squares solution
+    of that identity over the radii of ``ref_points`` (``(y, x)`` offsets from the centre; a 40 x 40 grid of
+    +-1000 px in steps of 50 when not given).  ``mapping`` only names which of the two directions ``list_fact``
+    is -- the arithmetic is the same.  Points where ``F`` vanishes are left out.
+    """
+    coefs = np.asarray(list_fact, dtype=np.float64)
+    if ref_points is None:
+        ticks = np.arange(-1000, 1000, 50)
+        pts = np.stack(np.meshgrid(ticks, ticks, indexing="ij"), axis=-1).reshape(-1, 2).astype(np.float64)
+    else:
+        if len(ref_points) < coefs.size:
+            raise ValueError("Number of reference-points must be equal or "
+                             "larger than the number of coefficients!!!")
+        pts = np.asarray(ref_points, dtype=np.float64).reshape(-1, 2)
+    if mapping not in ("backward", "forward"):
+        raise ValueError("mapping must be 'backward' or 'forward'")
+    expo = np.arange(coefs.size, dtype=np.int16)
+    radius = np.sqrt(pts[:, 1] * pts[:, 1] + pts[:, 0] * pts[:, 0])
+    scale = np.sum(coefs[None, :] * np.power(radius[:, None], expo[None, :]), axis=1)
+    keep = scale != 0.0
+    moved = scale[keep] * radius[keep]
+    design = np.power(moved[:, None], expo[None, :])
+    return np.linalg.lstsq(design, 1.0 / scale[keep], rcond=1e-64)[0]
+
+
 def _auto_pad(height, width, xcenter, ycenter, list_fact):
-    """pad=True: how far the four image corners land outside the frame once the forward model (fitted from the
-    backward one by discorpy's CPU routine, which is not part of this package) is applied to them."""
-    try:
-        import discorpy.proc.processing as proc
-    except ImportError:
-        raise NotImplementedError(
-            "pad=True needs discorpy.proc.transform_coef_backward_and_forward (the CPU model fit, "
-            "not part of this package); install discorpy or pass explicit pad widths")
+    """pad=True (reference ``utility.py:238-263``): how far the four image corners land outside the frame once the
+    forward model -- fitted from the backward one on a 40 x 40 grid over the frame -- is applied to them."""
     grid = [[gy - ycenter, gx - xcenter] for gy in np.linspace(0, height, 40) for gx in np.linspace(0, width, 40)]
-    forward = proc.transform_coef_backward_and_forward(list_fact, ref_points=grid)
+    forward = transform_coef_backward_and_forward(list_fact, ref_points=grid)
     corners = {name: find_point_to_point(rc, xcenter, ycenter, forward)
                for name, rc in (("tl", (0, 0)), ("tr", (0, width - 1)), ("br", (height - 1, width - 1)),
                                 ("bl", (height - 1, 0)))}
@@ -125,7 +150,7 @@ def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode=
     mode : str, optional
         Accepted for compatibility; inert for order <= 1.
     pad : bool, int, or tuple of int.
-        Use to keep the original view.  ``True`` (automatic width) needs discorpy's CPU model fit.
+        Use to keep the original view.  ``True``: the width is calculated automatically.
     pad_mode : str
         numpy.pad mode ('constant', 'reflect', 'edge', 'mean', 'linear_ramp', 'symmetric', ...).
 

@@ -74,6 +74,27 @@ def test_pad_argument_validation():
         util._calc_pad("2", *args)
 
 
+
+def test_g14_model_reversal_and_automatic_pads():
+    """proc.transform_coef_backward_and_forward restated (processing.py:615-674) and the pad=True widths of
+    utility.py:238-263, against the reference's own numbers (golden G14)."""
+    g = golden("g14_autopad40x56x3")
+    fact = list(g["list_fact"])
+    grid = [[gy - 19.1, gx - 27.4] for gy in np.linspace(0, 40, 40) for gx in np.linspace(0, 56, 40)]
+    assert np.allclose(util.transform_coef_backward_and_forward(fact, ref_points=grid), g["forward_fact"], rtol=1e-9, atol=0)
+    assert np.allclose(util.transform_coef_backward_and_forward([1.0, -3e-5, 9e-8]), g["default_grid_backward"], rtol=1e-9, atol=0)
+    assert np.allclose(util.transform_coef_backward_and_forward([1.0, -3e-5, 9e-8], mapping="forward"),
+                       g["default_grid_forward"], rtol=1e-9, atol=0)
+    assert util._calc_pad(True, 40, 56, 27.4, 19.1, fact) == tuple(int(v) for v in g["pads"]) == (8, 7, 11, 11)
+    # the reference's own pad=True case (tests/test_utility.py:92-101)
+    ref = [[i - 20.0, j - 30.0] for i in range(0, 40, 10) for j in range(0, 60, 10)]
+    tfact = util.transform_coef_backward_and_forward([1.0, 0.1, 0.01], ref_points=ref)
+    assert np.allclose(tfact, g["reftest_tfact"], rtol=1e-9, atol=0)
+    assert util._calc_pad(True, 40, 60, 30.0, 20.0, tfact) == tuple(int(v) for v in g["reftest_pads"])
+    with pytest.raises(ValueError, match="Number of reference-points"):
+        util.transform_coef_backward_and_forward([1.0, 0.1, 0.01], ref_points=[[1.0, 2.0]])
+
+
 # ---------------------------------------------------------------- f1: the kernels (GPU)
 
 @pytest.mark.gpu
@@ -109,3 +130,28 @@ def test_color_unwarp_on_device_tensors(hip):
                           g["pad_4_reflect_order0"])
     with pytest.raises(NotImplementedError, match="pad_mode"):
         util.unwarp_color_image_backward(t, *a, pad=4, pad_mode="mean")
+
+
+@pytest.mark.gpu
+def test_g14_pad_true_matches_the_reference(hip):
+    """pad=True end to end (the call form of docs/source/technical_notes/fisheye_correction.rst:374) without the
+    reference installed: pad widths from the restated fit, padded unwarp on the GPU, bit-equal to golden G14."""
+    g = golden("g14_autopad40x56x3")
+    rgb = noise(g["seed"], g["shape"])
+    a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    out = util.unwarp_color_image_backward(rgb, *a, pad=True, blend="scipy")
+    assert out.shape == (40 + 8 + 7, 56 + 11 + 11, 3) and np.array_equal(out, g["pad_true_constant"])
+    assert np.array_equal(util.unwarp_color_image_backward(rgb, *a, order=0, pad=True, pad_mode="edge"), g["pad_true_edge_order0"])
+    assert np.array_equal(util.unwarp_color_image_backward(rgb[:, :, 2], *a, pad=True, pad_mode="reflect", blend="scipy"),
+                          g["gray_pad_true_reflect"])
+    # tests/test_utility.py:75-101 restated
+    box = np.ones((40, 60), dtype=np.float32)
+    box[:5] = 0
+    box[-5:] = 0
+    box[:, :5] = 0
+    box[:, -5:] = 0
+    ref = [[i - 20.0, j - 30.0] for i in range(0, 40, 10) for j in range(0, 60, 10)]
+    tfact = util.transform_coef_backward_and_forward([1.0, 0.1, 0.01], ref_points=ref)
+    cor = util.unwarp_color_image_backward(box, 30.0, 20.0, tfact, 1, "constant", True, "constant", blend="scipy")
+    assert cor.shape != (40, 60) and cor.shape == g["reftest_pad_true"].shape
+    assert np.max(np.abs(cor - g["reftest_pad_true"])) <= 1e-5    # tfact from lstsq may differ in its last bits

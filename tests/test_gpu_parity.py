@@ -952,6 +952,30 @@ def test_randomised_differential_campaign(hip, orc):
 
 # --------------------------------------------------------------------------- (c) BASELINE sizes
 
+def test_cfg1_full_frame_equals_the_reference(hip, orc):
+    """BASELINE config 1 at full size: unwarp_image_backward on the decoded data/dot_pattern_05.jpg (shipped as uint8 --
+    JPEG is never decoded here) with data/coef_dot_05.txt, the call of examples/example_02.py:81.  SHA-256 of the whole
+    float32 output == the reference's, for the scipy blend, the default blend and order 0; G4's rows and statistics."""
+    import hashlib
+    g, g4 = golden("g4b_dot_pattern_05_full"), golden("g4_dot_pattern_05")
+    img = g["frame_u8"].astype(np.float32)
+    a = (img, float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    assert a[1:] == (configs.XCENTER_DOT_05, configs.YCENTER_DOT_05, list(configs.COEF_DOT_05))
+    for blend in ("scipy", "f64lerp"):
+        out = pp.unwarp_image_backward(*a, blend=blend)
+        assert out.shape == (800, 1280) and out.dtype == np.float32
+        assert np.array_equal(out[g4["full_rows"]], g4["full_out_rows"]) and np.array_equal(out[::32, ::32], g["out_lattice"])
+        assert out[400, 640] == np.float32(213.037353515625) and out[10, 10] == np.float32(195.14744567871094)
+        assert out[799, 1279] == np.float32(89.43257141113281)
+        assert abs(float(out.mean(dtype=np.float64)) - float(g4["full_stats"][3])) < 1e-4
+        assert hashlib.sha256(out.tobytes()).digest() == g["out_sha256"].tobytes(), blend
+    out0 = pp.unwarp_image_backward(*a, order=0)
+    assert hashlib.sha256(out0.tobytes()).digest() == g["out_order0_sha256"].tobytes()
+    # the uint8 frame itself (output dtype = input dtype, scipy's rounding): against the oracle
+    u8 = pp.unwarp_image_backward(g["frame_u8"], *a[1:])
+    assert u8.dtype == np.uint8 and np.array_equal(u8, orc.unwarp_image_backward(g["frame_u8"], *a[1:], poly=orc.POLY_KERNEL))
+
+
 def test_cfg2_full_frame_against_oracle_and_properties(hip, orc):
     c = configs.cfg2()
     h, w = c["shape"]

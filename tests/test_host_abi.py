@@ -138,6 +138,10 @@ def test_no_silent_cpu_path(monkeypatch):
                 text = open(path).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), path
                 assert "libunwarp_oracle" not in text, path
+                # nor may the product lean on the reference itself (VERDICT r1: utility.py once imported discorpy.proc)
+                assert not re.search(r"^\s*(import|from)\s+discorpy(\.|\s|$)", text, flags=re.M), path
+                code = re.sub(r"#[^\n]*", "", re.sub(r'"""[\s\S]*?"""', "", text))     # citations in comments are fine
+                assert "/root/reference" not in code, path
             elif f.endswith((".cpp", ".hip", ".h")) or f == "Makefile":
                 text = open(path).read()
                 assert not re.search(r"#\s*include[^\n]*oracle", text), path

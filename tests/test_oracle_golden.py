@@ -56,6 +56,25 @@ def test_g4_dot_pattern_05(orc, poly):
 
 
 @pytest.mark.parametrize("poly", POLYS)
+def test_g4b_config1_full_frame(orc, poly):
+    """BASELINE config 1 at full size (examples/example_02.py:81): the oracle on the decoded 800 x 1280 frame equals
+    the reference's output bit for bit (SHA-256 of the float32 output, a lattice of its pixels, G4's eight rows)."""
+    import hashlib
+    g, g4 = golden("g4b_dot_pattern_05_full"), golden("g4_dot_pattern_05")
+    img = g["frame_u8"].astype(np.float32)
+    assert img.shape == (800, 1280) and np.array_equal(img[395:406], g4["full_in_rows_band"])
+    out = orc.unwarp_image_backward(img, g["xcenter"], g["ycenter"], g["list_fact"], poly=poly_of(orc, poly))
+    assert np.array_equal(out[::32, ::32], g["out_lattice"])
+    assert np.array_equal(out[g4["full_rows"]], g4["full_out_rows"])
+    st = g4["full_stats"]
+    assert (img.min(), img.max()) == (st[0], st[1]) and out[400, 640] == np.float32(213.037353515625)
+    assert (out[400, 640], out[10, 10], out[799, 1279]) == (st[4], st[5], st[6])
+    assert hashlib.sha256(out.tobytes()).digest() == g["out_sha256"].tobytes()
+    out0 = orc.unwarp_image_backward(img, g["xcenter"], g["ycenter"], g["list_fact"], order=0, poly=poly_of(orc, poly))
+    assert hashlib.sha256(out0.tobytes()).digest() == g["out_order0_sha256"].tobytes()
+
+
+@pytest.mark.parametrize("poly", POLYS)
 @pytest.mark.parametrize("name", ["g5_cfg2_160", "g5_offcentre_150x200", "g5_cfg5_9term_144"])
 def test_g5_configs_reduced(orc, name, poly):
     g = golden(name)

@@ -102,6 +102,17 @@ save("g4_dot_pattern_05", crop_in=crop_in, crop_xcenter=f64(xc - 492), crop_ycen
      full_stats=f64([img.min(), img.max(), img.mean(), full.mean(), full[400, 640], full[10, 10], full[799, 1279]]),
      full_in_rows_band=img[395:406])
 
+# ---- G4b: config 1 at full size -- the decoded 800 x 1280 frame as uint8 (mode L: the decode IS integers, so this
+# is the float32 image the reference loads, losslessly), the SHA-256 of the reference's full float32 output and a
+# 25 x 40 lattice of its pixels.  (The 4 MB output itself is not stored.)
+import hashlib  # noqa: E402
+assert np.array_equal(img, img.astype(np.uint8).astype(np.float32))
+lat = (slice(0, 800, 32), slice(0, 1280, 32))
+save("g4b_dot_pattern_05_full", frame_u8=img.astype(np.uint8), xcenter=f64(xc), ycenter=f64(yc), list_fact=f64(coef),
+     out_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(full).tobytes()).digest(), dtype=np.uint8),
+     out_lattice=np.ascontiguousarray(full[lat]), out_order0_sha256=np.frombuffer(hashlib.sha256(
+         np.ascontiguousarray(post.unwarp_image_backward(img, xc, yc, coef, order=0)).tobytes()).digest(), dtype=np.uint8))
+
 # ---- G5: configs 2 / 5 at reduced size, seeded noise; float32 coordinate planes kept
 def coords_ref(h, w, xc, yc, fact):
     xu = np.arange(w) - xc
@@ -262,4 +273,29 @@ lines13 = [np.column_stack([np.full(12, 40.0 * k) + rng13.uniform(-2, 2, 12), np
 fact13 = np.asarray([1.0, -2.9e-5, 8.9e-8, -1.5e-10, 8.0e-14])
 save("g13_lines_forward", lines=np.asarray(lines13), xcenter=f64(588.69), ycenter=f64(462.09), list_fact=fact13,
      out=np.asarray(post.unwarp_line_forward(lines13, 588.69, 462.09, fact13)))
+# ---- G14: pad=True of util.unwarp_color_image_backward (utility.py:238-263): automatic pad widths from the forward
+# model fitted by proc.transform_coef_backward_and_forward (processing.py:615-674), then the padded unwarp; plus the
+# reference's own pad=True case (tests/test_utility.py:92-101) and the fitted coefficients themselves
+rgb14 = np.random.default_rng(141).random((40, 56, 3), dtype=np.float32)
+fact14 = [1.0, -6e-3, -2e-5]
+g14 = dict(seed=np.int64(141), shape=np.array(rgb14.shape), xcenter=f64(27.4), ycenter=f64(19.1), list_fact=f64(fact14))
+g14["pads"] = np.asarray(util._calc_pad(True, 40, 56, 27.4, 19.1, fact14), dtype=np.int64)
+g14["pad_true_constant"] = util.unwarp_color_image_backward(rgb14, 27.4, 19.1, fact14, pad=True)
+g14["pad_true_edge_order0"] = util.unwarp_color_image_backward(rgb14, 27.4, 19.1, fact14, order=0, pad=True, pad_mode="edge")
+g14["gray_pad_true_reflect"] = util.unwarp_color_image_backward(rgb14[:, :, 2], 27.4, 19.1, fact14, pad=True, pad_mode="reflect")
+grid14 = [[gy - 19.1, gx - 27.4] for gy in np.linspace(0, 40, 40) for gx in np.linspace(0, 56, 40)]
+g14["forward_fact"] = f64(proc.transform_coef_backward_and_forward(fact14, ref_points=grid14))
+g14["default_grid_backward"] = f64(proc.transform_coef_backward_and_forward([1.0, -3e-5, 9e-8]))
+g14["default_grid_forward"] = f64(proc.transform_coef_backward_and_forward([1.0, -3e-5, 9e-8], mapping="forward"))
+box = np.ones((40, 60), dtype=np.float32)      # tests/test_utility.py:75-101
+box[:5] = 0
+box[-5:] = 0
+box[:, :5] = 0
+box[:, -5:] = 0
+ref14 = [[i - 20.0, j - 30.0] for i in range(0, 40, 10) for j in range(0, 60, 10)]
+tfact14 = proc.transform_coef_backward_and_forward([1.0, 0.1, 0.01], ref_points=ref14)
+g14["reftest_tfact"] = f64(tfact14)
+g14["reftest_pads"] = np.asarray(util._calc_pad(True, 40, 60, 30.0, 20.0, tfact14), dtype=np.int64)
+g14["reftest_pad_true"] = util.unwarp_color_image_backward(box, 30.0, 20.0, tfact14, 1, "constant", True, "constant")
+save("g14_autopad40x56x3", **g14)
 print("done")
