@@ -21,7 +21,7 @@ const char* last_error();
     if (e_ != hipSuccess) return dcpapi::fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
-extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb, g_stack_lds, g_host_duplex, g_host_bands;
+extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb, g_stack_lds, g_host_duplex, g_host_bands, g_tile_cert, g_wg_box;
 dcp::LaunchOpts current_opts();
 
 // Selects `device` for the calling thread for the lifetime of the object (no-op for device < 0).
@@ -114,6 +114,10 @@ uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs);
 size_t extent_bytes_typed(int64_t H, int64_t W, int64_t rs, int64_t cs, int dtype);
 int fill_map(dcp::MapArgs* m, double xc, double yc, const double* fact, int nfact, const double* coef);
 int homography_is_tame(const double* c, int64_t H, int64_t W);
+// level 1: inside any 64 x 16 output tile the map stays within 0.95 px of the bilinear interpolant of the tile's corners;
+// level 2: the same for 128 x 32 tiles (kind: dcp::kRadial or dcp::kPersp; anything else 0) -- lets the staged kernels
+// take a tile's source box from its corner pixels alone, without a per-pixel containment vote
+int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W);
 void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0, int64_t* b1);
 void host_row_band_rect(const dcp::MapArgs& m, int64_t H, double x_lo, double x_hi, double y_lo, double y_hi, int64_t* b0,
                         int64_t* b1);

@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -32,6 +32,7 @@ dcp::LaunchOpts current_opts() {
   o.pipe_depth = g_pipe_depth.load();
   o.lds_gather = g_lds_gather.load();
   o.stack_lds = g_stack_lds.load();
+  o.wg_box = g_wg_box.load();
   return o;
 }
 
@@ -100,6 +101,110 @@ int homography_is_tame(const double* c, int64_t H, int64_t W) {
   const double m = std::fabs(lo) < std::fabs(hi) ? std::fabs(lo) : std::fabs(hi);
   const double M = std::fabs(lo) > std::fabs(hi) ? std::fabs(lo) : std::fabs(hi);
   return m > 1e-6 && M < 1e6;
+}
+
+// ---- tile deviation certificate (MapArgs::tile_dev_ok) ---------------------------------------------------------
+// remap_lds_kernel predicts the source box of a 64 x 16 output tile from the tile's four corner pixels.  For a map
+// f in C^{1,1} the bilinear interpolant of the corner values deviates from f inside the tile by at most
+//     (w^2 sup|f_xx| + h^2 sup|f_yy|) / 8,   w = 63, h = 15  (pixel spans of the tile),
+// and the interpolant itself lies inside the hull of the corner values.  When that bound is below one pixel, the
+// corner hull grown by one pixel contains every tap of the tile and the kernel needs no per-pixel check.  The answer
+// is a level: 1 = holds for 64 x 16 tiles, 2 = also for the 128 x 32 tiles of remap_wg_kernel (w = 127, h = 31).
+//   radial map (x - xc) B(r):  |f_xx|, |f_yy| <= 4 |B'(r)| + r |B''(r)|   (the x and the y coordinate alike;
+//     f_xx = 3 xu B'/r + xu^3 (B''/r^2 - B'/r^3), f_yy = xu B'/r + xu yu^2 (B''/r^2 - B'/r^3), |xu|, |yu| <= r).
+//     The supremum over [0, rmax] (rmax: farthest frame corner from the centre) is taken on 128 midpoints plus the
+//     half-interval times a triangle-inequality bound of the derivative -- rigorous, and tight enough because the
+//     intervals are short.
+//   homography N(x, y) / D(x, y), N and D affine, D of one sign over the frame ("tame"):
+//     f_xx = -2 c7 (N_x D - c7 N) / D^3, f_yy = -2 c8 (N_y D - c8 N) / D^3 with |N|, |D| bounded at the frame corners.
+// The final clip to the frame and the float32 rounding are monotone, so they keep a coordinate inside the (clipped,
+// rounded) hull +- the deviation; 0.95 px leaves room for the rounding (one float32 ulp of a coordinate < 2^24).
+namespace {
+constexpr double kTileDevLimit = 0.95;
+// (w^2, h^2) / 8 of the two tile shapes: the 64 x 16 wave tile of remap_lds_kernel, the 128 x 32 workgroup tile of remap_wg_kernel
+constexpr double kSpanX2[2] = {63.0 * 63.0 / 8.0, 127.0 * 127.0 / 8.0}, kSpanY2[2] = {15.0 * 15.0 / 8.0, 31.0 * 31.0 / 8.0};
+
+double radial_curvature_bound(const dcp::MapArgs& m, double rmax) {
+  const int n = m.nfact;
+  if (n <= 1) return 0.0;                      // B constant: the map is affine
+  if (!(rmax >= 0.0) || !std::isfinite(rmax)) return INFINITY;
+  // P1 = B' = sum i a_i r^(i-1),  P2 = r B'' = sum i (i-1) a_i r^(i-1); their derivatives bounded by the triangle inequality
+  double l1 = 0.0, l2 = 0.0, rp = 1.0;         // rp = rmax^(i-2)
+  for (int i = 2; i < n; ++i) {
+    const double a = std::fabs(m.fact[i]);
+    l1 += (double)i * (i - 1) * a * rp;
+    l2 += (double)i * (i - 1) * (i - 1) * a * rp;
+    rp *= rmax;
+  }
+  constexpr int kNodes = 128;
+  const double h = rmax / kNodes;
+  double sup = 0.0;
+  for (int k = 0; k < kNodes; ++k) {
+    const double r = (k + 0.5) * h;
+    double p1 = 0.0, p2 = 0.0;
+    for (int i = n - 1; i >= 1; --i) {
+      p1 = p1 * r + (double)i * m.fact[i];
+      p2 = p2 * r + (double)i * (i - 1) * m.fact[i];
+    }
+    const double v = 4.0 * std::fabs(p1) + std::fabs(p2);
+    sup = v > sup ? v : sup;
+  }
+  sup += 0.5 * h * (4.0 * l1 + l2);
+  return std::isfinite(sup) ? sup : INFINITY;
+}
+
+thread_local struct {
+  int kind = -1, nfact = -1;
+  int64_t H = 0, W = 0;
+  double xc = 0, yc = 0, fact[dcp::kMaxFact], coef[8];
+  int ok = 0;
+} g_cert_cache;
+}  // namespace
+
+int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) {
+  if (H < 1 || W < 1) return 0;
+  auto& c = g_cert_cache;        // the same calibration is applied to frame after frame: keep the last answer
+  if (c.kind == kind && c.nfact == m.nfact && c.H == H && c.W == W && c.xc == m.xc && c.yc == m.yc &&
+      memcmp(c.fact, m.fact, sizeof(double) * (size_t)(m.nfact > 0 ? m.nfact : 0)) == 0 && memcmp(c.coef, m.coef, sizeof(c.coef)) == 0)
+    return c.ok;
+  int ok = 0;
+  if (kind == dcp::kRadial) {
+    double rmax = 0.0;
+    for (double x : {0.0, (double)(W - 1)})
+      for (double y : {0.0, (double)(H - 1)}) rmax = std::max(rmax, std::hypot(x - m.xc, y - m.yc));
+    const double k2 = radial_curvature_bound(m, rmax * (1.0 + 1e-12) + 1e-9);
+    for (int lvl = 0; lvl < 2; ++lvl)
+      if ((kSpanX2[lvl] + kSpanY2[lvl]) * k2 <= kTileDevLimit) ok = lvl + 1;
+  } else if (kind == dcp::kPersp) {
+    if (homography_is_tame(m.coef, H, W)) {
+      double dmin = 1e300, dmax = 0.0, nxmax = 0.0, nymax = 0.0;
+      for (double x : {0.0, (double)(W - 1)})
+        for (double y : {0.0, (double)(H - 1)}) {
+          const double d = std::fabs((m.coef[6] * x + m.coef[7] * y) + 1.0);
+          dmin = std::min(dmin, d);
+          dmax = std::max(dmax, d);
+          nxmax = std::max(nxmax, std::fabs((m.coef[0] * x + m.coef[1] * y) + m.coef[2]));
+          nymax = std::max(nymax, std::fabs((m.coef[3] * x + m.coef[4] * y) + m.coef[5]));
+        }
+      const double d3 = dmin * dmin * dmin, c7 = std::fabs(m.coef[6]), c8 = std::fabs(m.coef[7]);
+      const double xxx = 2.0 * c7 * (std::fabs(m.coef[0]) * dmax + c7 * nxmax) / d3, xyy = 2.0 * c8 * (std::fabs(m.coef[1]) * dmax + c8 * nxmax) / d3;
+      const double yxx = 2.0 * c7 * (std::fabs(m.coef[3]) * dmax + c7 * nymax) / d3, yyy = 2.0 * c8 * (std::fabs(m.coef[4]) * dmax + c8 * nymax) / d3;
+      for (int lvl = 0; lvl < 2; ++lvl) {
+        const double devx = kSpanX2[lvl] * xxx + kSpanY2[lvl] * xyy, devy = kSpanX2[lvl] * yxx + kSpanY2[lvl] * yyy;
+        if (std::isfinite(devx) && std::isfinite(devy) && devx <= kTileDevLimit && devy <= kTileDevLimit) ok = lvl + 1;
+      }
+    }
+  }
+  c.kind = kind;
+  c.nfact = m.nfact;
+  c.H = H;
+  c.W = W;
+  c.xc = m.xc;
+  c.yc = m.yc;
+  memcpy(c.fact, m.fact, sizeof(c.fact));
+  memcpy(c.coef, m.coef, sizeof(c.coef));
+  c.ok = ok;
+  return ok;
 }
 
 uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs) {
@@ -233,6 +338,10 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "host_bands")) {
     if (value < 1 || value > 256) return fail(DCP_ERR_INVALID_ARG, "host_bands must be in [1, 256]");
     g_host_bands = value;
+  } else if (!strcmp(key, "wg_box")) {
+    g_wg_box = value ? 1 : 0;         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
+  } else if (!strcmp(key, "tile_cert")) {
+    g_tile_cert = value ? 1 : 0;      // 0: never use the host's tile-deviation certificate (remap_lds_kernel then votes)
   } else if (!strcmp(key, "stack_chunk_kb")) {
     if (value < 1) return fail(DCP_ERR_INVALID_ARG, "stack_chunk_kb must be >= 1");
     g_stack_chunk_kb = value;
@@ -254,6 +363,8 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "stack_lds")) *value = g_stack_lds;
   else if (!strcmp(key, "host_duplex")) *value = g_host_duplex;
   else if (!strcmp(key, "host_bands")) *value = g_host_bands;
+  else if (!strcmp(key, "tile_cert")) *value = g_tile_cert;
+  else if (!strcmp(key, "wg_box")) *value = g_wg_box;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }

@@ -29,6 +29,7 @@ struct ImageArgs {
   int32_t xcd_remap;       // 1: contiguous band of tiles per XCD
   int32_t pipe_depth;      // rows of gathers in flight per thread (1, 2 or 4)
   int32_t lds_gather;      // 1: stage the source box of each wave tile in LDS (remap_lds_kernel)
+  int32_t wg_box;          // 1: one box per workgroup (remap_wg_kernel) when the certificate allows it
   int32_t y_origin;        // a launch may cover only output rows [y_origin, y_origin + rows_out) of the H x W map;
   int32_t rows_out;        // dst then points at row y_origin (0 / 0 = the whole image)
 };
@@ -39,6 +40,9 @@ struct MapArgs {
   double coef[8];          // perspective c1..c8
   int32_t nfact;
   int32_t fast_div;        // 1: operands of the homography division stay in the normal range over the image
+  int32_t tile_dev_ok;     // host certificate -- inside any output tile every source coordinate stays within 0.95 px of
+                           // the bilinear interpolant of the tile's corner coordinates: 1 for 64 x 16 tiles, 2 also
+                           // for 128 x 32 tiles (radial and perspective maps; api_core.cpp tile_deviation_certified)
 };
 
 struct StackArgs {
@@ -114,6 +118,7 @@ struct LaunchOpts {
   int coef_lds = 0;        // 1: force the LDS-staged coefficient path even for short vectors
   int d_chunk = 16;
   int stack_lds = 1;       // LDS-staged stack kernel: 0 never, 1 when the launch has enough wave tiles, 2 always
+  int wg_box = 1;          // 1: remap_wg_kernel (one source box per 128 x 32 workgroup tile) for certified maps
 };
 
 // launchers (unwarp_kernels.hip)

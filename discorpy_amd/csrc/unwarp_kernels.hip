@@ -373,6 +373,19 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
 // [1] containment vote failed.  Read through dcp_debug_counters().
 __device__ unsigned long long g_lds_stats[2];
 
+#ifdef DCP_EXPERIMENT_TRACE   // timing experiment: per-wave phase timestamps (tools/trace_k1.py)
+__device__ unsigned long long g_trace[65536 * 8];
+#define DCP_TRACE(slot)                                                                                         \
+  do {                                                                                                          \
+    if (trace_on) {                                                                                             \
+      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
+      if (lane == 0) g_trace[trace_id * 8 + (slot)] = t_;                                                       \
+    }                                                                                                           \
+  } while (0)
+#else
+#define DCP_TRACE(slot) do { } while (0)
+#endif
+
 #ifndef DCP_LDS_TH
 #define DCP_LDS_TH 16
 #endif
@@ -395,8 +408,14 @@ constexpr int kLdsTW = 64, kLdsTH = DCP_LDS_TH;
 constexpr int kBoxW = DCP_BOXW, kBoxH = DCP_BOXH;
 constexpr int kLdsBW = DCP_LDS_BLOCK_WAVES;
 
-template <int KIND, int NF, int SAMPLER>
+// VOTE = false: the host has certified (MapArgs::tile_dev_ok, api_core.cpp: tile_deviation_certified) that inside any
+// 64 x 16 tile every source coordinate stays within one pixel of the bilinear interpolant of the tile's four corner
+// coordinates.  The box is then the corner hull grown by one pixel on every side, it contains every tap by
+// construction, and the per-pixel containment vote (two min3/max3 per pixel and a ballot) is not compiled in.
+// VOTE = true: no certificate (fused map, strongly curved models): zero margin, every pixel verified.
+template <int KIND, int NF, int SAMPLER, bool VOTE>
 __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
+  constexpr int kMargin = VOTE ? DCP_LDS_MARGIN : 1;
   // 4 x 7680 B slabs + row table + coefficients <= 32 KB: five workgroups (20 waves) per CU
   __shared__ float s_box[kLdsBW][kBoxH * kBoxW];
   __shared__ double s_row[kLdsBW * kLdsTH][KIND == kRadial ? 2 : 4];
@@ -407,6 +426,18 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
   // is treated as divergent and wrapped in a waterfall loop
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
+#ifdef DCP_EXPERIMENT_TRACE
+  const unsigned trace_id = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * kLdsBW + (unsigned)wave;
+  const bool trace_on = trace_id < 65536u;
+  DCP_TRACE(0);
+  if (trace_on && lane == 0) {
+    unsigned hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_trace[trace_id * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+  }
+#endif
   int tx, ty;
   if (img.xcd_remap == 2) {
     // stripe order without divisions: a 2-D grid whose x extent is 8 * (widest stripe); the
@@ -432,6 +463,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
     if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
   }
   __syncthreads();
+  DCP_TRACE(1);
   if (y0 >= img.rows_out) return;                 // whole wave past the band of output rows (wave-uniform)
   const int rows = min(kLdsTH, img.rows_out - y0);
 
@@ -473,23 +505,40 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
     cy0 = min(min(ya0, ya1), min(yb0, yb1));
     cy1 = max(max(ya0, ya1), max(yb0, yb1));
   }
-  const int bx0 = max(min(cx0 - DCP_LDS_MARGIN, img.W - 2), 0);
-  const int bx1 = min(cx1 + 1 + DCP_LDS_MARGIN, img.W - 1);   // last column held: tap x0+1 of the largest x0 (+ margin)
-  const int by0 = max(min(cy0 - DCP_LDS_MARGIN, img.H - 2), 0);
-  const int by1 = min(cy1 + 1 + DCP_LDS_MARGIN, img.H - 1);
+  const int bx0 = max(min(cx0 - kMargin, img.W - 2), 0);
+  const int bx1 = min(cx1 + 1 + kMargin, img.W - 1);   // last column held: tap x0+1 of the largest x0 (+ margin)
+  const int by0 = max(min(cy0 - kMargin, img.H - 2), 0);
+  const int by1 = min(cy1 + 1 + kMargin, img.H - 1);
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   const bool fits = bw <= kBoxW && bh <= kBoxH;
+  DCP_TRACE(2);
 
   // ---- fill: box rows by0..by1 from column bx0, row-contiguous loads that land directly in LDS
   // (buffer_load ... lds, no VGPR round trip).  The row group advances through the scalar offset.
   // All rows are in flight at once and complete underneath phase 1b.  (The slab is filled to its
   // full 80-float pitch: up to 12 columns more than the box needs, from cache lines the
   // neighbouring tile fetches anyway.)
-#ifdef DCP_EXPERIMENT_NO_FILL
+#if defined(DCP_EXPERIMENT_VGPR_FILL)        // timing experiment: the same box through VGPRs (buffer loads, then ds_write_b128)
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 fillv[8];
+  const int lrow = (int)(__umul24((uint32_t)lane, 13u) >> 8);
+  const int lcol = lane - lrow * 20;
+  {
+    const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
+    const uint32_t rstep = (uint32_t)img.src_stride * 4u;
+    const uint32_t voff = (uint32_t)lrow * rstep + (uint32_t)lcol * 16u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool pred = fits && lane < 60 && 3 * j + lrow < bh;
+      fillv[j] = __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, pred ? voff + (org + (uint32_t)(3 * j) * rstep) : 0xfffffff0u, 0, 0);
+    }
+  }
+#elif defined(DCP_EXPERIMENT_NO_FILL)
   if (false) {
 #else
   if (fits) {
 #endif
+#if !defined(DCP_EXPERIMENT_VGPR_FILL)
     // 16 bytes per lane: 20 lanes cover one slab row (pitch 80 floats), so one instruction fills
     // three consecutive box rows (lanes 0-59) and the LDS image stays lane-linear as LDS-DMA needs
     const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
@@ -498,7 +547,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
     static_assert(kBoxW == 80, "the fill maps 20 lanes of 16 bytes to one slab row");
     const int lrow = (int)(__umul24((uint32_t)lane, 13u) >> 8);        // lane / 20 for lane < 64
     const int lcol = lane - lrow * 20;
-    const uint32_t voff = __umul24((uint32_t)lrow, rstep) + (uint32_t)lcol * 16u;   // rows < 16 MB
+    const uint32_t voff = (uint32_t)lrow * rstep + (uint32_t)lcol * 16u;   // full 32-bit product: a row stride may exceed 2^24 bytes
     if (lane < 60) {
 #pragma unroll 2
       for (int r = 0; r < bh; r += 3) {
@@ -511,15 +560,20 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
       }
     }
   }
+#endif
 
+  DCP_TRACE(3);
   // ---- phase 1b: the other rows, and this lane's extremes for the containment vote.
   // When the predicted box lies strictly inside the image the clip is skipped: a coordinate that
   // would have been clipped is then outside the box, fails the vote below and the fallback path
   // clips it.  (Border tiles keep the clip: their clipped coordinates are legitimate box members.)
-  const bool box_inside = cx0 - DCP_LDS_MARGIN >= 0 && cx1 + 1 + DCP_LDS_MARGIN <= img.W - 1 &&
-                          cy0 - DCP_LDS_MARGIN >= 0 && cy1 + 1 + DCP_LDS_MARGIN <= img.H - 1;
-  float xmn = __builtin_fminf(xf[0], xf[kLdsTH - 1]), xmx = __builtin_fmaxf(xf[0], xf[kLdsTH - 1]);
-  float ymn = __builtin_fminf(yf[0], yf[kLdsTH - 1]), ymx = __builtin_fmaxf(yf[0], yf[kLdsTH - 1]);
+  const bool box_inside = cx0 - kMargin >= 0 && cx1 + 1 + kMargin <= img.W - 1 &&
+                          cy0 - kMargin >= 0 && cy1 + 1 + kMargin <= img.H - 1;
+  float xmn = 0.f, xmx = 0.f, ymn = 0.f, ymx = 0.f;
+  if constexpr (VOTE) {
+    xmn = __builtin_fminf(xf[0], xf[kLdsTH - 1]), xmx = __builtin_fmaxf(xf[0], xf[kLdsTH - 1]);
+    ymn = __builtin_fminf(yf[0], yf[kLdsTH - 1]), ymx = __builtin_fmaxf(yf[0], yf[kLdsTH - 1]);
+  }
   auto rows_1b = [&](auto noclip, auto fastdiv) {
 #pragma unroll
     for (int k = 1; k < kLdsTH - 1; ++k) {
@@ -533,10 +587,12 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
         xf[k] = round_clip_f32(xd, wmaxf);
         yf[k] = round_clip_f32(yd, hmaxf);
       }
-      xmn = __builtin_fminf(xmn, xf[k]);
-      xmx = __builtin_fmaxf(xmx, xf[k]);
-      ymn = __builtin_fminf(ymn, yf[k]);
-      ymx = __builtin_fmaxf(ymx, yf[k]);
+      if constexpr (VOTE) {
+        xmn = __builtin_fminf(xmn, xf[k]);
+        xmx = __builtin_fmaxf(xmx, xf[k]);
+        ymn = __builtin_fminf(ymn, yf[k]);
+        ymx = __builtin_fmaxf(ymx, yf[k]);
+      }
     }
   };
   const bool unclipped = box_inside && fits;
@@ -551,51 +607,71 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
   }
   // tap columns are min(floor(xf), W-2) and +1: inside [bx0, bx1] iff xf >= bx0 and (xf < bx1 or
   // the coordinate was clipped and the box ends at the image edge)
-  const bool inside = xmn >= (float)bx0 && (xmx < (float)bx1 || (!unclipped && bx1 == img.W - 1)) &&
-                      ymn >= (float)by0 && (ymx < (float)by1 || (!unclipped && by1 == img.H - 1));
-  const bool staged = fits && __builtin_amdgcn_ballot_w64(!inside) == 0;
+  bool staged = fits;
+  if constexpr (VOTE) {
+    const bool inside = xmn >= (float)bx0 && (xmx < (float)bx1 || (!unclipped && bx1 == img.W - 1)) &&
+                        ymn >= (float)by0 && (ymx < (float)by1 || (!unclipped && by1 == img.H - 1));
+    staged = fits && __builtin_amdgcn_ballot_w64(!inside) == 0;
+  }
   if (!staged && lane == 0) atomicAdd(&g_lds_stats[fits ? 1 : 0], 1ull);
-#ifndef DCP_EXPERIMENT_NO_FILL_WAIT      // timing experiment only (results are then garbage)
+  DCP_TRACE(4);
+#if defined(DCP_EXPERIMENT_VGPR_FILL)
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    if (fits && lane < 60 && 3 * j + lrow < bh) *(u32x4*)(box + (3 * j + lrow) * kBoxW + lcol * 4) = fillv[j];
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#elif !defined(DCP_EXPERIMENT_NO_FILL_WAIT)      // timing experiment only (results are then garbage)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #endif
 
+  DCP_TRACE(5);
   // one descriptor for the rows of the tile that exist; the row offset goes through the scalar
   // offset (not bounds-checked, hence the explicit row and column predicates)
   if (!(x < img.W)) return;                      // no cross-lane work from here on
   if (staged) {
     // ---- phase 2: taps from LDS, blend, store.  Byte address of tap (y0, x0) in the slab:
     // (y0 - by0) * pitch + (x0 - bx0) floats = y0 * (4 pitch) + (4 x0 - 4 (by0 pitch + bx0))
-    const uint32_t negorg4 = (uint32_t)(-(by0 * kBoxW + bx0) * 4);
-    const char* boxb = (const char*)box;
+    // the slab's own byte offset inside the workgroup's LDS is folded into the origin term (one scalar add per tile
+    // instead of a vector add per pixel)
+    const uint32_t negorg4 = (uint32_t)(-(by0 * kBoxW + bx0) * 4) + (uint32_t)(wave * (kBoxH * kBoxW * 4));
+    const char* boxb = (const char*)&s_box[0][0];
     // A box that ends before the last image column/row cannot contain the clipped coordinate
     // W-1 / H-1, so interior tiles need no base-tap clamp: floor and fraction are one op each.
     const bool interior = bx1 < img.W - 1 && by1 < img.H - 1;
+    // interior tiles form the address in float32 (the only VALU ops that issue a wave in 2 cycles instead of 4):
+    // floor = c - fract(c) exactly, address = floor_y * 4 pitch + floor_x * 4 + origin, every term an integer
+    // below 2^24 (launch_lds checks H and W), one conversion at the end
+    const float negorg4f = (float)(int32_t)negorg4;
     auto tile_rows_loop = [&](auto full, auto inner) {
 #pragma unroll
       for (int k = 0; k < kLdsTH; ++k) {
         FetchT f;
-        int xi, yi;
+        uint32_t addr;
         if constexpr (SAMPLER == kNearest) {
           // order 0: index = floor(c + 0.5); it is one of the two bilinear tap indices, so it lies inside the box
-          xi = (int)xf[k];
-          yi = (int)yf[k];
+          int xi = (int)xf[k];
+          int yi = (int)yf[k];
           xi += (xf[k] - (float)xi >= 0.5f) ? 1 : 0;
           yi += (yf[k] - (float)yi >= 0.5f) ? 1 : 0;
+          uint32_t xa;
+          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
+          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kBoxW * 4), "v"(xa));
         } else if constexpr (decltype(inner)::value) {
-          xi = (int)xf[k];
-          yi = (int)yf[k];
           f.fx = __builtin_amdgcn_fractf(xf[k]);      // x - floor(x), exact
           f.fy = __builtin_amdgcn_fractf(yf[k]);
+          const float flx = xf[k] - f.fx, fly = yf[k] - f.fy;
+          const float af = __builtin_fmaf(fly, (float)(kBoxW * 4), __builtin_fmaf(flx, 4.0f, negorg4f));
+          addr = (uint32_t)(int32_t)af;
         } else {
-          xi = min((int)xf[k], img.W - 2);
-          yi = min((int)yf[k], img.H - 2);
+          const int xi = min((int)xf[k], img.W - 2);
+          const int yi = min((int)yf[k], img.H - 2);
           f.fx = xf[k] - (float)xi;
           f.fy = yf[k] - (float)yi;
+          uint32_t xa;
+          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
+          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kBoxW * 4), "v"(xa));
         }
-        uint32_t addr, xa;
-        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kBoxW * 4), "v"(xa));
         const float* t = (const float*)(boxb + addr);
         float v;
         if constexpr (SAMPLER == kNearest) {
@@ -619,8 +695,253 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
     if (rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{});
     else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
     else tile_rows_loop(std::false_type{}, std::false_type{});
+    DCP_TRACE(6);
   } else {
     // ---- box too large for the slab, or a tap outside the predicted box: direct global gather
+#pragma unroll
+    for (int k = 0; k < kLdsTH; ++k) {
+      const FetchT f = fetch<SAMPLER, true, float>(src, __builtin_amdgcn_fmed3f(xf[k], 0.0f, wmaxf),
+                                                   __builtin_amdgcn_fmed3f(yf[k], 0.0f, hmaxf));
+      const float v = finish<SAMPLER, true, float>(f);
+      if (k < rows)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
+                                              DCP_STORE_AUX);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ K1 / K2, workgroup-shared source box
+
+// The per-CU rate at which streamed source data can be brought in (vector L1 misses served by the L2: ~10 B/clk per
+// CU, ~5 TB/s over the chip -- MI355X_MICROARCH.md, "global_load_dwordx4 (HBM-bound)") is what bounds the staged
+// kernels, not HBM: with one box per WAVE tile (64 x 16 outputs, 80 x 21..24 floats fetched, every row segment cut
+// into 128-byte lines at both ends) the L2 -> L1 traffic is 8 B per output pixel for 4 B of source.  This kernel
+// stages ONE box per WORKGROUP: the four waves own a 2 x 2 arrangement of 64 x 16 sub-tiles (a 128 x 32 output tile),
+// the box is the hull of the workgroup tile's four corner pixels grown by one pixel (host certificate for that tile
+// shape: MapArgs::tile_dev_ok == 2), and the four waves copy it into one shared slab with 16-byte LDS-DMA loads --
+// longer row segments (fewer partial lines) and half the halo rows: ~5.9 B per output pixel.
+//   phase 1a  every wave evaluates the first and last row of its sub-tile; each wave owns one corner pixel of the
+//             workgroup tile and publishes its integer tap position through LDS (one barrier);
+//   fill      the slab is a linear array of 16-byte chunks, 36 per row of pitch 144 floats; chunk (4 j + wave) 64 + lane
+//             belongs to lane `lane` of wave `wave` in its j-th load (at most 6 per wave);
+//   phase 1b  the other 14 rows of the sub-tile while the loads are in flight;
+//   barrier   every wave waits for its own loads, then for the other waves';
+//   phase 2   taps from the shared slab, blend, store -- as in remap_lds_kernel.
+// A box that does not fit the slab (magnification > ~1.1) sends the whole workgroup to the direct global gather.
+constexpr int kWgTW = 128, kWgTH = 32;            // outputs per workgroup: 2 x 2 wave tiles of kLdsTW x kLdsTH
+constexpr int kWgBoxW = 144, kWgBoxH = 40;        // slab: 36 lanes x 16 B per row; 23 040 B
+static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wave tiles");
+
+template <int KIND, int NF, int SAMPLER>
+__global__ void __launch_bounds__(256, 6) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
+  __shared__ float s_box[kWgBoxH * kWgBoxW];
+  __shared__ double s_row[kWgTH][KIND == kRadial ? 2 : 4];
+  __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
+  __shared__ int s_corner[4][2];
+  using FetchT = Fetch<SAMPLER, true, float>;
+  constexpr int RW = KIND == kRadial ? 2 : 4;
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int wx = wave & 1, wy = wave >> 1;
+  // tile order: XCD blockIdx.x & 7 owns a vertical stripe of tile columns and sweeps it row by row (see remap_lds_kernel)
+  int tx, ty;
+  {
+    const int s = blockIdx.x & 7, c = blockIdx.x >> 3;
+    const int wq = img.tiles_x >> 3, wr = img.tiles_x & 7;
+    if (c >= wq + (s < wr ? 1 : 0)) return;
+    tx = s * wq + min(s, wr) + c;
+    ty = blockIdx.y;
+  }
+  const int yblk = ty * kWgTH;
+  // (wave-uniform by construction; said explicitly, or the store descriptor derived from it lands in VGPRs and every
+  // store is wrapped in a waterfall loop)
+  const int y0 = __builtin_amdgcn_readfirstlane(yblk + wy * kLdsTH);   // first row of this wave's sub-tile (inside the band of output rows)
+  const int x = tx * kWgTW + wx * kLdsTW + lane;
+
+  if ((int)threadIdx.x < kWgTH)
+    fill_row<KIND, RW>(map, s_row, threadIdx.x, (double)(img.y_origin + min(yblk + (int)threadIdx.x, img.rows_out - 1)));
+  if constexpr (NF < 0 && KIND != kPersp) {
+    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
+  }
+  __syncthreads();
+  // a wave whose sub-tile lies outside the image still publishes its corner and copies its share of the box
+  // (max(0, min(..)) selects v_med3_i32, a VALU-only instruction: without the readfirstlane the value -- and the store
+  // descriptor built from it -- would live in VGPRs)
+  const int rows = __builtin_amdgcn_readfirstlane(max(0, min(kLdsTH, img.rows_out - y0)));
+  const int ybase = __builtin_amdgcn_readfirstlane(min(y0, img.rows_out - 1));
+
+  const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
+  const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
+  const ColCtx col = make_col<KIND, NF>(map, min(x, img.W - 1));
+  const auto* rowtab = s_row + wy * kLdsTH;
+  const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
+  const char* out_base = (const char*)(img.dst + (size_t)ybase * (size_t)img.W);
+  const uint32_t xoff = (uint32_t)x * 4u;         // lanes with x >= W: the store is out of range and dropped
+  const __amdgpu_buffer_rsrc_t dst =
+      __builtin_amdgcn_make_buffer_rsrc((void*)out_base, 0, (int)((uint32_t)rows * row_bytes_out), 0x00020000);
+
+  // ---- phase 1a: first and last row of the sub-tile
+  float xf[kLdsTH], yf[kLdsTH];
+  auto eval_row = [&](int k) {
+    double xd, yd;
+    map_coord<KIND, NF, RW>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+    xf[k] = round_clip_f32(xd, wmaxf);
+    yf[k] = round_clip_f32(yd, hmaxf);
+  };
+  eval_row(0);
+  eval_row(kLdsTH - 1);
+  // this wave's corner of the workgroup tile: row 0 or 15 of its sub-tile, lane 0 or 63 (rows and columns past the
+  // image were clamped to the last valid ones, so the four corners span exactly the valid part of the tile)
+  {
+    const int cxa = (int)(wy ? xf[kLdsTH - 1] : xf[0]), cya = (int)(wy ? yf[kLdsTH - 1] : yf[0]);
+    const int cxs = wx ? __builtin_amdgcn_readlane(cxa, 63) : __builtin_amdgcn_readlane(cxa, 0);
+    const int cys = wx ? __builtin_amdgcn_readlane(cya, 63) : __builtin_amdgcn_readlane(cya, 0);
+    if (lane == 0) {
+      s_corner[wave][0] = cxs;
+      s_corner[wave][1] = cys;
+    }
+  }
+  __syncthreads();
+  int cx0, cx1, cy0, cy1;
+  {
+    int cx[4], cy[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      cx[w] = __builtin_amdgcn_readfirstlane(s_corner[w][0]);
+      cy[w] = __builtin_amdgcn_readfirstlane(s_corner[w][1]);
+    }
+    cx0 = min(min(cx[0], cx[1]), min(cx[2], cx[3]));
+    cx1 = max(max(cx[0], cx[1]), max(cx[2], cx[3]));
+    cy0 = min(min(cy[0], cy[1]), min(cy[2], cy[3]));
+    cy1 = max(max(cy[0], cy[1]), max(cy[2], cy[3]));
+  }
+  // hull of the corner taps grown by one pixel (the certified deviation is below one pixel)
+  const int bx0 = max(min(cx0 - 1, img.W - 2), 0);
+  const int bx1 = min(cx1 + 2, img.W - 1);
+  const int by0 = max(min(cy0 - 1, img.H - 2), 0);
+  const int by1 = min(cy1 + 2, img.H - 1);
+  const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+  const bool fits = bw <= kWgBoxW && bh <= kWgBoxH;          // workgroup-uniform
+
+  // ---- fill: this wave's share of the box
+  if (fits) {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    static_assert(kWgBoxW == 144, "the fill maps 36 chunks of 16 bytes to one slab row");
+    const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
+    const uint32_t rstep = (uint32_t)img.src_stride * 4u;
+    // chunk (4 j + wave) * 64 + lane = 36 row + c16; advancing j by one adds 256 chunks = 7 rows + 4 chunks
+    int c = wave * 64 + lane;
+    int crow = (int)(__umul24((uint32_t)c, 1821u) >> 16);       // c / 36 for c < 256 (1821 = ceil(65536 / 36))
+    int c16 = c - crow * 36;
+    const int nchunk = bh * 36;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      // wave-uniform: does any chunk of this load lie inside the box rows?
+      if ((j * 4 + wave) * 64 < nchunk) {
+        // lanes whose chunk lies past the last box row are masked off (an out-of-range offset would still write
+        // zeros into LDS -- past the end of the slab when the box is 40 rows tall)
+        if (crow < bh)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 256), 16,
+                                                   org + (uint32_t)crow * rstep + (uint32_t)c16 * 16u, 0, 0, 0);
+      }
+      c16 += 4;
+      crow += 7;
+      if (c16 >= 36) {
+        c16 -= 36;
+        crow += 1;
+      }
+    }
+  }
+
+  // ---- phase 1b: the other rows.  A box strictly inside the image needs no clip (every coordinate lies inside the box).
+  const bool box_inside = cx0 - 1 >= 0 && cx1 + 2 <= img.W - 1 && cy0 - 1 >= 0 && cy1 + 2 <= img.H - 1;
+  const bool unclipped = box_inside && fits;
+  auto rows_1b = [&](auto noclip, auto fastdiv) {
+#pragma unroll
+    for (int k = 1; k < kLdsTH - 1; ++k) {
+      double xd, yd;
+      map_coord<KIND, NF, RW, decltype(fastdiv)::value>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+      if constexpr (decltype(noclip)::value) {
+        xf[k] = (float)xd;
+        yf[k] = (float)yd;
+      } else {
+        xf[k] = round_clip_f32(xd, wmaxf);
+        yf[k] = round_clip_f32(yd, hmaxf);
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  if (rows > 0) {
+    if (KIND == kRadial || !map.fast_div) {
+      if (unclipped) rows_1b(std::true_type{}, I0{});
+      else rows_1b(std::false_type{}, I0{});
+    } else {
+      if (unclipped) rows_1b(std::true_type{}, I1{});
+      else rows_1b(std::false_type{}, I1{});
+    }
+  }
+  if (!fits && lane == 0 && wave == 0) atomicAdd(&g_lds_stats[0], 1ull);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();                                 // every wave's share of the box has landed
+
+  if (rows == 0 || !(x < img.W)) return;           // no cross-lane work from here on
+  if (fits) {
+    // ---- phase 2: taps from the shared slab, blend, store
+    const uint32_t negorg4 = (uint32_t)(-(by0 * kWgBoxW + bx0) * 4);
+    const char* boxb = (const char*)s_box;
+    const bool interior = bx1 < img.W - 1 && by1 < img.H - 1;
+    const float negorg4f = (float)(int32_t)negorg4;
+    auto tile_rows_loop = [&](auto full, auto inner) {
+#pragma unroll
+      for (int k = 0; k < kLdsTH; ++k) {
+        FetchT f;
+        uint32_t addr;
+        if constexpr (SAMPLER == kNearest) {
+          int xi = (int)xf[k];
+          int yi = (int)yf[k];
+          xi += (xf[k] - (float)xi >= 0.5f) ? 1 : 0;
+          yi += (yf[k] - (float)yi >= 0.5f) ? 1 : 0;
+          uint32_t xa;
+          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
+          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kWgBoxW * 4), "v"(xa));
+        } else if constexpr (decltype(inner)::value) {
+          f.fx = __builtin_amdgcn_fractf(xf[k]);      // x - floor(x), exact
+          f.fy = __builtin_amdgcn_fractf(yf[k]);
+          const float flx = xf[k] - f.fx, fly = yf[k] - f.fy;
+          const float af = __builtin_fmaf(fly, (float)(kWgBoxW * 4), __builtin_fmaf(flx, 4.0f, negorg4f));
+          addr = (uint32_t)(int32_t)af;
+        } else {
+          const int xi = min((int)xf[k], img.W - 2);
+          const int yi = min((int)yf[k], img.H - 2);
+          f.fx = xf[k] - (float)xi;
+          f.fy = yf[k] - (float)yi;
+          uint32_t xa;
+          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
+          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kWgBoxW * 4), "v"(xa));
+        }
+        const float* t = (const float*)(boxb + addr);
+        float v;
+        if constexpr (SAMPLER == kNearest) {
+          v = t[0];
+        } else {
+          f.a.x = __float_as_uint(t[0]);
+          f.a.y = __float_as_uint(t[1]);
+          f.b.x = __float_as_uint(t[kWgBoxW]);
+          f.b.y = __float_as_uint(t[kWgBoxW + 1]);
+          v = finish<SAMPLER, true, float>(f);
+        }
+        if (decltype(full)::value || k < rows)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
+                                                DCP_STORE_AUX);
+      }
+    };
+    if (rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{});
+    else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
+    else tile_rows_loop(std::false_type{}, std::false_type{});
+  } else {
+    // ---- box too large for the slab: direct global gather
 #pragma unroll
     for (int k = 0; k < kLdsTH; ++k) {
       const FetchT f = fetch<SAMPLER, true, float>(src, __builtin_amdgcn_fmed3f(xf[k], 0.0f, wmaxf),
@@ -917,24 +1238,55 @@ static hipError_t launch_one(const ImageArgs& img, const MapArgs& map, hipStream
   return hipGetLastError();
 }
 
-template <int KIND, int NF, int SAMPLER>
+// The staged kernel forms LDS addresses in float32: every term must be an integer below 2^24.
+static bool lds_addressable(const ImageArgs& img) {
+  return (int64_t)img.H * (kWgBoxW * 4) + (int64_t)img.W * 4 + 4 * (int64_t)(kLdsBW * kBoxH * kBoxW * 4) < (1 << 24);
+}
+
+template <int KIND, int NF, int SAMPLER, bool VOTE>
 static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {
   ImageArgs img = img_in;
   img.tiles_x = (img.W + kLdsTW - 1) / kLdsTW;
   img.tiles_y = (img.rows_out + kLdsBW * kLdsTH - 1) / (kLdsBW * kLdsTH);
   dim3 grid(img.tiles_x * img.tiles_y);
   if (img.xcd_remap == 2) grid = dim3(8 * ((img.tiles_x + 7) / 8), img.tiles_y);   // see the kernel's tile order
-  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER>), grid, dim3(64 * kLdsBW), 0, stream, img, map);
+  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER, VOTE>), grid, dim3(64 * kLdsBW), 0, stream, img, map);
   return hipGetLastError();
+}
+
+template <int KIND, int NF, int SAMPLER>
+static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {
+  ImageArgs img = img_in;
+  img.tiles_x = (img.W + kWgTW - 1) / kWgTW;
+  img.tiles_y = (img.rows_out + kWgTH - 1) / kWgTH;
+  const dim3 grid(8 * ((img.tiles_x + 7) / 8), img.tiles_y);     // XCD stripe order, see the kernel
+  hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), 0, stream, img, map);
+  return hipGetLastError();
+}
+
+// VOTE = false needs the host's certificate (MapArgs::tile_dev_ok); without it the runtime-length polynomial
+// variant with the per-pixel vote runs (one uncertified instantiation per map kind and sampler instead of eleven).
+// The fused map always votes: its inner clip (the perspective position clipped to the frame before the radial model
+// is applied) makes the composed map non-smooth, so no curvature bound holds for it.
+template <int KIND, int NF, int SAMPLER>
+static hipError_t launch_lds_vote(const ImageArgs& img, const MapArgs& map, hipStream_t stream) {
+  if constexpr (KIND == kFused) {
+    return launch_lds<KIND, NF, SAMPLER, true>(img, map, stream);
+  } else {
+    // certificate levels: 2 = holds for 128 x 32 tiles (workgroup-shared box), 1 = for 64 x 16 tiles only
+    if (map.tile_dev_ok >= 2 && img.wg_box && img.xcd_remap == 2) return launch_wg<KIND, NF, SAMPLER>(img, map, stream);
+    if (map.tile_dev_ok) return launch_lds<KIND, NF, SAMPLER, false>(img, map, stream);
+    return launch_lds<KIND, -1, SAMPLER, true>(img, map, stream);
+  }
 }
 
 template <int KIND, int NF>
 static hipError_t launch_lds_any(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
   switch (sampler) {
-    case kNearest: return launch_lds<KIND, NF, kNearest>(img, map, stream);
-    case kScipy: return launch_lds<KIND, NF, kScipy>(img, map, stream);
-    case kF64Lerp: return launch_lds<KIND, NF, kF64Lerp>(img, map, stream);
-    default: return launch_lds<KIND, NF, kF32Lerp>(img, map, stream);
+    case kNearest: return launch_lds_vote<KIND, NF, kNearest>(img, map, stream);
+    case kScipy: return launch_lds_vote<KIND, NF, kScipy>(img, map, stream);
+    case kF64Lerp: return launch_lds_vote<KIND, NF, kF64Lerp>(img, map, stream);
+    default: return launch_lds_vote<KIND, NF, kF32Lerp>(img, map, stream);
   }
 }
 
@@ -974,13 +1326,14 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
   img.tiles_y = (img.rows_out + tr - 1) / tr;
   img.xcd_remap = opts.xcd_remap;
   img.pipe_depth = opts.pipe_depth;
-  img.lds_gather = opts.lds_gather;
+  img.lds_gather = opts.lds_gather && lds_addressable(img);
+  img.wg_box = opts.wg_box;
   // the 8-byte pair gather needs unit column stride and at least a 2x2 image
   const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2;
   const int nf = map.nfact;
 
   // order-1 remaps of dense float32 images with float32 coordinates: LDS-staged gather
-  const bool lds = pair && round_f32 && opts.lds_gather;
+  const bool lds = pair && round_f32 && img.lds_gather;
   if (kind == kPersp) {
     if (lds) return launch_lds_any<kPersp, -1>(img, map, sampler, stream);
     if (pair) return launch_generic<kPersp, true, true>(img, map, sampler, stream);
@@ -1083,6 +1436,12 @@ static hipError_t launch_stack_t(const StackArgs& st, const MapArgs& map, int sa
   }
   return hipGetLastError();
 }
+
+#ifdef DCP_EXPERIMENT_TRACE
+extern "C" int dcp_experiment_read_trace(unsigned long long* out, int nwaves) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8 * (size_t)nwaves);
+}
+#endif
 
 hipError_t read_lds_stats(unsigned long long* out, bool reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lds_stats), sizeof(g_lds_stats));
