@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -33,6 +33,7 @@ dcp::LaunchOpts current_opts() {
   o.lds_gather = g_lds_gather.load();
   o.stack_lds = g_stack_lds.load();
   o.wg_box = g_wg_box.load();
+  o.wg_per_cu = g_wg_per_cu.load();
   return o;
 }
 
@@ -338,6 +339,9 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "host_bands")) {
     if (value < 1 || value > 256) return fail(DCP_ERR_INVALID_ARG, "host_bands must be in [1, 256]");
     g_host_bands = value;
+  } else if (!strcmp(key, "wg_per_cu")) {
+    if (value < 0 || value > 6) return fail(DCP_ERR_INVALID_ARG, "wg_per_cu must be in [0, 6]");
+    g_wg_per_cu = value;
   } else if (!strcmp(key, "wg_box")) {
     g_wg_box = value ? 1 : 0;         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
   } else if (!strcmp(key, "tile_cert")) {
@@ -365,6 +369,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "host_bands")) *value = g_host_bands;
   else if (!strcmp(key, "tile_cert")) *value = g_tile_cert;
   else if (!strcmp(key, "wg_box")) *value = g_wg_box;
+  else if (!strcmp(key, "wg_per_cu")) *value = g_wg_per_cu;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }

@@ -30,6 +30,7 @@ struct ImageArgs {
   int32_t pipe_depth;      // rows of gathers in flight per thread (1, 2 or 4)
   int32_t lds_gather;      // 1: stage the source box of each wave tile in LDS (remap_lds_kernel)
   int32_t wg_box;          // 1: one box per workgroup (remap_wg_kernel) when the certificate allows it
+  int32_t wg_per_cu;       // remap_wg_kernel: workgroups resident per CU (0 = as many as fit: 6)
   int32_t y_origin;        // a launch may cover only output rows [y_origin, y_origin + rows_out) of the H x W map;
   int32_t rows_out;        // dst then points at row y_origin (0 / 0 = the whole image)
 };
@@ -119,6 +120,7 @@ struct LaunchOpts {
   int d_chunk = 16;
   int stack_lds = 1;       // LDS-staged stack kernel: 0 never, 1 when the launch has enough wave tiles, 2 always
   int wg_box = 1;          // 1: remap_wg_kernel (one source box per 128 x 32 workgroup tile) for certified maps
+  int wg_per_cu = 0;       // remap_wg_kernel: cap on resident workgroups per CU (0 = none)
 };
 
 // launchers (unwarp_kernels.hip)

@@ -374,12 +374,12 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
 __device__ unsigned long long g_lds_stats[2];
 
 #ifdef DCP_EXPERIMENT_TRACE   // timing experiment: per-wave phase timestamps (tools/trace_k1.py)
-__device__ unsigned long long g_trace[65536 * 8];
+__device__ unsigned long long g_trace[65536 * 12];
 #define DCP_TRACE(slot)                                                                                         \
   do {                                                                                                          \
     if (trace_on) {                                                                                             \
       const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
-      if (lane == 0) g_trace[trace_id * 8 + (slot)] = t_;                                                       \
+      if (lane == 0) g_trace[trace_id * 12 + (slot)] = t_;                                                      \
     }                                                                                                           \
   } while (0)
 #else
@@ -435,7 +435,8 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_trace[trace_id * 8 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    g_trace[trace_id * 12 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    g_trace[trace_id * 12 + 8] = __builtin_readcyclecounter() * 0 + __builtin_amdgcn_s_memrealtime();
   }
 #endif
   int tx, ty;
@@ -696,6 +697,9 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
     else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
     else tile_rows_loop(std::false_type{}, std::false_type{});
     DCP_TRACE(6);
+#ifdef DCP_EXPERIMENT_TRACE
+    if (trace_on && lane == 0) g_trace[trace_id * 12 + 9] = __builtin_amdgcn_s_memrealtime();
+#endif
   } else {
     // ---- box too large for the slab, or a tap outside the predicted box: direct global gather
 #pragma unroll
@@ -720,30 +724,47 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
 // the box is the hull of the workgroup tile's four corner pixels grown by one pixel (host certificate for that tile
 // shape: MapArgs::tile_dev_ok == 2), and the four waves copy it into one shared slab with 16-byte LDS-DMA loads --
 // longer row segments (fewer partial lines) and half the halo rows: ~5.9 B per output pixel.
-//   phase 1a  every wave evaluates the first and last row of its sub-tile; each wave owns one corner pixel of the
-//             workgroup tile and publishes its integer tap position through LDS (one barrier);
+//   corners   every wave evaluates the workgroup tile's four corner pixels itself (lanes 0..3): no exchange, no barrier;
 //   fill      the slab is a linear array of 16-byte chunks, 36 per row of pitch 144 floats; chunk (4 j + wave) 64 + lane
 //             belongs to lane `lane` of wave `wave` in its j-th load (at most 6 per wave);
-//   phase 1b  the other 14 rows of the sub-tile while the loads are in flight;
-//   barrier   every wave waits for its own loads, then for the other waves';
+//   phase 1   the source coordinates of the sub-tile's 16 rows while the loads are in flight (row table per wave);
+//   barrier   every wave waits for its own loads, then for the other waves' (the only barrier of the kernel);
 //   phase 2   taps from the shared slab, blend, store -- as in remap_lds_kernel.
 // A box that does not fit the slab (magnification > ~1.1) sends the whole workgroup to the direct global gather.
 constexpr int kWgTW = 128, kWgTH = 32;            // outputs per workgroup: 2 x 2 wave tiles of kLdsTW x kLdsTH
-constexpr int kWgBoxW = 144, kWgBoxH = 40;        // slab: 36 lanes x 16 B per row; 23 040 B
+constexpr int kWgBoxW = 144, kWgBoxH = 40;        // largest box: 36 chunks of 16 B per row, 40 rows
+constexpr int kWgSlabRows = 40;                   // 23 040 B
 static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wave tiles");
 
+#ifndef DCP_WG_FILL_EVERY
+#define DCP_WG_FILL_EVERY 1   // phase 1 rows between two loads of the fill (0: all six loads in one burst in front of phase 1)
+#endif
+#ifndef DCP_WG_WAVES
+#define DCP_WG_WAVES 6      // waves per SIMD the register allocation aims at (six 24 KB workgroups fit a CU's LDS)
+#endif
 template <int KIND, int NF, int SAMPLER>
-__global__ void __launch_bounds__(256, 6) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
-  __shared__ float s_box[kWgBoxH * kWgBoxW];
-  __shared__ double s_row[kWgTH][KIND == kRadial ? 2 : 4];
+__global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
+  __shared__ float s_box[kWgSlabRows * kWgBoxW];
+  __shared__ double s_row[4][kLdsTH][KIND == kRadial ? 2 : 4];     // one row table per wave: no barrier before it is read
   __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
-  __shared__ int s_corner[4][2];
   using FetchT = Fetch<SAMPLER, true, float>;
   constexpr int RW = KIND == kRadial ? 2 : 4;
 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
   const int wx = wave & 1, wy = wave >> 1;
+#ifdef DCP_EXPERIMENT_TRACE
+  const unsigned trace_id = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+  const bool trace_on = trace_id < 65536u;
+  DCP_TRACE(0);
+  if (trace_on && lane == 0) {
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_trace[trace_id * 12 + 7] = ((unsigned long long)xcc << 32) | hwid;
+    g_trace[trace_id * 12 + 8] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   // tile order: XCD blockIdx.x & 7 owns a vertical stripe of tile columns and sweeps it row by row (see remap_lds_kernel)
   int tx, ty;
   {
@@ -758,63 +779,45 @@ __global__ void __launch_bounds__(256, 6) remap_wg_kernel(const ImageArgs img, c
   // store is wrapped in a waterfall loop)
   const int y0 = __builtin_amdgcn_readfirstlane(yblk + wy * kLdsTH);   // first row of this wave's sub-tile (inside the band of output rows)
   const int x = tx * kWgTW + wx * kLdsTW + lane;
-
-  if ((int)threadIdx.x < kWgTH)
-    fill_row<KIND, RW>(map, s_row, threadIdx.x, (double)(img.y_origin + min(yblk + (int)threadIdx.x, img.rows_out - 1)));
-  if constexpr (NF < 0 && KIND != kPersp) {
-    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
-  }
-  __syncthreads();
-  // a wave whose sub-tile lies outside the image still publishes its corner and copies its share of the box
-  // (max(0, min(..)) selects v_med3_i32, a VALU-only instruction: without the readfirstlane the value -- and the store
-  // descriptor built from it -- would live in VGPRs)
-  const int rows = __builtin_amdgcn_readfirstlane(max(0, min(kLdsTH, img.rows_out - y0)));
-  const int ybase = __builtin_amdgcn_readfirstlane(min(y0, img.rows_out - 1));
-
-  const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
   const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
-  const ColCtx col = make_col<KIND, NF>(map, min(x, img.W - 1));
-  const auto* rowtab = s_row + wy * kLdsTH;
-  const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
-  const char* out_base = (const char*)(img.dst + (size_t)ybase * (size_t)img.W);
-  const uint32_t xoff = (uint32_t)x * 4u;         // lanes with x >= W: the store is out of range and dropped
-  const __amdgpu_buffer_rsrc_t dst =
-      __builtin_amdgcn_make_buffer_rsrc((void*)out_base, 0, (int)((uint32_t)rows * row_bytes_out), 0x00020000);
 
-  // ---- phase 1a: first and last row of the sub-tile
-  float xf[kLdsTH], yf[kLdsTH];
-  auto eval_row = [&](int k) {
-    double xd, yd;
-    map_coord<KIND, NF, RW>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
-    xf[k] = round_clip_f32(xd, wmaxf);
-    yf[k] = round_clip_f32(yd, hmaxf);
-  };
-  eval_row(0);
-  eval_row(kLdsTH - 1);
-  // this wave's corner of the workgroup tile: row 0 or 15 of its sub-tile, lane 0 or 63 (rows and columns past the
-  // image were clamped to the last valid ones, so the four corners span exactly the valid part of the tile)
-  {
-    const int cxa = (int)(wy ? xf[kLdsTH - 1] : xf[0]), cya = (int)(wy ? yf[kLdsTH - 1] : yf[0]);
-    const int cxs = wx ? __builtin_amdgcn_readlane(cxa, 63) : __builtin_amdgcn_readlane(cxa, 0);
-    const int cys = wx ? __builtin_amdgcn_readlane(cya, 63) : __builtin_amdgcn_readlane(cya, 0);
-    if (lane == 0) {
-      s_corner[wave][0] = cxs;
-      s_corner[wave][1] = cys;
-    }
-  }
-  __syncthreads();
+  // ---- the workgroup tile's four corner pixels, one per lane 0..3, by every wave for itself (no exchange, no barrier:
+  // the fill below can start a few hundred cycles into the wave's life).  Pixels past the image are clamped to the
+  // last valid ones, so the corners span exactly the valid part of the tile.  The values may differ from the
+  // row-hoisted evaluation of phase 1 in the last bits; the certificate leaves 0.05 px for that.
   int cx0, cx1, cy0, cy1;
   {
-    int cx[4], cy[4];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      cx[w] = __builtin_amdgcn_readfirstlane(s_corner[w][0]);
-      cy[w] = __builtin_amdgcn_readfirstlane(s_corner[w][1]);
+    const double X = (double)min(tx * kWgTW + (lane & 1) * (kWgTW - 1), img.W - 1);
+    const double Y = (double)(img.y_origin + min(yblk + ((lane >> 1) & 1) * (kWgTH - 1), img.rows_out - 1));
+    double xd, yd;
+    if constexpr (KIND == kRadial) {
+      const double xu = X - map.xc, yu = Y - map.yc;
+      const double r2 = xu * xu + yu * yu;
+      const double ru = sqrt_rn(r2);
+      double f;
+      if constexpr (NF >= 0) {
+        double le, lo;
+        poly_leads<NF>(map.fact, &le, &lo);
+        f = poly_inline<NF>(map.fact, le, lo, r2, ru);
+      } else {
+        f = poly_lds(map.fact, map.nfact, r2, ru);          // straight from the kernel arguments (uniform loads)
+      }
+      xd = __builtin_fma(f, xu, map.xc);
+      yd = __builtin_fma(f, yu, map.yc);
+    } else {
+      const double den = (map.coef[6] * X + map.coef[7] * Y) + 1.0;
+      xd = ((map.coef[0] * X + map.coef[1] * Y) + map.coef[2]) / den;
+      yd = ((map.coef[3] * X + map.coef[4] * Y) + map.coef[5]) / den;
     }
-    cx0 = min(min(cx[0], cx[1]), min(cx[2], cx[3]));
-    cx1 = max(max(cx[0], cx[1]), max(cx[2], cx[3]));
-    cy0 = min(min(cy[0], cy[1]), min(cy[2], cy[3]));
-    cy1 = max(max(cy[0], cy[1]), max(cy[2], cy[3]));
+    const int cxi = (int)round_clip_f32(xd, wmaxf), cyi = (int)round_clip_f32(yd, hmaxf);
+    const int xa = __builtin_amdgcn_readlane(cxi, 0), xb = __builtin_amdgcn_readlane(cxi, 1);
+    const int xc_ = __builtin_amdgcn_readlane(cxi, 2), xd_ = __builtin_amdgcn_readlane(cxi, 3);
+    const int ya = __builtin_amdgcn_readlane(cyi, 0), yb = __builtin_amdgcn_readlane(cyi, 1);
+    const int yc_ = __builtin_amdgcn_readlane(cyi, 2), yd_ = __builtin_amdgcn_readlane(cyi, 3);
+    cx0 = min(min(xa, xb), min(xc_, xd_));
+    cx1 = max(max(xa, xb), max(xc_, xd_));
+    cy0 = min(min(ya, yb), min(yc_, yd_));
+    cy1 = max(max(ya, yb), max(yc_, yd_));
   }
   // hull of the corner taps grown by one pixel (the certified deviation is below one pixel)
   const int bx0 = max(min(cx0 - 1, img.W - 2), 0);
@@ -823,43 +826,80 @@ __global__ void __launch_bounds__(256, 6) remap_wg_kernel(const ImageArgs img, c
   const int by1 = min(cy1 + 2, img.H - 1);
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   const bool fits = bw <= kWgBoxW && bh <= kWgBoxH;          // workgroup-uniform
+  DCP_TRACE(1);
+  DCP_TRACE(2);
 
-  // ---- fill: this wave's share of the box
-  if (fits) {
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-    static_assert(kWgBoxW == 144, "the fill maps 36 chunks of 16 bytes to one slab row");
-    const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
-    const uint32_t rstep = (uint32_t)img.src_stride * 4u;
-    // chunk (4 j + wave) * 64 + lane = 36 row + c16; advancing j by one adds 256 chunks = 7 rows + 4 chunks
-    int c = wave * 64 + lane;
-    int crow = (int)(__umul24((uint32_t)c, 1821u) >> 16);       // c / 36 for c < 256 (1821 = ceil(65536 / 36))
-    int c16 = c - crow * 36;
-    const int nchunk = bh * 36;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      // wave-uniform: does any chunk of this load lie inside the box rows?
-      if ((j * 4 + wave) * 64 < nchunk) {
-        // lanes whose chunk lies past the last box row are masked off (an out-of-range offset would still write
-        // zeros into LDS -- past the end of the slab when the box is 40 rows tall)
-        if (crow < bh)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 256), 16,
-                                                   org + (uint32_t)crow * rstep + (uint32_t)c16 * 16u, 0, 0, 0);
-      }
-      c16 += 4;
-      crow += 7;
-      if (c16 >= 36) {
-        c16 -= 36;
-        crow += 1;
-      }
+  // ---- fill: this wave's share of the box.  The slab is a linear array of 16-byte chunks, 36 per row of pitch 144
+  // floats; chunk (4 j + wave) 64 + lane belongs to lane `lane` of wave `wave` in its j-th load (at most 6 per wave).
+  // Advancing j adds 256 chunks = 7 rows + 4 chunks: row and byte offset of load j follow from those of load 0 with
+  // one wrap test.  (A/B-tested against dealing whole row triples to the waves through per-load descriptors -- no
+  // vector arithmetic per load at all, but 5 us slower per frame.)  The loads are not issued in one burst: load j
+  // goes out in front of coordinate row DCP_WG_FILL_EVERY * j of phase 1 (a wave stuck at a full memory queue does no arithmetic).
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  static_assert(kWgBoxW == 144 && kWgBoxH * 36 <= 6 * 256, "six loads of 64 chunks per wave cover the slab");
+  const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
+  const uint32_t rstep = (uint32_t)img.src_stride * 4u;
+  const int fc = wave * 64 + lane;
+  const int crow0 = (int)(__umul24((uint32_t)fc, 1821u) >> 16);       // fc / 36 for fc < 256 (1821 = ceil(65536 / 36))
+  const int c160 = fc - crow0 * 36;
+  const uint32_t off0 = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u + (uint32_t)crow0 * rstep + (uint32_t)c160 * 16u;
+  const int nchunk = bh * 36;
+  auto issue_fill = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if (fits && (j * 4 + wave) * 64 < nchunk) {               // wave-uniform: does any chunk of this load lie inside the box?
+      const bool wrap = c160 >= 36 - 4 * j;                   // (c160 + 4 j) mod 36 wrapped into the next row (at most once: c160 + 20 < 72)
+      const int crow = crow0 + 7 * j + (wrap ? 1 : 0);
+      // lanes whose chunk lies past the last box row are masked off (an out-of-range offset would still write
+      // zeros into LDS -- past the end of the slab when the box is 40 rows tall)
+      if (crow < bh)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 256), 16,
+                                                 off0 + (wrap ? rstep - 576u : 0u) + (uint32_t)j * (7u * rstep + 64u), 0, 0, 0);
     }
-  }
+  };
 
-  // ---- phase 1b: the other rows.  A box strictly inside the image needs no clip (every coordinate lies inside the box).
+  DCP_TRACE(3);
+  // ---- row table of this wave's 16 rows (lanes 0..15; same-wave LDS traffic is ordered, no barrier)
+  if (lane < kLdsTH)
+    fill_row<KIND, RW>(map, s_row[wave], lane, (double)(img.y_origin + min(y0 + lane, img.rows_out - 1)));
+  if constexpr (NF < 0 && KIND != kPersp) {
+    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
+    __syncthreads();
+  }
+  // (max(0, min(..)) selects v_med3_i32, a VALU-only instruction: without the readfirstlane the value -- and the store
+  // descriptor built from it -- would live in VGPRs)
+  const int rows = __builtin_amdgcn_readfirstlane(max(0, min(kLdsTH, img.rows_out - y0)));
+  const int ybase = __builtin_amdgcn_readfirstlane(min(y0, img.rows_out - 1));
+  const ColCtx col = make_col<KIND, NF>(map, min(x, img.W - 1));
+  const auto* rowtab = s_row[wave];
+  const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
+  const char* out_base = (const char*)(img.dst + (size_t)ybase * (size_t)img.W);
+  const uint32_t xoff = (uint32_t)x * 4u;         // lanes with x >= W: the store is out of range and dropped
+  const __amdgpu_buffer_rsrc_t dst =
+      __builtin_amdgcn_make_buffer_rsrc((void*)out_base, 0, (int)((uint32_t)rows * row_bytes_out), 0x00020000);
+
+  // ---- phase 1: the source coordinates of the sub-tile's 16 rows, while the loads are in flight.  A box strictly
+  // inside the image needs no clip (every coordinate lies inside the box).
+  float xf[kLdsTH], yf[kLdsTH];
   const bool box_inside = cx0 - 1 >= 0 && cx1 + 2 <= img.W - 1 && cy0 - 1 >= 0 && cy1 + 2 <= img.H - 1;
   const bool unclipped = box_inside && fits;
-  auto rows_1b = [&](auto noclip, auto fastdiv) {
+  auto rows_1 = [&](auto noclip, auto fastdiv) {
+    issue_fill(std::integral_constant<int, 0>{});
+    if constexpr (DCP_WG_FILL_EVERY == 0) {
+      issue_fill(std::integral_constant<int, 1>{});
+      issue_fill(std::integral_constant<int, 2>{});
+      issue_fill(std::integral_constant<int, 3>{});
+      issue_fill(std::integral_constant<int, 4>{});
+      issue_fill(std::integral_constant<int, 5>{});
+    }
 #pragma unroll
-    for (int k = 1; k < kLdsTH - 1; ++k) {
+    for (int k = 0; k < kLdsTH; ++k) {
+      if constexpr (DCP_WG_FILL_EVERY > 0) {
+        if (k == 1 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 1>{});
+        if (k == 2 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 2>{});
+        if (k == 3 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 3>{});
+        if (k == 4 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 4>{});
+        if (k == 5 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 5>{});
+      }
       double xd, yd;
       map_coord<KIND, NF, RW, decltype(fastdiv)::value>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
       if constexpr (decltype(noclip)::value) {
@@ -875,16 +915,25 @@ __global__ void __launch_bounds__(256, 6) remap_wg_kernel(const ImageArgs img, c
   using I1 = std::integral_constant<int, 1>;
   if (rows > 0) {
     if (KIND == kRadial || !map.fast_div) {
-      if (unclipped) rows_1b(std::true_type{}, I0{});
-      else rows_1b(std::false_type{}, I0{});
+      if (unclipped) rows_1(std::true_type{}, I0{});
+      else rows_1(std::false_type{}, I0{});
     } else {
-      if (unclipped) rows_1b(std::true_type{}, I1{});
-      else rows_1b(std::false_type{}, I1{});
+      if (unclipped) rows_1(std::true_type{}, I1{});
+      else rows_1(std::false_type{}, I1{});
     }
+  } else {                                         // nothing to compute for this wave: only its share of the copy
+    issue_fill(std::integral_constant<int, 0>{});
+    issue_fill(std::integral_constant<int, 1>{});
+    issue_fill(std::integral_constant<int, 2>{});
+    issue_fill(std::integral_constant<int, 3>{});
+    issue_fill(std::integral_constant<int, 4>{});
+    issue_fill(std::integral_constant<int, 5>{});
   }
   if (!fits && lane == 0 && wave == 0) atomicAdd(&g_lds_stats[0], 1ull);
+  DCP_TRACE(4);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();                                 // every wave's share of the box has landed
+  DCP_TRACE(5);
 
   if (rows == 0 || !(x < img.W)) return;           // no cross-lane work from here on
   if (fits) {
@@ -940,6 +989,10 @@ __global__ void __launch_bounds__(256, 6) remap_wg_kernel(const ImageArgs img, c
     if (rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{});
     else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
     else tile_rows_loop(std::false_type{}, std::false_type{});
+    DCP_TRACE(6);
+#ifdef DCP_EXPERIMENT_TRACE
+    if (trace_on && lane == 0) g_trace[trace_id * 12 + 9] = __builtin_amdgcn_s_memrealtime();
+#endif
   } else {
     // ---- box too large for the slab: direct global gather
 #pragma unroll
@@ -1260,7 +1313,10 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
   img.tiles_x = (img.W + kWgTW - 1) / kWgTW;
   img.tiles_y = (img.rows_out + kWgTH - 1) / kWgTH;
   const dim3 grid(8 * ((img.tiles_x + 7) / 8), img.tiles_y);     // XCD stripe order, see the kernel
-  hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), 0, stream, img, map);
+  // workgroups per CU capped through unused dynamic LDS (the static 23.5 KB allow six): img.wg_per_cu in 1..5
+  unsigned pad = 0;
+  if (img.wg_per_cu >= 1 && img.wg_per_cu <= 5) pad = (unsigned)(160 * 1024 / img.wg_per_cu - 24 * 1024) & ~255u;
+  hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), pad, stream, img, map);
   return hipGetLastError();
 }
 
@@ -1328,6 +1384,7 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
   img.pipe_depth = opts.pipe_depth;
   img.lds_gather = opts.lds_gather && lds_addressable(img);
   img.wg_box = opts.wg_box;
+  img.wg_per_cu = opts.wg_per_cu;
   // the 8-byte pair gather needs unit column stride and at least a 2x2 image
   const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2;
   const int nf = map.nfact;
@@ -1439,7 +1496,7 @@ static hipError_t launch_stack_t(const StackArgs& st, const MapArgs& map, int sa
 
 #ifdef DCP_EXPERIMENT_TRACE
 extern "C" int dcp_experiment_read_trace(unsigned long long* out, int nwaves) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 8 * (size_t)nwaves);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 12 * (size_t)nwaves);
 }
 #endif
 

@@ -13,7 +13,7 @@ src = [F.DeviceBuffer(img.nbytes).upload(img) for _ in range(NR)]
 dst = [F.DeviceBuffer(img.nbytes) for _ in range(NR)]
 fa, n = F.fact_array(c["list_fact"])
 blend = int(os.environ.get("DCP_BLEND", "1")); order = int(os.environ.get("DCP_ORDER", "1"))
-DEFAULTS = {k: F.get_option(k) for k in ("tile_rows", "pipe_depth", "xcd_remap", "coef_lds", "lds_gather", "tile_cert", "wg_box")}
+DEFAULTS = {k: F.get_option(k) for k in ("tile_rows", "pipe_depth", "xcd_remap", "coef_lds", "lds_gather", "tile_cert", "wg_box", "wg_per_cu")}
 
 
 def run(reps=60):
