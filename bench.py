@@ -1,11 +1,19 @@
 #!/usr/bin/env python
 """bench.py -- Mpixels/s of the backward unwarp on MI355X (BASELINE.json metric).
 
-Workload at every N: BASELINE config 2 -- 4096x4096 float32 frames, 5-term backward polynomial
-(coef_dot_05 rescaled), bilinear -- device-resident.  One "step" is one pass of the hot path over
-a batch of `--batch` DISTINCT frames (default 24: 3.2 GB of input+output per GPU, so the 256 MiB
-Infinity Cache cannot hold the working set and the kernel streams from HBM).  With N > 1 every
-rank unwarps its own batch (independent frames, no data-path collective): weak scaling.
+Headline at every N: BASELINE config 2 -- 4096x4096 float32 frames, 5-term backward polynomial
+(coef_dot_05 rescaled), bilinear -- device-resident, ONE launch of dcp_unwarp_image_f32 per frame.  One "step"
+is one pass of the hot path over a batch of `--batch` DISTINCT frames (default 24: 3.2 GB of input+output per
+GPU, so the 256 MiB Infinity Cache cannot hold the working set).  With N > 1 every rank unwarps its own batch
+(independent frames, no data-path collective): weak scaling.
+
+After the timed region the same run also measures, outside it and reported beside the headline:
+  other_configs   (N = 1) config 2 with scipy's exact blend and at order 0, config 3 fused / two-pass /
+                  perspective only, config 5, config 4 on one GPU (whole stack when it fits) and one sinogram --
+                  each with its per-launch time from HIP events, the kernel that ran and verified_vs_oracle;
+  stack_scaling   (every N) config 4 sharded by depth over the ranks: compute only, and compute + the RCCL
+                  all-gather that reassembles the (depth, rows, width) block on every rank -- the two curves
+                  north_star asks for fall out of the driver's N = 1, 2, 4, 8 runs without a flag.
 
     python bench.py                      # 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -31,7 +39,7 @@ from discorpy_amd import configs  # noqa: E402
 BLEND_NAMES = {"scipy": F.BLEND_SCIPY, "f64lerp": F.BLEND_F64LERP, "f32lerp": F.BLEND_F32LERP}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -45,15 +53,19 @@ def parse():
     ap.add_argument("--blend", default="f64lerp", choices=sorted(BLEND_NAMES))
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip other_configs and stack_scaling")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = the CPUs this process may use (affinity, cgroup quota)")
     ap.add_argument("--option", action="append", default=[], help="kernel option key=value (dcp_set_option)")
     ap.add_argument("--workload", default="frame", choices=["frame", "stack"],
-                    help="frame: BASELINE config 2 (default, the headline metric); stack: config 4, the "
+                    help="frame: BASELINE config 2 (default, the headline metric); stack: config 4 as the metric, the "
                          "(depth, 2560, 2560) stack sharded over the ranks by depth + all-gather")
-    ap.add_argument("--depth", type=int, default=2048, help="stack workload: total number of projections")
-    ap.add_argument("--rows", type=int, default=2560, help="stack workload: output rows per step (2560 = whole stack)")
+    ap.add_argument("--depth", type=int, default=2048, help="stack: total number of projections")
+    ap.add_argument("--rows", type=int, default=2560, help="stack: output rows per step (2560 = whole stack)")
     ap.add_argument("--no-gather", action="store_true", help="stack workload: skip the all-gather")
-    return ap.parse_args()
+    ap.add_argument("--shard", default="depth", choices=["depth", "rows"],
+                    help="stack workload: depth = projections split over the ranks (+ all-gather); rows = every rank owns "
+                         "output rows of every projection (the whole stack on every rank, no collective)")
+    return ap.parse_args(argv)
 
 
 def usable_cpus():
@@ -81,12 +93,18 @@ def usable_cpus():
     return max(1, n)
 
 
+def oracle_module(threads=0):
+    from oracle import oracle as orc
+    orc.build()
+    orc.set_threads(threads if threads > 0 else min(orc.max_threads(), usable_cpus()))
+    return orc
+
+
 def cpu_baseline(cfg, img, blend, threads):
     """Time the oracle (a C port of the reference arithmetic) on the host: whole 4096^2 frames."""
-    from oracle import oracle as orc
+    orc = oracle_module(threads)
     ncores = orc.max_threads()
     t = threads if threads > 0 else min(ncores, usable_cpus())
-    orc.set_threads(t)
     kw = dict(order=cfg["order"], poly=orc.POLY_NUMPY, blend=orc.BLEND_SCIPY)
     orc.unwarp_image_backward(img, cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], **kw)  # warm
     frames, t0 = 0, time.perf_counter()
@@ -104,110 +122,396 @@ def cpu_baseline(cfg, img, blend, threads):
                       % (frames, img.shape[0], img.shape[1], t, ncores, usable_cpus(), dt)}
 
 
-def stack_main(a, world, rank, dev, dist, backend):
-    """BASELINE config 4: strong scaling -- the stack is fixed, ranks own contiguous depth shards."""
-    from discorpy_amd import stack as st
+# ----------------------------------------------------------------------------------------- timing helpers
+
+def timed_launches(fn, reps, dev, settle_ms=120.0):
+    """Average device time of fn(i) per call: HIP events on the launch stream around `reps` back-to-back calls, after
+    `settle_ms` of the same calls (clock ramp)."""
     L = F.lib()
-    cfg = configs.cfg4(a.depth)
+    t0 = time.perf_counter()
+    i = 0
+    while (time.perf_counter() - t0) * 1e3 < settle_ms or i < 3:
+        fn(i)
+        i += 1
+        if i % 64 == 0:
+            F.check(L.dcp_stream_synchronize(dev, None))
+    F.check(L.dcp_stream_synchronize(dev, None))
+    e0, e1 = F.Event(dev), F.Event(dev)
+    e0.record()
+    for r in range(reps):
+        fn(r)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_ms(e1) * 1e3 / reps
+
+
+def entry(us, pixels, bytes_per_pixel, kernel, verified, **more):
+    gbps = bytes_per_pixel * pixels / (us * 1e-6) / 1e9
+    d = {"launch_us": round(us, 3), "Mpixels_per_s": round(pixels / us, 1), "achieved_GBps": round(gbps, 1),
+         "frac": round(gbps / configs.HBM_PEAK_GBPS, 4), "algorithmic_bytes_per_pixel": bytes_per_pixel, "kernel": kernel,
+         "verified_vs_oracle": bool(verified)}
+    d.update(more)
+    return d
+
+
+def download(buf_ptr, shape, dev, offset=0):
+    out = np.empty(shape, np.float32)
+    F.check(F.lib().dcp_memcpy(out.ctypes.data, buf_ptr + offset, out.nbytes, F.COPY_D2H, dev, None))
+    return out
+
+
+def clocks_under_load(step, sync):
+    """Core clock and package power while the headline kernel runs back to back (rocm-smi sampled from this thread while a second
+    thread keeps launching): boxes of the pool differ by ~10 % in what they sustain, and the number says which kind this run got."""
+    import re
+    import subprocess
+    import threading
+    stop = threading.Event()
+
+    def spin():
+        while not stop.is_set():
+            step()
+            sync()
+    th = threading.Thread(target=spin, daemon=True)
+    th.start()
+    samples = []
+    try:
+        time.sleep(0.35)
+        for _ in range(2):
+            txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+            m = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", txt)
+            w = re.search(r"Power \(W\): ([0-9.]+)", txt)
+            if m and w:
+                samples.append((int(m.group(1)), float(w.group(1))))
+    except Exception:      # noqa: BLE001 -- context only
+        pass
+    finally:
+        stop.set()
+        th.join()
+    if not samples:
+        return None
+    return {"sclk_MHz_under_this_kernel": [s_[0] for s_ in samples], "package_power_W": [s_[1] for s_ in samples]}
+
+
+# ----------------------------------------------------------------------------------------- other configurations (N = 1)
+
+def other_configs(a, dev, srcs, dsts, img0):
+    """Per-launch times of the other BASELINE configurations and blend variants, each checked against the oracle on one
+    frame (outside any timed region).  `srcs` / `dsts` / `img0`: the headline's ring of 4096^2 frames and the host copy of
+    frame 0."""
+    L = F.lib()
+    orc = oracle_module(a.cpu_threads)
+    out = {}
+    c2, c3 = configs.cfg2(), configs.cfg3()
+    H, W = c2["shape"]
+    fa, nf = F.fact_array(c2["list_fact"])
+    ca, _ = F.fact_array(c3["list_coef"])
+    nring = len(srcs)
+    reps = max(48, min(480, a.steps * 4))
+
+    def radial(i, order, blend):
+        F.check(L.dcp_unwarp_image_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c2["xcenter"], c2["ycenter"], fa, nf,
+                                       order, 1, blend, F.MEM_DEVICE, dev, None))
+
+    def persp(i, src, dst):
+        F.check(L.dcp_perspective_image_f32(src[i % nring].ptr, dst[i % nring].ptr, H, W, W, 1, ca, 1, F.BLEND_F64LERP, F.MEM_DEVICE,
+                                            dev, None))
+
+    def fused(i):
+        F.check(L.dcp_unwarp_fused_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c3["xcenter"], c3["ycenter"], fa, nf,
+                                       ca, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+
+    a2 = (img0, c2["xcenter"], c2["ycenter"], c2["list_fact"])
+    # config 2, scipy's exact operation order (bit-equal to the reference; the headline's f64lerp is <= 1 float32 ulp from it)
+    us = timed_launches(lambda i: radial(i, 1, F.BLEND_SCIPY), reps, dev)
+    k = F.last_kernel()
+    radial(0, 1, F.BLEND_SCIPY)
+    ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.unwarp_image_backward(*a2, poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY))
+    out["cfg2_scipy_exact_blend"] = entry(us, H * W, 8, k, ok)
+    us = timed_launches(lambda i: radial(i, 0, F.BLEND_SCIPY), reps, dev)
+    k = F.last_kernel()
+    radial(0, 0, F.BLEND_SCIPY)
+    ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.unwarp_image_backward(*a2, order=0, poly=orc.POLY_KERNEL))
+    out["cfg2_order0_nearest"] = entry(us, H * W, 8, k, ok)
+    # config 3: homography fused with the radial map in one resampling (north star), and what the reference does (two passes)
+    us = timed_launches(fused, reps, dev)
+    k = F.last_kernel()
+    fused(0)
+    ok = np.array_equal(download(dsts[0].ptr, (H, W), dev),
+                        orc.unwarp_fused(img0, c3["xcenter"], c3["ycenter"], c3["list_fact"], c3["list_coef"], poly=orc.POLY_KERNEL,
+                                         blend=orc.BLEND_F64LERP))
+    out["cfg3_fused"] = entry(us, H * W, 8, k, ok)
+    us = timed_launches(lambda i: persp(i, srcs, dsts), reps, dev)
+    k = F.last_kernel()
+    persp(0, srcs, dsts)
+    ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.correct_perspective_image(img0, c3["list_coef"], blend=orc.BLEND_F64LERP))
+    out["cfg3_perspective_only"] = entry(us, H * W, 8, k, ok)
+
+    def two_pass(i):
+        radial(i, 1, F.BLEND_F64LERP)                # srcs[i] -> dsts[i]
+        # dsts[i] -> srcs[i + 1]: the chain runs frame to frame through the ring
+        F.check(L.dcp_perspective_image_f32(dsts[i % nring].ptr, srcs[(i + 1) % nring].ptr, H, W, W, 1, ca, 1, F.BLEND_F64LERP,
+                                            F.MEM_DEVICE, dev, None))
+
+    # (the two-pass chain overwrites ring inputs with corrected frames: it runs last among the 4096^2 cases, and frame 0 is
+    # re-uploaded for its check)
+    us = timed_launches(two_pass, reps // 2, dev)
+    srcs[0].upload(img0)
+    radial(0, 1, F.BLEND_F64LERP)
+    F.check(L.dcp_perspective_image_f32(dsts[0].ptr, dsts[1].ptr, H, W, W, 1, ca, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+    want = orc.correct_perspective_image(orc.unwarp_image_backward(*a2, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP), c3["list_coef"],
+                                         blend=orc.BLEND_F64LERP)
+    ok = np.array_equal(download(dsts[1].ptr, (H, W), dev), want)
+    out["cfg3_two_pass_reference_semantics"] = entry(us, H * W, 16, "remap (radial) then remap (perspective): two launches", ok,
+                                                     note="two resamplings: 16 algorithmic bytes per output pixel")
+    return out
+
+
+def config5(a, dev):
+    L = F.lib()
+    orc = oracle_module(a.cpu_threads)
+    c5 = configs.cfg5()
+    H, W = c5["shape"]
+    fa, nf = F.fact_array(c5["list_fact"])
+    img = np.random.default_rng(c5["seed"]).random((H, W), dtype=np.float32)
+    nring = 4                                          # 4 x (268 + 268) MB = 2.1 GB
+    src = [F.DeviceBuffer(img.nbytes, dev).upload(img) for _ in range(nring)]
+    dst = [F.DeviceBuffer(img.nbytes, dev) for _ in range(nring)]
+
+    def run(i):
+        F.check(L.dcp_unwarp_image_f32(src[i % nring].ptr, dst[i % nring].ptr, H, W, W, 1, c5["xcenter"], c5["ycenter"], fa, nf, 1, 1,
+                                       F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+    us = timed_launches(run, max(24, min(120, a.steps)), dev)
+    k = F.last_kernel()
+    run(0)
+    ok = np.array_equal(download(dst[0].ptr, (H, W), dev),
+                        orc.unwarp_image_backward(img, c5["xcenter"], c5["ycenter"], c5["list_fact"], poly=orc.POLY_KERNEL,
+                                                  blend=orc.BLEND_F64LERP))
+    for b in src + dst:
+        b.free()
+    return entry(us, H * W, 8, k, ok, shape=[H, W], nfact=nf)
+
+
+# ----------------------------------------------------------------------------------------- config 4: the stack
+
+class DevBlock:
+    """A device allocation with a raw pointer: F.DeviceBuffer at N = 1, a torch tensor (needed by the collective) at N > 1."""
+
+    def __init__(self, shape, dev, use_torch, device_str="cuda"):
+        self.shape = tuple(int(s) for s in shape)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * 4
+        if use_torch:
+            import torch
+            self.tensor = torch.empty(self.shape, dtype=torch.float32, device=device_str)
+            self.ptr = self.tensor.data_ptr()
+            self.buf = None
+        else:
+            self.tensor = None
+            self.buf = F.DeviceBuffer(max(self.nbytes, 4), dev)
+            self.ptr = self.buf.ptr
+
+    def free(self):
+        if self.buf is not None:
+            self.buf.free()
+        self.tensor = None
+
+
+def fill_projections(block, dev, seed, upload=None):
+    """Synthetic projections: one host chunk of noise replicated over the block (53.7 GB do not pass through PCIe)."""
+    D, H, W = block.shape
+    chunk = np.random.default_rng(seed).random((min(D, 8), H, W), dtype=np.float32)
+    if upload is not None:
+        upload(block, chunk)
+        return chunk
+    L = F.lib()
+    F.check(L.dcp_memcpy(block.ptr, chunk.ctypes.data, chunk.nbytes, F.COPY_H2D, dev, None))
+    done = chunk.shape[0]
+    while done < D:                                    # doubling device-to-device copies
+        n = min(done, D - done)
+        F.check(L.dcp_memcpy(block.ptr + done * H * W * 4, block.ptr, n * H * W * 4, F.COPY_D2D, dev, None))
+        done += n
+    F.check(L.dcp_stream_synchronize(dev, None))
+    return chunk
+
+
+def hip_stack_launch(cfg, nrows, blend, dev, stream=None, row_start=0.0):
+    """launch(vol_block, out_block, d_local): one dcp_unwarp_stack_rows_f32 call on device pointers."""
+    L = F.lib()
+    fa, nf = F.fact_array(cfg["list_fact"])
+    _, H, W = cfg["shape"]
+
+    def launch(vol, out, dl):
+        F.check(L.dcp_unwarp_stack_rows_f32(vol.ptr, out.ptr, dl, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf,
+                                            float(row_start), nrows, 1, blend, F.MEM_DEVICE, dev, stream))
+    launch.keep = (fa,)
+    return launch
+
+
+def stack_scaling(cfg, world, rank, dist, steps, warmup, nrows, make_block, launch, sync, fill, barrier_device="cuda",
+                  verify=None, collective_name="all_gather_into_tensor"):
+    """BASELINE config 4 with the projections sharded by depth over `world` ranks (discorpy_amd.stack.shard_bounds): time
+    `steps` passes of (a) the local kernel alone and (b) the kernel followed by the all-gather that reassembles the
+    (depth, nrows, width) block on every rank.  The max over ranks is what counts.  `make_block(shape)`, `launch(vol, out,
+    d_local)`, `sync()` and `fill(block, seed)` abstract the device (HIP on the GPU boxes, the CPU oracle in the 2-rank gloo
+    test of this very function: tests/test_bench_paths.py).  Returns the result dict on every rank."""
+    from discorpy_amd import stack as st
     D, H, W = cfg["shape"]
     d0, d1 = st.shard_bounds(D, world, rank)
     dl = d1 - d0
-    nrows = a.rows
-    fa, nf = F.fact_array(cfg["list_fact"])
-    blend = BLEND_NAMES[a.blend]
-    gather = world > 1 and not a.no_gather
-    if gather:
+    even = len({st.shard_bounds(D, world, r)[1] - st.shard_bounds(D, world, r)[0] for r in range(world)}) == 1
+    vol = make_block((dl, H, W))
+    out = make_block((dl, nrows, W))
+    chunk = fill(vol, cfg["seed"] + rank)
+    gather = world > 1 and even
+    full = make_block((D, nrows, W)) if gather else None
+
+    def timed(body):
+        for _ in range(warmup):
+            body()
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            body()
+        sync()
+        if dist is not None:
+            dist.barrier()
+        sync()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([wall], dtype=torch.float64, device=barrier_device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall = float(tt[0])
+        return wall * 1e3 / steps
+
+    def compute_only():
+        launch(vol, out, dl)
+
+    def compute_and_gather():
+        launch(vol, out, dl)
+        dist.all_gather_into_tensor(full.tensor, out.tensor)
+
+    ms_compute = timed(compute_only)
+    try:
+        kernel = F.last_kernel()
+    except Exception:      # noqa: BLE001 -- no library (CPU test of this function)
+        kernel = ""
+    ms_gather = timed(compute_and_gather) if gather else None
+    verified = None
+    if verify is not None:
+        verified = bool(verify(chunk, out, full if gather else None, d0, dl))
+    vox = float(D) * nrows * W
+    res = {"what": "config 4: (%d, %d, %d) float32 stack, %d output rows of every projection, projections sharded by depth over "
+                   "%d rank(s)" % (D, H, W, nrows, world),
+           "depth_per_gpu": dl, "steps": steps,
+           "compute_only": {"ms_per_step": round(ms_compute, 4), "Mpixels_per_s": round(vox / ms_compute / 1e3, 1),
+                            "per_gpu_GBps": round(configs.BYTES_PER_PIXEL * dl * nrows * W / (ms_compute * 1e-3) / 1e9, 1)},
+           "compute_plus_allgather": None if ms_gather is None else {
+               "ms_per_step": round(ms_gather, 4), "Mpixels_per_s": round(vox / ms_gather / 1e3, 1),
+               "gathered_bytes_received_per_gpu": int((D - dl) * nrows * W * 4), "collective": collective_name},
+           "kernel": kernel, "verified_vs_oracle": verified}
+    if world > 1 and not even:
+        res["note"] = "depth does not divide evenly over the ranks: the timed all-gather needs even shards (discorpy_amd.stack pads ragged ones)"
+    if world == 1:
+        res["note"] = "one rank: the local block IS the whole result, no collective"
+    for b in (vol, out, full):
+        if b is not None:
+            b.free()
+    return res
+
+
+def hip_stack_verify(cfg, nrows, dev, a, orc_blend_name="f64lerp"):
+    """verify(chunk, out_block, full_block, d0, dl): projections 0 and (dl - 1) of the local result (and this rank's first
+    projection inside the gathered block) against the oracle -- every row, all of the width."""
+    def verify(chunk, out, full, d0, dl):
+        orc = oracle_module(a.cpu_threads)
+        _, H, W = cfg["shape"]
+        picks = sorted({0, dl - 1})
+        ok = True
+        for d in picks:
+            src = chunk[d % chunk.shape[0]][None]          # the block is the chunk replicated
+            want = orc.unwarp_stack_rows(src, cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], 0, nrows, coord_round_f32=True,
+                                         poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+            got = download(out.ptr, (1, nrows, W), dev, offset=d * nrows * W * 4)
+            ok = ok and np.array_equal(got, want)
+            if full is not None:
+                got = download(full.ptr, (1, nrows, W), dev, offset=(d0 + d) * nrows * W * 4)
+                ok = ok and np.array_equal(got, want)
+        return ok
+    return verify
+
+
+def stack_on_hip(a, world, rank, dev, dist, backend, depth, nrows, steps, warmup, blend):
+    """stack_scaling on this rank's GPU."""
+    L = F.lib()
+    cfg = configs.cfg4(depth)
+    use_torch = world > 1
+    stream = None
+    if use_torch:
         import torch
-        vol_t = torch.empty((dl, H, W), dtype=torch.float32, device="cuda")
-        out_t = torch.empty((dl, nrows, W), dtype=torch.float32, device="cuda")
-        full_t = torch.empty((D, nrows, W), dtype=torch.float32, device="cuda")
-        vol_ptr, out_ptr = vol_t.data_ptr(), out_t.data_ptr()
         stream = torch.cuda.current_stream().cuda_stream
-    else:
-        vol_b = F.DeviceBuffer(dl * H * W * 4, dev)
-        out_b = F.DeviceBuffer(dl * nrows * W * 4, dev)
-        vol_ptr, out_ptr, stream = vol_b.ptr, out_b.ptr, None
-    # synthetic projections: one host chunk of noise, replicated on the device
-    chunk = np.random.default_rng(cfg["seed"] + rank).random((min(dl, 16), H, W), dtype=np.float32)
-    done = 0
-    while done < dl:
-        n = min(chunk.shape[0], dl - done)
-        F.check(L.dcp_memcpy(vol_ptr + done * H * W * 4, chunk.ctypes.data, n * H * W * 4, F.COPY_H2D, dev, None))
-        done += n
-    uneven = len({st.shard_bounds(D, world, r)[1] - st.shard_bounds(D, world, r)[0] for r in range(world)}) > 1
-    if gather and uneven:
-        raise SystemExit("stack workload: depth must divide evenly over the ranks for the timed all-gather")
-
-    nsub = max(1, min(a.pipeline, dl)) if gather else 1
-
-    def step():
-        if nsub == 1:
-            F.check(L.dcp_unwarp_stack_rows_f32(vol_ptr, out_ptr, dl, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf,
-                                                0.0, nrows, 1, blend, F.MEM_DEVICE, dev, stream))
-            if gather:
-                dist.all_gather_into_tensor(full_t, out_t)
-            return
-        # the all-gather of sub-block s (asynchronous) runs while the kernel of sub-block s + 1 computes; every
-        # rank's piece lands directly in its place of the (depth, rows, W) result
-        pending = []
-        for s_ in range(nsub):
-            s0, s1 = st.shard_bounds(dl, nsub, s_)
-            F.check(L.dcp_unwarp_stack_rows_f32(vol_ptr + s0 * H * W * 4, out_ptr + s0 * nrows * W * 4, s1 - s0, H, W, H * W, W,
-                                                cfg["xcenter"], cfg["ycenter"], fa, nf, 0.0, nrows, 1, blend, F.MEM_DEVICE, dev,
-                                                stream))
-            pieces = [full_t[r * dl + s0:r * dl + s1] for r in range(world)]
-            pending.append(dist.all_gather(pieces, out_t[s0:s1], async_op=True))
-        for work in pending:
-            work.wait()
 
     def sync():
         F.check(L.dcp_stream_synchronize(dev, None))
-        if dist is not None:
+        if use_torch:
             import torch
             torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    sync()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt[0])
-    if rank == 0:
-        vox = float(D) * nrows * W * a.steps
-        ms = wall * 1e3 / a.steps
-        per_gpu_bytes = configs.BYTES_PER_PIXEL * dl * nrows * W
-        achieved = per_gpu_bytes / (ms * 1e-3) / 1e9
-        print(json.dumps({
-            "metric": "Mpixels/s unwarp of a (depth, 2560, 2560) stack, rows of every projection (+ all-gather)",
-            "value": round(vox / wall / 1e6, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic (uniform [0,1) float32 projections, device-resident)",
-            "config": {"workload": cfg["name"], "depth": D, "rows": nrows, "width": W, "depth_per_gpu": dl,
-                       "all_gather": bool(gather), "gather_pipeline": nsub, "blend": a.blend,
-                       "parallelism": "depth-sharded, %s" % ("RCCL all-gather of the (depth, rows, W) block" if gather
-                                                            else "no collective")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "stack_lds_kernel / stack_rows_kernel by launch size (per GPU, step time includes the all-gather when enabled)"}}),
-            flush=True)
+    return stack_scaling(cfg, world, rank, dist, steps, warmup, nrows,
+                         make_block=lambda shape: DevBlock(shape, dev, use_torch),
+                         launch=hip_stack_launch(cfg, nrows, blend, dev, stream), sync=sync,
+                         fill=lambda block, seed: fill_projections(block, dev, seed),
+                         barrier_device="cuda" if backend == "nccl" else "cpu",
+                         verify=hip_stack_verify(cfg, nrows, dev, a),
+                         collective_name="all_gather_into_tensor, backend nccl = RCCL over xGMI" if backend == "nccl"
+                         else "all_gather_into_tensor, backend %s (test hook DCP_BENCH_BACKEND: not RCCL)" % backend)
 
 
-def main():
-    a = parse()
+def free_device_bytes(dev):
+    try:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        fr, tot = C.c_size_t(0), C.c_size_t(0)
+        if hip.hipMemGetInfo(C.byref(fr), C.byref(tot)) == 0:
+            return int(fr.value)
+    except Exception:      # noqa: BLE001
+        pass
+    return None
+
+
+def stack_one_gpu_cases(a, dev):
+    """other_configs entries of config 4 on one GPU: one sinogram of a depth-256 shard (unwarp_slice_backward, float64
+    coordinates, launch-bound) -- the whole-stack number is stack_scaling's compute_only at N = 1."""
+    L = F.lib()
+    orc = oracle_module(a.cpu_threads)
+    cfg = configs.cfg4(256)
+    D, H, W = cfg["shape"]
+    fa, nf = F.fact_array(cfg["list_fact"])
+    vol = DevBlock((D, H, W), dev, False)
+    out = DevBlock((D, 1, W), dev, False)
+    chunk = fill_projections(vol, dev, cfg["seed"])
+    row = 1277.0
+
+    def run(i):
+        F.check(L.dcp_unwarp_stack_rows_f32(vol.ptr, out.ptr, D, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf, row, 1, 0,
+                                            F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+    us = timed_launches(run, 200, dev, settle_ms=50.0)
+    k = F.last_kernel()
+    got = download(out.ptr, (chunk.shape[0], 1, W), dev)
+    want = orc.unwarp_stack_rows(chunk, cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], row, 1, coord_round_f32=False,
+                                 poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+    ok = np.array_equal(got, want)
+    vol.free()
+    out.free()
+    return entry(us, D * W, 12, k, ok, note="unwarp_slice_backward of a depth-256 shard: one output row per projection reads two "
+                                            "source rows (12 B per voxel); 2.6 MB per launch -- launch-bound")
+
+
+# ----------------------------------------------------------------------------------------- main
+
+def init_dist():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,6 +527,72 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
+    return world, rank, dev_index, dist, backend
+
+
+def stack_main(a, world, rank, dev, dist, backend):
+    """--workload stack: config 4 IS the metric (strong scaling: the stack is fixed)."""
+    blend = BLEND_NAMES[a.blend]
+    if a.shard == "rows":
+        # no collective: every rank holds the whole stack and owns output rows [r0, r1) of every projection -- complete
+        # sinograms for its rows, which is what a per-sinogram reconstructor downstream wants
+        from discorpy_amd import stack as st
+        L = F.lib()
+        cfg = configs.cfg4(a.depth)
+        D, H, W = cfg["shape"]
+        r0, r1 = st.row_shard_bounds(a.rows, world, rank)
+        vol = DevBlock((D, H, W), dev, False)
+        out = DevBlock((D, max(r1 - r0, 1), W), dev, False)
+        fill_projections(vol, dev, cfg["seed"])            # the same stack on every rank
+        launch = hip_stack_launch(cfg, r1 - r0, blend, dev, None, row_start=float(r0))
+
+        def sync():
+            F.check(L.dcp_stream_synchronize(dev, None))
+        for _ in range(a.warmup):
+            launch(vol, out, D)
+        sync()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            launch(vol, out, D)
+        sync()
+        if dist is not None:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            import torch
+            tt = torch.tensor([wall], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall = float(tt[0])
+        ms = wall * 1e3 / a.steps
+        res = {"ms_per_step": ms, "Mpixels_per_s": float(D) * a.rows * W / ms / 1e3, "rows_per_gpu": r1 - r0, "kernel": F.last_kernel()}
+        mode = "row-sharded, no collective (every rank holds the stack, owns output rows of every projection)"
+    else:
+        r = stack_on_hip(a, world, rank, dev, dist, backend, a.depth, a.rows, a.steps, a.warmup, blend)
+        use = r["compute_plus_allgather"] if (r["compute_plus_allgather"] and not a.no_gather) else r["compute_only"]
+        res = {"ms_per_step": use["ms_per_step"], "Mpixels_per_s": use["Mpixels_per_s"], "kernel": r["kernel"], "detail": r}
+        mode = "depth-sharded, %s" % ("RCCL all-gather of the (depth, rows, W) block" if use is r["compute_plus_allgather"] else "no collective")
+    if rank == 0:
+        cfg = configs.cfg4(a.depth)
+        D, H, W = cfg["shape"]
+        per_gpu = configs.BYTES_PER_PIXEL * float(D) * a.rows * W / world
+        achieved = per_gpu / (res["ms_per_step"] * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "Mpixels/s unwarp of a (depth, 2560, 2560) stack, rows of every projection", "value": round(res["Mpixels_per_s"], 1),
+            "unit": "Mpixels/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(res["ms_per_step"], 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic (uniform [0,1) float32 projections, device-resident)",
+            "config": {"workload": cfg["name"], "depth": D, "rows": a.rows, "width": W, "blend": a.blend, "parallelism": mode},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
+                         "kernel": res["kernel"]},
+            "detail": res.get("detail")}), flush=True)
+
+
+def main(argv=None):
+    a = parse(argv)
+    world, rank, dev_index, dist, backend = init_dist()
     n_gpus = world
     if a.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
@@ -290,33 +660,47 @@ def main():
     sync()
     wall = time.perf_counter() - t0
     dev_ms = e0.elapsed_ms(e1)            # HIP events on the launch stream: device time of the K steps
+    headline_kernel = F.last_kernel()
     if dist is not None:
         import torch
         tt = torch.tensor([wall, dev_ms], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall, dev_ms = float(tt[0]), float(tt[1])
 
+    # ---- everything below is outside the timed region
+    verified = None
     copy_gbps = None
     if rank == 0:
+        try:                   # frame 0 of the timed launches against the oracle (kernel arithmetic order, the same blend)
+            orc = oracle_module(a.cpu_threads)
+            ob = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32lerp": orc.BLEND_F32LERP}[a.blend]
+            want = orc.unwarp_image_backward(img0, cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], order=a.order, poly=orc.POLY_KERNEL,
+                                             blend=ob)
+            verified = bool(np.array_equal(download(dsts[0].ptr, (H, W), dev), want))
+        except Exception as e:      # noqa: BLE001
+            verified = "error: %r" % (e,)
         # context for roofline.frac: what a plain device-to-device copy of the same frames reaches on this box
-        # (hipMemcpyAsync D2D over the ring, outside the timed region)
         try:
             nbytes = H * W * 4
-            for s, d in zip(srcs, dsts):
-                F.check(L.dcp_memcpy(d.ptr, s.ptr, nbytes, F.COPY_D2D, dev, None))
+            scratch = F.DeviceBuffer(nbytes, dev)
             c0, c1 = F.Event(dev), F.Event(dev)
-            c0.record()
-            for _ in range(4):
-                for s, d in zip(srcs, dsts):
-                    F.check(L.dcp_memcpy(d.ptr, s.ptr, nbytes, F.COPY_D2D, dev, None))
+            for rep in range(2):
+                if rep == 1:
+                    c0.record()
+                for _ in range(4):
+                    for s in srcs:
+                        F.check(L.dcp_memcpy(scratch.ptr, s.ptr, nbytes, F.COPY_D2D, dev, None))
             c1.record()
             c1.synchronize()
             copy_gbps = round(2.0 * nbytes * 4 * len(srcs) / (c0.elapsed_ms(c1) * 1e-3) / 1e9, 1)
-        except Exception:
+            scratch.free()
+        except Exception:      # noqa: BLE001
             copy_gbps = None
 
+    box = clocks_under_load(step, sync) if (rank == 0 and n_gpus == 1 and not a.no_extras) else None
+
     batched = None
-    if rank == 0 and n_gpus == 1 and a.order == 1:
+    if rank == 0 and n_gpus == 1 and a.order == 1 and not a.no_extras:
         # context, not the metric: the frames of a step share one calibration, so the whole batch can also go
         # through ONE launch of the stack entry point (depth = batch, all rows) -- bit-identical output, the
         # coordinates evaluated once per pixel position instead of once per frame
@@ -326,34 +710,24 @@ def main():
             for i, sbuf in enumerate(srcs):
                 F.check(L.dcp_memcpy(vsrc.ptr + i * nbytes, sbuf.ptr, nbytes, F.COPY_D2D, dev, None))
 
-            def stack_step():
+            def stack_step(_i):
                 F.check(L.dcp_unwarp_stack_rows_f32(vsrc.ptr, vdst.ptr, a.batch, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"],
                                                     fa, nf, 0.0, H, 1, blend, F.MEM_DEVICE, dev, None))
-            stack_step()
-            b0, b1 = F.Event(dev), F.Event(dev)
-            b0.record()
-            for _ in range(max(4, a.steps // 4)):
-                stack_step()
-            b1.record()
-            b1.synchronize()
-            per_frame_us = b0.elapsed_ms(b1) * 1e3 / (max(4, a.steps // 4) * a.batch)
-            chk = np.empty((H, W), np.float32)
-            F.check(L.dcp_memcpy(chk.ctypes.data, vdst.ptr + (a.batch - 1) * nbytes, nbytes, F.COPY_D2H, dev, None))
-            ref = np.empty((H, W), np.float32)
-            F.check(L.dcp_unwarp_image_f32(srcs[a.batch - 1].ptr, dsts[a.batch - 1].ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"],
-                                           fa, nf, a.order, 1, blend, F.MEM_DEVICE, dev, None))
-            F.check(L.dcp_memcpy(ref.ctypes.data, dsts[a.batch - 1].ptr, nbytes, F.COPY_D2H, dev, None))
+            per_frame_us = timed_launches(stack_step, max(4, a.steps // 4), dev) / a.batch
+            kb = F.last_kernel()
+            chk = download(vdst.ptr, (H, W), dev, offset=(a.batch - 1) * nbytes)
+            ref = download(dsts[a.batch - 1].ptr, (H, W), dev)
             batched = {"what": "the %d frames of a step in one dcp_unwarp_stack_rows_f32 launch (same calibration)" % a.batch,
                        "Mpixels_per_s": round(H * W / per_frame_us, 1), "us_per_frame": round(per_frame_us, 3),
                        "frac_of_hbm_peak": round(configs.BYTES_PER_PIXEL * H * W / (per_frame_us * 1e-6) / 1e9 / configs.HBM_PEAK_GBPS, 4),
-                       "identical_to_per_frame_launches": bool(np.array_equal(chk, ref))}
+                       "kernel": kb, "identical_to_per_frame_launches": bool(np.array_equal(chk, ref))}
             vsrc.free()
             vdst.free()
         except Exception as e:      # noqa: BLE001 -- context only, never fails the bench
             batched = {"error": repr(e)}
 
     overlapped = None
-    if rank == 0 and n_gpus == 1:
+    if rank == 0 and n_gpus == 1 and not a.no_extras:
         # context, not the metric: the same frames alternated over two streams, so that the drain of one launch
         # overlaps the ramp of the next (per-launch durations are then not meaningful; only throughput is)
         try:
@@ -376,11 +750,44 @@ def main():
             for st_ in s2:
                 st_.synchronize()
             dt2 = time.perf_counter() - t2
-            overlapped = {"what": "the same step with its frames alternated over two HIP streams",
+            overlapped = {"what": "the same step with its frames alternated over two HIP streams (throughput only: the drain of "
+                                  "one launch overlaps the ramp of the next)",
                           "Mpixels_per_s": round(n2 * a.batch * H * W / dt2 / 1e6, 1),
                           "us_per_frame": round(dt2 * 1e6 / (n2 * a.batch), 3)}
         except Exception as e:      # noqa: BLE001 -- context only
             overlapped = {"error": repr(e)}
+
+    others = None
+    if rank == 0 and n_gpus == 1 and not a.no_extras:
+        try:
+            others = other_configs(a, dev, srcs, dsts, img0)
+        except Exception as e:      # noqa: BLE001 -- context only
+            others = {"error": repr(e)}
+    for b in srcs + dsts:           # the ring is no longer needed: make room for the 8192^2 frames and the stack
+        b.free()
+    if others is not None and "error" not in others:
+        for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev))):
+            try:
+                others[name] = fn()
+            except Exception as e:      # noqa: BLE001
+                others[name] = {"error": repr(e)}
+
+    scaling = None
+    if not a.no_extras:
+        try:
+            depth = a.depth
+            if world == 1:            # the whole stack needs 2 x 53.7 GB; fall back to one 8-GPU shard if that does not fit
+                fr = free_device_bytes(dev)
+                if fr is not None and fr < 2.2 * depth * 2560 * 2560 * 4:
+                    depth = 256
+            scaling = stack_on_hip(a, world, rank, dev, dist, backend, depth, 2560, steps=3, warmup=1, blend=F.BLEND_F64LERP)
+            if others is not None and "error" not in others and world == 1:
+                D_, _, W_ = configs.cfg4(depth)["shape"]
+                ms = scaling["compute_only"]["ms_per_step"]
+                others["cfg4_stack_one_gpu"] = entry(ms * 1e3, D_ * 2560 * W_, 8, scaling["kernel"], scaling["verified_vs_oracle"],
+                                                     shape=[D_, 2560, W_], note="every row of every projection in one launch")
+        except Exception as e:      # noqa: BLE001
+            scaling = {"error": repr(e)}
 
     if rank == 0:
         launches = a.steps * a.batch
@@ -389,12 +796,18 @@ def main():
         value = total_pix / wall / 1e6
         launch_us = dev_ms * 1e3 / launches
         achieved = configs.BYTES_PER_PIXEL * pix_per_launch / (launch_us * 1e-6) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
+                j = json.load(open(pmc))
+                if j.get("kernel", "").split("<")[0] == headline_kernel.split("<")[0]:
+                    traffic = j.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/pmc_latest.json: rocprofv3 PMC passes of %s over this command (%s), not measured in this run" % (
+                        j.get("kernel"), j.get("collected", "date not recorded"))
+                else:
+                    traffic_source = "none: profiles/pmc_latest.json is of %s, this run launched %s" % (j.get("kernel"), headline_kernel)
+            except Exception:      # noqa: BLE001
                 traffic = None
         out = {
             "metric": "Mpixels/s backward unwarp (4096x4096, 5-term poly, bilinear)",
@@ -404,15 +817,23 @@ def main():
             "data": "synthetic (numpy default_rng uniform [0,1) float32 frames, device-resident)",
             "config": {"workload": cfg["name"], "frames_per_step_per_gpu": a.batch, "height": H, "width": W,
                        "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True, "pixel_dtype": "f32",
-                       "arithmetic": "coordinates and blend in float64 (as numpy / scipy compute them), pixels float32", "clock_settle_ms": a.settle_ms,
+                       "arithmetic": "coordinates and blend in float64 (as numpy / scipy compute them), pixels float32; the f64lerp "
+                                     "blend is a factorisation within one float32 ulp of scipy's operation order (other_configs."
+                                     "cfg2_scipy_exact_blend is the bit-equal mode)", "clock_settle_ms": a.settle_ms,
                        "parallelism": "independent frames per GPU (no collective)" if n_gpus > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": ("remap_lds_kernel<Radial,NF=5>" if F.get_option("lds_gather") and a.order == 1
-                                    else "remap_tile_kernel<Radial,NF=5>"), "launch_us": round(launch_us, 3),
+                         "traffic_source": traffic_source, "kernel": headline_kernel, "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch),
                          "d2d_copy_same_frames_GBps": copy_gbps},
+            "verified_vs_oracle": verified,
         }
+        if box is not None:
+            out["box"] = box
+        if others is not None:
+            out["other_configs"] = others
+        if scaling is not None:
+            out["stack_scaling"] = scaling
         if batched is not None:
             out["batched_same_calibration"] = batched
         if overlapped is not None:

@@ -80,6 +80,7 @@ SIGNATURES = {
     "dcp_map_points_f64": (_int, [_vp, _vp, _i64, _dbl, _dbl, _dp, _int, _int, _int, _vp]),
     "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
+    "dcp_debug_last_kernel": (C.c_char_p, []),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
     "dcp_free": (_int, [_vp, _int]),
     "dcp_memcpy": (_int, [_vp, _vp, _sz, _int, _int, _vp]),
@@ -188,6 +189,12 @@ def debug_counters(reset=True):
     out = (C.c_uint64 * 2)()
     check(lib().dcp_debug_counters(out, 2, int(reset)))
     return int(out[0]), int(out[1])
+
+
+def last_kernel():
+    """Name of the float32 image / stack kernel this thread launched last, e.g. 'remap_wg_kernel<Radial,NF=5,f64lerp>'."""
+    v = lib().dcp_debug_last_kernel()
+    return v.decode() if v else ""
 
 
 def stack_row_band(height, width, xcenter, ycenter, list_fact, row_start, nrows):

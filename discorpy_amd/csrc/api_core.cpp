@@ -391,6 +391,8 @@ int dcp_debug_counters(uint64_t* out, int n, int reset) {
   return DCP_OK;
 }
 
+const char* dcp_debug_last_kernel(void) { return dcp::last_kernel_name(); }
+
 int dcp_malloc(void** ptr, size_t bytes, int device) {
   if (!ptr) return fail(DCP_ERR_INVALID_ARG, "null out pointer");
   DeviceScope scope(device);

@@ -133,6 +133,7 @@ hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bo
                         const LaunchOpts& opts, hipStream_t stream);
 
 hipError_t read_lds_stats(unsigned long long* out, bool reset);
+const char* last_kernel_name();   // unwarp_kernels.hip: the kernel the calling thread launched last (float32 image / stack launchers)
 // spline_kernels.hip: map_kind 0 radial, 1 perspective, 2 explicit coordinates
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream);

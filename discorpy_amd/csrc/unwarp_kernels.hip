@@ -34,6 +34,7 @@
 #include "dcp_internal.h"
 #include "dcp_device.h"
 #include <type_traits>
+#include <cstdio>
 
 namespace dcp {
 
@@ -1270,9 +1271,21 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 
 // ------------------------------------------------------------------ launchers
 
+// Name of the kernel the calling thread launched last (dcp_debug_last_kernel): tests and bench.py use it to state --
+// and assert -- which kernel a call really took.
+static thread_local char g_last_kernel[96] = "";
+static const char* kind_name(int k) { return k == kRadial ? "Radial" : k == kPersp ? "Persp" : "Fused"; }
+static const char* sampler_name(int s) { return s == kNearest ? "nearest" : s == kScipy ? "scipy" : s == kF64Lerp ? "f64lerp" : "f32lerp"; }
+static void note_kernel(const char* kernel, int kind, int nf, int sampler, const char* extra = "") {
+  if (kind >= 0) snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<%s,NF=%d,%s%s>", kernel, kind_name(kind), nf, sampler_name(sampler), extra);
+  else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<NF=%d,%s%s>", kernel, nf, sampler_name(sampler), extra);
+}
+const char* last_kernel_name() { return g_last_kernel; }
+
 template <int KIND, int NF, int SAMPLER, bool ROUND32, bool PAIR>
 static hipError_t launch_one(const ImageArgs& img, const MapArgs& map, hipStream_t stream) {
   const int nb = img.tiles_x * img.tiles_y;
+  note_kernel("remap_tile_kernel", KIND, NF, SAMPLER, ROUND32 ? (PAIR ? "" : ",strided") : ",f64coords");
   if constexpr (KIND == kRadial && NF >= 0) {
     // the headline path also exists with 1 and 4 rows in flight (option pipe_depth) for A/B runs
     if (img.pipe_depth == 1) {
@@ -1303,6 +1316,7 @@ static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStr
   img.tiles_y = (img.rows_out + kLdsBW * kLdsTH - 1) / (kLdsBW * kLdsTH);
   dim3 grid(img.tiles_x * img.tiles_y);
   if (img.xcd_remap == 2) grid = dim3(8 * ((img.tiles_x + 7) / 8), img.tiles_y);   // see the kernel's tile order
+  note_kernel("remap_lds_kernel", KIND, NF, SAMPLER, VOTE ? ",vote" : ",certified");
   hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER, VOTE>), grid, dim3(64 * kLdsBW), 0, stream, img, map);
   return hipGetLastError();
 }
@@ -1316,6 +1330,7 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
   // workgroups per CU capped through unused dynamic LDS (the static 23.5 KB allow six): img.wg_per_cu in 1..5
   unsigned pad = 0;
   if (img.wg_per_cu >= 1 && img.wg_per_cu <= 5) pad = (unsigned)(160 * 1024 / img.wg_per_cu - 24 * 1024) & ~255u;
+  note_kernel("remap_wg_kernel", KIND, NF, SAMPLER);
   hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), pad, stream, img, map);
   return hipGetLastError();
 }
@@ -1479,6 +1494,7 @@ hipError_t launch_coord_map(MapKind kind, const ImageArgs& img_in, const MapArgs
 
 template <int NF, bool ROUND32>
 static hipError_t launch_stack_t(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
+  note_kernel("stack_rows_kernel", -1, NF, sampler, ROUND32 ? "" : ",f64coords");
   const dim3 grid((st.W + kBlock - 1) / kBlock, st.nrows, (st.D + st.d_chunk - 1) / st.d_chunk);
   switch (sampler) {
     case kScipy:
@@ -1509,6 +1525,7 @@ hipError_t read_lds_stats(unsigned long long* out, bool reset) {
 
 template <int NF>
 static hipError_t launch_stack_lds(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
+  note_kernel("stack_lds_kernel", -1, NF, sampler);
   const dim3 grid((unsigned)((st.W + kLdsTW - 1) / kLdsTW), (unsigned)((st.nrows + kLdsBW * kLdsTH - 1) / (kLdsBW * kLdsTH)),
                   (unsigned)((st.D + st.d_chunk - 1) / st.d_chunk));
   const dim3 block(64 * kLdsBW);

@@ -241,6 +241,11 @@ int dcp_map_points_f64(const double* yx_in, double* yx_out, int64_t npts, double
  * to the direct gather).  Synchronises the device. */
 int dcp_debug_counters(uint64_t* out, int n, int reset);
 
+/* Name of the float32 image / stack kernel the calling thread launched last, e.g.
+ * "remap_wg_kernel<Radial,NF=5,f64lerp>" (empty before the first launch).  For tests and benchmarks that must say
+ * -- and assert -- which kernel a call took; the reference has no counterpart. */
+const char* dcp_debug_last_kernel(void);
+
 /* ---- device memory / stream / event helpers (so a host language needs no other GPU runtime) ---- */
 int dcp_malloc(void** ptr, size_t bytes, int device);
 int dcp_free(void* ptr, int device);

@@ -1,0 +1,55 @@
+"""GPU suite: bench.py itself -- the line the driver records must carry every configuration, each verified against the
+oracle, and the N > 1 path (depth-sharded config 4 + all-gather) must run.  Two ranks share the one GPU of the test box
+through the DCP_BENCH_BACKEND=gloo / DCP_BENCH_DEVICE=0 hooks (RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _last_json(text):
+    lines = [ln for ln in text.strip().split("\n") if ln.startswith("{")]
+    assert lines, text[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_line_carries_every_config_verified(hip):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "6"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["unit"] == "Mpixels/s" and j["verified_vs_oracle"] is True
+    assert j["config"]["workload"] == "cfg2_frame4096_radial5_bilinear" and j["dtype"] == "f64"
+    roof = j["roofline"]
+    assert roof["bound"] == "hbm" and roof["kernel"].startswith("remap_wg_kernel<Radial,NF=5,f64lerp") and "traffic_source" in roof
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    oc = j["other_configs"]
+    for key in ("cfg2_scipy_exact_blend", "cfg2_order0_nearest", "cfg3_fused", "cfg3_perspective_only",
+                "cfg3_two_pass_reference_semantics", "cfg5_frame8192_radial9", "cfg4_one_sinogram", "cfg4_stack_one_gpu"):
+        assert key in oc and oc[key].get("verified_vs_oracle") is True, (key, oc.get(key))
+        assert oc[key]["launch_us"] > 0 and oc[key]["kernel"]
+    assert "stack_lds_kernel" in oc["cfg4_stack_one_gpu"]["kernel"]          # the staged stack kernel, auto-selected
+    ss = j["stack_scaling"]
+    assert ss["compute_plus_allgather"] is None and ss["verified_vs_oracle"] is True and ss["compute_only"]["ms_per_step"] > 0
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+
+
+def test_bench_two_ranks_share_the_gpu_through_gloo(hip):
+    pytest.importorskip("torch")
+    env = dict(os.environ, DCP_BENCH_BACKEND="gloo", DCP_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch", "4", "--depth", "16"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified_vs_oracle"] is True and "cpu_baseline" not in j
+    ss = j["stack_scaling"]
+    assert ss["depth_per_gpu"] == 8 and ss["verified_vs_oracle"] is True
+    assert ss["compute_plus_allgather"]["ms_per_step"] >= ss["compute_only"]["ms_per_step"] > 0
+    assert ss["compute_plus_allgather"]["gathered_bytes_received_per_gpu"] == 8 * 2560 * 2560 * 4
