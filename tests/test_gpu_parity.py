@@ -1039,3 +1039,121 @@ def test_cfg4_stack_sample(hip, orc):
                           orc.unwarp_slice_backward(vol, *a, 1277, **kernel_oracle(orc, "f64lerp")))
     assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, 2000, 2015),
                           orc.unwarp_chunk_slices_backward(vol, *a, 2000, 2015, **kernel_oracle(orc, "f64lerp")))
+
+
+# --------------------------------------------------------------------------- (d) the benched calls themselves, at full size
+
+def _device_call(hip, fn, img, *args):
+    """fn(src_ptr, dst_ptr) on device-resident buffers -- bench.py's call form (mem_kind = DEVICE, default stream)."""
+    H, W = img.shape
+    src = hip.DeviceBuffer(img.nbytes).upload(img)
+    dst = hip.DeviceBuffer(img.nbytes)
+    hip.check(fn(src.ptr, dst.ptr))
+    out = dst.download((H, W), np.float32)
+    src.free()
+    dst.free()
+    return out
+
+
+@pytest.mark.parametrize("blend", ["f64lerp", "scipy"])
+def test_cfg2_device_resident_call_is_the_benched_kernel_and_equals_the_oracle(hip, orc, blend):
+    """BASELINE config 2 exactly as bench.py times it: dcp_unwarp_image_f32 on device pointers, 4096 x 4096, default options
+    -> remap_wg_kernel; every pixel against the oracle.  Then the NumPy boundary with the banded host path forced off and on."""
+    c = configs.cfg2()
+    H, W = c["shape"]
+    img = noise(c["seed"] + 7, (H, W))
+    fa, nf = hip.fact_array(c["list_fact"])
+    L = hip.lib()
+    b = hip.BLEND_BY_NAME[blend]
+    out = _device_call(hip, lambda s, d: L.dcp_unwarp_image_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, 1, 1, b,
+                                                                 hip.MEM_DEVICE, -1, None), img)
+    assert hip.last_kernel() == "remap_wg_kernel<Radial,NF=5,%s>" % blend
+    want = orc.unwarp_image_backward(img, c["xcenter"], c["ycenter"], c["list_fact"], **kernel_oracle(orc, blend))
+    assert np.array_equal(out, want)
+    old = hip.get_option("host_duplex")
+    try:
+        for mode in (0, 2):                         # one-shot upload / kernel / download, and the banded full-duplex path
+            hip.set_option("host_duplex", mode)
+            assert np.array_equal(pp.unwarp_image_backward(img, c["xcenter"], c["ycenter"], c["list_fact"], blend=blend), want), mode
+    finally:
+        hip.set_option("host_duplex", old)
+    # the two other staged kernels on the same frame: one box per wave tile with the certificate, and with the per-pixel vote
+    for opt, name in (("wg_box", "remap_lds_kernel<Radial,NF=5,%s,certified>" % blend), ("tile_cert", "remap_lds_kernel<Radial,NF=-1,%s,vote>" % blend)):
+        hip.set_option(opt, 0)
+        try:
+            got = _device_call(hip, lambda s, d: L.dcp_unwarp_image_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, 1, 1, b,
+                                                                         hip.MEM_DEVICE, -1, None), img)
+            assert hip.last_kernel() == name and np.array_equal(got, want), name
+        finally:
+            hip.set_option(opt, 1)
+
+
+def test_cfg3_device_resident_calls_equal_the_oracle(hip, orc):
+    """BASELINE config 3 as bench.py times it: the fused map, the perspective map alone and the reference's two passes."""
+    c = configs.cfg3()
+    H, W = c["shape"]
+    img = noise(c["seed"] + 8, (H, W))
+    fa, nf = hip.fact_array(c["list_fact"])
+    ca, _ = hip.fact_array(c["list_coef"])
+    L = hip.lib()
+    fused = _device_call(hip, lambda s, d: L.dcp_unwarp_fused_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, ca, 1,
+                                                                   hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None), img)
+    assert hip.last_kernel().startswith("remap_lds_kernel<Fused,NF=5,f64lerp")
+    assert np.array_equal(fused, orc.unwarp_fused(img, c["xcenter"], c["ycenter"], c["list_fact"], c["list_coef"],
+                                                  **kernel_oracle(orc, "f64lerp")))
+    persp = _device_call(hip, lambda s, d: L.dcp_perspective_image_f32(s, d, H, W, W, 1, ca, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None), img)
+    assert hip.last_kernel() == "remap_wg_kernel<Persp,NF=-1,f64lerp>"
+    assert np.array_equal(persp, orc.correct_perspective_image(img, c["list_coef"], blend=orc.BLEND_F64LERP))
+    old = hip.get_option("host_duplex")
+    try:
+        for mode in (0, 2):
+            hip.set_option("host_duplex", mode)
+            assert np.array_equal(pp.unwarp_perspective_fused(img, c["xcenter"], c["ycenter"], c["list_fact"], c["list_coef"]), fused), mode
+            assert np.array_equal(pp.correct_perspective_image(img, c["list_coef"]), persp), mode
+    finally:
+        hip.set_option("host_duplex", old)
+
+
+def test_cfg5_device_resident_call_equals_the_oracle(hip, orc):
+    c = configs.cfg5()
+    H, W = c["shape"]
+    img = noise(c["seed"] + 9, (H, W))
+    fa, nf = hip.fact_array(c["list_fact"])
+    L = hip.lib()
+    out = _device_call(hip, lambda s, d: L.dcp_unwarp_image_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, 1, 1, hip.BLEND_F64LERP,
+                                                                 hip.MEM_DEVICE, -1, None), img)
+    assert "NF=9" in hip.last_kernel() and "vote" not in hip.last_kernel()          # a certified, inline-coefficient kernel
+    want = orc.unwarp_image_backward(img, c["xcenter"], c["ycenter"], c["list_fact"], **kernel_oracle(orc, "f64lerp"))
+    assert np.array_equal(out, want)
+    old = hip.get_option("host_duplex")
+    try:
+        for mode in (0, 2):
+            hip.set_option("host_duplex", mode)
+            assert np.array_equal(pp.unwarp_image_backward(img, c["xcenter"], c["ycenter"], c["list_fact"]), want), mode
+    finally:
+        hip.set_option("host_duplex", old)
+
+
+def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
+    """One 8-GPU shard's worth of config 4's geometry -- (64, 2560, 2560), ALL 2560 rows, default options, device-resident:
+    the launcher must pick stack_lds_kernel<5> by itself (the kernel behind the 23 ms whole-stack number), and every voxel
+    must equal the oracle."""
+    c = configs.cfg4(64)
+    D, H, W = c["shape"]
+    vol = noise(c["seed"] + 3, (D, H, W))
+    fa, nf = hip.fact_array(c["list_fact"])
+    L = hip.lib()
+    src = hip.DeviceBuffer(vol.nbytes).upload(vol)
+    dst = hip.DeviceBuffer(D * H * W * 4)
+    hip.debug_counters()
+    hip.check(L.dcp_unwarp_stack_rows_f32(src.ptr, dst.ptr, D, H, W, H * W, W, c["xcenter"], c["ycenter"], fa, nf, 0.0, H, 1,
+                                          hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None))
+    assert hip.last_kernel() == "stack_lds_kernel<NF=5,f64lerp>"
+    nofit, vote = hip.debug_counters()
+    assert nofit == 0 and vote <= 64                     # staged throughout (a handful of tiles may fail the zero-margin vote)
+    got = dst.download((D, H, W), np.float32)
+    src.free()
+    dst.free()
+    want = orc.unwarp_stack_rows(vol, c["xcenter"], c["ycenter"], c["list_fact"], 0, H, coord_round_f32=True,
+                                 **kernel_oracle(orc, "f64lerp"))
+    assert np.array_equal(got, want)
