@@ -249,10 +249,13 @@ void host_row_band_rect(const dcp::MapArgs& m, int64_t H, double x_lo, double x_
   const double ax_max = std::fmax(std::fabs(xl), std::fabs(xr));
   const double rlo = std::sqrt(ax_min * ax_min + ay_min * ay_min), rhi = std::sqrt(ax_max * ax_max + ay_max * ay_max);
   if (!std::isfinite(rlo) || !std::isfinite(rhi) || rhi > 1e9) return;
-  const int64_t ns = (int64_t)std::ceil((rhi - rlo) * 4.0) + 1;
+  // a sample every quarter pixel of radius, but never more than ~1e5 of them (a centre far outside the frame would
+  // otherwise cost seconds per call): a coarser step only widens the 2 * step safety margin below
+  const double dr = std::fmax(0.25, (rhi - rlo) / 1.0e5);
+  const int64_t ns = (int64_t)std::ceil((rhi - rlo) / dr) + 1;
   double bmin = 1e300, bmax = -1e300, step = 0.0, prev = 0.0;
   for (int64_t i = 0; i <= ns; ++i) {
-    const double r = i == ns ? rhi : rlo + 0.25 * (double)i;
+    const double r = i == ns ? rhi : rlo + dr * (double)i;
     const double v = B(r < rhi ? r : rhi);
     if (!std::isfinite(v)) return;
     if (i > 0) step = std::fmax(step, std::fabs(v - prev));

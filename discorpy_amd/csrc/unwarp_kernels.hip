@@ -1105,7 +1105,7 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
   Fetch<SAMPLER, true, CT> ft;
   ft.fx = xc - (CT)xi;
   ft.fy = yc - (CT)yi;
-  const uint32_t off = (__umul24(yi, st.row_stride) + (uint32_t)xi) << 2;
+  const uint32_t off = ((uint32_t)yi * (uint32_t)st.row_stride + (uint32_t)xi) << 2;   // full 32-bit product: a row stride may exceed 2^24
   const int row_bytes = st.row_stride * 4;
   const float* base = st.vol + (size_t)d0 * (size_t)st.proj_stride;
   float* out = st.out + ((size_t)d0 * (size_t)st.nrows + (size_t)r) * (size_t)st.W + (size_t)x;
@@ -1203,7 +1203,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
     fx[k] = xf[k] - (float)xi;
     fy[k] = yf[k] - (float)yi;
     // slab byte address when staged, byte offset inside the projection otherwise
-    addr[k] = staged ? (uint32_t)(((yi - by0) * kBoxW + (xi - bx0)) * 4) : (__umul24(yi, st.row_stride) + (uint32_t)xi) << 2;
+    addr[k] = staged ? (uint32_t)(((yi - by0) * kBoxW + (xi - bx0)) * 4) : ((uint32_t)yi * (uint32_t)st.row_stride + (uint32_t)xi) << 2;
   }
   const bool active = x < st.W;
   float* box = s_box[wave];
@@ -1214,7 +1214,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
   const uint32_t rstep = (uint32_t)st.row_stride * 4u;
   const int lrow = (int)(__umul24((uint32_t)lane, 13u) >> 8);        // lane / 20 for lane < 64
   const int lcol = lane - lrow * 20;
-  const uint32_t voff = __umul24((uint32_t)lrow, rstep) + (uint32_t)lcol * 16u;
+  const uint32_t voff = (uint32_t)lrow * rstep + (uint32_t)lcol * 16u;      // full 32-bit product (rows of 16 MB and more)
   const int row_bytes = st.row_stride * 4;
   const float* base = st.vol + (size_t)d0 * (size_t)st.proj_stride;
   float* out = st.out + ((size_t)d0 * (size_t)st.nrows + (size_t)r0) * (size_t)st.W;
@@ -1400,8 +1400,10 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
   img.lds_gather = opts.lds_gather && lds_addressable(img);
   img.wg_box = opts.wg_box;
   img.wg_per_cu = opts.wg_per_cu;
-  // the 8-byte pair gather needs unit column stride and at least a 2x2 image
-  const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2;
+  // the 8-byte pair gather needs unit column stride and at least a 2x2 image; its row offsets are 24-bit products
+  // (v_mul_u32_u24), so a source whose row stride reaches 2^22 elements (16 MB rows: a column-plane view of a large
+  // volume) or whose height reaches 2^24 takes the strided kernels with full 32-bit multiplies instead
+  const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2 && img.src_stride < (1 << 22) && img.H < (1 << 24);
   const int nf = map.nfact;
 
   // order-1 remaps of dense float32 images with float32 coordinates: LDS-staged gather
@@ -1462,7 +1464,7 @@ static hipError_t launch_coords_t(const ImageArgs& img, const CoordArgs& ca, hip
 }
 
 hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler, hipStream_t stream) {
-  const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2;
+  const bool pair = img.src_col_stride == 1 && img.W >= 2 && img.H >= 2 && img.src_stride < (1 << 22) && img.H < (1 << 24);   // see launch_image
 #define DCP_COORDS(S)                                                   \
   case S:                                                               \
     return pair ? launch_coords_t<S, true>(img, ca, stream) : launch_coords_t<S, false>(img, ca, stream);

@@ -65,6 +65,43 @@ def _is_cai(a):
     return hasattr(a, "__cuda_array_interface__") and not _is_torch(a)
 
 
+def _cai_dtype(a):
+    return np.dtype(a.__cuda_array_interface__["typestr"])
+
+
+def _is_device_coords(a):
+    """A C-contiguous float32 / float64 device array (``__cuda_array_interface__``) usable as a coordinate array in place."""
+    if not _is_cai(a):
+        return False
+    cai = a.__cuda_array_interface__
+    dt = np.dtype(cai["typestr"])
+    if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+        return False
+    st = cai.get("strides")
+    if st is None:
+        return True
+    acc = dt.itemsize
+    for n, v in zip(reversed(cai["shape"]), reversed(st)):
+        if int(n) > 1 and int(v) != acc:
+            return False
+        acc *= max(int(n), 1)
+    return True
+
+
+def _cai_to_host(a):
+    """Host copy of a ``__cuda_array_interface__`` array (C-contiguous ones only; anything else should be copied by its owner)."""
+    if hasattr(a, "copy_to_host"):
+        return a.copy_to_host()
+    if hasattr(a, "get"):
+        return a.get()
+    cai = a.__cuda_array_interface__
+    if cai.get("strides") is not None and not _is_device_coords(a):
+        raise ValueError("a strided device coordinate array cannot be read back; pass a contiguous one")
+    out = np.empty(tuple(int(v) for v in cai["shape"]), np.dtype(cai["typestr"]))
+    F.check(F.lib().dcp_memcpy(out.ctypes.data, int(cai["data"][0]), out.nbytes, F.COPY_D2H, -1, None))
+    return out
+
+
 def _default_blend():
     return os.environ.get("DISCORPY_AMD_BLEND", "f64lerp")
 
@@ -418,6 +455,12 @@ def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32,
             raise ValueError("a device stack must have unit column stride and non-overlapping rows / projections")
         vol = _Image(vol.keep.contiguous() if vol.torch else np.ascontiguousarray(vol.keep), 3)
         ps, rs, cs = vol.strides
+    if devices is not None:
+        if vol.torch or vol.cai:
+            raise ValueError("devices= shards a host (NumPy) stack; a device array already lives on one GPU "
+                             "(see discorpy_amd.stack for one process per GPU)")
+        if not vol.f32:
+            raise NotImplementedError("devices= is implemented for float32 stacks (this one is %s)" % (vol.dtype,))
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
     out, optr = vol.empty((depth, nrows, width), out_float32, out=out)
     F.require_device()
@@ -428,9 +471,6 @@ def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32,
                                                     vol.mem, vol.device, vol.stream))
         return out
     if devices is not None:
-        if vol.torch:
-            raise ValueError("devices= shards a host (NumPy) stack; a device tensor already lives on one GPU "
-                             "(see discorpy_amd.stack for one process per GPU)")
         devs = [int(d) for d in devices]
         arr = (C.c_int * max(len(devs), 1))(*devs)
         F.check(F.lib().dcp_unwarp_stack_rows_multi_f32(vol.ptr, optr, depth, height, width,
@@ -507,6 +547,12 @@ def _coordinate_map(shape, kind, xcenter, ycenter, list_fact, list_coef, like):
         yp, xp, mem = ymap.data_ptr(), xmap.data_ptr(), F.MEM_DEVICE
         dev = like.device.index if like.device.index is not None else torch.cuda.current_device()
         stream = torch.cuda.current_stream(dev).cuda_stream
+    elif like is not None and _is_cai(like):
+        # CuPy / Numba image: device-resident maps exposing the same interface
+        dev, stream = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1")), None
+        ymap = F.DeviceArray((height, width), np.float32, dev)
+        xmap = F.DeviceArray((height, width), np.float32, dev)
+        yp, xp, mem = ymap.ptr, xmap.ptr, F.MEM_DEVICE
     else:
         ymap = np.empty((height, width), np.float32)
         xmap = np.empty((height, width), np.float32)
@@ -595,6 +641,7 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
     order = _check_order_mode(order, mode)
     bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
+    staged = None
     if img.torch:
         import torch
         yc = torch.as_tensor(ycoords, device=img.keep.device)
@@ -606,7 +653,24 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
             raise RuntimeError("invalid shape for coordinate array")
         cdt = F.COORD_F32 if dt == torch.float32 else F.COORD_F64
         npts, yptr, xptr, shape = yc.numel(), yc.data_ptr(), xc.data_ptr(), tuple(yc.shape)
+    elif img.cai and _is_device_coords(ycoords) and _is_device_coords(xcoords) and \
+            _cai_dtype(ycoords) == _cai_dtype(xcoords):
+        # device image, device coordinates (CuPy / Numba arrays, or the DeviceArray maps of _generate_perspective_map):
+        # contiguous float32 / float64, used in place
+        yci, xci = ycoords.__cuda_array_interface__, xcoords.__cuda_array_interface__
+        dt = _cai_dtype(ycoords)
+        shape = tuple(int(v) for v in yci["shape"])
+        npts = int(np.prod(shape, dtype=np.int64))
+        if npts != int(np.prod(xci["shape"], dtype=np.int64)):
+            raise RuntimeError("invalid shape for coordinate array")
+        cdt = F.COORD_F32 if dt == np.float32 else F.COORD_F64
+        yptr, xptr = int(yci["data"][0]), int(xci["data"][0])
+        staged = (ycoords, xcoords)
     else:
+        if _is_cai(ycoords):
+            ycoords = _cai_to_host(ycoords)
+        if _is_cai(xcoords):
+            xcoords = _cai_to_host(xcoords)
         yc, xc = np.asarray(ycoords), np.asarray(xcoords)
         dt = np.float32 if (yc.dtype == np.float32 and xc.dtype == np.float32) else np.float64
         yc = np.ascontiguousarray(yc, dtype=dt)
@@ -615,6 +679,12 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
             raise RuntimeError("invalid shape for coordinate array")
         cdt = F.COORD_F32 if dt == np.float32 else F.COORD_F64
         npts, yptr, xptr, shape = yc.size, yc.ctypes.data, xc.ctypes.data, yc.shape
+        if img.mem == F.MEM_DEVICE:
+            # device image (a __cuda_array_interface__ array), host coordinates: the kernel reads the coordinates on the
+            # device, so they are uploaded first (the buffers live until the call has been enqueued and are freed -- which
+            # waits for the device -- when `staged` goes out of scope)
+            staged = (F.DeviceBuffer(max(yc.nbytes, 4), img.device).upload(yc), F.DeviceBuffer(max(xc.nbytes, 4), img.device).upload(xc))
+            yptr, xptr = staged[0].ptr, staged[1].ptr
     out, optr = img.empty(shape)
     F.require_device()
     if not img.f32:

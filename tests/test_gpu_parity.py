@@ -855,6 +855,58 @@ def test_cuda_array_interface_inputs(hip, orc):
     assert np.array_equal(sl.copy_to_host(), orc.unwarp_slice_backward(vol, 60.0, 45.0, [1.0, 1e-3], 33, poly=orc.POLY_KERNEL))
 
 
+def test_cuda_array_interface_image_with_map_index_and_explicit_coordinates(hip, orc):
+    """a CuPy / Numba image with map_index= (host maps, device maps, the maps _generate_perspective_map returns for
+    such an image) and remap_coordinates with host or device coordinates -- the kernel must never be handed a host pointer
+    for a device image."""
+    torch = pytest.importorskip("torch")
+    g = golden("g3_perspective64")
+    coef = list(g["coef_backward"])
+    t = torch.from_numpy(g["mat"]).cuda()
+    dev_img = CudaArrayInterfaceOnly(t)
+    ymap, xmap = pp._generate_perspective_map(dev_img, coef)
+    assert isinstance(ymap, hip.DeviceArray) and ymap.shape == (64 * 64, 1)        # device-resident maps for a device image
+    yh, xh = pp._generate_perspective_map(g["mat"], coef)
+    assert np.array_equal(ymap.copy_to_host(), yh) and np.array_equal(xmap.copy_to_host(), xh)
+    for maps in ((ymap, xmap), (yh, xh), (CudaArrayInterfaceOnly(torch.from_numpy(yh).cuda()), CudaArrayInterfaceOnly(torch.from_numpy(xh).cuda()))):
+        res = pp.correct_perspective_image(dev_img, coef, map_index=maps, blend="scipy")
+        torch.cuda.synchronize()
+        assert np.array_equal(res.copy_to_host(), g["cor_backward"])
+    g9 = golden("g9_points33x47")
+    im = noise(g9["seed"], g9["shape"])
+    d9 = CudaArrayInterfaceOnly(torch.from_numpy(im).cuda())
+    got = pp.remap_coordinates(d9, g9["ys"], g9["xs"], blend="scipy")                          # host float32 coordinates
+    assert np.array_equal(got.copy_to_host(), g9["out_order1"])
+    got = pp.remap_coordinates(d9, g9["ys64"], g9["xs64"], blend="scipy")                      # host float64 coordinates
+    assert np.array_equal(got.copy_to_host(), g9["out64_order1"])
+    ys_d = CudaArrayInterfaceOnly(torch.from_numpy(g9["ys64"]).cuda())
+    xs_d = CudaArrayInterfaceOnly(torch.from_numpy(g9["xs64"]).cuda())
+    assert np.array_equal(pp.remap_coordinates(d9, ys_d, xs_d, order=0).copy_to_host(), g9["out64_order0"])   # device coordinates
+    assert np.array_equal(pp.remap_coordinates(d9, ys_d, g9["xs64"], order=0).copy_to_host(), g9["out64_order0"])   # mixed
+
+
+def test_device_views_with_16_megabyte_row_strides(hip, orc):
+    """the tuned kernels form row offsets with 24-bit multiplies; a device view whose rows are 2^22 elements apart
+    -- vol[:, k, :] of a (depth, 4096, 1024) volume -- must take the kernels with full 32-bit products (frames and stacks)."""
+    torch = pytest.importorskip("torch")
+    vol = torch.from_numpy(noise(91, (24, 4096, 1024))).cuda()
+    a = (500.5, 11.25, [1.0, -1.0e-4, 2.0e-7])
+    for k in (0, 1777, 4095):
+        view = vol[:, k, :]
+        assert view.stride(0) == 1 << 22 and view.shape == (24, 1024)
+        host = np.ascontiguousarray(view.cpu().numpy())
+        for order in (0, 1):
+            got = pp.unwarp_image_backward(view, *a, order=order).cpu().numpy()
+            assert "strided" in hip.last_kernel()
+            assert np.array_equal(got, orc.unwarp_image_backward(host, *a, order=order, **kernel_oracle(orc, "f64lerp")))
+    # a stack whose projections' rows are 2^22 elements apart: (depth, rows, width) = vol[:, ::?] is not expressible with a
+    # row stride that large and 24 projections in 4 GiB, so one projection with huge rows: a (1, 24, 1024) stack view
+    st = vol[:, 100, :].unsqueeze(0)
+    assert st.stride(1) == 1 << 22
+    got = pp.unwarp_chunk_slices_backward(st, *a, 2, 20).cpu().numpy()
+    assert np.array_equal(got, orc.unwarp_chunk_slices_backward(np.ascontiguousarray(st.cpu().numpy()), *a, 2, 20, **kernel_oracle(orc, "f64lerp")))
+
+
 def test_element_types_on_device_tensors_and_stacks(hip, orc):
     torch = pytest.importorskip("torch")
     a = (70.0, 50.0, [1.0, 2e-3])
