@@ -113,7 +113,7 @@ int homography_is_tame(const double* c, int64_t H, int64_t W) {
 // is a level: 1 = holds for 64 x 16 tiles, 2 = also for the 128 x 32 tiles of remap_wg_kernel (w = 127, h = 31).
 //   radial map (x - xc) B(r):  |f_xx|, |f_yy| <= 4 |B'(r)| + r |B''(r)|   (the x and the y coordinate alike;
 //     f_xx = 3 xu B'/r + xu^3 (B''/r^2 - B'/r^3), f_yy = xu B'/r + xu yu^2 (B''/r^2 - B'/r^3), |xu|, |yu| <= r).
-//     The supremum over [0, rmax] (rmax: farthest frame corner from the centre) is taken on 128 midpoints plus the
+//     The supremum over [0, rmax] (rmax: farthest frame corner from the centre) is taken on 1024 midpoints plus the
 //     half-interval times a triangle-inequality bound of the derivative -- rigorous, and tight enough because the
 //     intervals are short.
 //   homography N(x, y) / D(x, y), N and D affine, D of one sign over the frame ("tame"):
@@ -137,7 +137,7 @@ double radial_curvature_bound(const dcp::MapArgs& m, double rmax) {
     l2 += (double)i * (i - 1) * (i - 1) * a * rp;
     rp *= rmax;
   }
-  constexpr int kNodes = 128;
+  constexpr int kNodes = 1024;      // (the answer is cached per calibration: ~20 us once)
   const double h = rmax / kNodes;
   double sup = 0.0;
   for (int k = 0; k < kNodes; ++k) {

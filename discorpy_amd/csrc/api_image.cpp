@@ -310,7 +310,30 @@ int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, in
   ca.npts = npts;
   ca.is_f64 = coord_dtype == DCP_COORD_F64;
   const int64_t nout = map_kind == 3 ? npts : H * W;
+  // 8- / 16-bit integers, radial or perspective map, certified: the workgroup-box kernel (same arithmetic, LDS-staged)
+  dcp::MapArgs mapc = map;
+  auto staged_launch = [&](const void* dsrc_, void* ddst_, int64_t rs_, bool* taken) -> hipError_t {
+    *taken = false;
+    if ((map_kind != 0 && map_kind != 1) || cs != 1 || (double)extent_bytes_typed(H, W, rs_, 1, dtype) > 4294900000.0) return hipSuccess;
+    const dcp::MapKind kind = map_kind == 0 ? dcp::kRadial : dcp::kPersp;
+    mapc.tile_dev_ok = g_tile_cert.load() ? tile_deviation_certified(kind, mapc, H, W) : 0;
+    if (kind == dcp::kPersp) mapc.fast_div = homography_is_tame(mapc.coef, H, W);
+    dcp::ImageArgs im;
+    memset(&im, 0, sizeof(im));
+    im.H = (int32_t)H;
+    im.W = (int32_t)W;
+    im.src = (const float*)dsrc_;
+    im.dst = (float*)ddst_;
+    im.src_stride = (int32_t)rs_;
+    im.src_col_stride = 1;
+    im.src_bytes = (uint32_t)extent_bytes_typed(H, W, rs_, 1, dtype);
+    im.xcd_remap = current_opts().xcd_remap;
+    return dcp::launch_wg_typed(kind, im, mapc, order, dtype, current_opts(), st, taken);
+  };
   if (mem_kind == DCP_MEM_DEVICE) {
+    bool taken = false;
+    DCP_HIP(staged_launch(src, dst, rs, &taken));
+    if (taken) return DCP_OK;
     a.src = src;
     a.dst = dst;
     ca.ycoord = ycoord;
@@ -335,7 +358,9 @@ int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, in
   a.dst = ddst;
   ca.ycoord = dy;
   ca.xcoord = dx;
-  DCP_HIP(dcp::launch_typed_image(map_kind, a, map, ca, st));
+  bool taken = false;
+  DCP_HIP(staged_launch(dsrc, ddst, rs, &taken));
+  if (!taken) DCP_HIP(dcp::launch_typed_image(map_kind, a, map, ca, st));
   DCP_HIP(hipMemcpyAsync(dst, ddst, (size_t)nout * esz, hipMemcpyDeviceToHost, st));
   DCP_HIP(hipStreamSynchronize(st));
   return DCP_OK;

@@ -174,16 +174,24 @@ __device__ __forceinline__ T to_elem(double t) {
   } else if constexpr (std::is_same<T, double>::value) {
     return t;
   } else if constexpr (std::is_unsigned<T>::value) {
-    constexpr double hi = (double)std::numeric_limits<T>::max();
-    t = t > 0.0 ? t + 0.5 : 0.0;
-    t = t > hi ? hi : t;
-    return (T)(uint32_t)t;
+    // scipy: t > 0 ? t + 0.5 : 0, clamped to the maximum, truncated.  v_cvt_u32_f64 truncates and saturates (negative
+    // and NaN -> 0, >= 2^32 -> 0xffffffff), so one add, one conversion and one integer minimum say the same: for
+    // t <= 0, t + 0.5 <= 0.5 truncates to 0; for t > 0 it is the same sum; anything above the maximum is clamped after.
+    uint32_t r;
+    const double th = t + 0.5;
+    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(th));
+    constexpr uint32_t hi = (uint32_t)std::numeric_limits<T>::max();
+    return (T)(r < hi ? r : hi);
   } else {
-    constexpr double lo = (double)std::numeric_limits<T>::min(), hi = (double)std::numeric_limits<T>::max();
-    t = t > 0.0 ? t + 0.5 : t - 0.5;
-    t = t > hi ? hi : t;
-    t = t < lo ? lo : t;
-    return (T)(int32_t)t;
+    // scipy: rounded half away from zero (t > 0 ? t + 0.5 : t - 0.5), clamped, truncated.  v_cvt_i32_f64 truncates and
+    // saturates to the int32 range, which contains every narrower type's bounds.
+    int32_t r;
+    const double th = t + (t > 0.0 ? 0.5 : -0.5);
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(th));
+    constexpr int32_t lo = (int32_t)std::numeric_limits<T>::min(), hi = (int32_t)std::numeric_limits<T>::max();
+    r = r > hi ? hi : r;
+    r = r < lo ? lo : r;
+    return (T)r;
   }
 }
 

@@ -126,6 +126,10 @@ struct LaunchOpts {
 // launchers (unwarp_kernels.hip)
 hipError_t launch_image(MapKind kind, const ImageArgs& img, const MapArgs& map, int sampler,
                         bool round_f32, const LaunchOpts& opts, hipStream_t stream);
+// 8- and 16-bit integer images on remap_wg_kernel (img.src / dst reinterpreted, src_stride in elements, src_bytes the extent
+// in bytes); *taken = false: the call does not qualify, use launch_typed_image
+hipError_t launch_wg_typed(MapKind kind, const ImageArgs& img, const MapArgs& map, int order, int dtype, const LaunchOpts& opts,
+                           hipStream_t stream, bool* taken);
 hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler, hipStream_t stream);
 hipError_t launch_coord_map(MapKind kind, const ImageArgs& img, const MapArgs& map, float* ymap, float* xmap,
                             hipStream_t stream);
@@ -133,6 +137,7 @@ hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bo
                         const LaunchOpts& opts, hipStream_t stream);
 
 hipError_t read_lds_stats(unsigned long long* out, bool reset);
+void set_last_kernel_name(const char* name);   // for the launchers of the other translation units
 const char* last_kernel_name();   // unwarp_kernels.hip: the kernel the calling thread launched last (float32 image / stack launchers)
 // spline_kernels.hip: map_kind 0 radial, 1 perspective, 2 explicit coordinates
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,

@@ -226,6 +226,7 @@ static hipError_t launch_image_t(int map_kind, const TypedImageArgs& a, const Ma
 
 hipError_t launch_typed_image(int map_kind, const TypedImageArgs& a, const MapArgs& map, const CoordArgs& ca,
                               hipStream_t stream) {
+  set_last_kernel_name("typed_image_kernel (one thread per pixel, any element type)");
 #define DCP_CALL(T) launch_image_t<T>(map_kind, a, map, ca, stream)
   DCP_TYPED_DISPATCH(a.dtype, DCP_CALL)
 #undef DCP_CALL
@@ -238,6 +239,7 @@ static hipError_t launch_channels_t(const TypedImageArgs& a, const MapArgs& map,
 }
 
 hipError_t launch_typed_channels(const TypedImageArgs& a, const MapArgs& map, int channels, hipStream_t stream) {
+  set_last_kernel_name("typed_channels_kernel (interleaved channels, one thread per pixel)");
 #define DCP_CALL(T) launch_channels_t<T>(a, map, channels, stream)
   DCP_TYPED_DISPATCH(a.dtype, DCP_CALL)
 #undef DCP_CALL
@@ -252,6 +254,7 @@ static hipError_t launch_stack_t(const TypedStackArgs& st, const MapArgs& map, h
 }
 
 hipError_t launch_typed_stack(const TypedStackArgs& st, const MapArgs& map, hipStream_t stream) {
+  set_last_kernel_name("typed_stack_kernel (one thread per (row, x), any element type)");
   if (st.D == 0 || st.nrows == 0) return hipSuccess;
 #define DCP_CALL(T) launch_stack_t<T>(st, map, stream)
   DCP_TYPED_DISPATCH(st.dtype, DCP_CALL)

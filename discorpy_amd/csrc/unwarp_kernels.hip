@@ -743,13 +743,28 @@ static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wav
 #ifndef DCP_WG_WAVES
 #define DCP_WG_WAVES 6      // waves per SIMD the register allocation aims at (six 24 KB workgroups fit a CU's LDS)
 #endif
-template <int KIND, int NF, int SAMPLER>
+// T: element type of source and result.  float is the tuned float32 path (any blend).  uint8 / int8 / uint16 / int16
+// (what detectors and cameras deliver) run the same kernel on narrower slab rows -- 16-bit: 20 chunks of 16 bytes =
+// 160 elements, 8-bit: 10 chunks = 160 elements, the box's first column rounded down to a 4-byte boundary -- read their
+// taps with ds_read_u16 / _i16 / _u8 / _i8, blend in scipy's exact float64 operation order (SAMPLER = kScipy; the
+// integer result depends on it at rounding ties) and convert as scipy does: round half away from zero, saturate.
+// ImageArgs::src / dst / src_stride / src_bytes keep their meaning (pointers reinterpreted, stride in ELEMENTS, extent in bytes).
+template <int KIND, int NF, int SAMPLER, typename T = float>
 __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
-  __shared__ float s_box[kWgSlabRows * kWgBoxW];
+  constexpr bool kIsF32 = std::is_same<T, float>::value;
+  constexpr int ES = (int)sizeof(T);                           // element size in bytes
+  constexpr int CH = ES == 4 ? 36 : (ES == 2 ? 20 : 10);       // 16-byte chunks per slab row
+  constexpr int PB = CH * 16;                                  // slab pitch in bytes
+  constexpr int kBoxWEl = PB / ES;                             // widest box in elements: 144 / 160 / 160
+  constexpr int NJ = (kWgBoxH * CH + 255) / 256;               // loads per wave that cover the slab: 6 / 4 / 2
+  static_assert(kIsF32 || SAMPLER == kNearest || SAMPLER == kScipy, "integer element types blend in scipy's exact order");
+  __shared__ __attribute__((aligned(16))) unsigned char s_box[kWgSlabRows * PB];
   __shared__ double s_row[4][kLdsTH][KIND == kRadial ? 2 : 4];     // one row table per wave: no barrier before it is read
   __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
   using FetchT = Fetch<SAMPLER, true, float>;
   constexpr int RW = KIND == kRadial ? 2 : 4;
+  const T* const srcT = (const T*)img.src;
+  T* const dstT = (T*)img.dst;
 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
@@ -821,12 +836,13 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
     cy1 = max(max(ya, yb), max(yc_, yd_));
   }
   // hull of the corner taps grown by one pixel (the certified deviation is below one pixel)
-  const int bx0 = max(min(cx0 - 1, img.W - 2), 0);
+  // (narrow element types: the first column rounded down to a 4-byte boundary of the source row, as the 16-byte copies need)
+  const int bx0 = max(min(cx0 - 1, img.W - 2), 0) & ~(4 / ES - 1);
   const int bx1 = min(cx1 + 2, img.W - 1);
   const int by0 = max(min(cy0 - 1, img.H - 2), 0);
   const int by1 = min(cy1 + 2, img.H - 1);
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
-  const bool fits = bw <= kWgBoxW && bh <= kWgBoxH;          // workgroup-uniform
+  const bool fits = bw <= kBoxWEl && bh <= kWgBoxH;          // workgroup-uniform
   DCP_TRACE(1);
   DCP_TRACE(2);
 
@@ -837,24 +853,28 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
   // vector arithmetic per load at all, but 5 us slower per frame.)  The loads are not issued in one burst: load j
   // goes out in front of coordinate row DCP_WG_FILL_EVERY * j of phase 1 (a wave stuck at a full memory queue does no arithmetic).
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  static_assert(kWgBoxW == 144 && kWgBoxH * 36 <= 6 * 256, "six loads of 64 chunks per wave cover the slab");
-  const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
-  const uint32_t rstep = (uint32_t)img.src_stride * 4u;
+  static_assert(kWgBoxW == 144 && kWgBoxH * 36 <= 6 * 256, "six loads of 64 chunks per wave cover the float32 slab");
+  const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img.src, 0, (int)img.src_bytes, 0x00020000);
+  const uint32_t rstep = (uint32_t)img.src_stride * (uint32_t)ES;      // source row pitch in bytes
   const int fc = wave * 64 + lane;
-  const int crow0 = (int)(__umul24((uint32_t)fc, 1821u) >> 16);       // fc / 36 for fc < 256 (1821 = ceil(65536 / 36))
-  const int c160 = fc - crow0 * 36;
-  const uint32_t off0 = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u + (uint32_t)crow0 * rstep + (uint32_t)c160 * 16u;
-  const int nchunk = bh * 36;
+  const int crow0 = fc / CH;                                            // (constant divisor: a multiply and a shift)
+  const int c160 = fc - crow0 * CH;
+  const uint32_t off0 = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * (uint32_t)ES + (uint32_t)crow0 * rstep + (uint32_t)c160 * 16u;
+  const int nchunk = bh * CH;
   auto issue_fill = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    if (fits && (j * 4 + wave) * 64 < nchunk) {               // wave-uniform: does any chunk of this load lie inside the box?
-      const bool wrap = c160 >= 36 - 4 * j;                   // (c160 + 4 j) mod 36 wrapped into the next row (at most once: c160 + 20 < 72)
-      const int crow = crow0 + 7 * j + (wrap ? 1 : 0);
-      // lanes whose chunk lies past the last box row are masked off (an out-of-range offset would still write
-      // zeros into LDS -- past the end of the slab when the box is 40 rows tall)
-      if (crow < bh)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 256), 16,
-                                                 off0 + (wrap ? rstep - 576u : 0u) + (uint32_t)j * (7u * rstep + 64u), 0, 0, 0);
+    if constexpr (j < NJ) {
+      if (fits && (j * 4 + wave) * 64 < nchunk) {             // wave-uniform: does any chunk of this load lie inside the box?
+        // 256 j chunks further on: (256 j) / CH whole rows, and the column wraps into the next row at most once
+        constexpr int qrow = (256 * j) / CH, rem = (256 * j) % CH;
+        const bool wrap = c160 >= CH - rem;
+        const int crow = crow0 + qrow + (wrap ? 1 : 0);
+        // lanes whose chunk lies past the last box row are masked off (an out-of-range offset would still write
+        // zeros into LDS -- past the end of the slab when the box is 40 rows tall)
+        if (crow < bh)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16,
+                                                   off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u, 0, 0, 0);
+      }
     }
   };
 
@@ -872,9 +892,9 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
   const int ybase = __builtin_amdgcn_readfirstlane(min(y0, img.rows_out - 1));
   const ColCtx col = make_col<KIND, NF>(map, min(x, img.W - 1));
   const auto* rowtab = s_row[wave];
-  const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
-  const char* out_base = (const char*)(img.dst + (size_t)ybase * (size_t)img.W);
-  const uint32_t xoff = (uint32_t)x * 4u;         // lanes with x >= W: the store is out of range and dropped
+  const uint32_t row_bytes_out = (uint32_t)img.W * (uint32_t)ES;
+  const char* out_base = (const char*)(dstT + (size_t)ybase * (size_t)img.W);
+  const uint32_t xoff = (uint32_t)x * (uint32_t)ES;         // lanes with x >= W: the store is out of range and dropped
   const __amdgpu_buffer_rsrc_t dst =
       __builtin_amdgcn_make_buffer_rsrc((void*)out_base, 0, (int)((uint32_t)rows * row_bytes_out), 0x00020000);
 
@@ -939,10 +959,18 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
   if (rows == 0 || !(x < img.W)) return;           // no cross-lane work from here on
   if (fits) {
     // ---- phase 2: taps from the shared slab, blend, store
-    const uint32_t negorg4 = (uint32_t)(-(by0 * kWgBoxW + bx0) * 4);
+    const uint32_t negorg4 = (uint32_t)(-(by0 * PB + bx0 * ES));
     const char* boxb = (const char*)s_box;
     const bool interior = bx1 < img.W - 1 && by1 < img.H - 1;
     const float negorg4f = (float)(int32_t)negorg4;
+    auto tap_addr = [&](int xi, int yi) -> uint32_t {            // yi * pitch + xi * element size + origin, 24-bit multiply
+      uint32_t xa, a_;
+      if constexpr (ES == 4) asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
+      else if constexpr (ES == 2) asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
+      else xa = (uint32_t)xi + negorg4;
+      asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a_) : "v"(yi), "s"(PB), "v"(xa));
+      return a_;
+    };
     auto tile_rows_loop = [&](auto full, auto inner) {
 #pragma unroll
       for (int k = 0; k < kLdsTH; ++k) {
@@ -953,38 +981,66 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
           int yi = (int)yf[k];
           xi += (xf[k] - (float)xi >= 0.5f) ? 1 : 0;
           yi += (yf[k] - (float)yi >= 0.5f) ? 1 : 0;
-          uint32_t xa;
-          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
-          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kWgBoxW * 4), "v"(xa));
+          addr = tap_addr(xi, yi);
         } else if constexpr (decltype(inner)::value) {
           f.fx = __builtin_amdgcn_fractf(xf[k]);      // x - floor(x), exact
           f.fy = __builtin_amdgcn_fractf(yf[k]);
           const float flx = xf[k] - f.fx, fly = yf[k] - f.fy;
-          const float af = __builtin_fmaf(fly, (float)(kWgBoxW * 4), __builtin_fmaf(flx, 4.0f, negorg4f));
+          const float af = __builtin_fmaf(fly, (float)PB, __builtin_fmaf(flx, (float)ES, negorg4f));
           addr = (uint32_t)(int32_t)af;
         } else {
           const int xi = min((int)xf[k], img.W - 2);
           const int yi = min((int)yf[k], img.H - 2);
           f.fx = xf[k] - (float)xi;
           f.fy = yf[k] - (float)yi;
-          uint32_t xa;
-          asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
-          asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kWgBoxW * 4), "v"(xa));
+          addr = tap_addr(xi, yi);
         }
-        const float* t = (const float*)(boxb + addr);
-        float v;
-        if constexpr (SAMPLER == kNearest) {
-          v = t[0];
+        const T* t = (const T*)(boxb + addr);
+        if constexpr (kIsF32) {
+          float v;
+          if constexpr (SAMPLER == kNearest) {
+            v = t[0];
+          } else {
+            f.a.x = __float_as_uint(t[0]);
+            f.a.y = __float_as_uint(t[1]);
+            f.b.x = __float_as_uint(t[kBoxWEl]);
+            f.b.y = __float_as_uint(t[kBoxWEl + 1]);
+            v = finish<SAMPLER, true, float>(f);
+          }
+          if (decltype(full)::value || k < rows)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
         } else {
-          f.a.x = __float_as_uint(t[0]);
-          f.a.y = __float_as_uint(t[1]);
-          f.b.x = __float_as_uint(t[kWgBoxW]);
-          f.b.y = __float_as_uint(t[kWgBoxW + 1]);
-          v = finish<SAMPLER, true, float>(f);
+          T v;
+          if constexpr (SAMPLER == kNearest) {
+            v = t[0];
+          } else {
+            // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right, then its integer store
+            const double fx = (double)f.fx, fy = (double)f.fy;
+            const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
+            const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
+            // The tap pair (x0, x0 + 1) of a row starts at any multiple of the element size: read the two ALIGNED dwords
+            // around it (one ds_read2_b32) and shift the pair down -- a dword read at a 2- or 1-byte boundary works on this
+            // hardware but costs 40 us per frame.
+            const uint32_t* q = (const uint32_t*)(boxb + (addr & ~3u));
+            const uint32_t sh = (addr & 3u) * 8u;
+            const uint32_t top = __builtin_amdgcn_alignbit(q[1], q[0], sh), bot = __builtin_amdgcn_alignbit(q[PB / 4 + 1], q[PB / 4], sh);
+            auto tap = [](uint32_t w, int i) -> double {            // element i (0 / 1) of the pair, as scipy reads it: a double
+              if constexpr (std::is_signed<T>::value) return (double)(int32_t)__builtin_amdgcn_sbfe(w, i * ES * 8, ES * 8);
+              else return (double)__builtin_amdgcn_ubfe(w, i * ES * 8, ES * 8);
+            };
+            double acc = (tap(top, 0) * wy0) * wx0;
+            acc += (tap(top, 1) * wy0) * wx1;
+            acc += (tap(bot, 0) * wy1) * wx0;
+            acc += (tap(bot, 1) * wy1) * wx1;
+            v = to_elem<T>(acc);
+          }
+          if (decltype(full)::value || k < rows) {
+            if constexpr (ES == 2)
+              __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
+            else
+              __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
+          }
         }
-        if (decltype(full)::value || k < rows)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
-                                                DCP_STORE_AUX);
       }
     };
     if (rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{});
@@ -998,12 +1054,39 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
     // ---- box too large for the slab: direct global gather
 #pragma unroll
     for (int k = 0; k < kLdsTH; ++k) {
-      const FetchT f = fetch<SAMPLER, true, float>(src, __builtin_amdgcn_fmed3f(xf[k], 0.0f, wmaxf),
-                                                   __builtin_amdgcn_fmed3f(yf[k], 0.0f, hmaxf));
-      const float v = finish<SAMPLER, true, float>(f);
-      if (k < rows)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
-                                              DCP_STORE_AUX);
+      const float xc = __builtin_amdgcn_fmed3f(xf[k], 0.0f, wmaxf), yc = __builtin_amdgcn_fmed3f(yf[k], 0.0f, hmaxf);
+      if constexpr (kIsF32) {
+        const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
+        const FetchT f = fetch<SAMPLER, true, float>(src, xc, yc);
+        const float v = finish<SAMPLER, true, float>(f);
+        if (k < rows)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
+      } else {
+        T v;
+        if constexpr (SAMPLER == kNearest) {
+          int xi = (int)xc, yi = (int)yc;
+          xi += (xc - (float)xi >= 0.5f) ? 1 : 0;
+          yi += (yc - (float)yi >= 0.5f) ? 1 : 0;
+          v = srcT[(size_t)yi * (size_t)img.src_stride + (size_t)xi];
+        } else {
+          const int xi = min((int)xc, img.W - 2), yi = min((int)yc, img.H - 2);
+          const double fx = (double)(xc - (float)xi), fy = (double)(yc - (float)yi);
+          const T* t = srcT + (size_t)yi * (size_t)img.src_stride + (size_t)xi;
+          const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
+          const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
+          double acc = ((double)t[0] * wy0) * wx0;
+          acc += ((double)t[1] * wy0) * wx1;
+          acc += ((double)t[img.src_stride] * wy1) * wx0;
+          acc += ((double)t[img.src_stride + 1] * wy1) * wx1;
+          v = to_elem<T>(acc);
+        }
+        if (k < rows) {
+          if constexpr (ES == 2)
+            __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
+          else
+            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
+        }
+      }
     }
   }
 }
@@ -1281,6 +1364,7 @@ static void note_kernel(const char* kernel, int kind, int nf, int sampler, const
   else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<NF=%d,%s%s>", kernel, nf, sampler_name(sampler), extra);
 }
 const char* last_kernel_name() { return g_last_kernel; }
+void set_last_kernel_name(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
 
 template <int KIND, int NF, int SAMPLER, bool ROUND32, bool PAIR>
 static hipError_t launch_one(const ImageArgs& img, const MapArgs& map, hipStream_t stream) {
@@ -1333,6 +1417,59 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
   note_kernel("remap_wg_kernel", KIND, NF, SAMPLER);
   hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), pad, stream, img, map);
   return hipGetLastError();
+}
+
+// Narrow integer element types on remap_wg_kernel (typed entry points of the C ABI, orders 0 / 1): taken = false when the
+// call does not qualify (no level-2 certificate, column-strided or unaligned source, image too wide for float32 LDS
+// addresses) and the generic one-thread-per-pixel kernels of typed_kernels.hip must serve it.
+template <int KIND, int NF, typename T>
+static hipError_t launch_wg_typed_t(const ImageArgs& img_in, const MapArgs& map, int order, hipStream_t stream) {
+  ImageArgs img = img_in;
+  img.tiles_x = (img.W + kWgTW - 1) / kWgTW;
+  img.tiles_y = (img.rows_out + kWgTH - 1) / kWgTH;
+  const dim3 grid(8 * ((img.tiles_x + 7) / 8), img.tiles_y);
+  if (order == 0) {
+    note_kernel("remap_wg_kernel", KIND, NF, kNearest, sizeof(T) == 2 ? ",16-bit" : ",8-bit");
+    hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, kNearest, T>), grid, dim3(256), 0, stream, img, map);
+  } else {
+    note_kernel("remap_wg_kernel", KIND, NF, kScipy, sizeof(T) == 2 ? ",16-bit" : ",8-bit");
+    hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, kScipy, T>), grid, dim3(256), 0, stream, img, map);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_wg_typed_k(MapKind kind, const ImageArgs& img, const MapArgs& map, int order, hipStream_t stream) {
+  if (kind == kPersp) return launch_wg_typed_t<kPersp, -1, T>(img, map, order, stream);
+  if (map.nfact == 5) return launch_wg_typed_t<kRadial, 5, T>(img, map, order, stream);
+  if (map.nfact == 4) return launch_wg_typed_t<kRadial, 4, T>(img, map, order, stream);
+  return launch_wg_typed_t<kRadial, -1, T>(img, map, order, stream);
+}
+
+hipError_t launch_wg_typed(MapKind kind, const ImageArgs& img_in, const MapArgs& map, int order, int dtype, const LaunchOpts& opts,
+                           hipStream_t stream, bool* taken) {
+  *taken = false;
+  const int es = elem_size(dtype);
+  if ((kind != kRadial && kind != kPersp) || (order != 0 && order != 1) || map.tile_dev_ok < 2 || !opts.wg_box || !opts.lds_gather ||
+      opts.xcd_remap != 2 || opts.coef_lds)
+    return hipSuccess;
+  if (dtype != kU8 && dtype != kI8 && dtype != kU16 && dtype != kI16) return hipSuccess;
+  ImageArgs img = img_in;
+  if (img.rows_out <= 0) {
+    img.y_origin = 0;
+    img.rows_out = img.H;
+  }
+  // unit column stride, at least 2 x 2, 4-byte aligned rows (the 16-byte LDS-DMA copies), 24-bit products, float32 LDS addresses
+  if (img.src_col_stride != 1 || img.W < 2 || img.H < 2 || ((uintptr_t)img.src & 3u) || (((int64_t)img.src_stride * es) & 3) ||
+      img.src_stride >= (1 << 22) || img.H >= (1 << 24) || !lds_addressable(img))
+    return hipSuccess;
+  *taken = true;
+  switch (dtype) {
+    case kU8: return launch_wg_typed_k<uint8_t>(kind, img, map, order, stream);
+    case kI8: return launch_wg_typed_k<int8_t>(kind, img, map, order, stream);
+    case kU16: return launch_wg_typed_k<uint16_t>(kind, img, map, order, stream);
+    default: return launch_wg_typed_k<int16_t>(kind, img, map, order, stream);
+  }
 }
 
 // VOTE = false needs the host's certificate (MapArgs::tile_dev_ok); without it the runtime-length polynomial
