@@ -247,6 +247,25 @@ def other_configs(a, dev, srcs, dsts, img0):
     ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.correct_perspective_image(img0, c3["list_coef"], blend=orc.BLEND_F64LERP))
     out["cfg3_perspective_only"] = entry(us, H * W, 8, k, ok)
 
+    # 16-bit detector frames (the element type tomography cameras deliver): the same kernel on narrower slab rows, scipy's
+    # exact blend and integer store; 2 B read + 2 B written per pixel
+    u16 = (img0 * 60000.0).astype(np.uint16)
+    s16 = [F.DeviceBuffer(u16.nbytes, dev).upload(u16) for _ in range(4)]
+    d16 = [F.DeviceBuffer(u16.nbytes, dev) for _ in range(4)]
+
+    def radial_u16(i):
+        F.check(L.dcp_unwarp_image_typed(s16[i % 4].ptr, d16[i % 4].ptr, F.DTYPE_BY_NAME["uint16"], H, W, W, 1, c2["xcenter"], c2["ycenter"],
+                                         fa, nf, 1, 0, F.MEM_DEVICE, dev, None))
+    us = timed_launches(radial_u16, reps, dev)
+    k = F.last_kernel()
+    radial_u16(0)
+    got = np.empty((H, W), np.uint16)
+    F.check(L.dcp_memcpy(got.ctypes.data, d16[0].ptr, got.nbytes, F.COPY_D2H, dev, None))
+    ok = np.array_equal(got, orc.unwarp_image_backward(u16, c2["xcenter"], c2["ycenter"], c2["list_fact"], poly=orc.POLY_KERNEL))
+    out["cfg2_uint16_frame"] = entry(us, H * W, 4, k, ok, note="uint16 in, uint16 out: 4 algorithmic bytes per pixel")
+    for b in s16 + d16:
+        b.free()
+
     def two_pass(i):
         radial(i, 1, F.BLEND_F64LERP)                # srcs[i] -> dsts[i]
         # dsts[i] -> srcs[i + 1]: the chain runs frame to frame through the ring
@@ -479,6 +498,34 @@ def free_device_bytes(dev):
     except Exception:      # noqa: BLE001
         pass
     return None
+
+
+def stack_uint16_shard(a, dev):
+    """One 8-GPU shard of config 4 as uint16 projections (64 of them, every row): dcp_unwarp_stack_rows_typed."""
+    L = F.lib()
+    orc = oracle_module(a.cpu_threads)
+    cfg = configs.cfg4(64)
+    D, H, W = cfg["shape"]
+    fa, nf = F.fact_array(cfg["list_fact"])
+    chunk = (np.random.default_rng(cfg["seed"] + 5).random((4, H, W), dtype=np.float32) * 60000.0).astype(np.uint16)
+    vol = F.DeviceBuffer(D * H * W * 2, dev)
+    out = F.DeviceBuffer(D * H * W * 2, dev)
+    for d in range(0, D, 4):
+        F.check(L.dcp_memcpy(vol.ptr + d * H * W * 2, chunk.ctypes.data, chunk.nbytes, F.COPY_H2D, dev, None))
+    code = F.DTYPE_BY_NAME["uint16"]
+
+    def run(_i):
+        F.check(L.dcp_unwarp_stack_rows_typed(vol.ptr, out.ptr, code, 0, D, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf, 0.0, H, 1,
+                                              F.MEM_DEVICE, dev, None))
+    us = timed_launches(run, 12, dev, settle_ms=60.0)
+    k = F.last_kernel()
+    got = np.empty((1, H, W), np.uint16)
+    F.check(L.dcp_memcpy(got.ctypes.data, out.ptr + 3 * H * W * 2, got.nbytes, F.COPY_D2H, dev, None))
+    want = orc.unwarp_chunk_slices_backward(chunk[3:4], cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], 0, H - 1, poly=orc.POLY_KERNEL)
+    ok = np.array_equal(got, want)
+    vol.free()
+    out.free()
+    return entry(us, D * H * W, 4, k, ok, shape=[D, H, W], note="uint16 projections, every row: 4 algorithmic bytes per voxel")
 
 
 def stack_one_gpu_cases(a, dev):
@@ -766,7 +813,8 @@ def main(argv=None):
     for b in srcs + dsts:           # the ring is no longer needed: make room for the 8192^2 frames and the stack
         b.free()
     if others is not None and "error" not in others:
-        for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev))):
+        for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev)),
+                         ("cfg4_uint16_shard64", lambda: stack_uint16_shard(a, dev))):
             try:
                 others[name] = fn()
             except Exception as e:      # noqa: BLE001

@@ -122,6 +122,7 @@ int homography_is_tame(const double* c, int64_t H, int64_t W) {
 // rounded) hull +- the deviation; 0.95 px leaves room for the rounding (one float32 ulp of a coordinate < 2^24).
 namespace {
 constexpr double kTileDevLimit = 0.95;
+constexpr double kWgBoxCols = 144.0, kWgBoxRows = 42.0;     // remap_wg_kernel's slab (unwarp_kernels.hip: kWgBoxW, kWgBoxH)
 // (w^2, h^2) / 8 of the two tile shapes: the 64 x 16 wave tile of remap_lds_kernel, the 128 x 32 workgroup tile of remap_wg_kernel
 constexpr double kSpanX2[2] = {63.0 * 63.0 / 8.0, 127.0 * 127.0 / 8.0}, kSpanY2[2] = {15.0 * 15.0 / 8.0, 31.0 * 31.0 / 8.0};
 
@@ -154,6 +155,46 @@ double radial_curvature_bound(const dcp::MapArgs& m, double rmax) {
   return std::isfinite(sup) ? sup : INFINITY;
 }
 
+// Level 2 is only worth taking when (nearly) every 128 x 32 tile's source box fits remap_wg_kernel's slab: a tile
+// that does not sends its whole workgroup to the direct gather, and with a fifth of the tiles doing so (the 9-term
+// fisheye model of config 5, whose tiles are sheared) the per-wave kernel is the faster one.  The boxes of a 24 x 24
+// lattice of tiles are formed exactly as the kernel forms them (corner hull, one pixel of margin, tap width).
+bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) {
+  const int64_t ntx = (W + 127) / 128, nty = (H + 31) / 32;
+  const int sx = (int)std::min<int64_t>(ntx, 24), sy = (int)std::min<int64_t>(nty, 24);
+  int bad = 0;
+  for (int iy = 0; iy < sy; ++iy)
+    for (int ix = 0; ix < sx; ++ix) {
+      const int64_t tx = sx > 1 ? (int64_t)ix * (ntx - 1) / (sx - 1) : 0, ty = sy > 1 ? (int64_t)iy * (nty - 1) / (sy - 1) : 0;
+      double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+      for (int cy = 0; cy < 2; ++cy)
+        for (int cx = 0; cx < 2; ++cx) {
+          const double X = (double)std::min<int64_t>(tx * 128 + cx * 127, W - 1), Y = (double)std::min<int64_t>(ty * 32 + cy * 31, H - 1);
+          double xd, yd;
+          if (kind == dcp::kRadial) {
+            const double xu = X - m.xc, yu = Y - m.yc, r = std::hypot(xu, yu);
+            double b = 0.0;
+            for (int i = m.nfact - 1; i >= 0; --i) b = b * r + m.fact[i];
+            xd = m.xc + b * xu;
+            yd = m.yc + b * yu;
+          } else {
+            const double den = (m.coef[6] * X + m.coef[7] * Y) + 1.0;
+            xd = ((m.coef[0] * X + m.coef[1] * Y) + m.coef[2]) / den;
+            yd = ((m.coef[3] * X + m.coef[4] * Y) + m.coef[5]) / den;
+          }
+          xd = std::min(std::max(xd, 0.0), (double)(W - 1));
+          yd = std::min(std::max(yd, 0.0), (double)(H - 1));
+          if (!(xd == xd) || !(yd == yd)) return false;
+          xlo = std::min(xlo, std::floor(xd));
+          xhi = std::max(xhi, std::floor(xd));
+          ylo = std::min(ylo, std::floor(yd));
+          yhi = std::max(yhi, std::floor(yd));
+        }
+      if (xhi - xlo + 4.0 > kWgBoxCols || yhi - ylo + 4.0 > kWgBoxRows) ++bad;
+    }
+  return bad * 50 <= sx * sy;          // at most 2 % of the sampled tiles
+}
+
 thread_local struct {
   int kind = -1, nfact = -1;
   int64_t H = 0, W = 0;
@@ -178,24 +219,29 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
       if ((kSpanX2[lvl] + kSpanY2[lvl]) * k2 <= kTileDevLimit) ok = lvl + 1;
   } else if (kind == dcp::kPersp) {
     if (homography_is_tame(m.coef, H, W)) {
-      double dmin = 1e300, dmax = 0.0, nxmax = 0.0, nymax = 0.0;
+      // N / D with N, D affine: d/dx = (N_x D - D_x N) / D^2 and d2/dx2 = -2 D_x (N_x D - D_x N) / D^3.  The numerators
+      // are affine in (x, y) too, so over the frame their magnitude peaks at a corner, where |D| is smallest as well.
+      double dmin = 1e300;
+      double gx[4] = {0, 0, 0, 0};      // max |N_t D - D_t N| for (N, t) = (Nx, x), (Nx, y), (Ny, x), (Ny, y)
       for (double x : {0.0, (double)(W - 1)})
         for (double y : {0.0, (double)(H - 1)}) {
-          const double d = std::fabs((m.coef[6] * x + m.coef[7] * y) + 1.0);
-          dmin = std::min(dmin, d);
-          dmax = std::max(dmax, d);
-          nxmax = std::max(nxmax, std::fabs((m.coef[0] * x + m.coef[1] * y) + m.coef[2]));
-          nymax = std::max(nymax, std::fabs((m.coef[3] * x + m.coef[4] * y) + m.coef[5]));
+          const double d = (m.coef[6] * x + m.coef[7] * y) + 1.0;
+          const double nx = (m.coef[0] * x + m.coef[1] * y) + m.coef[2], ny = (m.coef[3] * x + m.coef[4] * y) + m.coef[5];
+          dmin = std::min(dmin, std::fabs(d));
+          gx[0] = std::max(gx[0], std::fabs(m.coef[0] * d - m.coef[6] * nx));
+          gx[1] = std::max(gx[1], std::fabs(m.coef[1] * d - m.coef[7] * nx));
+          gx[2] = std::max(gx[2], std::fabs(m.coef[3] * d - m.coef[6] * ny));
+          gx[3] = std::max(gx[3], std::fabs(m.coef[4] * d - m.coef[7] * ny));
         }
-      const double d3 = dmin * dmin * dmin, c7 = std::fabs(m.coef[6]), c8 = std::fabs(m.coef[7]);
-      const double xxx = 2.0 * c7 * (std::fabs(m.coef[0]) * dmax + c7 * nxmax) / d3, xyy = 2.0 * c8 * (std::fabs(m.coef[1]) * dmax + c8 * nxmax) / d3;
-      const double yxx = 2.0 * c7 * (std::fabs(m.coef[3]) * dmax + c7 * nymax) / d3, yyy = 2.0 * c8 * (std::fabs(m.coef[4]) * dmax + c8 * nymax) / d3;
+      const double d2 = dmin * dmin, d3 = d2 * dmin, c7 = std::fabs(m.coef[6]), c8 = std::fabs(m.coef[7]);
+      const double xxx = 2.0 * c7 * gx[0] / d3, xyy = 2.0 * c8 * gx[1] / d3, yxx = 2.0 * c7 * gx[2] / d3, yyy = 2.0 * c8 * gx[3] / d3;
       for (int lvl = 0; lvl < 2; ++lvl) {
         const double devx = kSpanX2[lvl] * xxx + kSpanY2[lvl] * xyy, devy = kSpanX2[lvl] * yxx + kSpanY2[lvl] * yyy;
         if (std::isfinite(devx) && std::isfinite(devy) && devx <= kTileDevLimit && devy <= kTileDevLimit) ok = lvl + 1;
       }
     }
   }
+  if (ok == 2 && !wg_boxes_mostly_fit(kind, m, H, W)) ok = 1;
   c.kind = kind;
   c.nfact = m.nfact;
   c.H = H;

@@ -733,8 +733,8 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(c
 //   phase 2   taps from the shared slab, blend, store -- as in remap_lds_kernel.
 // A box that does not fit the slab (magnification > ~1.1) sends the whole workgroup to the direct global gather.
 constexpr int kWgTW = 128, kWgTH = 32;            // outputs per workgroup: 2 x 2 wave tiles of kLdsTW x kLdsTH
-constexpr int kWgBoxW = 144, kWgBoxH = 40;        // largest box: 36 chunks of 16 B per row, 40 rows
-constexpr int kWgSlabRows = 40;                   // 23 040 B
+constexpr int kWgBoxW = 144, kWgBoxH = 42;        // largest box: 36 chunks of 16 B per row, 42 rows (api_core.cpp: kWgBoxRows / kWgBoxCols)
+constexpr int kWgSlabRows = 42;                   // 24 192 B: six workgroups per CU
 static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wave tiles");
 
 #ifndef DCP_WG_FILL_EVERY
