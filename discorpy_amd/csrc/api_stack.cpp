@@ -333,4 +333,77 @@ int dcp_unwarp_stack_rows_multi_f32(const float* vol, float* out, int64_t depth,
   return DCP_OK;
 }
 
+// Device-resident shards, one per GPU of this process, and the exchange without torch / RCCL: after its kernel every
+// device PUSHES its (d1 - d0, nrows, width) block into the depth-outer result buffer of every other device with
+// hipMemcpyPeerAsync -- on an 8-GPU node seven copies per device, each over its own xGMI link (SURVEY.md section 2 C1 /
+// section 8(e): "7 concurrent hipMemcpyPeerAsync pushes").  Depth is the outer axis, so each block is contiguous at the
+// same offset in every buffer.  The same device may be listed more than once (shards of one GPU; the pushes are then
+// plain device-to-device copies) -- which is how the one-GPU test boxes exercise this path.
+int dcp_unwarp_stack_rows_peer_f32(const float* const* vol, float* const* out, int64_t depth, int64_t height, int64_t width,
+                                   int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                   const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
+                                   int blend_mode, const int* devices, int ndev, int gather) {
+  if (ndev < 1 || !devices || !vol || !out) return fail(DCP_ERR_INVALID_ARG, "need at least one device and the pointer arrays");
+  if (ndev > 64) return fail(DCP_ERR_INVALID_ARG, "ndev = %d > 64", ndev);
+  const int have = dcp_device_count();
+  for (int i = 0; i < ndev; ++i)
+    if (devices[i] < 0 || devices[i] >= have)
+      return have == 0 ? fail(DCP_ERR_NO_DEVICE, "no HIP device visible")
+                       : fail(DCP_ERR_INVALID_ARG, "devices[%d] = %d outside [0, %d)", i, devices[i], have);
+  if (depth < 0 || nrows < 0 || width <= 0 || height <= 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows or empty projections");
+  const int64_t base = depth / ndev, extra = depth % ndev;
+  std::vector<int64_t> d0((size_t)ndev + 1, 0);
+  for (int i = 0; i < ndev; ++i) d0[(size_t)i + 1] = d0[(size_t)i] + base + (i < extra ? 1 : 0);
+  for (int i = 0; i < ndev; ++i)
+    if ((d0[(size_t)i + 1] > d0[(size_t)i] && !vol[i]) || !out[i]) return fail(DCP_ERR_INVALID_ARG, "null shard / result pointer for device slot %d", i);
+  int prev = 0;
+  DCP_HIP(hipGetDevice(&prev));
+  std::vector<hipStream_t> streams((size_t)ndev, nullptr);
+  int rc = DCP_OK;
+  auto finish = [&](int code) {
+    for (int i = 0; i < ndev; ++i)
+      if (streams[(size_t)i]) {
+        (void)hipSetDevice(devices[i]);
+        (void)hipStreamSynchronize(streams[(size_t)i]);
+        (void)hipStreamDestroy(streams[(size_t)i]);
+      }
+    (void)hipSetDevice(prev);
+    return code;
+  };
+  const size_t block = (size_t)nrows * (size_t)width;           // floats per projection of the result
+  // 1. every device: its kernel on its own stream, writing its block in place (offset d0 of its result when gathering)
+  for (int i = 0; i < ndev && rc == DCP_OK; ++i) {
+    if (hipSetDevice(devices[i]) != hipSuccess || hipStreamCreateWithFlags(&streams[(size_t)i], hipStreamNonBlocking) != hipSuccess) {
+      rc = fail(DCP_ERR_HIP, "cannot set up device %d", devices[i]);
+      break;
+    }
+    if (gather)
+      for (int h = 0; h < ndev; ++h)
+        if (devices[h] != devices[i]) (void)hipDeviceEnablePeerAccess(devices[h], 0);     // already enabled: an error we ignore
+    (void)hipGetLastError();
+    const int64_t n = d0[(size_t)i + 1] - d0[(size_t)i];
+    if (n == 0) continue;
+    float* mine = out[i] + (gather ? (size_t)d0[(size_t)i] * block : 0);
+    rc = dcp_unwarp_stack_rows_f32(vol[i], mine, n, height, width, proj_stride, row_stride, xcenter, ycenter, list_fact, nfact, row_start,
+                                   nrows, coord_round_f32, blend_mode, DCP_MEM_DEVICE, devices[i], streams[(size_t)i]);
+  }
+  if (rc != DCP_OK) return finish(rc);
+  // 2. the exchange: device i pushes its block to every other slot's result, behind its kernel on the same stream
+  if (gather) {
+    for (int i = 0; i < ndev; ++i) {
+      const int64_t n = d0[(size_t)i + 1] - d0[(size_t)i];
+      if (n == 0) continue;
+      if (hipSetDevice(devices[i]) != hipSuccess) return finish(fail(DCP_ERR_HIP, "cannot select device %d", devices[i]));
+      const size_t off = (size_t)d0[(size_t)i] * block, bytes = (size_t)n * block * sizeof(float);
+      for (int k = 1; k < ndev; ++k) {
+        const int h = (i + k) % ndev;                           // staggered: at any moment the ndev pushes in flight go to distinct targets
+        if (out[h] == out[i]) continue;                         // slots sharing one result buffer (same device listed twice)
+        hipError_t e = hipMemcpyPeerAsync(out[h] + off, devices[h], out[i] + off, devices[i], bytes, streams[(size_t)i]);
+        if (e != hipSuccess) return finish(fail(DCP_ERR_HIP, "peer copy %d -> %d failed: %s", devices[i], devices[h], hipGetErrorString(e)));
+      }
+    }
+  }
+  return finish(DCP_OK);
+}
+
 }  // extern "C"

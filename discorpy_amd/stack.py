@@ -102,3 +102,45 @@ def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_star
     buf = torch.empty((world * m, nrows, width), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(buf, pad, group=group)
     return torch.cat([buf[r * m:r * m + counts[r]] for r in range(world)], dim=0)
+
+
+def unwarp_stack_row_sharded(vol, xcenter, ycenter, list_fact, row_start, nrows, *, coord_round_f32=True, group=None,
+                             blend=None, compute=None, world_size=None, rank=None):
+    """
+    The sharding that needs NO collective ("alternative"): every rank holds the whole stack (or
+    reads it from shared storage) and owns output rows ``[r0, r1)`` of EVERY projection -- complete sinograms for its
+    rows, which is what a per-sinogram reconstructor downstream consumes.  Only the source rows those output rows can
+    reach are touched (the reference's band, ``postprocessing.py:289-301``; the library computes it per call).
+
+    Returns ``(local, (r0, r1))`` with ``local`` of shape ``(depth, r1 - r0, width)``; rows are relative to ``row_start``.
+    """
+    if world_size is None:
+        import torch.distributed as dist
+        world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    r0, r1 = row_shard_bounds(nrows, world_size, rank)
+    fn = _hip_rows if compute is None else compute
+    local = fn(vol, xcenter, ycenter, list_fact, row_start + r0, r1 - r0, coord_round_f32, blend)
+    return local, (r0, r1)
+
+
+def unwarp_stack_peer_gather(shards, outs, depth, height, width, xcenter, ycenter, list_fact, row_start, nrows, devices, *,
+                             coord_round_f32=True, gather=True, blend=None):
+    """
+    Depth shards resident on the GPUs of THIS process and the exchange by direct peer copies (``hipMemcpyPeerAsync``),
+    through ``dcp_unwarp_stack_rows_peer_f32`` -- no torch, no RCCL.  ``shards[g]`` / ``outs[g]``: device pointers (int) on
+    ``devices[g]``; ``outs[g]`` holds ``(depth, nrows, width)`` floats when gathering.  See include/discorpy_hip.h.
+    """
+    import ctypes as C
+    from . import _ffi as F
+    from .post import postprocessing as pp
+    n = len(devices)
+    if len(shards) != n or len(outs) != n:
+        raise ValueError("one shard and one result pointer per device slot")
+    fa, nf = F.fact_array(list_fact)
+    F.require_device()
+    F.check(F.lib().dcp_unwarp_stack_rows_peer_f32((C.c_void_p * n)(*[int(p) if p else None for p in shards]),
+                                                   (C.c_void_p * n)(*[int(p) for p in outs]), int(depth), int(height), int(width),
+                                                   int(height) * int(width), int(width), float(xcenter), float(ycenter), fa, nf,
+                                                   float(row_start), int(nrows), int(bool(coord_round_f32)), pp._blend_code(blend),
+                                                   (C.c_int * n)(*[int(d) for d in devices]), n, int(bool(gather))))

@@ -124,6 +124,19 @@ int dcp_unwarp_stack_rows_multi_f32(const float* vol, float* out, int64_t depth,
                                     const double* list_fact, int nfact, double row_start, int64_t nrows,
                                     int coord_round_f32, int blend_mode, const int* devices, int ndev);
 
+/* Device-resident depth shards on the GPUs of ONE process and the exchange by direct peer copies (no torch, no RCCL):
+ * slot g holds projections [d0_g, d1_g) -- the split of numpy.array_split(range(depth), ndev) -- at vol[g] on
+ * devices[g]; its kernel writes its (d1_g - d0_g, nrows, width) block, and with gather != 0 every slot's block is
+ * pushed into the depth-outer (depth, nrows, width) result out[h] of every other slot with hipMemcpyPeerAsync (on an
+ * 8-GPU node: seven pushes per device, one per xGMI link).  out[g] holds (depth, nrows, width) floats when gathering
+ * (slot g writes at depth offset d0_g), (d1_g - d0_g, nrows, width) otherwise.  A device may appear in several slots.
+ * Returns after every stream has drained.  Reference: the loops over depth of postprocessing.py:226-228, 310-312 carry no
+ * state, so the projections may be split anywhere; the reference itself has no multi-device code. */
+int dcp_unwarp_stack_rows_peer_f32(const float* const* vol, float* const* out, int64_t depth, int64_t height, int64_t width,
+                                   int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
+                                   const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
+                                   int blend_mode, const int* devices, int ndev, int gather);
+
 /* ---- spline orders 2..5 (scipy.ndimage.map_coordinates with its B-spline prefilter) ----
  * The same maps as dcp_unwarp_image_f32 / dcp_perspective_image_f32 / dcp_remap_coords_f32 for
  * `order` in 2..5 -- what the reference computes when a caller passes order >= 2

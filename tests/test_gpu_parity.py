@@ -1209,3 +1209,42 @@ def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
     want = orc.unwarp_stack_rows(vol, c["xcenter"], c["ycenter"], c["list_fact"], 0, H, coord_round_f32=True,
                                  **kernel_oracle(orc, "f64lerp"))
     assert np.array_equal(got, want)
+
+
+def test_peer_copy_gather_of_device_resident_shards(hip, orc):
+    """dcp_unwarp_stack_rows_peer_f32: depth shards on the devices of one process, each block pushed into every other slot's
+    depth-outer result by hipMemcpyPeerAsync.  The test box has one GPU, so the three slots all name device 0 (ragged shards
+    3 + 2 + 2); the pushes are then same-device copies -- the code path, the offsets and the ordering are the ones an 8-GPU
+    node runs.  No measurement of xGMI is claimed."""
+    from discorpy_amd import stack
+    D, H, W = 7, 96, 200
+    vol = noise(311, (D, H, W))
+    a = (101.5, 47.25, [1.0, 1.0e-3, -2.0e-6])
+    want = orc.unwarp_stack_rows(vol, *a, 5, 60, coord_round_f32=True, **kernel_oracle(orc, "f64lerp"))
+    bounds = [stack.shard_bounds(D, 3, r) for r in range(3)]
+    shards = [hip.DeviceBuffer(max((d1 - d0) * H * W * 4, 4)).upload(vol[d0:d1]) for d0, d1 in bounds]
+    outs = [hip.DeviceBuffer(D * 60 * W * 4) for _ in range(3)]
+    stack.unwarp_stack_peer_gather([b.ptr for b in shards], [b.ptr for b in outs], D, H, W, *a, 5, 60, [0, 0, 0])
+    for b in outs:                                              # every slot ends with the whole (depth, rows, width) block
+        assert np.array_equal(b.download((D, 60, W), np.float32), want)
+    # gather = 0: every slot keeps only its own block, at the start of its buffer
+    outs2 = [hip.DeviceBuffer(max((d1 - d0) * 60 * W * 4, 4)) for d0, d1 in bounds]
+    stack.unwarp_stack_peer_gather([b.ptr for b in shards], [b.ptr for b in outs2], D, H, W, *a, 5, 60, [0, 0, 0], gather=False)
+    for (d0, d1), b in zip(bounds, outs2):
+        assert np.array_equal(b.download((d1 - d0, 60, W), np.float32), want[d0:d1])
+    # one slot: the degenerate case (no peers); more slots than projections: empty shards are skipped
+    one = hip.DeviceBuffer(D * 60 * W * 4)
+    whole = hip.DeviceBuffer(vol.nbytes).upload(vol)
+    stack.unwarp_stack_peer_gather([whole.ptr], [one.ptr], D, H, W, *a, 5, 60, [0])
+    assert np.array_equal(one.download((D, 60, W), np.float32), want)
+    two = noise(312, (2, H, W))
+    sh = [hip.DeviceBuffer(H * W * 4).upload(two[0:1]), hip.DeviceBuffer(H * W * 4).upload(two[1:2]), hip.DeviceBuffer(4)]
+    ou = [hip.DeviceBuffer(2 * 60 * W * 4) for _ in range(3)]
+    stack.unwarp_stack_peer_gather([sh[0].ptr, sh[1].ptr, None], [b.ptr for b in ou], 2, H, W, *a, 5, 60, [0, 0, 0])
+    want2 = orc.unwarp_stack_rows(two, *a, 5, 60, coord_round_f32=True, **kernel_oracle(orc, "f64lerp"))
+    assert all(np.array_equal(b.download((2, 60, W), np.float32), want2) for b in ou)
+    # argument validation
+    with pytest.raises(ValueError, match="outside"):
+        stack.unwarp_stack_peer_gather([whole.ptr], [one.ptr], D, H, W, *a, 5, 60, [99])
+    with pytest.raises(ValueError, match="one shard and one result"):
+        stack.unwarp_stack_peer_gather([whole.ptr], [one.ptr, one.ptr], D, H, W, *a, 5, 60, [0, 0])

@@ -58,8 +58,10 @@ def _worker(rank, world, port, depth, result_dir):
         # the all-gather pipelined against the per-shard work in depth sub-blocks (falls back for ragged shards)
         piped = stack.unwarp_stack_sharded(local, depth, *args, 10, 6, coord_round_f32=True, compute=cpu_rows, pipeline=2)
         piped9 = stack.unwarp_stack_sharded(local, depth, *args, 10, 6, coord_round_f32=True, compute=cpu_rows, pipeline=9)
+        # the sharding without a collective: every rank holds the stack and owns output rows of every projection
+        rows, (r0, r1) = stack.unwarp_stack_row_sharded(torch.from_numpy(vol), *args, 3, 29, coord_round_f32=True, compute=cpu_rows)
         np.savez(os.path.join(result_dir, "rank%d.npz" % rank), full=full.numpy(), part=part.numpy(), sl=sl.numpy(),
-                 piped=piped.numpy(), piped9=piped9.numpy(), d0=d0, d1=d1)
+                 piped=piped.numpy(), piped9=piped9.numpy(), d0=d0, d1=d1, rows=np.asarray(rows), r0=r0, r1=r1)
     finally:
         dist.destroy_process_group()
 
@@ -75,6 +77,14 @@ def test_two_rank_gloo_all_gather_reassembles_the_stack(tmp_path, orc, depth):
                                  blend=orc.BLEND_F64LERP)
     want_sl = orc.unwarp_stack_rows(vol, *args, 21, 1, coord_round_f32=False, poly=orc.POLY_KERNEL,
                                     blend=orc.BLEND_F64LERP)
+    want_rows = orc.unwarp_stack_rows(vol, *args, 3, 29, coord_round_f32=True, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+    covered = []
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        r0, r1 = int(z["r0"]), int(z["r1"])
+        assert z["rows"].shape == (depth, r1 - r0, 56) and np.array_equal(z["rows"], want_rows[:, r0:r1])      # row-sharded: no collective
+        covered += list(range(r0, r1))
+    assert covered == list(range(29))
     for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         assert np.array_equal(z["full"], want)                       # every rank holds the whole block
