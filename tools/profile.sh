@@ -9,15 +9,15 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
-BENCH_FULL="python $ROOT/bench.py --no-cpu-baseline $*"    # the timing pass profiles the default command (40 steps, 5 warm-up)
+BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $*"      # counter passes: the headline kernel only
+BENCH_FULL="python $ROOT/bench.py --no-cpu-baseline $*"    # the timing pass profiles the default command: headline + every other configuration
 cd /tmp
 run() { # name, rocprof args...   (PASSES="trace fetch" restricts the passes that run)
   local name=$1; shift
   if [ -n "${PASSES:-}" ] && ! echo " $PASSES " | grep -q " $name "; then return; fi
   local cmd=$BENCH
   if [ "$name" = trace ]; then cmd=$BENCH_FULL; fi
-  timeout 180 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o out -- $cmd > "$OUT/$name.log" 2>&1
+  timeout 400 rocprofv3 "$@" --output-format csv -d "$OUT/$name" -o out -- $cmd > "$OUT/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 run trace --kernel-trace --stats

@@ -19,8 +19,10 @@ summ = json.load(open(os.path.join(src, "summary.json")))
 if "--latest" in sys.argv:
     best = None
     for k, v in summ.get("traffic", {}).items():
-        if "remap_tile_kernel" in k or "remap_lds_kernel" in k:
-            best = dict(v, kernel=k, source=tag + "_rocprofv3_summary.json")
+        if "remap_wg_kernel<0, 5, 2" in k or (best is None and ("remap_tile_kernel" in k or "remap_lds_kernel" in k or "remap_wg_kernel" in k)):
+            import datetime
+            best = dict(v, kernel=k.replace("void dcp::", "").split("(")[0].replace("<0, 5, 2, float>", "<Radial,NF=5,f64lerp>"),
+                        rocprof_kernel_name=k, source=tag + "_rocprofv3_summary.json", collected=datetime.date.today().isoformat())
     if best:
         json.dump(best, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
         print("pmc_latest.json:", best)
