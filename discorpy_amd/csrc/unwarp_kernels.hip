@@ -737,6 +737,9 @@ constexpr int kWgBoxW = 144, kWgBoxH = 42;        // largest box: 36 chunks of 1
 constexpr int kWgSlabRows = 42;                   // 24 192 B: six workgroups per CU
 static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wave tiles");
 
+#ifndef DCP_WG_FILL_START
+#define DCP_WG_FILL_START 0   // phase 1 row in front of which the first load of the fill is issued
+#endif
 #ifndef DCP_WG_FILL_EVERY
 #define DCP_WG_FILL_EVERY 1   // phase 1 rows between two loads of the fill (0: all six loads in one burst in front of phase 1)
 #endif
@@ -904,8 +907,8 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
   const bool box_inside = cx0 - 1 >= 0 && cx1 + 2 <= img.W - 1 && cy0 - 1 >= 0 && cy1 + 2 <= img.H - 1;
   const bool unclipped = box_inside && fits;
   auto rows_1 = [&](auto noclip, auto fastdiv) {
-    issue_fill(std::integral_constant<int, 0>{});
     if constexpr (DCP_WG_FILL_EVERY == 0) {
+      issue_fill(std::integral_constant<int, 0>{});
       issue_fill(std::integral_constant<int, 1>{});
       issue_fill(std::integral_constant<int, 2>{});
       issue_fill(std::integral_constant<int, 3>{});
@@ -915,11 +918,12 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
 #pragma unroll
     for (int k = 0; k < kLdsTH; ++k) {
       if constexpr (DCP_WG_FILL_EVERY > 0) {
-        if (k == 1 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 1>{});
-        if (k == 2 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 2>{});
-        if (k == 3 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 3>{});
-        if (k == 4 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 4>{});
-        if (k == 5 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 5>{});
+        if (k == DCP_WG_FILL_START + 0 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 0>{});
+        if (k == DCP_WG_FILL_START + 1 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 1>{});
+        if (k == DCP_WG_FILL_START + 2 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 2>{});
+        if (k == DCP_WG_FILL_START + 3 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 3>{});
+        if (k == DCP_WG_FILL_START + 4 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 4>{});
+        if (k == DCP_WG_FILL_START + 5 * DCP_WG_FILL_EVERY) issue_fill(std::integral_constant<int, 5>{});
       }
       double xd, yd;
       map_coord<KIND, NF, RW, decltype(fastdiv)::value>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
