@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -34,6 +34,7 @@ dcp::LaunchOpts current_opts() {
   o.stack_lds = g_stack_lds.load();
   o.wg_box = g_wg_box.load();
   o.wg_per_cu = g_wg_per_cu.load();
+  o.stack_wg = g_stack_wg.load();
   return o;
 }
 
@@ -388,6 +389,9 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "host_bands")) {
     if (value < 1 || value > 256) return fail(DCP_ERR_INVALID_ARG, "host_bands must be in [1, 256]");
     g_host_bands = value;
+  } else if (!strcmp(key, "stack_wg")) {
+    if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "stack_wg must be 0, 1 or 2");
+    g_stack_wg = value;               // 0: the per-wave-box stack kernels; 1: stack_wg_kernel for float32; 2: also for 8- / 16-bit integers
   } else if (!strcmp(key, "wg_per_cu")) {
     if (value < 0 || value > 6) return fail(DCP_ERR_INVALID_ARG, "wg_per_cu must be in [0, 6]");
     g_wg_per_cu = value;
@@ -419,6 +423,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "tile_cert")) *value = g_tile_cert;
   else if (!strcmp(key, "wg_box")) *value = g_wg_box;
   else if (!strcmp(key, "wg_per_cu")) *value = g_wg_per_cu;
+  else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }

@@ -54,6 +54,29 @@ hipError_t launch_stack_any(const StackCall& c, bool fast, const void* base, voi
     st.proj_bytes = (uint32_t)(((rows_end - 1) * row_stride + c.width) * 4);
     return dcp::launch_stack(st, c.map, c.sampler, c.round_f32 != 0, opts, hs);
   }
+  if (c.round_f32 && !c.out_f32 && opts.stack_wg >= 2) {
+    // 8- / 16-bit integer stacks under a certified map on the workgroup-box kernel: opt-in (stack_wg = 2) -- with scipy's
+    // blend and 2-byte stores it is VALU-bound and measures 10 % slower than the generic kernel (uint16 cfg4 shard: 0.27 against 0.30)
+    const int64_t esz = dcp::elem_size(c.dtype);
+    const double ext = (double)((rows_end - 1) * row_stride + c.width) * (double)esz;
+    if (ext < 4294900000.0) {
+      dcp::StackArgs sw;
+      memset(&sw, 0, sizeof(sw));
+      sw.D = (int32_t)n;
+      sw.H = (int32_t)c.height;
+      sw.W = (int32_t)c.width;
+      sw.row_start = c.row_start;
+      sw.nrows = (int32_t)c.nrows;
+      sw.vol = (const float*)base;
+      sw.out = (float*)out;
+      sw.proj_stride = proj_stride;
+      sw.row_stride = (int32_t)row_stride;
+      sw.proj_bytes = (uint32_t)ext;
+      bool taken = false;
+      hipError_t e = dcp::launch_stack_wg_typed(sw, c.map, c.dtype, opts, hs, &taken);
+      if (e != hipSuccess || taken) return e;
+    }
+  }
   dcp::TypedStackArgs st;
   memset(&st, 0, sizeof(st));
   st.D = (int32_t)n;
@@ -231,7 +254,10 @@ int make_stack_call(StackCall* c, const void* vol, void* out, int dtype, int out
   c->stream = stream;
   c->sampler = dcp::kScipy;
   if (dtype == dcp::kF32 && !out_f32 && (rc = sampler_of(1, blend_mode, &c->sampler)) != DCP_OK) return rc;
-  return fill_map(&c->map, xcenter, ycenter, list_fact, nfact, nullptr);
+  if ((rc = fill_map(&c->map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
+  if (g_tile_cert.load() && coord_round_f32 && height > 0 && width > 0)
+    c->map.tile_dev_ok = tile_deviation_certified(dcp::kRadial, c->map, height, width);
+  return DCP_OK;
 }
 
 }  // namespace

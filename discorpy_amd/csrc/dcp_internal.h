@@ -121,6 +121,8 @@ struct LaunchOpts {
   int stack_lds = 1;       // LDS-staged stack kernel: 0 never, 1 when the launch has enough wave tiles, 2 always
   int wg_box = 1;          // 1: remap_wg_kernel (one source box per 128 x 32 workgroup tile) for certified maps
   int wg_per_cu = 0;       // remap_wg_kernel: cap on resident workgroups per CU (0 = none)
+  int stack_wg = 1;        // stack_wg_kernel (one box per workgroup, two slabs) for chunks of rows under a certified map: 0 never,
+                           // 1 float32 stacks when the launch has enough workgroups, 2 whenever eligible, 8- / 16-bit integers too
 };
 
 // launchers (unwarp_kernels.hip)
@@ -130,6 +132,7 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img, const MapArgs& map, 
 // in bytes); *taken = false: the call does not qualify, use launch_typed_image
 hipError_t launch_wg_typed(MapKind kind, const ImageArgs& img, const MapArgs& map, int order, int dtype, const LaunchOpts& opts,
                            hipStream_t stream, bool* taken);
+hipError_t launch_stack_wg_typed(const StackArgs& st, const MapArgs& map, int dtype, const LaunchOpts& opts, hipStream_t stream, bool* taken);
 hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler, hipStream_t stream);
 hipError_t launch_coord_map(MapKind kind, const ImageArgs& img, const MapArgs& map, float* ymap, float* xmap,
                             hipStream_t stream);

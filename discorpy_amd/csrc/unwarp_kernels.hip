@@ -1356,6 +1356,216 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
   }
 }
 
+// ------------------------------------------------------------------ K4, workgroup-shared source box
+
+// stack_lds_kernel's scheme with remap_wg_kernel's box: a workgroup owns a 128 x 32 tile of (x, row) positions of the
+// requested rows (four waves, 2 x 2 sub-tiles of 64 x 16); corner pixels -> box (certificate level 2), per-pixel slab
+// address and fractions ONCE; then for every projection of the depth chunk the four waves copy the box of THAT
+// projection into one of two slabs (LDS-DMA, the loads of projection d + 1 issued before projection d is blended, so the
+// copy runs under the arithmetic inside the workgroup) and blend their 1024 pixels each out of the other.  One barrier
+// per projection.  T as in remap_wg_kernel: float (any blend) or an 8- / 16-bit integer type (scipy's blend and integer
+// store) -- tomography detectors deliver uint16.  float32 coordinates only (unwarp_chunk_slices_backward).
+template <int NF, int SAMPLER, typename T = float>
+__global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, const MapArgs map) {
+  constexpr bool kIsF32 = std::is_same<T, float>::value;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int CH = ES == 4 ? 36 : (ES == 2 ? 20 : 10);
+  constexpr int PB = CH * 16;
+  constexpr int kBoxWEl = PB / ES;
+  constexpr int NJ = (kWgBoxH * CH + 255) / 256;
+  static_assert(kIsF32 || SAMPLER == kScipy, "integer element types blend in scipy's exact order");
+  __shared__ __attribute__((aligned(16))) unsigned char s_box[2][kWgSlabRows * PB];
+  __shared__ double s_row[4][kLdsTH][2];
+  __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
+  using FetchT = Fetch<SAMPLER, true, float>;
+
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int wx = wave & 1, wy = wave >> 1;
+  const int rblk = blockIdx.y * kWgTH;
+  const int r0 = __builtin_amdgcn_readfirstlane(rblk + wy * kLdsTH);   // first requested row of this wave's sub-tile
+  const int x = blockIdx.x * kWgTW + wx * kLdsTW + lane;
+  const int d0 = blockIdx.z * st.d_chunk, d1 = min(st.D, d0 + st.d_chunk);
+  const float wmaxf = (float)(st.W - 1), hmaxf = (float)(st.H - 1);
+  const T* const volT = (const T*)st.vol;
+  T* const outT = (T*)st.out;
+
+  // ---- the tile's four corner pixels (lanes 0..3, every wave for itself) -> box
+  int cx0, cx1, cy0, cy1;
+  {
+    const double X = (double)min(blockIdx.x * kWgTW + (lane & 1) * (kWgTW - 1), st.W - 1);
+    const double Y = st.row_start + (double)min(rblk + ((lane >> 1) & 1) * (kWgTH - 1), st.nrows - 1);
+    const double xu = X - map.xc, yu = Y - map.yc;
+    const double r2 = xu * xu + yu * yu;
+    const double ru = sqrt_rn(r2);
+    double f;
+    if constexpr (NF >= 0) {
+      double le, lo;
+      poly_leads<NF>(map.fact, &le, &lo);
+      f = poly_inline<NF>(map.fact, le, lo, r2, ru);
+    } else {
+      f = poly_lds(map.fact, map.nfact, r2, ru);
+    }
+    const int cxi = (int)round_clip_f32(__builtin_fma(f, xu, map.xc), wmaxf), cyi = (int)round_clip_f32(__builtin_fma(f, yu, map.yc), hmaxf);
+    const int xa = __builtin_amdgcn_readlane(cxi, 0), xb = __builtin_amdgcn_readlane(cxi, 1);
+    const int xc_ = __builtin_amdgcn_readlane(cxi, 2), xd_ = __builtin_amdgcn_readlane(cxi, 3);
+    const int ya = __builtin_amdgcn_readlane(cyi, 0), yb = __builtin_amdgcn_readlane(cyi, 1);
+    const int yc_ = __builtin_amdgcn_readlane(cyi, 2), yd_ = __builtin_amdgcn_readlane(cyi, 3);
+    cx0 = min(min(xa, xb), min(xc_, xd_));
+    cx1 = max(max(xa, xb), max(xc_, xd_));
+    cy0 = min(min(ya, yb), min(yc_, yd_));
+    cy1 = max(max(ya, yb), max(yc_, yd_));
+  }
+  const int bx0 = max(min(cx0 - 1, st.W - 2), 0) & ~(4 / ES - 1);
+  const int bx1 = min(cx1 + 2, st.W - 1);
+  const int by0 = max(min(cy0 - 1, st.H - 2), 0);
+  const int by1 = min(cy1 + 2, st.H - 1);
+  const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+  const bool fits = bw <= kBoxWEl && bh <= kWgBoxH;          // workgroup-uniform
+  if (!fits && lane == 0 && wave == 0) atomicAdd(&g_lds_stats[0], 1ull);
+
+  // ---- coordinates of this wave's 16 rows, once for all projections: slab address (or byte offset inside a projection
+  // when the box does not fit) and fractions
+  if (lane < kLdsTH) fill_row<kRadial, 2>(map, s_row[wave], lane, st.row_start + (double)min(r0 + lane, st.nrows - 1));
+  if constexpr (NF < 0) {
+    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
+    __syncthreads();
+  }
+  const int rows = __builtin_amdgcn_readfirstlane(max(0, min(kLdsTH, st.nrows - r0)));
+  const ColCtx col = make_col<kRadial, NF>(map, min(x, st.W - 1));
+  uint32_t addr[kLdsTH];
+  float fx[kLdsTH], fy[kLdsTH];
+  const uint32_t negorg = (uint32_t)(-(by0 * PB + bx0 * ES));
+#pragma unroll
+  for (int k = 0; k < kLdsTH; ++k) {
+    double xd, yd;
+    map_coord<kRadial, NF, 2>(map, s_row[wave], s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+    const float xc = round_clip_f32(xd, wmaxf), yc = round_clip_f32(yd, hmaxf);
+    int xi, yi;
+    if constexpr (SAMPLER == kNearest) {
+      xi = (int)xc;
+      yi = (int)yc;
+      xi += (xc - (float)xi >= 0.5f) ? 1 : 0;
+      yi += (yc - (float)yi >= 0.5f) ? 1 : 0;
+      fx[k] = fy[k] = 0.0f;
+    } else {
+      xi = min((int)xc, st.W - 2);
+      yi = min((int)yc, st.H - 2);
+      fx[k] = xc - (float)xi;
+      fy[k] = yc - (float)yi;
+    }
+    addr[k] = fits ? (uint32_t)yi * (uint32_t)PB + (uint32_t)xi * (uint32_t)ES + negorg
+                   : ((uint32_t)yi * (uint32_t)st.row_stride + (uint32_t)xi) * (uint32_t)ES;
+  }
+
+  // ---- the fill of one projection: this wave's chunks (see remap_wg_kernel)
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  const uint32_t rstep = (uint32_t)st.row_stride * (uint32_t)ES;
+  const int fc = wave * 64 + lane;
+  const int crow0 = fc / CH;
+  const int c160 = fc - crow0 * CH;
+  const uint32_t off0 = ((uint32_t)by0 * (uint32_t)st.row_stride + (uint32_t)bx0) * (uint32_t)ES + (uint32_t)crow0 * rstep + (uint32_t)c160 * 16u;
+  const int nchunk = bh * CH;
+  auto fill = [&](const T* proj, int slab) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)proj, 0, (int)st.proj_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if ((j * 4 + wave) * 64 < nchunk) {
+        const int qrow = (256 * j) / CH, rem = (256 * j) % CH;
+        const bool wrap = c160 >= CH - rem;
+        const int crow = crow0 + qrow + (wrap ? 1 : 0);
+        if (crow < bh)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(s_box[slab] + (j * 4 + wave) * 1024), 16,
+                                                   off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u, 0, 0, 0);
+      }
+    }
+  };
+
+  const bool active = x < st.W && rows > 0;
+  const uint32_t out_row = (uint32_t)st.W * (uint32_t)ES, xoff = (uint32_t)x * (uint32_t)ES;
+  const T* proj = volT + (size_t)d0 * (size_t)st.proj_stride;
+  T* out = outT + ((size_t)d0 * (size_t)st.nrows + (size_t)min(r0, st.nrows - 1)) * (size_t)st.W;
+  const size_t out_step = (size_t)st.nrows * (size_t)st.W;
+  auto blend_store = [&](const T* t_lo, const T* t_hi, float fxk, float fyk, const __amdgpu_buffer_rsrc_t& dst, int k, uint32_t a_) {
+    // t_lo / t_hi: the tap pairs of the two rows (LDS or global); a_: the byte address (for the aligned-dword extraction)
+    if constexpr (kIsF32) {
+      FetchT f;
+      f.fx = fxk;
+      f.fy = fyk;
+      f.a.x = __float_as_uint(t_lo[0]);
+      if constexpr (SAMPLER != kNearest) {
+        f.a.y = __float_as_uint(t_lo[1]);
+        f.b.x = __float_as_uint(t_hi[0]);
+        f.b.y = __float_as_uint(t_hi[1]);
+      }
+      const float v = finish<SAMPLER, true, float>(f);
+      if (k < rows) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+    } else {
+      const double fxd = (double)fxk, fyd = (double)fyk;
+      const double wy0 = 1.0 - fyd, wy1 = 1.0 - wy0;
+      const double wx0 = 1.0 - fxd, wx1 = 1.0 - wx0;
+      double acc = ((double)t_lo[0] * wy0) * wx0;
+      acc += ((double)t_lo[1] * wy0) * wx1;
+      acc += ((double)t_hi[0] * wy1) * wx0;
+      acc += ((double)t_hi[1] * wy1) * wx1;
+      const T v = to_elem<T>(acc);
+      if (k < rows) {
+        if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+        else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+      }
+    }
+  };
+
+  if (fits) {
+    fill(proj, 0);
+    for (int d = d0; d < d1; ++d) {
+      const int cur = (d - d0) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of projection d (and its earlier stores)
+      __syncthreads();                                      // everyone's share has landed; everyone is done with the other slab
+      if (d + 1 < d1) fill(proj + st.proj_stride, cur ^ 1); // projection d + 1 streams in under the blend of d
+      if (active) {
+        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((uint32_t)rows * out_row), 0x00020000);
+        const char* boxb = (const char*)s_box[cur];
+#pragma unroll
+        for (int k = 0; k < kLdsTH; ++k) {
+          if constexpr (kIsF32) {
+            const float* t = (const float*)(boxb + addr[k]);
+            blend_store(t, t + kBoxWEl, fx[k], fy[k], dst, k, addr[k]);
+          } else {
+            // tap pairs as the two aligned dwords around them, shifted down (see remap_wg_kernel)
+            const uint32_t* q = (const uint32_t*)(boxb + (addr[k] & ~3u));
+            const uint32_t sh = (addr[k] & 3u) * 8u;
+            const uint32_t top = __builtin_amdgcn_alignbit(q[1], q[0], sh), bot = __builtin_amdgcn_alignbit(q[PB / 4 + 1], q[PB / 4], sh);
+            T lo[2], hi[2];
+            if constexpr (std::is_signed<T>::value) {
+              lo[0] = (T)__builtin_amdgcn_sbfe(top, 0, ES * 8); lo[1] = (T)__builtin_amdgcn_sbfe(top, ES * 8, ES * 8);
+              hi[0] = (T)__builtin_amdgcn_sbfe(bot, 0, ES * 8); hi[1] = (T)__builtin_amdgcn_sbfe(bot, ES * 8, ES * 8);
+            } else {
+              lo[0] = (T)__builtin_amdgcn_ubfe(top, 0, ES * 8); lo[1] = (T)__builtin_amdgcn_ubfe(top, ES * 8, ES * 8);
+              hi[0] = (T)__builtin_amdgcn_ubfe(bot, 0, ES * 8); hi[1] = (T)__builtin_amdgcn_ubfe(bot, ES * 8, ES * 8);
+            }
+            blend_store(lo, hi, fx[k], fy[k], dst, k, addr[k]);
+          }
+        }
+      }
+      proj += st.proj_stride;
+      out += out_step;
+    }
+  } else if (active) {
+    // ---- box too large for the slab: direct global gather, projection by projection
+    for (int d = d0; d < d1; ++d) {
+      const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((uint32_t)rows * out_row), 0x00020000);
+#pragma unroll
+      for (int k = 0; k < kLdsTH; ++k) {
+        const T* t = (const T*)((const char*)proj + addr[k]);
+        blend_store(t, t + st.row_stride, fx[k], fy[k], dst, k, addr[k]);
+      }
+      proj += st.proj_stride;
+      out += out_step;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 
 // Name of the kernel the calling thread launched last (dcp_debug_last_kernel): tests and bench.py use it to state --
@@ -1680,11 +1890,80 @@ static hipError_t launch_stack_lds(const StackArgs& st, const MapArgs& map, int 
   return hipGetLastError();
 }
 
+// Depth chunk for stack_wg_kernel: a workgroup streams its projections through two slabs, so it wants several of
+// them, and the launch wants a few thousand workgroups (three fit a CU).  0: too little work even at 4 per workgroup.
+static int wg_stack_chunk(const StackArgs& st, int d_chunk, bool force = false) {
+  const int64_t tiles = (int64_t)((st.W + kWgTW - 1) / kWgTW) * ((st.nrows + kWgTH - 1) / kWgTH);
+  int dc = d_chunk < 4 ? 4 : d_chunk;
+  auto wgs = [&](int c) { return tiles * ((st.D + c - 1) / c); };
+  while (dc > 4 && wgs(dc) < 3072) dc >>= 1;
+  if (dc < 4) dc = 4;
+  if ((wgs(dc) < 1024 && !force) || (st.D + dc - 1) / dc > 65535) return 0;
+  return dc;
+}
+
+static bool wg_stack_eligible(const StackArgs& st, const MapArgs& map, const LaunchOpts& opts, int es) {
+  return map.tile_dev_ok >= 2 && opts.wg_box && opts.lds_gather && opts.stack_lds && !opts.coef_lds && st.nrows >= 8 && st.W >= 2 && st.H >= 2 &&
+         st.row_stride < (1 << 22) && st.H < (1 << 24) && (((uintptr_t)st.vol) & 3u) == 0 && (((int64_t)st.row_stride * es) & 3) == 0 &&
+         (((int64_t)st.proj_stride * es) & 3) == 0;
+}
+
+template <int NF, typename T>
+static hipError_t launch_stack_wg_t(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
+  const dim3 grid((unsigned)((st.W + kWgTW - 1) / kWgTW), (unsigned)((st.nrows + kWgTH - 1) / kWgTH), (unsigned)((st.D + st.d_chunk - 1) / st.d_chunk));
+  if constexpr (std::is_same<T, float>::value) {
+    note_kernel("stack_wg_kernel", -1, NF, sampler);
+    switch (sampler) {
+      case kScipy: hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, float>), grid, dim3(256), 0, stream, st, map); break;
+      case kF64Lerp: hipLaunchKernelGGL((stack_wg_kernel<NF, kF64Lerp, float>), grid, dim3(256), 0, stream, st, map); break;
+      default: hipLaunchKernelGGL((stack_wg_kernel<NF, kF32Lerp, float>), grid, dim3(256), 0, stream, st, map); break;
+    }
+  } else {
+    note_kernel("stack_wg_kernel", -1, NF, kScipy, sizeof(T) == 2 ? ",16-bit" : ",8-bit");
+    hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, T>), grid, dim3(256), 0, stream, st, map);
+  }
+  return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch_stack_wg_n(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
+  if (map.nfact == 5) return launch_stack_wg_t<5, T>(st, map, sampler, stream);
+  if (map.nfact == 4) return launch_stack_wg_t<4, T>(st, map, sampler, stream);
+  return launch_stack_wg_t<-1, T>(st, map, sampler, stream);
+}
+
+// 8- / 16-bit integer stacks, float32 coordinates, result of the input's type (unwarp_chunk_slices_backward): st.vol / out
+// reinterpreted, strides in elements, proj_bytes the extent of a projection in bytes.  *taken = false: use launch_typed_stack.
+hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int dtype, const LaunchOpts& opts, hipStream_t stream,
+                                 bool* taken) {
+  *taken = false;
+  if (dtype != kU8 && dtype != kI8 && dtype != kU16 && dtype != kI16) return hipSuccess;
+  if (st_in.D == 0 || st_in.nrows == 0 || !wg_stack_eligible(st_in, map, opts, elem_size(dtype))) return hipSuccess;
+  StackArgs st = st_in;
+  st.d_chunk = wg_stack_chunk(st, opts.d_chunk, opts.stack_wg >= 2);
+  if (st.d_chunk == 0) return hipSuccess;
+  *taken = true;
+  switch (dtype) {
+    case kU8: return launch_stack_wg_n<uint8_t>(st, map, kScipy, stream);
+    case kI8: return launch_stack_wg_n<int8_t>(st, map, kScipy, stream);
+    case kU16: return launch_stack_wg_n<uint16_t>(st, map, kScipy, stream);
+    default: return launch_stack_wg_n<int16_t>(st, map, kScipy, stream);
+  }
+}
+
 hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream) {
   StackArgs st = st_in;
   st.d_chunk = opts.d_chunk < 1 ? 1 : opts.d_chunk;
   if (st.D == 0 || st.nrows == 0) return hipSuccess;
+  // chunks of rows under a certified map: one box per workgroup, two slabs (stack_wg_kernel)
+  if (round_f32 && opts.stack_wg && wg_stack_eligible(st, map, opts, 4)) {
+    const int dc = wg_stack_chunk(st, st.d_chunk, opts.stack_wg >= 2);
+    if (dc > 0) {
+      st.d_chunk = dc;
+      return launch_stack_wg_n<float>(st, map, sampler, stream);
+    }
+  }
   // chunks of rows (float32 coordinates): the LDS-staged kernel; a few rows only, or the float64-coordinate
   // slice path: the direct gather
   if (opts.lds_gather && opts.stack_lds && round_f32 && (st.nrows >= 8 || opts.stack_lds == 2) && !opts.coef_lds) {

@@ -35,7 +35,7 @@ def test_bench_line_carries_every_config_verified(hip):
                 "cfg4_uint16_shard64"):
         assert key in oc and oc[key].get("verified_vs_oracle") is True, (key, oc.get(key))
         assert oc[key]["launch_us"] > 0 and oc[key]["kernel"]
-    assert "stack_lds_kernel" in oc["cfg4_stack_one_gpu"]["kernel"]          # the staged stack kernel, auto-selected
+    assert "stack_wg_kernel" in oc["cfg4_stack_one_gpu"]["kernel"]          # the workgroup-box stack kernel, auto-selected
     ss = j["stack_scaling"]
     assert ss["compute_plus_allgather"] is None and ss["verified_vs_oracle"] is True and ss["compute_only"]["ms_per_step"] > 0
     assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0

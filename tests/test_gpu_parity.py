@@ -1188,8 +1188,8 @@ def test_cfg5_device_resident_call_equals_the_oracle(hip, orc):
 
 def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
     """One 8-GPU shard's worth of config 4's geometry -- (64, 2560, 2560), ALL 2560 rows, default options, device-resident:
-    the launcher must pick stack_lds_kernel<5> by itself (the kernel behind the 23 ms whole-stack number), and every voxel
-    must equal the oracle."""
+    the launcher must pick the workgroup-box stack kernel by itself (the kernel behind the whole-stack number), and every
+    voxel must equal the oracle; the same through round 1's per-wave-box kernel (stack_wg = 0), which it must select then."""
     c = configs.cfg4(64)
     D, H, W = c["shape"]
     vol = noise(c["seed"] + 3, (D, H, W))
@@ -1197,54 +1197,54 @@ def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
     L = hip.lib()
     src = hip.DeviceBuffer(vol.nbytes).upload(vol)
     dst = hip.DeviceBuffer(D * H * W * 4)
-    hip.debug_counters()
-    hip.check(L.dcp_unwarp_stack_rows_f32(src.ptr, dst.ptr, D, H, W, H * W, W, c["xcenter"], c["ycenter"], fa, nf, 0.0, H, 1,
-                                          hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None))
-    assert hip.last_kernel() == "stack_lds_kernel<NF=5,f64lerp>"
-    nofit, vote = hip.debug_counters()
-    assert nofit == 0 and vote <= 64                     # staged throughout (a handful of tiles may fail the zero-margin vote)
-    got = dst.download((D, H, W), np.float32)
-    src.free()
-    dst.free()
     want = orc.unwarp_stack_rows(vol, c["xcenter"], c["ycenter"], c["list_fact"], 0, H, coord_round_f32=True,
                                  **kernel_oracle(orc, "f64lerp"))
-    assert np.array_equal(got, want)
+    for stack_wg, name in ((1, "stack_wg_kernel<NF=5,f64lerp>"), (0, "stack_lds_kernel<NF=5,f64lerp>")):
+        hip.set_option("stack_wg", stack_wg)
+        try:
+            hip.debug_counters()
+            hip.check(L.dcp_memcpy(dst.ptr, src.ptr, 4096, hip.COPY_D2D, -1, None))        # (scribble: the result must be rewritten)
+            hip.check(L.dcp_unwarp_stack_rows_f32(src.ptr, dst.ptr, D, H, W, H * W, W, c["xcenter"], c["ycenter"], fa, nf, 0.0, H, 1,
+                                                  hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None))
+            assert hip.last_kernel() == name
+            nofit, vote = hip.debug_counters()
+            assert nofit == 0 and vote <= 64             # staged throughout (a handful of tiles may fail the zero-margin vote of the per-wave kernel)
+            assert np.array_equal(dst.download((D, H, W), np.float32), want), name
+        finally:
+            hip.set_option("stack_wg", 1)
+    src.free()
+    dst.free()
 
 
-def test_peer_copy_gather_of_device_resident_shards(hip, orc):
-    """dcp_unwarp_stack_rows_peer_f32: depth shards on the devices of one process, each block pushed into every other slot's
-    depth-outer result by hipMemcpyPeerAsync.  The test box has one GPU, so the three slots all name device 0 (ragged shards
-    3 + 2 + 2); the pushes are then same-device copies -- the code path, the offsets and the ordering are the ones an 8-GPU
-    node runs.  No measurement of xGMI is claimed."""
-    from discorpy_amd import stack
-    D, H, W = 7, 96, 200
-    vol = noise(311, (D, H, W))
-    a = (101.5, 47.25, [1.0, 1.0e-3, -2.0e-6])
-    want = orc.unwarp_stack_rows(vol, *a, 5, 60, coord_round_f32=True, **kernel_oracle(orc, "f64lerp"))
-    bounds = [stack.shard_bounds(D, 3, r) for r in range(3)]
-    shards = [hip.DeviceBuffer(max((d1 - d0) * H * W * 4, 4)).upload(vol[d0:d1]) for d0, d1 in bounds]
-    outs = [hip.DeviceBuffer(D * 60 * W * 4) for _ in range(3)]
-    stack.unwarp_stack_peer_gather([b.ptr for b in shards], [b.ptr for b in outs], D, H, W, *a, 5, 60, [0, 0, 0])
-    for b in outs:                                              # every slot ends with the whole (depth, rows, width) block
-        assert np.array_equal(b.download((D, 60, W), np.float32), want)
-    # gather = 0: every slot keeps only its own block, at the start of its buffer
-    outs2 = [hip.DeviceBuffer(max((d1 - d0) * 60 * W * 4, 4)) for d0, d1 in bounds]
-    stack.unwarp_stack_peer_gather([b.ptr for b in shards], [b.ptr for b in outs2], D, H, W, *a, 5, 60, [0, 0, 0], gather=False)
-    for (d0, d1), b in zip(bounds, outs2):
-        assert np.array_equal(b.download((d1 - d0, 60, W), np.float32), want[d0:d1])
-    # one slot: the degenerate case (no peers); more slots than projections: empty shards are skipped
-    one = hip.DeviceBuffer(D * 60 * W * 4)
-    whole = hip.DeviceBuffer(vol.nbytes).upload(vol)
-    stack.unwarp_stack_peer_gather([whole.ptr], [one.ptr], D, H, W, *a, 5, 60, [0])
-    assert np.array_equal(one.download((D, 60, W), np.float32), want)
-    two = noise(312, (2, H, W))
-    sh = [hip.DeviceBuffer(H * W * 4).upload(two[0:1]), hip.DeviceBuffer(H * W * 4).upload(two[1:2]), hip.DeviceBuffer(4)]
-    ou = [hip.DeviceBuffer(2 * 60 * W * 4) for _ in range(3)]
-    stack.unwarp_stack_peer_gather([sh[0].ptr, sh[1].ptr, None], [b.ptr for b in ou], 2, H, W, *a, 5, 60, [0, 0, 0])
-    want2 = orc.unwarp_stack_rows(two, *a, 5, 60, coord_round_f32=True, **kernel_oracle(orc, "f64lerp"))
-    assert all(np.array_equal(b.download((2, 60, W), np.float32), want2) for b in ou)
-    # argument validation
-    with pytest.raises(ValueError, match="outside"):
-        stack.unwarp_stack_peer_gather([whole.ptr], [one.ptr], D, H, W, *a, 5, 60, [99])
-    with pytest.raises(ValueError, match="one shard and one result"):
-        stack.unwarp_stack_peer_gather([whole.ptr], [one.ptr, one.ptr], D, H, W, *a, 5, 60, [0, 0])
+def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
+    """stack_wg_kernel beyond the benched geometry: ragged tiles and depth chunks, rows not starting at 0, every blend, a
+    9-term model (coefficients from LDS), strided projections, and the 8- / 16-bit integer instantiation (stack_wg = 2 routes the
+    typed entry point to it; by default those stacks stay on the generic kernel, which is faster for them)."""
+    torch = pytest.importorskip("torch")
+    D, H, W = 21, 300, 517
+    vol = noise(501, (D, H, W))
+    a = (250.3, 140.8, [1.0, 3.0e-5, -4.0e-8])
+    hip.set_option("stack_wg", 2)                         # also for launches this small, and for the integer types
+    try:
+        for blend in ("f64lerp", "scipy", "f32"):
+            got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *a, 7, 291, blend=blend).cpu().numpy()
+            assert hip.last_kernel().startswith("stack_wg_kernel<NF=-1"), hip.last_kernel()
+            assert np.array_equal(got, orc.unwarp_chunk_slices_backward(vol, *a, 7, 291, **kernel_oracle(orc, blend))), blend
+        nine = (250.3, 140.8, [1.0, 1e-5, -2e-8, 1e-11, -3e-14, 2e-17, 1e-20, -1e-23, 1e-26])
+        got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *nine, 0, 299).cpu().numpy()
+        assert np.array_equal(got, orc.unwarp_chunk_slices_backward(vol, *nine, 0, 299, **kernel_oracle(orc, "f64lerp")))
+        five = (250.3, 140.8, [1.0, 3.0e-5, -4.0e-8, 1e-11, -2e-14])
+        got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *five, 0, 299).cpu().numpy()
+        assert hip.last_kernel() == "stack_wg_kernel<NF=5,f64lerp>"
+        assert np.array_equal(got, orc.unwarp_chunk_slices_backward(vol, *five, 0, 299, **kernel_oracle(orc, "f64lerp")))
+        big = torch.from_numpy(noise(502, (D, H + 9, W + 11))).cuda()
+        view = big[:, 4:4 + H, 8:8 + W]                      # row stride W + 11 = 528 (4-byte aligned rows), offset base
+        got = pp.unwarp_chunk_slices_backward(view, *a, 30, 200).cpu().numpy()
+        assert np.array_equal(got, orc.unwarp_chunk_slices_backward(np.ascontiguousarray(view.cpu().numpy()), *a, 30, 200, **kernel_oracle(orc, "f64lerp")))
+        for dt in ("uint16", "int16", "uint8", "int8"):
+            v = typed_image(dt, (D, H, W + 3), 600 + len(dt))        # W + 3 = 520: rows are 4-byte aligned for every type
+            got = pp.unwarp_chunk_slices_backward(torch.from_numpy(v).cuda(), *a, 3, 280).cpu().numpy()
+            assert hip.last_kernel().startswith("stack_wg_kernel<NF=-1,scipy,"), (dt, hip.last_kernel())
+            assert got.dtype == np.dtype(dt) and np.array_equal(got, orc.unwarp_chunk_slices_backward(v, *a, 3, 280, poly=orc.POLY_KERNEL)), dt
+    finally:
+        hip.set_option("stack_wg", 1)
