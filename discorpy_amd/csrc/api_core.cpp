@@ -391,7 +391,7 @@ int dcp_set_option(const char* key, int value) {
     g_host_bands = value;
   } else if (!strcmp(key, "stack_wg")) {
     if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "stack_wg must be 0, 1 or 2");
-    g_stack_wg = value;               // 0: the per-wave-box stack kernels; 1: stack_wg_kernel for float32; 2: also for 8- / 16-bit integers
+    g_stack_wg = value;               // 0: round 1's stack kernels; 1: stack_wg_kernel when the launch is large enough; 2: whenever eligible
   } else if (!strcmp(key, "wg_per_cu")) {
     if (value < 0 || value > 6) return fail(DCP_ERR_INVALID_ARG, "wg_per_cu must be in [0, 6]");
     g_wg_per_cu = value;

@@ -54,9 +54,9 @@ hipError_t launch_stack_any(const StackCall& c, bool fast, const void* base, voi
     st.proj_bytes = (uint32_t)(((rows_end - 1) * row_stride + c.width) * 4);
     return dcp::launch_stack(st, c.map, c.sampler, c.round_f32 != 0, opts, hs);
   }
-  if (c.round_f32 && !c.out_f32 && opts.stack_wg >= 2) {
-    // 8- / 16-bit integer stacks under a certified map on the workgroup-box kernel: opt-in (stack_wg = 2) -- with scipy's
-    // blend and 2-byte stores it is VALU-bound and measures 10 % slower than the generic kernel (uint16 cfg4 shard: 0.27 against 0.30)
+  if (c.round_f32 && !c.out_f32 && opts.stack_wg) {
+    // 8- / 16-bit integer stacks under a certified map: the workgroup-box kernel (uint16 cfg4 shard 0.42 of the 8 TB/s peak
+    // against 0.30 for the generic kernel; its launcher declines small launches and ineligible layouts)
     const int64_t esz = dcp::elem_size(c.dtype);
     const double ext = (double)((rows_end - 1) * row_stride + c.width) * (double)esz;
     if (ext < 4294900000.0) {

@@ -122,7 +122,7 @@ struct LaunchOpts {
   int wg_box = 1;          // 1: remap_wg_kernel (one source box per 128 x 32 workgroup tile) for certified maps
   int wg_per_cu = 0;       // remap_wg_kernel: cap on resident workgroups per CU (0 = none)
   int stack_wg = 1;        // stack_wg_kernel (one box per workgroup, two slabs) for chunks of rows under a certified map: 0 never,
-                           // 1 float32 stacks when the launch has enough workgroups, 2 whenever eligible, 8- / 16-bit integers too
+                           // 1 when the launch has enough workgroups (float32 and 8- / 16-bit integers), 2 whenever eligible
 };
 
 // launchers (unwarp_kernels.hip)

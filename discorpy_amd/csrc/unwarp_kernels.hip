@@ -414,8 +414,9 @@ constexpr int kLdsBW = DCP_LDS_BLOCK_WAVES;
 // coordinates.  The box is then the corner hull grown by one pixel on every side, it contains every tap by
 // construction, and the per-pixel containment vote (two min3/max3 per pixel and a ballot) is not compiled in.
 // VOTE = true: no certificate (fused map, strongly curved models): zero margin, every pixel verified.
+// (the fused map with runtime-length coefficients needs > 96 VGPRs: three waves per SIMD is what it gets, and what it declares)
 template <int KIND, int NF, int SAMPLER, bool VOTE>
-__global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
+__global__ void __launch_bounds__(64 * kLdsBW, (KIND == kFused && NF < 0) ? 3 : DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
   constexpr int kMargin = VOTE ? DCP_LDS_MARGIN : 1;
   // 4 x 7680 B slabs + row table + coefficients <= 32 KB: five workgroups (20 waves) per CU
   __shared__ float s_box[kLdsBW][kBoxH * kBoxW];
@@ -1434,7 +1435,10 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
   const int rows = __builtin_amdgcn_readfirstlane(max(0, min(kLdsTH, st.nrows - r0)));
   const ColCtx col = make_col<kRadial, NF>(map, min(x, st.W - 1));
   uint32_t addr[kLdsTH];
-  float fx[kLdsTH], fy[kLdsTH];
+  float fx[kIsF32 ? kLdsTH : 1], fy[kIsF32 ? kLdsTH : 1];
+  // integer element types: scipy's four float64 weights per pixel, kept in registers for all projections (128 VGPRs of the
+  // 170 a wave may use at three waves per SIMD) -- recomputing them per voxel costs 6 of 34 VALU instructions
+  double wy0[kIsF32 ? 1 : kLdsTH], wy1[kIsF32 ? 1 : kLdsTH], wx0[kIsF32 ? 1 : kLdsTH], wx1[kIsF32 ? 1 : kLdsTH];
   const uint32_t negorg = (uint32_t)(-(by0 * PB + bx0 * ES));
 #pragma unroll
   for (int k = 0; k < kLdsTH; ++k) {
@@ -1451,8 +1455,16 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
     } else {
       xi = min((int)xc, st.W - 2);
       yi = min((int)yc, st.H - 2);
-      fx[k] = xc - (float)xi;
-      fy[k] = yc - (float)yi;
+      if constexpr (kIsF32) {
+        fx[k] = xc - (float)xi;
+        fy[k] = yc - (float)yi;
+      } else {
+        const double fxd = (double)(xc - (float)xi), fyd = (double)(yc - (float)yi);
+        wy0[k] = 1.0 - fyd;
+        wy1[k] = 1.0 - wy0[k];
+        wx0[k] = 1.0 - fxd;
+        wx1[k] = 1.0 - wx0[k];
+      }
     }
     addr[k] = fits ? (uint32_t)yi * (uint32_t)PB + (uint32_t)xi * (uint32_t)ES + negorg
                    : ((uint32_t)yi * (uint32_t)st.row_stride + (uint32_t)xi) * (uint32_t)ES;
@@ -1486,12 +1498,12 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
   const T* proj = volT + (size_t)d0 * (size_t)st.proj_stride;
   T* out = outT + ((size_t)d0 * (size_t)st.nrows + (size_t)min(r0, st.nrows - 1)) * (size_t)st.W;
   const size_t out_step = (size_t)st.nrows * (size_t)st.W;
-  auto blend_store = [&](const T* t_lo, const T* t_hi, float fxk, float fyk, const __amdgpu_buffer_rsrc_t& dst, int k, uint32_t a_) {
+  auto blend_store = [&](const T* t_lo, const T* t_hi, const __amdgpu_buffer_rsrc_t& dst, int k) {
     // t_lo / t_hi: the tap pairs of the two rows (LDS or global); a_: the byte address (for the aligned-dword extraction)
     if constexpr (kIsF32) {
       FetchT f;
-      f.fx = fxk;
-      f.fy = fyk;
+      f.fx = fx[k];
+      f.fy = fy[k];
       f.a.x = __float_as_uint(t_lo[0]);
       if constexpr (SAMPLER != kNearest) {
         f.a.y = __float_as_uint(t_lo[1]);
@@ -1501,13 +1513,10 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
       const float v = finish<SAMPLER, true, float>(f);
       if (k < rows) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
     } else {
-      const double fxd = (double)fxk, fyd = (double)fyk;
-      const double wy0 = 1.0 - fyd, wy1 = 1.0 - wy0;
-      const double wx0 = 1.0 - fxd, wx1 = 1.0 - wx0;
-      double acc = ((double)t_lo[0] * wy0) * wx0;
-      acc += ((double)t_lo[1] * wy0) * wx1;
-      acc += ((double)t_hi[0] * wy1) * wx0;
-      acc += ((double)t_hi[1] * wy1) * wx1;
+      double acc = ((double)t_lo[0] * wy0[k]) * wx0[k];
+      acc += ((double)t_lo[1] * wy0[k]) * wx1[k];
+      acc += ((double)t_hi[0] * wy1[k]) * wx0[k];
+      acc += ((double)t_hi[1] * wy1[k]) * wx1[k];
       const T v = to_elem<T>(acc);
       if (k < rows) {
         if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
@@ -1530,7 +1539,7 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
         for (int k = 0; k < kLdsTH; ++k) {
           if constexpr (kIsF32) {
             const float* t = (const float*)(boxb + addr[k]);
-            blend_store(t, t + kBoxWEl, fx[k], fy[k], dst, k, addr[k]);
+            blend_store(t, t + kBoxWEl, dst, k);
           } else {
             // tap pairs as the two aligned dwords around them, shifted down (see remap_wg_kernel)
             const uint32_t* q = (const uint32_t*)(boxb + (addr[k] & ~3u));
@@ -1544,7 +1553,7 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
               lo[0] = (T)__builtin_amdgcn_ubfe(top, 0, ES * 8); lo[1] = (T)__builtin_amdgcn_ubfe(top, ES * 8, ES * 8);
               hi[0] = (T)__builtin_amdgcn_ubfe(bot, 0, ES * 8); hi[1] = (T)__builtin_amdgcn_ubfe(bot, ES * 8, ES * 8);
             }
-            blend_store(lo, hi, fx[k], fy[k], dst, k, addr[k]);
+            blend_store(lo, hi, dst, k);
           }
         }
       }
@@ -1558,7 +1567,7 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
 #pragma unroll
       for (int k = 0; k < kLdsTH; ++k) {
         const T* t = (const T*)((const char*)proj + addr[k]);
-        blend_store(t, t + st.row_stride, fx[k], fy[k], dst, k, addr[k]);
+        blend_store(t, t + st.row_stride, dst, k);
       }
       proj += st.proj_stride;
       out += out_step;

@@ -1218,13 +1218,13 @@ def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
 
 def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
     """stack_wg_kernel beyond the benched geometry: ragged tiles and depth chunks, rows not starting at 0, every blend, a
-    9-term model (coefficients from LDS), strided projections, and the 8- / 16-bit integer instantiation (stack_wg = 2 routes the
-    typed entry point to it; by default those stacks stay on the generic kernel, which is faster for them)."""
+    9-term model (coefficients from LDS), strided projections, and the 8- / 16-bit integer instantiations (stack_wg = 2: also for
+    launches this small)."""
     torch = pytest.importorskip("torch")
     D, H, W = 21, 300, 517
     vol = noise(501, (D, H, W))
     a = (250.3, 140.8, [1.0, 3.0e-5, -4.0e-8])
-    hip.set_option("stack_wg", 2)                         # also for launches this small, and for the integer types
+    hip.set_option("stack_wg", 2)                         # also for launches this small
     try:
         for blend in ("f64lerp", "scipy", "f32"):
             got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *a, 7, 291, blend=blend).cpu().numpy()
