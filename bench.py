@@ -577,6 +577,19 @@ def init_dist():
     return world, rank, dev_index, dist, backend
 
 
+def stack_traffic(a, world, kernel):
+    """roofline.traffic of the stack workload: the PMC figure committed under profiles/ applies to a 256-projection shard, every row."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    try:
+        j = json.load(open(pmc)).get("stack_shard256")
+        if j and a.depth // world == 256 and a.rows == 2560 and kernel.split("<")[0] in j.get("rocprof_kernel_name", ""):
+            return {"traffic": j.get("hbm_bytes_per_launch"),
+                    "traffic_source": "profiles/pmc_latest.json: rocprofv3 PMC passes of %s on a 256-projection shard, not measured in this run" % j.get("rocprof_kernel_name")}
+    except Exception:      # noqa: BLE001
+        pass
+    return {"traffic": None, "traffic_source": None}
+
+
 def stack_main(a, world, rank, dev, dist, backend):
     """--workload stack: config 4 IS the metric (strong scaling: the stack is fixed)."""
     blend = BLEND_NAMES[a.blend]
@@ -632,8 +645,7 @@ def stack_main(a, world, rank, dev, dist, backend):
             "data": "synthetic (uniform [0,1) float32 projections, device-resident)",
             "config": {"workload": cfg["name"], "depth": D, "rows": a.rows, "width": W, "blend": a.blend, "parallelism": mode},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
-                         "kernel": res["kernel"]},
+                         "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "kernel": res["kernel"], **stack_traffic(a, world, res["kernel"])},
             "detail": res.get("detail")}), flush=True)
 
 

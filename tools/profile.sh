@@ -25,6 +25,12 @@ run sq1 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VM
 run sq2 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_LDS GRBM_GUI_ACTIVE
 run fetch --kernel-trace --pmc FETCH_SIZE
 run write --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+# HBM traffic of the stack kernel too: config 4, one 8-GPU shard (256 projections, every row)
+BENCH_SAVE=$BENCH
+BENCH="python $ROOT/bench.py --workload stack --depth 256 --steps 2 --warmup 1"
+run sfetch --kernel-trace --pmc FETCH_SIZE
+run swrite --kernel-trace --pmc WRITE_SIZE
+BENCH=$BENCH_SAVE
 run tcc --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 run tcc2 --kernel-trace --pmc TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_EA0_RDREQ_DRAM_sum
 run tcp --kernel-trace --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum

@@ -24,6 +24,9 @@ if "--latest" in sys.argv:
             best = dict(v, kernel=k.replace("void dcp::", "").split("(")[0].replace("<0, 5, 2, float>", "<Radial,NF=5,f64lerp>"),
                         rocprof_kernel_name=k, source=tag + "_rocprofv3_summary.json", collected=datetime.date.today().isoformat())
     if best:
+        for k, v in summ.get("traffic", {}).items():       # the stack kernel's pass: config 4, a 256-projection shard, every row
+            if "stack_wg_kernel" in k or "stack_lds_kernel" in k:
+                best["stack_shard256"] = dict(v, rocprof_kernel_name=k, algorithmic_bytes_per_launch=8 * 256 * 2560 * 2560)
         json.dump(best, open(os.path.join(dst, "pmc_latest.json"), "w"), indent=1)
         print("pmc_latest.json:", best)
 print("saved", tag)

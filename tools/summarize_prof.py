@@ -54,10 +54,10 @@ def main(out):
     wf = fw.get("calib_copy_dword", 1.0)
     traffic = {}
     for kern, cs in summary["counters"].items():
-        if "remap_" in kern or "stack_rows" in kern:
+        if "remap_" in kern or "stack_" in kern:
             # remap_lds_kernel streams 16-byte-per-lane row segments (the dwordx4 copy shape); the
             # direct kernels gather 8-byte tap pairs at 4-byte lane stride (the dwordx2 gather shape)
-            if "remap_lds_kernel" in kern or "remap_wg_kernel" in kern:
+            if "remap_lds_kernel" in kern or "remap_wg_kernel" in kern or "stack_wg_kernel" in kern or "stack_lds_kernel" in kern:
                 rf = fr.get("calib_copy_dwordx4", 2.0)
             else:
                 rf = fr.get("calib_gather_dwordx2", fr.get("calib_copy_dword", 2.0))
