@@ -186,16 +186,23 @@ def main():
     F.lib()
     F.require_device()
     rng = np.random.default_rng(seed)
-    counts, t0 = {}, time.time()
+    counts, kernels, t0 = {}, {}, time.time()
     F.debug_counters()
     for k in range(cases):
         F.set_option("stack_lds", (1, 2, 0)[k % 3])       # stack cases: automatic choice / forced staged kernel / direct
+        F.set_option("stack_wg", (2, 1, 2, 0)[k % 4])     # workgroup-box stack kernel: whenever eligible / automatic / off
+        F.set_option("wg_box", 0 if k % 5 == 4 else 1)    # one box per workgroup, or per wave tile
+        F.set_option("tile_cert", 0 if k % 7 == 6 else 1) # the host certificate, or the per-pixel vote
         kind = one_case(rng, k)
         counts[kind] = counts.get(kind, 0) + 1
+        name = F.last_kernel().split("<")[0].split(" ")[0] or "(spline / point kernels)"
+        kernels[name] = kernels.get(name, 0) + 1
     nofit, vote = F.debug_counters()
-    F.set_option("stack_lds", 1)
-    print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; LDS-kernel fallbacks exercised: %d tiles did not fit, "
-          "%d tiles failed the vote" % (cases, seed, time.time() - t0, dict(sorted(counts.items())), nofit, vote))
+    for key in ("stack_lds", "stack_wg", "wg_box", "tile_cert"):
+        F.set_option(key, 1)
+    print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; last kernel of each case: %s; LDS-kernel fallbacks exercised: "
+          "%d tiles did not fit, %d tiles failed the vote" % (cases, seed, time.time() - t0, dict(sorted(counts.items())),
+                                                              dict(sorted(kernels.items())), nofit, vote))
 
 
 if __name__ == "__main__":
