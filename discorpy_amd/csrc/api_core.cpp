@@ -396,7 +396,7 @@ int dcp_set_option(const char* key, int value) {
     if (value < 0 || value > 6) return fail(DCP_ERR_INVALID_ARG, "wg_per_cu must be in [0, 6]");
     g_wg_per_cu = value;
   } else if (!strcmp(key, "wg_box")) {
-    g_wg_box = value == 2 ? 2 : (value ? 1 : 0);         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
+    g_wg_box = value ? 1 : 0;         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
   } else if (!strcmp(key, "tile_cert")) {
     g_tile_cert = value ? 1 : 0;      // 0: never use the host's tile-deviation certificate (remap_lds_kernel then votes)
   } else if (!strcmp(key, "stack_chunk_kb")) {

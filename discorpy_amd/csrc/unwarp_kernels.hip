@@ -33,7 +33,6 @@
 // the arithmetic is the same sequence of IEEE operations as oracle/unwarp_oracle.c.
 #include "dcp_internal.h"
 #include "dcp_device.h"
-#include <atomic>
 #include <type_traits>
 #include <cstdio>
 
@@ -1100,299 +1099,6 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
   }
 }
 
-// ------------------------------------------------------------------ K1c: persistent workgroups, double-buffered box
-
-// remap_wg_kernel's tile work with the launch taken out of the per-tile path: 3 workgroups per CU stay resident and walk
-// a static list of 128 x 32 tiles.  Two slabs: the box of tile i + 1 streams into the idle slab (LDS-DMA, issued row by
-// row inside the blend loop of tile i) and its coordinates are computed after the blend, so the copy of one tile runs
-// under the arithmetic of its neighbours instead of in front of its own.  One barrier per tile.  float32 only.
-// Tile order: XCD (blockIdx.x & 7) owns every eighth tile (plain) or a stripe of tile columns (xcd_remap == 2, tiles_x a
-// multiple of eight); the workgroups of an XCD take consecutive tiles of its list, round after round.
-#ifndef DCP_STREAM_FILL_EVERY
-#define DCP_STREAM_FILL_EVERY 2
-#endif
-template <int KIND, int NF, int SAMPLER>
-__global__ void __launch_bounds__(256, 3) remap_stream_kernel(const ImageArgs img, const MapArgs map) {
-  constexpr int CH = 36, PB = CH * 16, NJ = 6;
-  __shared__ __attribute__((aligned(16))) unsigned char s_box[2][kWgSlabRows * PB];
-  __shared__ double s_row[4][kLdsTH][KIND == kRadial ? 2 : 4];
-  __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
-  using FetchT = Fetch<SAMPLER, true, float>;
-  constexpr int RW = KIND == kRadial ? 2 : 4;
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int lane = (int)threadIdx.x & 63;
-  const int wx = wave & 1, wy = wave >> 1;
-  const int xcd = blockIdx.x & 7, per_xcd = (int)gridDim.x >> 3;
-  const bool striped = img.xcd_remap == 2;
-  const int ws = img.tiles_x >> 3;
-  const int ntiles = img.tiles_x * img.tiles_y;
-  const int count = striped ? ws * img.tiles_y : (ntiles - xcd + 7) >> 3;
-  const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
-  const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img.src, 0, (int)img.src_bytes, 0x00020000);
-  const uint32_t rstep = (uint32_t)img.src_stride * 4u;
-  const uint32_t row_bytes_out = (uint32_t)img.W * 4u;
-  // this lane's chunk of load 0 inside a box: row crow0, chunk c160 (see remap_wg_kernel)
-  const int fc = wave * 64 + lane;
-  const int crow0 = fc / CH;
-  const int c160 = fc - crow0 * CH;
-  const uint32_t lane_off = (uint32_t)crow0 * rstep + (uint32_t)c160 * 16u;
-  if constexpr (NF < 0 && KIND != kPersp) {
-    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
-    __syncthreads();
-  }
-
-  struct Box {
-    int bx0, by0, bx1, by1, bh;
-    bool fits, inside;
-  };
-  struct Tile {
-    int y0, rows, xcol;
-    uint32_t xoff;                  // byte offset of this lane's column in an output row; out of range for lanes past the image
-    __amdgpu_buffer_rsrc_t dst;
-  };
-  auto tile_of = [&](int q, int* tx, int* ty) {
-    if (striped) {
-      const int r = q / ws;
-      *ty = r;
-      *tx = xcd * ws + (q - r * ws);
-    } else {
-      const int g = q * 8 + xcd;
-      const int r = g / img.tiles_x;
-      *ty = r;
-      *tx = g - r * img.tiles_x;
-    }
-  };
-  // the four corner pixels of a workgroup tile (lanes 0..3 of every wave) -> the box that holds all its taps
-  auto box_of = [&](int tx, int ty) -> Box {
-    const int yblk = ty * kWgTH;
-    const double X = (double)min(tx * kWgTW + (lane & 1) * (kWgTW - 1), img.W - 1);
-    const double Y = (double)(img.y_origin + min(yblk + ((lane >> 1) & 1) * (kWgTH - 1), img.rows_out - 1));
-    double xd, yd;
-    if constexpr (KIND == kRadial) {
-      const double xu = X - map.xc, yu = Y - map.yc;
-      const double r2 = xu * xu + yu * yu;
-      const double ru = sqrt_rn(r2);
-      double f;
-      if constexpr (NF >= 0) {
-        double le, lo;
-        poly_leads<NF>(map.fact, &le, &lo);
-        f = poly_inline<NF>(map.fact, le, lo, r2, ru);
-      } else {
-        f = poly_lds(map.fact, map.nfact, r2, ru);
-      }
-      xd = __builtin_fma(f, xu, map.xc);
-      yd = __builtin_fma(f, yu, map.yc);
-    } else {
-      const double den = (map.coef[6] * X + map.coef[7] * Y) + 1.0;
-      xd = ((map.coef[0] * X + map.coef[1] * Y) + map.coef[2]) / den;
-      yd = ((map.coef[3] * X + map.coef[4] * Y) + map.coef[5]) / den;
-    }
-    const int cxi = (int)round_clip_f32(xd, wmaxf), cyi = (int)round_clip_f32(yd, hmaxf);
-    const int xa = __builtin_amdgcn_readlane(cxi, 0), xb = __builtin_amdgcn_readlane(cxi, 1);
-    const int xc_ = __builtin_amdgcn_readlane(cxi, 2), xd_ = __builtin_amdgcn_readlane(cxi, 3);
-    const int ya = __builtin_amdgcn_readlane(cyi, 0), yb = __builtin_amdgcn_readlane(cyi, 1);
-    const int yc_ = __builtin_amdgcn_readlane(cyi, 2), yd_ = __builtin_amdgcn_readlane(cyi, 3);
-    const int cx0 = min(min(xa, xb), min(xc_, xd_)), cx1 = max(max(xa, xb), max(xc_, xd_));
-    const int cy0 = min(min(ya, yb), min(yc_, yd_)), cy1 = max(max(ya, yb), max(yc_, yd_));
-    Box b;
-    b.bx0 = __builtin_amdgcn_readfirstlane(max(min(cx0 - 1, img.W - 2), 0));
-    b.bx1 = min(cx1 + 2, img.W - 1);
-    b.by0 = __builtin_amdgcn_readfirstlane(max(min(cy0 - 1, img.H - 2), 0));
-    b.by1 = min(cy1 + 2, img.H - 1);
-    b.bh = b.by1 - b.by0 + 1;
-    b.fits = b.bx1 - b.bx0 + 1 <= kWgBoxW && b.bh <= kWgBoxH;
-    b.inside = cx0 - 1 >= 0 && cx1 + 2 <= img.W - 1 && cy0 - 1 >= 0 && cy1 + 2 <= img.H - 1;
-    return b;
-  };
-  auto tile_ctx = [&](int tx, int ty) -> Tile {
-    Tile t;
-    t.y0 = __builtin_amdgcn_readfirstlane(ty * kWgTH + wy * kLdsTH);
-    t.rows = __builtin_amdgcn_readfirstlane(max(0, min(kLdsTH, img.rows_out - t.y0)));
-    const int ybase = __builtin_amdgcn_readfirstlane(min(t.y0, img.rows_out - 1));
-    const int x = tx * kWgTW + wx * kLdsTW + lane;
-    t.xcol = min(x, img.W - 1);
-    t.xoff = x < img.W ? (uint32_t)x * 4u : 0x40000000u;
-    t.dst = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)(img.dst + (size_t)ybase * (size_t)img.W)), 0,
-                                              (int)((uint32_t)t.rows * row_bytes_out), 0x00020000);
-    return t;
-  };
-  // load j of this wave's share of box b into slab `slab` (linear 16-byte chunks, as in remap_wg_kernel)
-  auto issue_fill = [&](auto jc, const Box& b, unsigned char* slab) {
-    constexpr int j = decltype(jc)::value;
-    if constexpr (j < NJ) {
-      if (b.fits && (j * 4 + wave) * 64 < b.bh * CH) {
-        constexpr int qrow = (256 * j) / CH, rem = (256 * j) % CH;
-        const bool wrap = c160 >= CH - rem;
-        const int crow = crow0 + qrow + (wrap ? 1 : 0);
-        const uint32_t base = ((uint32_t)b.by0 * (uint32_t)img.src_stride + (uint32_t)b.bx0) * 4u + (uint32_t)qrow * rstep + (uint32_t)rem * 16u;
-        if (crow < b.bh)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(slab + (j * 4 + wave) * 1024), 16,
-                                                   lane_off + (wrap ? rstep - (uint32_t)PB : 0u), base, 0, 0);
-      }
-    }
-  };
-  auto issue_fill_at = [&](int k, int every, int start, const Box& b, unsigned char* slab) {
-    if (k == start + 0 * every) issue_fill(std::integral_constant<int, 0>{}, b, slab);
-    if (k == start + 1 * every) issue_fill(std::integral_constant<int, 1>{}, b, slab);
-    if (k == start + 2 * every) issue_fill(std::integral_constant<int, 2>{}, b, slab);
-    if (k == start + 3 * every) issue_fill(std::integral_constant<int, 3>{}, b, slab);
-    if (k == start + 4 * every) issue_fill(std::integral_constant<int, 4>{}, b, slab);
-    if (k == start + 5 * every) issue_fill(std::integral_constant<int, 5>{}, b, slab);
-  };
-  auto issue_fill_all = [&](const Box& b, unsigned char* slab) {
-    issue_fill(std::integral_constant<int, 0>{}, b, slab);
-    issue_fill(std::integral_constant<int, 1>{}, b, slab);
-    issue_fill(std::integral_constant<int, 2>{}, b, slab);
-    issue_fill(std::integral_constant<int, 3>{}, b, slab);
-    issue_fill(std::integral_constant<int, 4>{}, b, slab);
-    issue_fill(std::integral_constant<int, 5>{}, b, slab);
-  };
-
-  float xf[kLdsTH], yf[kLdsTH];
-  // ---- the coordinates of tile t's 16 rows of this wave (fill = true: the copy of its own box goes out in between)
-  auto coords = [&](const Tile& t, const Box& b, auto fill, unsigned char* slab) {
-    if (lane < kLdsTH)
-      fill_row<KIND, RW>(map, s_row[wave], lane, (double)(img.y_origin + min(t.y0 + lane, img.rows_out - 1)));
-    const ColCtx col = make_col<KIND, NF>(map, t.xcol);
-    const auto* rowtab = s_row[wave];
-    auto rows_1 = [&](auto noclip, auto fastdiv) {
-      for (int k = 0; k < kLdsTH; ++k) {
-        if constexpr (decltype(fill)::value) issue_fill_at(k, 1, 0, b, slab);
-        double xd, yd;
-        map_coord<KIND, NF, RW, decltype(fastdiv)::value>(map, rowtab, s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
-        if constexpr (decltype(noclip)::value) {
-          xf[k] = (float)xd;
-          yf[k] = (float)yd;
-        } else {
-          xf[k] = round_clip_f32(xd, wmaxf);
-          yf[k] = round_clip_f32(yd, hmaxf);
-        }
-      }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    const bool unclipped = b.inside && b.fits;
-    if (t.rows > 0) {
-      if (KIND == kRadial || !map.fast_div) {
-        if (unclipped) rows_1(std::true_type{}, I0{});
-        else rows_1(std::false_type{}, I0{});
-      } else {
-        if (unclipped) rows_1(std::true_type{}, I1{});
-        else rows_1(std::false_type{}, I1{});
-      }
-    } else if constexpr (decltype(fill)::value) {
-      issue_fill_all(b, slab);
-    }
-  };
-  // ---- taps of tile t from its slab, blend, store; the copy of box `nb` into `nslab` goes out in between (has_next)
-  auto blend = [&](const Tile& t, const Box& b, const unsigned char* slab, bool has_next, const Box& nb, unsigned char* nslab) {
-    if (t.rows == 0) {
-      if (has_next) issue_fill_all(nb, nslab);
-      return;
-    }
-    if (b.fits) {
-      const uint32_t negorg4 = (uint32_t)(-(b.by0 * PB + b.bx0 * 4));
-      const char* boxb = (const char*)slab;
-      const bool interior = b.bx1 < img.W - 1 && b.by1 < img.H - 1;
-      const float negorg4f = (float)(int32_t)negorg4;
-      auto tap_addr = [&](int xi, int yi) -> uint32_t {
-        uint32_t xa, a_;
-        asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a_) : "v"(yi), "s"(PB), "v"(xa));
-        return a_;
-      };
-      auto tile_rows_loop = [&](auto full, auto inner) {
-#pragma unroll
-        for (int k = 0; k < kLdsTH; ++k) {
-          if (has_next) issue_fill_at(k, DCP_STREAM_FILL_EVERY, 0, nb, nslab);
-          FetchT f;
-          uint32_t addr;
-          if constexpr (SAMPLER == kNearest) {
-            int xi = (int)xf[k];
-            int yi = (int)yf[k];
-            xi += (xf[k] - (float)xi >= 0.5f) ? 1 : 0;
-            yi += (yf[k] - (float)yi >= 0.5f) ? 1 : 0;
-            addr = tap_addr(xi, yi);
-          } else if constexpr (decltype(inner)::value) {
-            f.fx = __builtin_amdgcn_fractf(xf[k]);
-            f.fy = __builtin_amdgcn_fractf(yf[k]);
-            const float flx = xf[k] - f.fx, fly = yf[k] - f.fy;
-            const float af = __builtin_fmaf(fly, (float)PB, __builtin_fmaf(flx, 4.0f, negorg4f));
-            addr = (uint32_t)(int32_t)af;
-          } else {
-            const int xi = min((int)xf[k], img.W - 2);
-            const int yi = min((int)yf[k], img.H - 2);
-            f.fx = xf[k] - (float)xi;
-            f.fy = yf[k] - (float)yi;
-            addr = tap_addr(xi, yi);
-          }
-          const float* tp = (const float*)(boxb + addr);
-          float v;
-          if constexpr (SAMPLER == kNearest) {
-            v = tp[0];
-          } else {
-            f.a.x = __float_as_uint(tp[0]);
-            f.a.y = __float_as_uint(tp[1]);
-            f.b.x = __float_as_uint(tp[kWgBoxW]);
-            f.b.y = __float_as_uint(tp[kWgBoxW + 1]);
-            v = finish<SAMPLER, true, float>(f);
-          }
-          if (decltype(full)::value || k < t.rows)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), t.dst, t.xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
-        }
-      };
-      if (t.rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{});
-      else if (t.rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
-      else tile_rows_loop(std::false_type{}, std::false_type{});
-    } else {
-      if (has_next) issue_fill_all(nb, nslab);
-      const SrcView src = make_view(img.src, img.src_bytes, img.W, img.H, img.src_stride, 1);
-#pragma unroll
-      for (int k = 0; k < kLdsTH; ++k) {
-        const float xc = __builtin_amdgcn_fmed3f(xf[k], 0.0f, wmaxf), yc = __builtin_amdgcn_fmed3f(yf[k], 0.0f, hmaxf);
-        const FetchT f = fetch<SAMPLER, true, float>(src, xc, yc);
-        const float v = finish<SAMPLER, true, float>(f);
-        if (k < t.rows)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), t.dst, t.xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
-      }
-    }
-  };
-
-  int q = (int)blockIdx.x >> 3;
-  if (q >= count) return;                            // (the whole workgroup)
-  int tx, ty;
-  tile_of(q, &tx, &ty);
-  Box cur = box_of(tx, ty);
-  Tile tc = tile_ctx(tx, ty);
-  coords(tc, cur, std::true_type{}, s_box[0]);
-  if (!cur.fits && lane == 0 && wave == 0) atomicAdd(&g_lds_stats[0], 1ull);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int buf = 0;
-  for (;;) {
-    const int qn = q + per_xcd;
-    const bool has_next = qn < count;                // workgroup-uniform
-    Box nxt = cur;
-    Tile tn = tc;
-    if (has_next) {
-      tile_of(qn, &tx, &ty);
-      nxt = box_of(tx, ty);
-      tn = tile_ctx(tx, ty);
-    }
-    blend(tc, cur, s_box[buf], has_next, nxt, s_box[buf ^ 1]);
-    if (!has_next) break;
-    coords(tn, nxt, std::false_type{}, nullptr);
-    if (!nxt.fits && lane == 0 && wave == 0) atomicAdd(&g_lds_stats[0], 1ull);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                 // box i + 1 has landed; nobody reads slab `buf` any more
-    cur = nxt;
-    tc = tn;
-    buf ^= 1;
-    q = qn;
-  }
-}
-
 // ------------------------------------------------------------------ K5: explicit coordinates
 
 template <int SAMPLER, bool PAIR, typename CT>
@@ -1925,18 +1631,6 @@ static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStr
   return hipGetLastError();
 }
 
-static int device_cu_count() {
-  static std::atomic<int> cached[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-  int n = cached[dev].load(std::memory_order_relaxed);
-  if (n == 0) {
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    cached[dev].store(n, std::memory_order_relaxed);
-  }
-  return n;
-}
-
 template <int KIND, int NF, int SAMPLER>
 static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {
   ImageArgs img = img_in;
@@ -1946,17 +1640,6 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
   // balance when the number of tile columns divides by eight: 20 columns (2560 px) put 3 on four XCDs and 2 on the other
   // four, 7 % slower than the plain order.  Stripes when the widest XCD carries at most 7 % more than the average.
   if (img.xcd_remap == 2 && 8 * ((img.tiles_x + 7) / 8) * 100 > img.tiles_x * 107) img.xcd_remap = 0;
-  if (img.wg_box == 2) {
-    // persistent workgroups (remap_stream_kernel): worth it from two rounds of tiles per resident workgroup on
-    const int per_cu = img.wg_per_cu >= 1 && img.wg_per_cu <= 3 ? img.wg_per_cu : 3;
-    const int G = (device_cu_count() * per_cu) & ~7;
-    if (G >= 8 && img.tiles_x * img.tiles_y >= 2 * G) {
-      if (img.xcd_remap == 2 && (img.tiles_x & 7)) img.xcd_remap = 0;
-      note_kernel("remap_stream_kernel", KIND, NF, SAMPLER);
-      hipLaunchKernelGGL((remap_stream_kernel<KIND, NF, SAMPLER>), dim3(G), dim3(256), 0, stream, img, map);
-      return hipGetLastError();
-    }
-  }
   const dim3 grid(img.xcd_remap == 2 ? 8 * ((img.tiles_x + 7) / 8) : img.tiles_x, img.tiles_y);
   // workgroups per CU capped through unused dynamic LDS (the static 23.5 KB allow six): img.wg_per_cu in 1..5
   unsigned pad = 0;
