@@ -37,4 +37,4 @@ def run(order, blend, reps=1920):
 
 for name, order, blend in [("f64lerp", 1, 1), ("scipy", 1, 0), ("f32lerp", 1, 2), ("nearest", 0, 0), ("f64lerp", 1, 1)]:
     us = run(order, blend)
-    print("%-24s %-8s %7.2f us  %5.3f of 8 TB/s" % (tag, name, us, 8.0 * H * W / us / 1e6 / 8.0), flush=True)
+    print("%-24s %-8s %7.2f us  %5.3f of 8 TB/s  %s" % (tag, name, us, 8.0 * H * W / us / 1e6 / 8.0, F.last_kernel()), flush=True)
