@@ -95,6 +95,18 @@ def test_g6_stack_rows(hip):
         assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a, s0, s1), g[key]).max() <= 1
 
 
+def test_g15_folding_model_pins_the_documented_band_deviation(hip):
+    """See tests/test_oracle_golden.py: equal to the reference inside its band, absolute-coordinate sampling outside."""
+    g = golden("g15_folding_chunk")
+    vol = noise(g["seed"], g["shape"])
+    a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]), int(g["start"]), int(g["stop"]))
+    outside = g["outside_band"]
+    out = pp.unwarp_chunk_slices_backward(vol, *a, blend="scipy")
+    assert np.array_equal(out[:, ~outside], g["ref_out"][:, ~outside])
+    assert np.array_equal(out, g["absolute_out"])
+    assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a), g["absolute_out"]).max() <= 1
+
+
 def test_g7_fused_and_two_pass(hip):
     g = golden("g7_fused144")
     img = noise(g["seed"], g["shape"])

@@ -101,6 +101,21 @@ def test_g6_stack_rows(orc, poly):
         assert np.array_equal(orc.unwarp_chunk_slices_backward(vol, *a, s0, s1, poly=p), g[key])
 
 
+def test_g15_folding_model_pins_the_documented_band_deviation(orc):
+    """A non-monotone model: where a chunk row's coordinate stays inside the reference's band [yd_min, yd_max) we equal
+    the reference bit for bit; where it leaves it the reference reads samples reflected inside the band
+    (postprocessing.py:289-312) and we read the projection at the absolute coordinate."""
+    g = golden("g15_folding_chunk")
+    vol = noise(g["seed"], g["shape"])
+    out = orc.unwarp_chunk_slices_backward(vol, float(g["xcenter"]), float(g["ycenter"]), g["list_fact"], int(g["start"]),
+                                           int(g["stop"]))
+    outside = g["outside_band"]
+    assert 0 < outside.sum() < outside.size
+    assert np.array_equal(out[:, ~outside], g["ref_out"][:, ~outside])
+    assert np.array_equal(out, g["absolute_out"])
+    assert not np.array_equal(g["ref_out"][:, outside], g["absolute_out"][:, outside])
+
+
 def test_chunk_equals_image_rows_and_slice_differs(orc):
     """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
     g = golden("g6_stack3x800x1280")

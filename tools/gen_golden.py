@@ -298,4 +298,37 @@ g14["reftest_tfact"] = f64(tfact14)
 g14["reftest_pads"] = np.asarray(util._calc_pad(True, 40, 60, 30.0, 20.0, tfact14), dtype=np.int64)
 g14["reftest_pad_true"] = util.unwarp_color_image_backward(box, 30.0, 20.0, tfact14, 1, "constant", True, "constant")
 save("g14_autopad40x56x3", **g14)
+
+# G15: a FOLDING radial model on a chunk of rows -- the one documented deviation of the stack path that the reference's
+# own tests never reach.  The reference crops the band [yd_min, yd_max) from the first row's minimum and the last row's
+# maximum (postprocessing.py:289-301) and lets map_coordinates reflect inside that band; rows whose coordinates leave
+# the band (possible only for a non-monotone map) therefore read reflected samples.  discorpy_amd samples the
+# projection at the absolute coordinate.  The fixture pins both: the reference's output, the mask of pixels whose row
+# coordinate leaves the band, and the absolute-coordinate result (scipy on the whole projection, same float32 coordinates).
+def g15():
+    d, h, w = 4, 64, 96
+    xc, yc, fact = 48.3, 30.2, [1.0, 0.0, -4.0e-4]
+    start, stop = 2, 20
+    vol = np.random.default_rng(1515).random((d, h, w), dtype=np.float32)
+    ref = post.unwarp_chunk_slices_backward(vol, xc, yc, fact, start, stop)
+    xu = np.arange(0, w) - xc
+    yu = np.arange(start, stop + 1) - yc
+    xu_mat, yu_mat = np.meshgrid(xu, yu)
+    ru = np.sqrt(xu_mat ** 2 + yu_mat ** 2)
+    fm = np.sum(np.asarray([f * ru ** i for i, f in enumerate(fact)]), axis=0)
+    xd = np.float32(np.clip(xc + fm * xu_mat, 0, w - 1))
+    yd = np.float32(np.clip(yc + fm * yu_mat, 0, h - 1))
+    yd_min = int(np.floor(np.amin(yd[0].astype(np.float64))))        # as the reference: first row's minimum,
+    yd_max = int(np.ceil(np.amax(yd[-1].astype(np.float64)))) + 1    # last row's maximum (float64 there; same integers here)
+    outside = (yd < yd_min) | (yd > yd_max - 1)
+    absolute = np.asarray([map_coordinates(vol[i], (yd, xd), order=1, mode="reflect") for i in range(d)])
+    assert outside.any() and not outside.all()
+    assert np.array_equal(ref[:, ~outside], absolute[:, ~outside])
+    assert not np.array_equal(ref[:, outside], absolute[:, outside])
+    save("g15_folding_chunk", seed=np.int64(1515), shape=np.array([d, h, w]), xcenter=f64(xc), ycenter=f64(yc),
+         list_fact=f64(fact), start=np.int64(start), stop=np.int64(stop), ref_out=ref, outside_band=outside,
+         absolute_out=absolute.astype(np.float32), band=np.array([yd_min, yd_max]))
+
+
+g15()
 print("done")
