@@ -397,6 +397,8 @@ int dcp_set_option(const char* key, int value) {
     g_wg_per_cu = value;
   } else if (!strcmp(key, "wg_box")) {
     g_wg_box = value ? 1 : 0;         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
+  } else if (!strcmp(key, "spline_tiled")) {
+    dcp::set_spline_tiled(value ? 1 : 0);
   } else if (!strcmp(key, "tile_cert")) {
     g_tile_cert = value ? 1 : 0;      // 0: never use the host's tile-deviation certificate (remap_lds_kernel then votes)
   } else if (!strcmp(key, "stack_chunk_kb")) {
@@ -423,6 +425,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "tile_cert")) *value = g_tile_cert;
   else if (!strcmp(key, "wg_box")) *value = g_wg_box;
   else if (!strcmp(key, "wg_per_cu")) *value = g_wg_per_cu;
+  else if (!strcmp(key, "spline_tiled")) *value = dcp::get_spline_tiled();
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;

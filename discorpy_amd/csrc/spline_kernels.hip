@@ -21,6 +21,9 @@
 namespace dcp {
 
 constexpr int kSplBlock = 256;
+int g_spline_tiled = 1;          // 0: always the chunked passes + transposes (option spline_tiled; A/B runs and tests)
+void set_spline_tiled(int v) { g_spline_tiled = v; }
+int get_spline_tiled() { return g_spline_tiled; }
 
 __global__ void __launch_bounds__(kSplBlock) spline_expand_kernel(const SplineArgs a) {
   const int64_t i = (int64_t)blockIdx.x * kSplBlock + threadIdx.x;
@@ -202,6 +205,191 @@ __global__ void __launch_bounds__(kSplBlock) spline_anticausal_kernel(const Filt
   }
 }
 
+// ---- the prefilter of one axis in ONE pass over the plane ---------------------------------------
+// A workgroup stages kTfLines lines x up to kTfSamples samples (its core of `core` samples and `halo` samples on both
+// sides) in LDS as float64, runs every pole's causal and anti-causal recursion there (lane = line, wave 0), and writes
+// the core back: the plane is read once and written once per axis instead of four times plus two transposes.  The halo
+// plays kWarm's part -- a recursion restarted from a zero state forgets like |z|^k; the host sizes it so that every pole
+// has decayed below 2^-70 of the signal before the core -- and a tile that reaches the start (end) of the line uses the
+// exact initial sums of the oracle.  AXIS 0: lines are columns (lane = column: every global and LDS access is
+// contiguous across the wave); AXIS 1: lines are rows (loads and stores run along the row, the recursion walks LDS rows
+// of pitch kTfSamples + 1).  Used for the reflect / mirror boundary kinds on lines long enough that z^n underflows to zero
+// (the far end of the line then does not enter the initial sums); everything else takes the chunked passes above.
+constexpr int kTfLines = 64;
+constexpr int kTfSamples = 256;
+constexpr int kTfPitch1 = kTfSamples + 1;
+
+struct TileFilter {
+  const void* in;
+  double* out;
+  int64_t in_ls, in_ss;      // input strides in elements: between lines, between samples of a line
+  int64_t out_ls, out_ss;
+  int32_t n, nlines, kind, npoles, halo, core;
+  double z[2];
+  double lam;
+};
+
+constexpr int kTfBlock = 1024;       // 16 waves move the tile (16 rows of loads in flight each); wave 0 runs the recursions
+constexpr int kTfWaves = kTfBlock / 64;
+
+template <int AXIS, bool IN_F32>
+__global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const TileFilter f) {
+  extern __shared__ double s_t[];
+  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  const int l0 = blockIdx.x * kTfLines;
+  const int g0 = blockIdx.y * f.core;                         // first sample this tile writes
+  const int gs = max(0, g0 - f.halo), ge = min(f.n, g0 + f.core + f.halo);
+  const int R = ge - gs;
+  auto ld = [&](int64_t off) -> double {
+    if constexpr (IN_F32) return (double)((const float*)f.in)[off];
+    else return ((const double*)f.in)[off];
+  };
+  // ---- global -> LDS: 16 loads in flight per wave
+  constexpr int NL = kTfSamples / kTfWaves;                   // 16
+  if constexpr (AXIS == 0) {
+    const int line = min(l0 + lane, f.nlines - 1);            // lanes past the last line repeat it (never stored)
+    const int64_t base = (int64_t)line * f.in_ls + (int64_t)gs * f.in_ss;
+    double v[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int r = wave + kTfWaves * j;
+      v[j] = r < R ? ld(base + (int64_t)r * f.in_ss) : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int r = wave + kTfWaves * j;
+      if (r < R) s_t[r * kTfLines + lane] = v[j];
+    }
+  } else {
+    constexpr int LW = kTfLines / kTfWaves;                   // 4 lines per wave, 4 segments of 64 samples each
+    double v[LW * 4];
+#pragma unroll
+    for (int q = 0; q < LW; ++q) {
+      const int line = min(l0 + wave * LW + q, f.nlines - 1);
+      const int64_t base = (int64_t)line * f.in_ls + (int64_t)gs * f.in_ss;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[q * 4 + j] = lane + 64 * j < R ? ld(base + (int64_t)(lane + 64 * j) * f.in_ss) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < LW; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (lane + 64 * j < R) s_t[(wave * LW + q) * kTfPitch1 + lane + 64 * j] = v[q * 4 + j];
+  }
+  __syncthreads();
+  // ---- the recursions, lane = line.  The LDS reads of the next eight samples are issued before the dependent chain
+  // of the current eight (different addresses; said explicitly because the compiler cannot know it).
+  if (wave == 0) {
+    double* a = AXIS == 0 ? s_t + lane : s_t + lane * kTfPitch1;
+    constexpr int S = AXIS == 0 ? kTfLines : 1;               // LDS distance between consecutive samples of a line
+    for (int p = 0; p < f.npoles; ++p) {
+      const double z = f.z[p], lam = p == 0 ? f.lam : 1.0;
+      double t;
+      int i;
+      if (gs == 0) {
+        // exact start of the line, z^n == 0 (the expressions of spline_filter_line() in the oracle with that factor dropped)
+        const double x0 = a[0] * lam;
+        double z_i = z, acc = x0;
+        if (f.kind == kSplReflect) {
+          const int m = min(f.n - 1, kHorizon);
+          for (int k = 1; k <= m; ++k) {
+            acc += z_i * (a[k * S] * lam);
+            z_i *= z;
+          }
+          t = acc * z / (1.0 - z_i * z_i) + x0;
+        } else {
+          const int m = min(f.n - 2, kHorizon);
+          for (int k = 1; k <= m; ++k) {
+            acc += z_i * (a[k * S] * lam);
+            z_i *= z;
+          }
+          t = acc;
+        }
+        a[0] = t;
+        i = 1;
+      } else {
+        t = 0.0;
+        i = 0;
+      }
+      {
+        double v[8], w[8];
+        if (i + 8 <= R) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = a[(i + j) * S];
+        }
+        for (; i + 8 <= R; i += 8) {
+          const bool more = i + 16 <= R;
+          if (more) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = a[(i + 8 + j) * S];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            t = v[j] * lam + z * t;
+            a[(i + j) * S] = t;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = w[j];
+        }
+      }
+      for (; i < R; ++i) {
+        t = a[i * S] * lam + z * t;
+        a[i * S] = t;
+      }
+      // anti-causal
+      if (ge == f.n) {
+        if (f.kind == kSplReflect) t = a[(R - 1) * S] * (z / (z - 1.0));
+        else t = (z / (z * z - 1.0)) * (a[(R - 1) * S] + z * a[(R - 2) * S]);
+        a[(R - 1) * S] = t;
+        i = R - 2;
+      } else {
+        t = 0.0;
+        i = R - 1;
+      }
+      {
+        double v[8], w[8];
+        if (i - 7 >= 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = a[(i - j) * S];
+        }
+        for (; i - 7 >= 0; i -= 8) {
+          const bool more = i - 15 >= 0;
+          if (more) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = a[(i - 8 - j) * S];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            t = z * (t - v[j]);
+            a[(i - j) * S] = t;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = w[j];
+        }
+      }
+      for (; i >= 0; --i) {
+        t = z * (t - a[i * S]);
+        a[i * S] = t;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- LDS -> global: the core
+  const int c_lo = g0 - gs, c_n = min(f.core, f.n - g0);
+  if constexpr (AXIS == 0) {
+    if (l0 + lane < f.nlines) {
+      double* o = f.out + (int64_t)(l0 + lane) * f.out_ls + (int64_t)g0 * f.out_ss;
+      for (int r = wave; r < c_n; r += kTfWaves) o[(int64_t)r * f.out_ss] = s_t[(c_lo + r) * kTfLines + lane];
+    }
+  } else {
+    for (int li = wave; li < kTfLines; li += kTfWaves) {
+      if (l0 + li >= f.nlines) break;
+      double* o = f.out + (int64_t)(l0 + li) * f.out_ls + (int64_t)g0 * f.out_ss;
+      for (int sI = lane; sI < c_n; sI += 64) o[(int64_t)sI * f.out_ss] = s_t[li * kTfPitch1 + c_lo + sI];
+    }
+  }
+}
+
 // (rows x cols) -> (cols x rows), 32 x 32 tiles through LDS
 __global__ void __launch_bounds__(kSplBlock) spline_transpose_kernel(const double* in, double* out, int rows, int cols) {
   __shared__ double tile[32][33];
@@ -356,6 +544,62 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     hipLaunchKernelGGL(spline_expand_kernel, dim3((unsigned)((plane + kSplBlock - 1) / kSplBlock)), dim3(kSplBlock), 0,
                        stream, a);
   }
+  // the one-pass tiles when both axes qualify (reflect / mirror kind, z^n underflowed to zero for every pole)
+  bool tiled = (a.filter_kind == kSplReflect || a.filter_kind == kSplMirror) && a.Hp >= kTfSamples && a.Wp >= kTfSamples && g_spline_tiled;
+  int halo = 0;
+  for (int p = 0; p < a.npoles; ++p) {
+    tiled = tiled && a.zpow[0][p] == 0.0 && a.zpow[1][p] == 0.0;
+    halo += (int)ceil(-70.0 * 0.6931471805599453 / log(fabs(a.poles[p])));      // |z|^h <= 2^-70
+  }
+  if (tiled && kTfSamples - 2 * halo >= 64) {
+    static bool attr_set = false;
+    const size_t lds0 = (size_t)kTfSamples * kTfLines * sizeof(double), lds1 = (size_t)kTfLines * kTfPitch1 * sizeof(double);
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+      (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+      (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+      attr_set = true;
+    }
+    TileFilter f;
+    f.kind = a.filter_kind;
+    f.npoles = a.npoles;
+    f.z[0] = a.poles[0];
+    f.z[1] = a.npoles > 1 ? a.poles[1] : 0.0;
+    f.lam = lam;
+    f.halo = halo;
+    f.core = kTfSamples - 2 * halo;
+    // axis 0: lines are the columns of the (Hp x Wp) plane; source image (or its expanded copy A) -> B
+    f.n = a.Hp;
+    f.nlines = a.Wp;
+    f.out = a.scratch;
+    f.out_ls = 1;
+    f.out_ss = a.Wp;
+    dim3 grid((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
+    if (direct) {
+      f.in = a.src;
+      f.in_ls = a.src_cstride;
+      f.in_ss = a.src_stride;
+      hipLaunchKernelGGL((spline_tile_filter_kernel<0, true>), grid, dim3(kTfBlock), lds0, stream, f);
+    } else {
+      f.in = a.coef;
+      f.in_ls = 1;
+      f.in_ss = a.Wp;
+      hipLaunchKernelGGL((spline_tile_filter_kernel<0, false>), grid, dim3(kTfBlock), lds0, stream, f);
+    }
+    // axis 1: lines are the rows; B -> A
+    f.n = a.Wp;
+    f.nlines = a.Hp;
+    f.in = a.scratch;
+    f.in_ls = a.Wp;
+    f.in_ss = 1;
+    f.out = a.coef;
+    f.out_ls = a.Wp;
+    f.out_ss = 1;
+    grid = dim3((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
+    hipLaunchKernelGGL((spline_tile_filter_kernel<1, false>), grid, dim3(kTfBlock), lds1, stream, f);
+  } else {
+    tiled = false;
+  }
   auto filter_axis = [&](double* A, double* B, int n, int nlines, int axis, bool from_src) {
     const dim3 grid((unsigned)((nlines + kSplBlock - 1) / kSplBlock), (unsigned)((n + kChunk - 1) / kChunk));
     for (int p = 0; p < a.npoles; ++p) {
@@ -376,12 +620,14 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       hipLaunchKernelGGL(spline_anticausal_kernel, grid, dim3(kSplBlock), 0, stream, f);
     }
   };
-  filter_axis(a.coef, a.scratch, a.Hp, a.Wp, 0, direct);   // float32: the first pass reads the image itself
-  hipLaunchKernelGGL(spline_transpose_kernel, dim3((unsigned)((a.Wp + 31) / 32), (unsigned)((a.Hp + 31) / 32)),
-                     dim3(kSplBlock), 0, stream, (const double*)a.coef, a.scratch, a.Hp, a.Wp);
-  filter_axis(a.scratch, a.coef, a.Wp, a.Hp, 1, false);
-  hipLaunchKernelGGL(spline_transpose_kernel, dim3((unsigned)((a.Hp + 31) / 32), (unsigned)((a.Wp + 31) / 32)),
-                     dim3(kSplBlock), 0, stream, (const double*)a.scratch, a.coef, a.Wp, a.Hp);
+  if (!tiled) {
+    filter_axis(a.coef, a.scratch, a.Hp, a.Wp, 0, direct);   // float32: the first pass reads the image itself
+    hipLaunchKernelGGL(spline_transpose_kernel, dim3((unsigned)((a.Wp + 31) / 32), (unsigned)((a.Hp + 31) / 32)),
+                       dim3(kSplBlock), 0, stream, (const double*)a.coef, a.scratch, a.Hp, a.Wp);
+    filter_axis(a.scratch, a.coef, a.Wp, a.Hp, 1, false);
+    hipLaunchKernelGGL(spline_transpose_kernel, dim3((unsigned)((a.Hp + 31) / 32), (unsigned)((a.Wp + 31) / 32)),
+                       dim3(kSplBlock), 0, stream, (const double*)a.scratch, a.coef, a.Wp, a.Hp);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int64_t total = map_kind == 2 ? ca.npts : (int64_t)a.H * a.W;
