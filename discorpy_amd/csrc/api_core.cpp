@@ -397,6 +397,8 @@ int dcp_set_option(const char* key, int value) {
     g_wg_per_cu = value;
   } else if (!strcmp(key, "wg_box")) {
     g_wg_box = value ? 1 : 0;         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
+  } else if (!strcmp(key, "spline_wg")) {
+    dcp::set_spline_wg(value ? 1 : 0);
   } else if (!strcmp(key, "spline_tiled")) {
     dcp::set_spline_tiled(value ? 1 : 0);
   } else if (!strcmp(key, "tile_cert")) {
@@ -426,6 +428,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "wg_box")) *value = g_wg_box;
   else if (!strcmp(key, "wg_per_cu")) *value = g_wg_per_cu;
   else if (!strcmp(key, "spline_tiled")) *value = dcp::get_spline_tiled();
+  else if (!strcmp(key, "spline_wg")) *value = dcp::get_spline_wg();
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;

@@ -89,10 +89,15 @@ int release_spline_workspace() {
 }
 
 int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs,
-               const dcp::MapArgs& map, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
+               const dcp::MapArgs& map_in, const void* ycoord, const void* xcoord, int coord_dtype, int64_t npts, int order,
                int mode, int mem_kind, int device, void* stream) {
   int rc;
   if ((rc = check_image_typed(src, dst, dtype, H, W, rs, cs)) != DCP_OK) return rc;
+  dcp::MapArgs map = map_in;
+  // the host's tile-deviation certificate lets the gather stage its taps in LDS (spline_wg_kernel)
+  map.tile_dev_ok = (map_kind == 0 || map_kind == 1) && g_tile_cert.load() && H > 0 && W > 0
+                        ? tile_deviation_certified(map_kind == 0 ? dcp::kRadial : dcp::kPersp, map, H, W)
+                        : 0;
   if (order < 2 || order > 5) return fail(DCP_ERR_INVALID_ARG, "spline order %d outside [2, 5]", order);
   if (mode < 0 || mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
   if (map_kind == 2) {

@@ -143,6 +143,8 @@ hipError_t read_lds_stats(unsigned long long* out, bool reset);
 void set_last_kernel_name(const char* name);   // for the launchers of the other translation units
 const char* last_kernel_name();   // unwarp_kernels.hip: the kernel the calling thread launched last (float32 image / stack launchers)
 // spline_kernels.hip: map_kind 0 radial, 1 perspective, 2 explicit coordinates
+void set_spline_wg(int v);      // 0: spline taps always from global memory (option "spline_wg")
+int get_spline_wg();
 void set_spline_tiled(int v);   // 0: chunked prefilter passes + transposes even where the one-pass tiles qualify (option "spline_tiled")
 int get_spline_tiled();
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,

@@ -17,10 +17,14 @@
 // straight from global memory.
 #include "dcp_internal.h"
 #include "dcp_device.h"
+#include <type_traits>
 
 namespace dcp {
 
 constexpr int kSplBlock = 256;
+int g_spline_wg = 1;             // 0: the (order + 1)^2 taps always gathered from global memory (option spline_wg)
+void set_spline_wg(int v) { g_spline_wg = v; }
+int get_spline_wg() { return g_spline_wg; }
 int g_spline_tiled = 1;          // 0: always the chunked passes + transposes (option spline_tiled; A/B runs and tests)
 void set_spline_tiled(int v) { g_spline_tiled = v; }
 int get_spline_tiled() { return g_spline_tiled; }
@@ -402,6 +406,17 @@ __global__ void __launch_bounds__(kSplBlock) spline_transpose_kernel(const doubl
     if (bx + j < cols && by + tx < rows) out[(size_t)(bx + j) * rows + (by + tx)] = tile[tx][j];
 }
 
+// x / D, correctly rounded, for the constants of the weight polynomials: q = x * RN(1/D), one exact residual, one
+// correction (Markstein) -- three instructions where the compiler's IEEE division takes about twenty, and the weights
+// need up to eight divisions per pixel.  |x| is O(1) here: nothing leaves the normal range.
+template <int D>
+__device__ __forceinline__ double div_c(double x) {
+  constexpr double r = 1.0 / (double)D;
+  const double q = x * r;
+  const double e = __builtin_fma(-(double)D, q, x);
+  return __builtin_fma(e, r, q);
+}
+
 // centred B-spline weights (the expressions of spline_weights() in the oracle); returns the first tap
 template <int ORDER>
 __device__ __forceinline__ int spline_weights(double x, double* w) {
@@ -417,32 +432,32 @@ __device__ __forceinline__ int spline_weights(double x, double* w) {
     w[2] = 0.5 * y * y;
     w[0] = 1.0 - w[1] - w[2];
   } else if constexpr (ORDER == 3) {
-    w[1] = (y * y * (y - 2.0) * 3.0 + 4.0) / 6.0;
-    w[2] = (z * z * (z - 2.0) * 3.0 + 4.0) / 6.0;
-    w[0] = z * z * z / 6.0;
+    w[1] = div_c<6>(y * y * (y - 2.0) * 3.0 + 4.0);
+    w[2] = div_c<6>(z * z * (z - 2.0) * 3.0 + 4.0);
+    w[0] = div_c<6>(z * z * z);
     w[3] = 1.0 - w[0] - w[1] - w[2];
   } else if constexpr (ORDER == 4) {
     t2 = t * t;
     w[2] = t2 * (t2 * 0.25 - 0.625) + 115.0 / 192.0;
     y = 1.0 + t;
     z = 1.0 - t;
-    w[1] = y * (y * (y * (5.0 - y) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
-    w[3] = z * (z * (z * (5.0 - z) / 6.0 - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+    w[1] = y * (y * (div_c<6>(y * (5.0 - y)) - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
+    w[3] = z * (z * (div_c<6>(z * (5.0 - z)) - 1.25) + 5.0 / 24.0) + 55.0 / 96.0;
     y = 0.5 - t;
     y *= y;
-    w[0] = y * y / 24.0;
+    w[0] = div_c<24>(y * y);
     w[4] = 1.0 - w[0] - w[1] - w[2] - w[3];
   } else {
     t2 = y * y;
-    w[2] = t2 * (t2 * (0.25 - y / 12.0) - 0.5) + 0.55;
+    w[2] = t2 * (t2 * (0.25 - div_c<12>(y)) - 0.5) + 0.55;
     t2 = z * z;
-    w[3] = t2 * (t2 * (0.25 - z / 12.0) - 0.5) + 0.55;
+    w[3] = t2 * (t2 * (0.25 - div_c<12>(z)) - 0.5) + 0.55;
     y += 1.0;
-    w[1] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+    w[1] = y * (y * (y * (y * (div_c<24>(y) - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
     y = z + 1.0;
-    w[4] = y * (y * (y * (y * (y / 24.0 - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
+    w[4] = y * (y * (y * (y * (div_c<24>(y) - 0.375) + 1.25) - 1.75) + 0.625) + 0.425;
     t2 = z * z;
-    w[0] = t2 * t2 * z / 120.0;
+    w[0] = div_c<120>(t2 * t2 * z);
     w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
   }
   return start;
@@ -515,6 +530,159 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
     for (int k = 0; k <= ORDER; ++k) t += (row[ix[k]] * wy[j]) * wx[k];
   }
   store_any(dst, a.dst_dtype, (size_t)i, t);
+}
+
+// ---- the gather out of LDS ---------------------------------------------------------------------
+// spline_remap_kernel's arithmetic with remap_wg_kernel's data path (unwarp_kernels.hip): a workgroup owns a 128 x 32
+// tile of output pixels (four waves, 2 x 2 sub-tiles of 64 x 16), evaluates the map at the tile's four corner pixels,
+// and -- under the host's tile-deviation certificate (MapArgs::tile_dev_ok >= 2: every coordinate of the tile within
+// 0.90 px of the bilinear interpolant of the corners) -- copies the box of float64 coefficients that holds every tap of
+// every pixel into LDS by LDS-DMA, the loads going out between the coordinate rows of phase 1.  The (order + 1)^2
+// taps of a pixel are then LDS reads instead of global gathers.  A tile whose box does not fit the slab or reaches
+// over the edge of the coefficient plane (there the taps fold according to the boundary mode) takes the global
+// gather of spline_remap_kernel for all its pixels.  Radial and perspective maps.
+constexpr int kSwTW = 128, kSwTH = 32;             // workgroup tile
+constexpr int kSwBoxW = 144, kSwBoxH = 46;         // slab: 144 x 46 float64 = 52 992 B, three workgroups per CU
+constexpr int kSwCH = kSwBoxW * 8 / 16;            // 16-byte chunks per slab row
+constexpr int kSwNJ = (kSwBoxH * kSwCH + 255) / 256;   // loads per wave that cover the slab: 13
+
+template <int KIND, int ORDER>
+__global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, const MapArgs map, void* dst) {
+  __shared__ __attribute__((aligned(16))) unsigned char s_box[kSwBoxH * kSwBoxW * 8];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  constexpr int PB = kSwBoxW * 8;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = (int)threadIdx.x & 63;
+  const int wx = wave & 1, wy = wave >> 1;
+  const int tx = blockIdx.x, ty = blockIdx.y;
+  const int y0 = __builtin_amdgcn_readfirstlane(ty * kSwTH + wy * 16);
+  const int x = tx * kSwTW + wx * 64 + lane;
+  const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
+  // ---- corner pixels (lanes 0..3) -> hull of their taps' base positions in the padded plane
+  int cx0, cx1, cy0, cy1;
+  {
+    const double X = (double)min(tx * kSwTW + (lane & 1) * (kSwTW - 1), a.W - 1);
+    const double Y = (double)min(ty * kSwTH + ((lane >> 1) & 1) * (kSwTH - 1), a.H - 1);
+    double xd, yd;
+    pixel_coord<KIND>(map, X, Y, wmaxf, hmaxf, &xd, &yd);
+    const int cxi = (int)round_clip_f32(xd, wmaxf) + a.pad, cyi = (int)round_clip_f32(yd, hmaxf) + a.pad;
+    const int xa = __builtin_amdgcn_readlane(cxi, 0), xb = __builtin_amdgcn_readlane(cxi, 1);
+    const int xc_ = __builtin_amdgcn_readlane(cxi, 2), xd_ = __builtin_amdgcn_readlane(cxi, 3);
+    const int ya = __builtin_amdgcn_readlane(cyi, 0), yb = __builtin_amdgcn_readlane(cyi, 1);
+    const int yc_ = __builtin_amdgcn_readlane(cyi, 2), yd_ = __builtin_amdgcn_readlane(cyi, 3);
+    cx0 = min(min(xa, xb), min(xc_, xd_));
+    cx1 = max(max(xa, xb), max(xc_, xd_));
+    cy0 = min(min(ya, yb), min(yc_, yd_));
+    cy1 = max(max(ya, yb), max(yc_, yd_));
+  }
+  // floor(coordinate) lies in [c0 - 1, c1 + 1]; odd orders tap floor - ORDER/2 .. + ORDER, even orders
+  // floor(coordinate + 0.5) - ORDER/2 .. + ORDER: all inside [c0 - 1 - ORDER/2, c1 + 2 + (ORDER + 1)/2]
+  const int bx0 = cx0 - 1 - ORDER / 2, bx1 = cx1 + 2 + (ORDER + 1) / 2;
+  const int by0 = cy0 - 1 - ORDER / 2, by1 = cy1 + 2 + (ORDER + 1) / 2;
+  const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+  // staged: the box fits the slab and lies inside the plane (no tap folds); workgroup-uniform
+  const bool staged = bw <= kSwBoxW && bh <= kSwBoxH && bx0 >= 0 && by0 >= 0 && bx1 <= a.Wp - 1 && by1 <= a.Hp - 1;
+  const __amdgpu_buffer_rsrc_t src_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (int)((uint32_t)a.Hp * (uint32_t)a.Wp * 8u), 0x00020000);
+  const uint32_t rstep = (uint32_t)a.Wp * 8u;
+  const int fc = wave * 64 + lane;
+  const int crow0 = fc / kSwCH;
+  const int c160 = fc - crow0 * kSwCH;
+  const uint32_t off0 = ((uint32_t)by0 * (uint32_t)a.Wp + (uint32_t)bx0) * 8u + (uint32_t)crow0 * rstep + (uint32_t)c160 * 16u;
+  const int nchunk = bh * kSwCH;
+  auto issue_fill = [&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    if constexpr (j < kSwNJ) {
+      if (staged && (j * 4 + wave) * 64 < nchunk) {
+        constexpr int qrow = (256 * j) / kSwCH, rem = (256 * j) % kSwCH;
+        const bool wrap = c160 >= kSwCH - rem;
+        const int crow = crow0 + qrow + (wrap ? 1 : 0);
+        if (crow < bh)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16,
+                                                   off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u, 0, 0, 0);
+      }
+    }
+  };
+  // ---- phase 1: the float32 coordinates of this wave's 16 rows, a load going out in front of each of the first 13
+  const int rows = __builtin_amdgcn_readfirstlane(max(0, min(16, a.H - y0)));
+  const double X = (double)min(x, a.W - 1);
+  float xf[16], yf[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k == 0) issue_fill(std::integral_constant<int, 0>{});
+    if (k == 1) issue_fill(std::integral_constant<int, 1>{});
+    if (k == 2) issue_fill(std::integral_constant<int, 2>{});
+    if (k == 3) issue_fill(std::integral_constant<int, 3>{});
+    if (k == 4) issue_fill(std::integral_constant<int, 4>{});
+    if (k == 5) issue_fill(std::integral_constant<int, 5>{});
+    if (k == 6) issue_fill(std::integral_constant<int, 6>{});
+    if (k == 7) issue_fill(std::integral_constant<int, 7>{});
+    if (k == 8) issue_fill(std::integral_constant<int, 8>{});
+    if (k == 9) issue_fill(std::integral_constant<int, 9>{});
+    if (k == 10) issue_fill(std::integral_constant<int, 10>{});
+    if (k == 11) issue_fill(std::integral_constant<int, 11>{});
+    if (k == 12) issue_fill(std::integral_constant<int, 12>{});
+    static_assert(kSwNJ <= 13, "one load per coordinate row");
+    double xd, yd;
+    pixel_coord<KIND>(map, X, (double)min(y0 + k, a.H - 1), wmaxf, hmaxf, &xd, &yd);
+    xf[k] = round_clip_f32(xd, wmaxf);
+    yf[k] = round_clip_f32(yd, hmaxf);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (rows == 0 || x >= a.W) return;
+  // ---- phase 2
+  const double padd = (double)a.pad;
+  if (staged) {
+    const int org = by0 * PB + bx0 * 8;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k >= rows) continue;
+      double wyv[6], wxv[6];
+      const int sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
+      const int sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+      const unsigned char* base = s_box + (sy * PB + sx * 8 - org);
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j <= ORDER; ++j) {
+        const double* row = (const double*)(base + j * PB);
+#pragma unroll
+        for (int q = 0; q <= ORDER; ++q) t += (row[q] * wyv[j]) * wxv[q];
+      }
+      store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, t);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k >= rows) continue;
+      double wyv[6], wxv[6];
+      const int sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
+      const int sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+      int ix[ORDER + 1];
+#pragma unroll
+      for (int q = 0; q <= ORDER; ++q) ix[q] = spline_fold(sx + q, a.Wp, a.mode);
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j <= ORDER; ++j) {
+        const double* row = a.coef + (size_t)spline_fold(sy + j, a.Hp, a.mode) * (size_t)a.Wp;
+#pragma unroll
+        for (int q = 0; q <= ORDER; ++q) t += (row[ix[q]] * wyv[j]) * wxv[q];
+      }
+      store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, t);
+    }
+  }
+}
+
+template <int KIND>
+static hipError_t launch_spline_wg(const SplineArgs& a, const MapArgs& map, void* dst, hipStream_t stream) {
+  const dim3 grid((unsigned)((a.W + kSwTW - 1) / kSwTW), (unsigned)((a.H + kSwTH - 1) / kSwTH));
+  switch (a.order) {
+    case 2: hipLaunchKernelGGL((spline_wg_kernel<KIND, 2>), grid, dim3(256), 0, stream, a, map, dst); break;
+    case 3: hipLaunchKernelGGL((spline_wg_kernel<KIND, 3>), grid, dim3(256), 0, stream, a, map, dst); break;
+    case 4: hipLaunchKernelGGL((spline_wg_kernel<KIND, 4>), grid, dim3(256), 0, stream, a, map, dst); break;
+    default: hipLaunchKernelGGL((spline_wg_kernel<KIND, 5>), grid, dim3(256), 0, stream, a, map, dst); break;
+  }
+  return hipGetLastError();
 }
 
 template <int MAPKIND>
@@ -632,6 +800,12 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
   if (e != hipSuccess) return e;
   const int64_t total = map_kind == 2 ? ca.npts : (int64_t)a.H * a.W;
   if (total == 0) return hipSuccess;
+  // certified radial / perspective maps on frames of at least one workgroup tile: the taps out of LDS
+  if ((map_kind == 0 || map_kind == 1) && map.tile_dev_ok >= 2 && g_spline_wg && a.H >= kSwTH && a.W >= kSwTW &&
+      (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH) {
+    if (map_kind == 0) return launch_spline_wg<kRadial>(a, map, dst, stream);
+    return launch_spline_wg<kPersp>(a, map, dst, stream);
+  }
   if (map_kind == 0) return launch_remap_order<0>(a, map, ca, dst, total, stream);
   if (map_kind == 1) return launch_remap_order<1>(a, map, ca, dst, total, stream);
   if (map_kind == 3) return launch_remap_order<3>(a, map, ca, dst, total, stream);
