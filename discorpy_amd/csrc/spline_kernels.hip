@@ -214,14 +214,15 @@ __global__ void __launch_bounds__(kSplBlock) spline_anticausal_kernel(const Filt
 // sides) in LDS as float64, runs every pole's causal and anti-causal recursion there (lane = line, wave 0), and writes
 // the core back: the plane is read once and written once per axis instead of four times plus two transposes.  The halo
 // plays kWarm's part -- a recursion restarted from a zero state forgets like |z|^k; the host sizes it so that every pole
-// has decayed below 2^-70 of the signal before the core -- and a tile that reaches the start (end) of the line uses the
+// has decayed below 2^-64 of the signal before the core -- and a tile that reaches the start (end) of the line uses the
 // exact initial sums of the oracle.  AXIS 0: lines are columns (lane = column: every global and LDS access is
 // contiguous across the wave); AXIS 1: lines are rows (loads and stores run along the row, the recursion walks LDS rows
 // of pitch kTfSamples + 1).  Used for the reflect / mirror boundary kinds on lines long enough that z^n underflows to zero
 // (the far end of the line then does not enter the initial sums); everything else takes the chunked passes above.
 constexpr int kTfLines = 64;
-constexpr int kTfSamples = 256;
-constexpr int kTfPitch1 = kTfSamples + 1;
+constexpr int kTfSamples = 256;        // samples per tile incl. halos: 128 KB of LDS, one workgroup per CU (two-pole orders 4 and 5)
+// (152-sample tiles -- 76 KB, two workgroups per CU, one moving data while the other's wave 0 recurses -- were slower:
+// cubic 4096^2 0.396 ms against 0.351, the shorter core pays the halo more often than the overlap returns)
 
 struct TileFilter {
   const void* in;
@@ -236,9 +237,10 @@ struct TileFilter {
 constexpr int kTfBlock = 1024;       // 16 waves move the tile (16 rows of loads in flight each); wave 0 runs the recursions
 constexpr int kTfWaves = kTfBlock / 64;
 
-template <int AXIS, bool IN_F32>
+template <int AXIS, bool IN_F32, int SAMPLES>
 __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const TileFilter f) {
   extern __shared__ double s_t[];
+  constexpr int kTfPitch1 = SAMPLES + 1;
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
   const int l0 = blockIdx.x * kTfLines;
   const int g0 = blockIdx.y * f.core;                         // first sample this tile writes
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
     else return ((const double*)f.in)[off];
   };
   // ---- global -> LDS: 16 loads in flight per wave
-  constexpr int NL = kTfSamples / kTfWaves;                   // 16
+  constexpr int NL = (SAMPLES + kTfWaves - 1) / kTfWaves;     // 16 (10)
   if constexpr (AXIS == 0) {
     const int line = min(l0 + lane, f.nlines - 1);            // lanes past the last line repeat it (never stored)
     const int64_t base = (int64_t)line * f.in_ls + (int64_t)gs * f.in_ss;
@@ -717,17 +719,10 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
   int halo = 0;
   for (int p = 0; p < a.npoles; ++p) {
     tiled = tiled && a.zpow[0][p] == 0.0 && a.zpow[1][p] == 0.0;
-    halo += (int)ceil(-70.0 * 0.6931471805599453 / log(fabs(a.poles[p])));      // |z|^h <= 2^-70
+    halo += (int)ceil(-64.0 * 0.6931471805599453 / log(fabs(a.poles[p])));      // |z|^h <= 2^-64
   }
-  if (tiled && kTfSamples - 2 * halo >= 64) {
-    static bool attr_set = false;
-    const size_t lds0 = (size_t)kTfSamples * kTfLines * sizeof(double), lds1 = (size_t)kTfLines * kTfPitch1 * sizeof(double);
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
-      (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
-      (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-      attr_set = true;
-    }
+  const int samples = kTfSamples;
+  if (tiled && samples - 2 * halo >= 32) {
     TileFilter f;
     f.kind = a.filter_kind;
     f.npoles = a.npoles;
@@ -735,7 +730,21 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.z[1] = a.npoles > 1 ? a.poles[1] : 0.0;
     f.lam = lam;
     f.halo = halo;
-    f.core = kTfSamples - 2 * halo;
+    f.core = samples - 2 * halo;
+    auto launch = [&](auto axis, auto in_f32, auto smp, const dim3& grid) {
+      constexpr int AX = decltype(axis)::value, SM = decltype(smp)::value;
+      constexpr bool F32 = decltype(in_f32)::value;
+      const size_t lds = AX == 0 ? (size_t)SM * kTfLines * sizeof(double) : (size_t)kTfLines * (SM + 1) * sizeof(double);
+      static bool attr_set = false;               // (one flag per instantiation of the lambda)
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<AX, F32, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((spline_tile_filter_kernel<AX, F32, SM>), grid, dim3(kTfBlock), lds, stream, f);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using SL = std::integral_constant<int, kTfSamples>;
     // axis 0: lines are the columns of the (Hp x Wp) plane; source image (or its expanded copy A) -> B
     f.n = a.Hp;
     f.nlines = a.Wp;
@@ -747,12 +756,12 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       f.in = a.src;
       f.in_ls = a.src_cstride;
       f.in_ss = a.src_stride;
-      hipLaunchKernelGGL((spline_tile_filter_kernel<0, true>), grid, dim3(kTfBlock), lds0, stream, f);
+      launch(I0{}, std::true_type{}, SL{}, grid);
     } else {
       f.in = a.coef;
       f.in_ls = 1;
       f.in_ss = a.Wp;
-      hipLaunchKernelGGL((spline_tile_filter_kernel<0, false>), grid, dim3(kTfBlock), lds0, stream, f);
+      launch(I0{}, std::false_type{}, SL{}, grid);
     }
     // axis 1: lines are the rows; B -> A
     f.n = a.Wp;
@@ -764,7 +773,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ls = a.Wp;
     f.out_ss = 1;
     grid = dim3((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
-    hipLaunchKernelGGL((spline_tile_filter_kernel<1, false>), grid, dim3(kTfBlock), lds1, stream, f);
+    launch(I1{}, std::false_type{}, SL{}, grid);
   } else {
     tiled = false;
   }

@@ -267,6 +267,34 @@ def test_spline_orders_on_ragged_and_large_inputs(hip, orc):
         assert np.count_nonzero(got != want) <= 8, (order, mode)
 
 
+def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip, orc):
+    """Frames large enough for the one-pass tile prefilter (spline_tile_filter_kernel: reflect / mirror kinds, z^n == 0)
+    and the LDS-staged gather (spline_wg_kernel: certified radial / perspective maps): equal to the chunked passes +
+    global gather (options spline_tiled = spline_wg = 0) and to the oracle up to the restart error of long lines."""
+    F = hip
+    c = configs.cfg2()
+    shape = (1100, 1347)          # partial tiles on both axes
+    img = noise(31, shape)
+    coef = [1.02, 0.015, -9.0, -0.012, 0.99, 6.0, 2.0e-6, -1.5e-6]
+    try:
+        for order, mode in [(2, "mirror"), (3, "reflect"), (3, "nearest"), (4, "reflect"), (5, "grid-constant"), (5, "reflect")]:
+            a = (img, c["xcenter"] * shape[1] / 4096.0, 500.0, c["list_fact"])
+            res = {}
+            for fast in (1, 0):
+                F.set_option("spline_tiled", fast)
+                F.set_option("spline_wg", fast)
+                res[fast] = (pp.unwarp_image_backward(*a, order=order, mode=mode),
+                             pp.correct_perspective_image(img, coef, order=order, mode=mode))
+            want = (orc.unwarp_image_backward(*a, order=order, mode=mode, poly=orc.POLY_KERNEL),
+                    orc.correct_perspective_image(img, coef, order=order, mode=mode))
+            for k in (0, 1):
+                assert np.count_nonzero(res[1][k] != res[0][k]) <= 4, (order, mode, k)
+                assert spline_close(res[1][k], want[k]) and np.count_nonzero(res[1][k] != want[k]) <= 8, (order, mode, k)
+    finally:
+        F.set_option("spline_tiled", 1)
+        F.set_option("spline_wg", 1)
+
+
 # --------------------------------------------------------------------------- (b) oracle, seeded inputs
 
 SHAPES = [(1, 1), (1, 7), (9, 1), (2, 2), (3, 5), (16, 64), (17, 65), (63, 257), (300, 517), (129, 1031)]
