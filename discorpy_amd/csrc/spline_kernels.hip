@@ -242,47 +242,80 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
   extern __shared__ double s_t[];
   constexpr int kTfPitch1 = SAMPLES + 1;
   const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-  const int l0 = blockIdx.x * kTfLines;
-  const int g0 = blockIdx.y * f.core;                         // first sample this tile writes
-  const int gs = max(0, g0 - f.halo), ge = min(f.n, g0 + f.core + f.halo);
-  const int R = ge - gs;
-  auto ld = [&](int64_t off) -> double {
-    if constexpr (IN_F32) return (double)((const float*)f.in)[off];
-    else return ((const double*)f.in)[off];
+  // The workgroup is persistent (one per CU: the tile takes most of the LDS) and walks tiles blockIdx.x, + gridDim.x, ...;
+  // the 16 loads per lane of tile i + 1 are issued into registers before wave 0 starts the recursions of tile i and are
+  // written to LDS when tile i has been stored, so the global reads run under the recursions.
+  constexpr int NL = AXIS == 0 ? (SAMPLES + kTfWaves - 1) / kTfWaves : (kTfLines / kTfWaves) * ((SAMPLES + 63) / 64);
+  constexpr int LW = kTfLines / kTfWaves;                     // AXIS 1: 4 lines per wave, segments of 64 samples each
+  constexpr int NS = (SAMPLES + 63) / 64;
+  const int tiles_l = (f.nlines + kTfLines - 1) / kTfLines, tiles_c = (f.n + f.core - 1) / f.core;
+  const int ntiles = tiles_l * tiles_c;
+  struct Geo {
+    int l0, g0, gs, ge, R;
   };
-  // ---- global -> LDS: 16 loads in flight per wave
-  constexpr int NL = (SAMPLES + kTfWaves - 1) / kTfWaves;     // 16 (10)
-  if constexpr (AXIS == 0) {
-    const int line = min(l0 + lane, f.nlines - 1);            // lanes past the last line repeat it (never stored)
-    const int64_t base = (int64_t)line * f.in_ls + (int64_t)gs * f.in_ss;
-    double v[NL];
+  auto geo_of = [&](int t) -> Geo {
+    Geo g;
+    const int bc = t / tiles_l;
+    g.l0 = (t - bc * tiles_l) * kTfLines;
+    g.g0 = bc * f.core;                                       // first sample the tile writes
+    g.gs = max(0, g.g0 - f.halo);
+    g.ge = min(f.n, g.g0 + f.core + f.halo);
+    g.R = g.ge - g.gs;
+    return g;
+  };
+  // (raw loaded values, every address valid: a conversion or a select here would make the compiler wait for the data
+  // where the loads are issued instead of where they are used)
+  using RawT = typename std::conditional<IN_F32, float, double>::type;
+  RawT pre[NL];
+  const RawT* const src_raw = (const RawT*)f.in;
+  auto issue_loads = [&](const Geo& g) {
+    if constexpr (AXIS == 0) {
+      const int line = min(g.l0 + lane, f.nlines - 1);        // lanes past the last line repeat it (never stored)
+      const int64_t base = (int64_t)line * f.in_ls + (int64_t)g.gs * f.in_ss;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int r = wave + kTfWaves * j;
-      v[j] = r < R ? ld(base + (int64_t)r * f.in_ss) : 0.0;
+      for (int j = 0; j < NL; ++j) {
+        const int r = min(wave + kTfWaves * j, g.R - 1);
+        pre[j] = src_raw[base + (int64_t)r * f.in_ss];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < LW; ++q) {
+        const int line = min(g.l0 + wave * LW + q, f.nlines - 1);
+        const int64_t base = (int64_t)line * f.in_ls + (int64_t)g.gs * f.in_ss;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) pre[q * NS + j] = src_raw[base + (int64_t)min(lane + 64 * j, g.R - 1) * f.in_ss];
+      }
     }
+  };
+  auto commit = [&](const Geo& g) {
+    if constexpr (AXIS == 0) {
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int r = wave + kTfWaves * j;
-      if (r < R) s_t[r * kTfLines + lane] = v[j];
+      for (int j = 0; j < NL; ++j) {
+        const int r = wave + kTfWaves * j;
+        if (r < g.R) s_t[r * kTfLines + lane] = (double)pre[j];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < LW; ++q)
+#pragma unroll
+        for (int j = 0; j < NS; ++j)
+          if (lane + 64 * j < g.R) s_t[(wave * LW + q) * kTfPitch1 + lane + 64 * j] = (double)pre[q * NS + j];
     }
-  } else {
-    constexpr int LW = kTfLines / kTfWaves;                   // 4 lines per wave, 4 segments of 64 samples each
-    double v[LW * 4];
-#pragma unroll
-    for (int q = 0; q < LW; ++q) {
-      const int line = min(l0 + wave * LW + q, f.nlines - 1);
-      const int64_t base = (int64_t)line * f.in_ls + (int64_t)gs * f.in_ss;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[q * 4 + j] = lane + 64 * j < R ? ld(base + (int64_t)(lane + 64 * j) * f.in_ss) : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < LW; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (lane + 64 * j < R) s_t[(wave * LW + q) * kTfPitch1 + lane + 64 * j] = v[q * 4 + j];
-  }
+  };
+  int tile = blockIdx.x;
+  if (tile >= ntiles) return;
+  Geo cur = geo_of(tile);
+  issue_loads(cur);
+  for (;;) {
+  commit(cur);
   __syncthreads();
+  const int l0 = cur.l0, g0 = cur.g0, gs = cur.gs, ge = cur.ge, R = cur.R;
+  const int next = tile + (int)gridDim.x;
+  Geo nxt = cur;
+  if (next < ntiles) {
+    nxt = geo_of(next);
+    issue_loads(nxt);
+  }
   // ---- the recursions, lane = line.  The LDS reads of the next eight samples are issued before the dependent chain
   // of the current eight (different addresses; said explicitly because the compiler cannot know it).
   if (wave == 0) {
@@ -325,15 +358,25 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
         }
         for (; i + 8 <= R; i += 8) {
           const bool more = i + 16 <= R;
+          // (the reads go out in the middle of the chain: the compiler waits for ALL LDS traffic at the loop head, so
+          // whatever is issued there is waited for at once; half a batch of arithmetic later it has mostly arrived)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t = v[j] * lam + z * t;
+            a[(i + j) * S] = t;
+          }
+          __builtin_amdgcn_sched_barrier(0);
           if (more) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = a[(i + 8 + j) * S];
           }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 4; j < 8; ++j) {
             t = v[j] * lam + z * t;
             a[(i + j) * S] = t;
           }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = w[j];
         }
@@ -360,15 +403,23 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
         }
         for (; i - 7 >= 0; i -= 8) {
           const bool more = i - 15 >= 0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            t = z * (t - v[j]);
+            a[(i - j) * S] = t;
+          }
+          __builtin_amdgcn_sched_barrier(0);
           if (more) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) w[j] = a[(i - 8 - j) * S];
           }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
+          for (int j = 4; j < 8; ++j) {
             t = z * (t - v[j]);
             a[(i - j) * S] = t;
           }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = w[j];
         }
@@ -393,6 +444,11 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
       double* o = f.out + (int64_t)(l0 + li) * f.out_ls + (int64_t)g0 * f.out_ss;
       for (int sI = lane; sI < c_n; sI += 64) o[(int64_t)sI * f.out_ss] = s_t[li * kTfPitch1 + c_lo + sI];
     }
+  }
+  if (next >= ntiles) break;
+  __syncthreads();                                            // the tile has been read out: LDS is free for the next one
+  tile = next;
+  cur = nxt;
   }
 }
 
@@ -740,7 +796,10 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
         (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<AX, F32, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
       }
-      hipLaunchKernelGGL((spline_tile_filter_kernel<AX, F32, SM>), grid, dim3(kTfBlock), lds, stream, f);
+      int ncu = 0, dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+      const unsigned ntiles = grid.x * grid.y;
+      hipLaunchKernelGGL((spline_tile_filter_kernel<AX, F32, SM>), dim3(ntiles < (unsigned)ncu ? ntiles : (unsigned)ncu), dim3(kTfBlock), lds, stream, f);
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
