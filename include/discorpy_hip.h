@@ -66,8 +66,12 @@ int dcp_release_scratch(void);
  * projection chunk when a host stack is streamed through the GPU), "stack_lds" (LDS-staged stack kernel:
  * 0 never, 1 when the launch has enough wave tiles, 2 always), "host_duplex" (host frames of the radial map
  * go through the GPU in bands of rows, uploads and downloads at the same time: 0 never, 1 when a one-off probe
- * finds that the HIP runtime overlaps the two directions, 2 always), "host_bands" (number of those bands, default 6).  Returns DCP_ERR_INVALID_ARG for an
- * unknown key. */
+ * finds that the HIP runtime overlaps the two directions, 2 always), "host_bands" (number of those bands, default 6),
+ * "tile_cert" (0: never use the host's tile-deviation certificate), "wg_box" (0: one source box per wave tile),
+ * "wg_per_cu", "stack_wg" (0 never / 1 when the launch is large enough / 2 whenever eligible: the workgroup-box stack
+ * kernel), "spline_tiled" (0: chunked spline prefilter passes + transposes instead of the one-pass LDS tiles),
+ * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box).  Returns
+ * DCP_ERR_INVALID_ARG for an unknown key. */
 int dcp_set_option(const char* key, int value);
 int dcp_get_option(const char* key, int* value);
 
