@@ -247,6 +247,23 @@ def other_configs(a, dev, srcs, dsts, img0):
     ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.correct_perspective_image(img0, c3["list_coef"], blend=orc.BLEND_F64LERP))
     out["cfg3_perspective_only"] = entry(us, H * W, 8, k, ok)
 
+    # order 3 (scipy's prefiltered cubic B-spline, the reference's `order` argument; mode "reflect"): two one-pass LDS tile
+    # prefilters + the LDS-staged 16-tap gather.  Algorithmic bytes: 4 read + 4 written per pixel, as for order 1 -- the
+    # float64 coefficient plane in between is the algorithm's own traffic.
+    def cubic(i):
+        F.check(L.dcp_unwarp_image_spline_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c2["xcenter"], c2["ycenter"], fa, nf,
+                                              3, 0, F.MEM_DEVICE, dev, None))
+    us = timed_launches(cubic, max(12, reps // 8), dev)
+    cubic(0)
+    got = download(dsts[0].ptr, (H, W), dev)
+    want = orc.unwarp_image_backward(*a2, order=3, mode="reflect", poly=orc.POLY_KERNEL)
+    # (lines longer than one prefilter tile restart the recursion inside a halo: equal to the serial oracle up to the odd
+    # float32 ulp)
+    ok = np.count_nonzero(got != want) <= 32 and float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-5
+    out["cfg2_order3_cubic_spline"] = entry(us, H * W, 8, "spline_tile_filter_kernel x 2 + spline_wg_kernel", ok,
+                                            note="three launches per frame; pixels differing from the oracle by one float32 ulp: %d"
+                                                 % int(np.count_nonzero(got != want)))
+
     # 16-bit detector frames (the element type tomography cameras deliver): the same kernel on narrower slab rows, scipy's
     # exact blend and integer store; 2 B read + 2 B written per pixel
     u16 = (img0 * 60000.0).astype(np.uint16)
