@@ -16,8 +16,9 @@ namespace {
 // Per-device float64 coefficient workspace (grow-only).  Reused across calls; a call on a stream
 // other than the previous one first waits for the device so that the old user is done.
 struct SplineWorkspace {
-  std::mutex use;          // held by run_spline from get() until its last kernel is enqueued (host callers: until the
-                           // result is back), so two host threads never interleave their passes over the shared planes
+  std::mutex use[64];      // per device: held by run_spline from get() until its last kernel is enqueued (host callers: until
+                           // the result is back), so two host threads never interleave their passes over that device's planes
+                           // -- calls on different GPUs run side by side
   std::mutex mu;
   void* buf[64] = {};
   size_t cap[64] = {};
@@ -72,11 +73,11 @@ int spline_poles(int order, double* z) {
 namespace dcpapi {
 
 int release_spline_workspace() {
-  std::lock_guard<std::mutex> exclusive(g_spline_ws.use);
-  std::lock_guard<std::mutex> lock(g_spline_ws.mu);
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess) return DCP_OK;      // no runtime / no device: nothing was ever allocated
   for (int dev = 0; dev < 64; ++dev) {
+    std::lock_guard<std::mutex> exclusive(g_spline_ws.use[dev]);
+    std::lock_guard<std::mutex> lock(g_spline_ws.mu);
     if (!g_spline_ws.buf[dev]) continue;
     DCP_HIP(hipSetDevice(dev));
     DCP_HIP(hipDeviceSynchronize());
@@ -129,7 +130,10 @@ int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, i
       a.zpow[axis][p] = std::pow(a.poles[p], a.filter_kind == dcp::kSplMirror ? n - 1.0 : n);
   }
   const size_t plane = (size_t)a.Hp * (size_t)a.Wp * sizeof(double);
-  std::lock_guard<std::mutex> exclusive(g_spline_ws.use);
+  int cur_dev = 0;
+  DCP_HIP(hipGetDevice(&cur_dev));                           // (DeviceScope above has selected it)
+  if (cur_dev < 0 || cur_dev >= 64) return fail(DCP_ERR_UNSUPPORTED, "device index %d", cur_dev);
+  std::lock_guard<std::mutex> exclusive(g_spline_ws.use[cur_dev]);
   DCP_HIP(g_spline_ws.get(2 * plane, st, &a.coef));
   a.scratch = a.coef + (size_t)a.Hp * (size_t)a.Wp;
   dcp::CoordArgs ca;

@@ -791,13 +791,15 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       constexpr int AX = decltype(axis)::value, SM = decltype(smp)::value;
       constexpr bool F32 = decltype(in_f32)::value;
       const size_t lds = AX == 0 ? (size_t)SM * kTfLines * sizeof(double) : (size_t)kTfLines * (SM + 1) * sizeof(double);
-      static bool attr_set = false;               // (one flag per instantiation of the lambda)
-      if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<AX, F32, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-      }
       int ncu = 0, dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+      // more than 64 KB of dynamic LDS has to be allowed once per kernel and device (one flag array per instantiation of the
+      // lambda; setting it twice from two threads is harmless)
+      static bool attr_set[64] = {};
+      if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void*)spline_tile_filter_kernel<AX, F32, SM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (dev >= 0 && dev < 64) attr_set[dev] = true;
+      }
       const unsigned ntiles = grid.x * grid.y;
       hipLaunchKernelGGL((spline_tile_filter_kernel<AX, F32, SM>), dim3(ntiles < (unsigned)ncu ? ntiles : (unsigned)ncu), dim3(kTfBlock), lds, stream, f);
     };

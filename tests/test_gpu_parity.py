@@ -711,8 +711,21 @@ def test_explicit_coordinates_match_oracle(hip, orc):
         xs = (rng.random(5000) * 96 - 3).astype(dt)
         for order, blend in [(0, "scipy"), (1, "scipy"), (1, "f64lerp"), (1, "f32")]:
             want = orc.remap_coords(img, ys, xs, order=order, blend=kernel_oracle(orc, blend)["blend"])
-            assert np.array_equal(pp.remap_coordinates(img, ys, xs, order=order, blend=blend), want)
+            assert np.array_equal(pp.remap_coordinates(img, ys, xs, order=order, mode="nearest", blend=blend), want)
     assert pp.remap_coordinates(img, np.zeros((0,), np.float32), np.zeros((0,), np.float32)).shape == (0,)
+    # coordinates outside the image are clamped (scipy's mode='nearest'): said with a warning under any other mode
+    import warnings
+    ys = (rng.random(500) * 75 - 3).astype(np.float32)
+    xs = (rng.random(500) * 96 - 3).astype(np.float32)
+    with pytest.warns(RuntimeWarning, match="clamped"):
+        clamped = pp.remap_coordinates(img, ys, xs, order=1, mode="reflect", blend="scipy")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert np.array_equal(pp.remap_coordinates(img, ys, xs, order=1, mode="nearest", blend="scipy"), clamped)
+        inside = pp.remap_coordinates(img, np.clip(ys, 0, 69), np.clip(xs, 0, 89), order=1, mode="reflect", blend="scipy")
+    assert np.array_equal(inside, clamped)
+    from scipy.ndimage import map_coordinates
+    assert np.array_equal(clamped, map_coordinates(img, (ys, xs), order=1, mode="nearest"))
 
 
 def test_device_resident_tensors_take_the_same_path(hip, orc):
