@@ -1,21 +1,25 @@
 // unwarp_kernels.hip -- hand-written gfx950 (CDNA4 / MI355X) kernels for the backward
 // unwarp path of discorpy (reference: /root/reference/discorpy/post/postprocessing.py).
 //
-//   remap_lds_kernel / remap_tile_kernel <Radial>  K1  unwarp_image_backward      postprocessing.py:137-148
-//   remap_lds_kernel / remap_tile_kernel <Persp>   K2  correct_perspective_image  postprocessing.py:448-459,486-492
+//   remap_wg_kernel / remap_lds_kernel / remap_tile_kernel <Radial>  K1  unwarp_image_backward      postprocessing.py:137-148
+//   remap_wg_kernel / remap_lds_kernel / remap_tile_kernel <Persp>   K2  correct_perspective_image  postprocessing.py:448-459,486-492
 //   remap_lds_kernel / remap_tile_kernel <Fused>   K3  perspective o radial in one pass
-//   stack_rows_kernel           K4  unwarp_slice_backward / unwarp_chunk_slices_backward  :211-229,:281-313
+//   stack_wg_kernel / stack_lds_kernel / stack_rows_kernel   K4  unwarp_slice_backward / unwarp_chunk_slices_backward  :211-229,:281-313
 //   remap_coords_kernel         K5  map_index= / _mapping            postprocessing.py:250-251,489-491
 //   coord_map_kernel            K6  the float32 (yd, xd) planes      postprocessing.py:144-145,444-459
 //
-// Design (see DESIGN.md for the numbers):
+// Design (see DESIGN.md section 4 for the selection table and the numbers):
 //  * one thread per output pixel column, 64-wide wavefronts along x: a wave's store is 256 B
-//    contiguous.  The default order-1 kernel (remap_lds_kernel) gives every wave a 64 x 16 output
-//    tile, predicts the tile's source box from its four corner pixels, copies the box into a
-//    wave-private LDS slab with row-contiguous 16-byte LDS-DMA loads while the remaining
-//    coordinates are computed, and gathers the four taps of every pixel from LDS.  The direct
-//    kernel (remap_tile_kernel) gathers tap pairs from global memory with 8-byte buffer loads;
-//    it serves order 0, float64 coordinates, strided / degenerate sources and the fallback.
+//    contiguous.  The order-1 frame kernels stage the source in LDS: remap_wg_kernel (certified maps --
+//    the host bounds how far a tile's coordinates can stray from the bilinear interpolant of its corner
+//    pixels) gives a workgroup of four waves a 128 x 32 output tile and ONE source box, predicted from
+//    the tile's four corner pixels and copied with row-contiguous 16-byte LDS-DMA loads that go out
+//    between the coordinate rows; remap_lds_kernel gives every wave its own 64 x 16 tile and box
+//    (certified, or with every pixel verified against the box: the fused map and uncertified models).
+//    The taps of every pixel then come from LDS.  The direct kernel (remap_tile_kernel) gathers tap
+//    pairs from global memory with 8-byte buffer loads; it serves float64 coordinates, strided /
+//    degenerate sources and the fallback.  stack_wg_kernel does the same for the rows of a stack, with
+//    two slabs: the box of projection d + 1 streams in while projection d is blended.
 //  * the coordinate polynomial is evaluated in fp64 (the reference computes float64 and only
 //    then rounds to float32, postprocessing.py:144-145; an fp32 evaluation changes 34 % of the
 //    coordinates by one ulp).  Everything that does not depend on x is staged once per
