@@ -254,13 +254,14 @@ def other_configs(a, dev, srcs, dsts, img0):
         F.check(L.dcp_unwarp_image_spline_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c2["xcenter"], c2["ycenter"], fa, nf,
                                               3, 0, F.MEM_DEVICE, dev, None))
     us = timed_launches(cubic, max(12, reps // 8), dev)
+    k = F.last_kernel()
     cubic(0)
     got = download(dsts[0].ptr, (H, W), dev)
     want = orc.unwarp_image_backward(*a2, order=3, mode="reflect", poly=orc.POLY_KERNEL)
     # (lines longer than one prefilter tile restart the recursion inside a halo: equal to the serial oracle up to the odd
     # float32 ulp)
     ok = np.count_nonzero(got != want) <= 32 and float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-5
-    out["cfg2_order3_cubic_spline"] = entry(us, H * W, 8, "spline_tile_filter_kernel x 2 + spline_wg_kernel", ok,
+    out["cfg2_order3_cubic_spline"] = entry(us, H * W, 8, k, ok,
                                             note="three launches per frame; pixels differing from the oracle by one float32 ulp: %d"
                                                  % int(np.count_nonzero(got != want)))
 

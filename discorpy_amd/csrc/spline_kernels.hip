@@ -17,6 +17,7 @@
 // straight from global memory.
 #include "dcp_internal.h"
 #include "dcp_device.h"
+#include <cstdio>
 #include <type_traits>
 
 namespace dcp {
@@ -871,8 +872,15 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
   const int64_t total = map_kind == 2 ? ca.npts : (int64_t)a.H * a.W;
   if (total == 0) return hipSuccess;
   // certified radial / perspective maps on frames of at least one workgroup tile: the taps out of LDS
-  if ((map_kind == 0 || map_kind == 1) && map.tile_dev_ok >= 2 && g_spline_wg && a.H >= kSwTH && a.W >= kSwTW &&
-      (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH) {
+  const bool wg = (map_kind == 0 || map_kind == 1) && map.tile_dev_ok >= 2 && g_spline_wg && a.H >= kSwTH && a.W >= kSwTW &&
+                  (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH;
+  {
+    char name[160];
+    snprintf(name, sizeof(name), "%s + %s<order=%d>", tiled ? "spline_tile_filter_kernel x 2" : "spline_causal / anticausal / transpose kernels",
+             wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
+    set_last_kernel_name(name);
+  }
+  if (wg) {
     if (map_kind == 0) return launch_spline_wg<kRadial>(a, map, dst, stream);
     return launch_spline_wg<kPersp>(a, map, dst, stream);
   }

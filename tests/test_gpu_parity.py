@@ -285,6 +285,9 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
                 F.set_option("spline_wg", fast)
                 res[fast] = (pp.unwarp_image_backward(*a, order=order, mode=mode),
                              pp.correct_perspective_image(img, coef, order=order, mode=mode))
+                want_name = ("spline_tile_filter_kernel x 2 + spline_wg_kernel<order=%d>" if fast else
+                             "spline_causal / anticausal / transpose kernels + spline_remap_kernel<order=%d>") % order
+                assert F.last_kernel() == want_name, F.last_kernel()
             want = (orc.unwarp_image_backward(*a, order=order, mode=mode, poly=orc.POLY_KERNEL),
                     orc.correct_perspective_image(img, coef, order=order, mode=mode))
             for k in (0, 1):
