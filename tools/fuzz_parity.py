@@ -155,7 +155,11 @@ def one_case(rng, k):
             got = pp.remap_coordinates(img, ys, xs, order=order, **kw)
         same(got, orc.remap_coords(img, ys, xs, order=order, **ok2), order, tag)
     elif kind == "spline":
-        h, w = min(h, 300), min(w, 300)
+        if os.environ.get("FUZZ_BIG") and rng.integers(0, 2):
+            # frames large enough for the one-pass tile prefilter (lines of >= ~900 samples) and many gather tiles
+            h, w = int(rng.integers(900, 1700)), int(rng.integers(900, 1700))
+        else:
+            h, w = min(h, 300), min(w, 300)
         img = rand_image(rng, (h, w), dt)
         so = int(rng.integers(2, 6))
         mode = MODES[int(rng.integers(0, 8))]
