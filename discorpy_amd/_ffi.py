@@ -50,6 +50,7 @@ SIGNATURES = {
     "dcp_perspective_image_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),
     "dcp_unwarp_fused_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dp, _int, _int,
                                     _int, _int, _vp]),
+    "dcp_remap_coords_mode_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _i64, _int, _int, _int, _int, _int, _vp]),
     "dcp_remap_coords_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _int, _i64, _int, _int, _int,
                                     _int, _vp]),
     "dcp_unwarp_stack_rows_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,

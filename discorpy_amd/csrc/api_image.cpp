@@ -309,6 +309,7 @@ int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, in
   memset(&ca, 0, sizeof(ca));
   ca.npts = npts;
   ca.is_f64 = coord_dtype == DCP_COORD_F64;
+  ca.mode = mode;
   const int64_t nout = map_kind == 3 ? npts : H * W;
   // 8- / 16-bit integers, radial or perspective map, certified: the workgroup-box kernel (same arithmetic, LDS-staged)
   dcp::MapArgs mapc = map;
@@ -426,13 +427,21 @@ int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t w
 int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
                          int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
                          int64_t npts, int order, int blend_mode, int mem_kind, int device, void* stream) {
+  return dcp_remap_coords_mode_f32(src, dst, height, width, src_row_stride, src_col_stride, ycoord, xcoord, coord_dtype, npts, order,
+                                   dcp::kModeNearest, blend_mode, mem_kind, device, stream);
+}
+
+int dcp_remap_coords_mode_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                              int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
+                              int64_t npts, int order, int boundary_mode, int blend_mode, int mem_kind, int device, void* stream) {
   int rc, sampler;
+  if (boundary_mode < 0 || boundary_mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", boundary_mode);
   if (beyond_32bit_offsets(height, width, src_row_stride, src_col_stride)) {
     dcp::MapArgs none;
     memset(&none, 0, sizeof(none));
     if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
     return run_typed(3, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, none, ycoord, xcoord, coord_dtype,
-                     npts, order, 0, mem_kind, device, stream);
+                     npts, order, boundary_mode, mem_kind, device, stream);
   }
   if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
   if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
@@ -454,6 +463,7 @@ int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t w
   dcp::CoordArgs ca;
   ca.npts = npts;
   ca.is_f64 = coord_dtype == DCP_COORD_F64;
+  ca.mode = boundary_mode;
   hipStream_t st = (hipStream_t)stream;
   if (mem_kind == DCP_MEM_DEVICE) {
     img.src = src;

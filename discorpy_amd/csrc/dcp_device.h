@@ -162,6 +162,134 @@ __device__ __forceinline__ void pixel_coord(const MapArgs& map, double X, double
   *yd_out = __builtin_fma(f, yu, map.yc);
 }
 
+// ------------------------------------------------------------------ explicit coordinates outside the image
+
+// What scipy.ndimage.map_coordinates does with a coordinate outside [0, len - 1] at orders 0 and 1 (the reference hands
+// `map_index` to it with the caller's `mode`, postprocessing.py:489-491): ni_interpolation.c map_coordinate() moves the
+// coordinate into the extended image, the taps that still fall outside fold by the same mode, and the two constant modes
+// read cval = 0 there.  Mode numbers: BoundaryMode in dcp_internal.h (0 reflect, 1 grid-mirror, 2 constant,
+// 3 grid-constant, 4 nearest, 5 mirror, 6 grid-wrap, 7 wrap).  Restated in oracle/unwarp_oracle.c; both are tested
+// against scipy itself.
+__device__ __forceinline__ double mc_map_coordinate(double in, int len, int mode) {
+  const double n = (double)len;
+  if (in < 0.0) {
+    switch (mode) {
+      case 5: {                                      // mirror
+        if (len <= 1) return 0.0;
+        const double sz2 = 2.0 * n - 2.0;
+        in = sz2 * (double)(long long)(-in / sz2) + in;
+        return in <= 1.0 - n ? in + sz2 : -in;
+      }
+      case 0:
+      case 1: {                                      // reflect / grid-mirror
+        if (len <= 1) return 0.0;
+        const double sz2 = 2.0 * n;
+        if (in < -sz2) in = sz2 * (double)(long long)(-in / sz2) + in;
+        return in < -n ? in + sz2 : (in > -1e-15 ? 1e-15 : -in) - 1.0;
+      }
+      case 7: {                                      // wrap
+        if (len <= 1) return 0.0;
+        const double sz = n - 1.0;
+        return in + sz * ((double)(long long)(-in / sz) + 1.0);
+      }
+      case 6: {                                      // grid-wrap
+        if (len <= 1) return 0.0;
+        return in + n * ((double)(long long)((-1.0 - in) / n) + 1.0);
+      }
+      case 4: return 0.0;                            // nearest
+      case 2: return -1.0;                           // constant
+      default: return in;                            // grid-constant
+    }
+  }
+  if (in > n - 1.0) {
+    switch (mode) {
+      case 5: {
+        if (len <= 1) return 0.0;
+        const double sz2 = 2.0 * n - 2.0;
+        in -= sz2 * (double)(long long)(in / sz2);
+        return in >= n ? sz2 - in : in;
+      }
+      case 0:
+      case 1: {
+        if (len <= 1) return 0.0;
+        const double sz2 = 2.0 * n;
+        in -= sz2 * (double)(long long)(in / sz2);
+        return in >= n ? sz2 - in - 1.0 : in;
+      }
+      case 7: {
+        if (len <= 1) return 0.0;
+        const double sz = n - 1.0;
+        return in - sz * (double)(long long)(in / sz);
+      }
+      case 6: {
+        if (len <= 1) return 0.0;
+        return in - n * (double)(long long)((in + 1.0) / n);
+      }
+      case 4: return n - 1.0;
+      case 2: return -1.0;
+      default: return in;
+    }
+  }
+  return in;
+}
+
+// index of tap i of a line of len samples under `mode`; -1: outside, reads cval (the two constant modes)
+__device__ __forceinline__ long long mc_fold_tap(long long i, long long len, int mode) {
+  if (i >= 0 && i < len) return i;
+  switch (mode) {
+    case 0:
+    case 1: {
+      const long long s2 = 2 * len;
+      i %= s2;
+      if (i < 0) i += s2;
+      return i < len ? i : s2 - 1 - i;
+    }
+    case 6: {
+      i %= len;
+      return i < 0 ? i + len : i;
+    }
+    case 4: return i < 0 ? 0 : len - 1;
+    case 5: {
+      if (len == 1) return 0;
+      const long long s2 = 2 * len - 2;
+      i %= s2;
+      if (i < 0) i += s2;
+      return i < len ? i : s2 - i;
+    }
+    case 7: {
+      if (len == 1) return 0;
+      const long long s = len - 1;
+      i %= s;
+      return i < 0 ? i + s : i;
+    }
+    default: return -1;
+  }
+}
+
+// t of map_coordinates(src, (yc, xc), order, mode) for a point with a coordinate outside the image (any point, in fact):
+// double arithmetic in scipy's order; LOAD(row, col) returns the element as a double
+template <typename LOAD>
+__device__ __forceinline__ double mc_sample_outside(LOAD&& load, int H, int W, double yc, double xc, int order, int mode) {
+  const double y = mc_map_coordinate(yc, H, mode), x = mc_map_coordinate(xc, W, mode);
+  if (mode == 2 && (y <= -1.0 || x <= -1.0)) return 0.0;
+  if (order == 0) {
+    const long long iy = mc_fold_tap((long long)__builtin_floor(y + 0.5), H, mode), ix = mc_fold_tap((long long)__builtin_floor(x + 0.5), W, mode);
+    return (iy < 0 || ix < 0) ? 0.0 : load(iy, ix);
+  }
+  const double y0 = __builtin_floor(y), x0 = __builtin_floor(x);
+  const double wy0 = 1.0 - (y - y0), wy1 = 1.0 - wy0;
+  const double wx0 = 1.0 - (x - x0), wx1 = 1.0 - wx0;
+  const long long iy0 = mc_fold_tap((long long)y0, H, mode), iy1 = mc_fold_tap((long long)y0 + 1, H, mode);
+  const long long ix0 = mc_fold_tap((long long)x0, W, mode), ix1 = mc_fold_tap((long long)x0 + 1, W, mode);
+  auto tap = [&](long long iy, long long ix) -> double { return (iy < 0 || ix < 0) ? 0.0 : load(iy, ix); };
+  double t = 0.0;
+  t += (tap(iy0, ix0) * wy0) * wx0;
+  t += (tap(iy0, ix1) * wy0) * wx1;
+  t += (tap(iy1, ix0) * wy1) * wx0;
+  t += (tap(iy1, ix1) * wy1) * wx1;
+  return t;
+}
+
 // ------------------------------------------------------------------ element types
 
 // scipy reads every element as a double and converts the double result on the way out

@@ -63,6 +63,7 @@ struct CoordArgs {
   const void* xcoord;
   int64_t npts;
   int32_t is_f64;
+  int32_t mode;            // BoundaryMode applied to coordinates OUTSIDE the image at orders 0 / 1 (kModeNearest = clamp)
 };
 
 // scipy boundary modes in the order of the reference's docstrings (postprocessing.py:128-130)

@@ -75,6 +75,13 @@ __global__ void __launch_bounds__(kTypedBlock) typed_image_kernel(const TypedIma
       yc = (double)((const float*)ca.ycoord)[i];
       xc = (double)((const float*)ca.xcoord)[i];
     }
+    if (ca.mode != kModeNearest && (yc < 0.0 || yc > (double)(a.H - 1) || xc < 0.0 || xc > (double)(a.W - 1))) {
+      const T* base = (const T*)a.src;
+      const int64_t rs = a.src_stride, cs = a.src_cstride;
+      ((T*)a.dst)[i] = to_elem<T>(mc_sample_outside([&](long long r, long long c) -> double { return (double)base[r * rs + c * cs]; }, a.H,
+                                                    a.W, yc, xc, a.order, ca.mode));
+      return;
+    }
     yc = clip_f64(yc, (double)(a.H - 1));
     xc = clip_f64(xc, (double)(a.W - 1));
   } else {

@@ -1113,6 +1113,15 @@ __global__ void __launch_bounds__(kBlock) remap_coords_kernel(const ImageArgs im
   CT yc = ((const CT*)ca.ycoord)[i];
   CT xc = ((const CT*)ca.xcoord)[i];
   const CT wmax = (CT)(img.W - 1), hmax = (CT)(img.H - 1);
+  if (ca.mode != kModeNearest && (yc < (CT)0 || yc > hmax || xc < (CT)0 || xc > wmax)) {
+    // outside the image under a mode other than 'nearest': scipy's coordinate mapping and tap folding, in double and in
+    // scipy's operation order whatever the blend (rare points: plain 64-bit addressing)
+    const float* base = img.src;
+    const int64_t rs = img.src_stride, cs = img.src_col_stride;
+    img.dst[i] = (float)mc_sample_outside([&](long long r, long long c) -> double { return (double)base[r * rs + c * cs]; }, img.H, img.W,
+                                          (double)yc, (double)xc, SAMPLER == kNearest ? 0 : 1, ca.mode);
+    return;
+  }
   xc = xc < (CT)0 ? (CT)0 : xc;
   xc = xc > wmax ? wmax : xc;
   yc = yc < (CT)0 ? (CT)0 : yc;

@@ -103,10 +103,20 @@ int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t w
 
 /* discorpy/post/postprocessing.py:489-491 (map_index given) and :250-251 (_mapping):
  * dst[i] = sample(src, ycoord[i], xcoord[i]) for npts caller-supplied coordinates of type
- * coord_dtype (DCP_COORD_F32 / DCP_COORD_F64), clamped to the image. */
+ * coord_dtype (DCP_COORD_F32 / DCP_COORD_F64), clamped to the image (scipy's mode='nearest'). */
 int dcp_remap_coords_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
                          int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
                          int64_t npts, int order, int blend_mode, int mem_kind, int device, void* stream);
+
+/* The same with the reference's `mode` argument honoured for coordinates OUTSIDE the image, as
+ * scipy.ndimage.map_coordinates -- which postprocessing.py:489-491 hands `map_index` and `mode` to -- treats them at
+ * orders 0 and 1: boundary_mode is the index of the mode in the reference's docstring order (0 reflect, 1 grid-mirror,
+ * 2 constant, 3 grid-constant, 4 nearest, 5 mirror, 6 grid-wrap, 7 wrap; cval = 0).  Such points are computed in double
+ * in scipy's operation order whatever blend_mode says; points inside the image are what dcp_remap_coords_f32 returns. */
+int dcp_remap_coords_mode_f32(const float* src, float* dst, int64_t height, int64_t width, int64_t src_row_stride,
+                              int64_t src_col_stride, const void* ycoord, const void* xcoord, int coord_dtype,
+                              int64_t npts, int order, int boundary_mode, int blend_mode, int mem_kind, int device,
+                              void* stream);
 
 /* discorpy/post/postprocessing.py:188-229 (unwarp_slice_backward: nrows = 1, coord_round_f32 = 0)
  * and :255-313 (unwarp_chunk_slices_backward: coord_round_f32 = 1) over a (depth, height, width)

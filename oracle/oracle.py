@@ -47,7 +47,7 @@ def lib():
         L.orc_unwarp_image_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, i32, i32, i32, i32]
         L.orc_perspective_image_f32.argtypes = [fp, fp, i64, i64, i64, dp, i32, i32]
         L.orc_unwarp_fused_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, dp, i32, i32, i32]
-        L.orc_remap_coords_f32.argtypes = [fp, fp, i64, i64, i64, vp, vp, i32, i64, i32, i32]
+        L.orc_remap_coords_f32.argtypes = [fp, fp, i64, i64, i64, vp, vp, i32, i64, i32, i32, i32]
         L.orc_unwarp_stack_rows_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, dbl, i64,
                                                 i32, i32, i32]
         L.orc_spline_pad.argtypes = [i32]
@@ -230,7 +230,8 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
 
 
 def remap_coords(mat, ycoord, xcoord, order=1, *, blend=BLEND_SCIPY, mode="reflect"):
-    """map_coordinates(mat, (ycoord, xcoord), order) for in-range coordinates."""
+    """map_coordinates(mat, (ycoord, xcoord), order, mode): coordinates outside the image follow scipy's `mode` at
+    orders 0 and 1 ('nearest' clamps them) and are clamped at the spline orders."""
     if np.asarray(mat).dtype != np.float32:
         return map_coordinates(mat, ycoord, xcoord, order, mode)
     if int(order) >= 2:
@@ -243,7 +244,7 @@ def remap_coords(mat, ycoord, xcoord, order=1, *, blend=BLEND_SCIPY, mode="refle
     out = np.empty(ycoord.shape, np.float32)
     _check(lib().orc_remap_coords_f32(_fp(mat), _fp(out), mat.shape[0], mat.shape[1], _row_stride(mat),
                                       ycoord.ctypes.data, xcoord.ctypes.data,
-                                      int(ycoord.dtype == np.float64), ycoord.size, int(order), blend))
+                                      int(ycoord.dtype == np.float64), ycoord.size, int(order), blend, MODES.index(mode)))
     return out
 
 

@@ -309,20 +309,146 @@ int orc_unwarp_fused_f32(const float *src, float *dst, int64_t H, int64_t W,
     return 0;
 }
 
+/* ---- scipy.ndimage.map_coordinates, order 0 / 1, a coordinate OUTSIDE [0, len-1] ----
+   The reference hands a caller's map_index and `mode` straight to scipy (postprocessing.py:489-491).  scipy's
+   ni_interpolation.c first moves such a coordinate into the extended image (map_coordinate()), the taps that still fall
+   outside fold by the same mode, and the two constant modes read cval = 0 there.  Restated here from scipy's documented
+   behaviour and pinned against scipy itself (tests/test_oracle_golden.py, every mode, orders 0 and 1) and against the
+   reference's own call (golden G16).  mode: index in ORC mode order (0 reflect, 1 grid-mirror, 2 constant,
+   3 grid-constant, 4 nearest, 5 mirror, 6 grid-wrap, 7 wrap). */
+static double mc_map_coordinate(double in, int64_t len, int mode)
+{
+    const double n = (double)len;
+    if (in < 0.0) {
+        switch (mode) {
+        case 5: {
+            if (len <= 1) return 0.0;
+            const double sz2 = 2.0 * n - 2.0;
+            in = sz2 * (double)(int64_t)(-in / sz2) + in;
+            return in <= 1.0 - n ? in + sz2 : -in;
+        }
+        case 0: case 1: {
+            if (len <= 1) return 0.0;
+            const double sz2 = 2.0 * n;
+            if (in < -sz2) in = sz2 * (double)(int64_t)(-in / sz2) + in;
+            return in < -n ? in + sz2 : (in > -1e-15 ? 1e-15 : -in) - 1.0;
+        }
+        case 7: {
+            if (len <= 1) return 0.0;
+            const double sz = n - 1.0;
+            return in + sz * ((double)(int64_t)(-in / sz) + 1.0);
+        }
+        case 6: {
+            if (len <= 1) return 0.0;
+            return in + n * ((double)(int64_t)((-1.0 - in) / n) + 1.0);
+        }
+        case 4: return 0.0;
+        case 2: return -1.0;
+        default: return in;
+        }
+    }
+    if (in > n - 1.0) {
+        switch (mode) {
+        case 5: {
+            if (len <= 1) return 0.0;
+            const double sz2 = 2.0 * n - 2.0;
+            in -= sz2 * (double)(int64_t)(in / sz2);
+            return in >= n ? sz2 - in : in;
+        }
+        case 0: case 1: {
+            if (len <= 1) return 0.0;
+            const double sz2 = 2.0 * n;
+            in -= sz2 * (double)(int64_t)(in / sz2);
+            return in >= n ? sz2 - in - 1.0 : in;
+        }
+        case 7: {
+            if (len <= 1) return 0.0;
+            const double sz = n - 1.0;
+            return in - sz * (double)(int64_t)(in / sz);
+        }
+        case 6: {
+            if (len <= 1) return 0.0;
+            return in - n * (double)(int64_t)((in + 1.0) / n);
+        }
+        case 4: return n - 1.0;
+        case 2: return -1.0;
+        default: return in;
+        }
+    }
+    return in;
+}
+
+static int64_t mc_fold_tap(int64_t i, int64_t len, int mode)
+{
+    if (i >= 0 && i < len) return i;
+    switch (mode) {
+    case 0: case 1: {
+        const int64_t s2 = 2 * len;
+        i %= s2;
+        if (i < 0) i += s2;
+        return i < len ? i : s2 - 1 - i;
+    }
+    case 6:
+        i %= len;
+        return i < 0 ? i + len : i;
+    case 4: return i < 0 ? 0 : len - 1;
+    case 5: {
+        if (len == 1) return 0;
+        const int64_t s2 = 2 * len - 2;
+        i %= s2;
+        if (i < 0) i += s2;
+        return i < len ? i : s2 - i;
+    }
+    case 7: {
+        if (len == 1) return 0;
+        const int64_t s = len - 1;
+        i %= s;
+        return i < 0 ? i + s : i;
+    }
+    default: return -1;          /* constant / grid-constant: cval */
+    }
+}
+
+/* element (row, col) as a double, or cval = 0 for a tap outside */
+static double mc_tap(const void *src, int dtype, int64_t rs, int64_t iy, int64_t ix);
+
+static double mc_sample_outside(const void *src, int dtype, int64_t H, int64_t W, int64_t rs, double yc, double xc,
+                                int order, int mode)
+{
+    const double y = mc_map_coordinate(yc, H, mode), x = mc_map_coordinate(xc, W, mode);
+    if (mode == 2 && (y <= -1.0 || x <= -1.0)) return 0.0;
+    if (order == 0)
+        return mc_tap(src, dtype, rs, mc_fold_tap((int64_t)floor(y + 0.5), H, mode), mc_fold_tap((int64_t)floor(x + 0.5), W, mode));
+    const double y0 = floor(y), x0 = floor(x);
+    const double wy0 = 1.0 - (y - y0), wy1 = 1.0 - wy0;
+    const double wx0 = 1.0 - (x - x0), wx1 = 1.0 - wx0;
+    const int64_t iy0 = mc_fold_tap((int64_t)y0, H, mode), iy1 = mc_fold_tap((int64_t)y0 + 1, H, mode);
+    const int64_t ix0 = mc_fold_tap((int64_t)x0, W, mode), ix1 = mc_fold_tap((int64_t)x0 + 1, W, mode);
+    double t = 0.0;
+    t += (mc_tap(src, dtype, rs, iy0, ix0) * wy0) * wx0;
+    t += (mc_tap(src, dtype, rs, iy0, ix1) * wy0) * wx1;
+    t += (mc_tap(src, dtype, rs, iy1, ix0) * wy1) * wx0;
+    t += (mc_tap(src, dtype, rs, iy1, ix1) * wy1) * wx1;
+    return t;
+}
+
 /* map_coordinates(mat, (ycoord, xcoord)) with caller-supplied coordinates:
    correct_perspective_image(map_index=...) :489-491 and _mapping :250-251.
-   Coordinates outside [0,len-1] are clamped (the reference's callers never
-   produce them; scipy would apply `mode`). */
+   Coordinates outside [0,len-1]: scipy's `mode` (mode 4 = 'nearest' clamps them). */
 int orc_remap_coords_f32(const float *src, float *dst, int64_t H, int64_t W,
                          int64_t src_row_stride, const void *ycoord,
                          const void *xcoord, int coord_is_f64, int64_t npts,
-                         int order, int blend_mode)
+                         int order, int blend_mode, int mode)
 {
-    if (H <= 0 || W <= 0 || npts < 0 || order < 0 || order > 1) return -1;
+    if (H <= 0 || W <= 0 || npts < 0 || order < 0 || order > 1 || mode < 0 || mode > 7) return -1;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int64_t i = 0; i < npts; ++i) {
         double y = coord_is_f64 ? ((const double *)ycoord)[i] : (double)((const float *)ycoord)[i];
         double x = coord_is_f64 ? ((const double *)xcoord)[i] : (double)((const float *)xcoord)[i];
+        if (mode != 4 && (y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1))) {
+            dst[i] = (float)mc_sample_outside(src, ORC_DT_F32, H, W, src_row_stride, y, x, order, mode);
+            continue;
+        }
         y = clipd(y, 0.0, (double)(H - 1));
         x = clipd(x, 0.0, (double)(W - 1));
         dst[i] = sample(src, H, W, src_row_stride, 1, y, x, order, blend_mode);
@@ -487,6 +613,11 @@ static inline double load_typed(const void *src, int dtype, int64_t i)
     case ORC_DT_U32: return (double)((const uint32_t *)src)[i];
     default: return (double)((const int32_t *)src)[i];
     }
+}
+
+static double mc_tap(const void *src, int dtype, int64_t rs, int64_t iy, int64_t ix)
+{
+    return (iy < 0 || ix < 0) ? 0.0 : load_typed(src, dtype, iy * rs + ix);
 }
 
 static inline double round_unsigned(double t, double hi)
@@ -702,6 +833,10 @@ int orc_map_coordinates_typed(const void *src, void *dst, int dtype, int64_t H, 
     for (int64_t i = 0; i < npts; ++i) {
         double y = coord_is_f64 ? ((const double *)ycoord)[i] : (double)((const float *)ycoord)[i];
         double x = coord_is_f64 ? ((const double *)xcoord)[i] : (double)((const float *)xcoord)[i];
+        if (order <= 1 && mode != 4 && (y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1))) {
+            store_typed(dst, dtype, i, mc_sample_outside(src, dtype, H, W, src_row_stride, y, x, order, mode));
+            continue;
+        }
         y = clipd(y, 0.0, (double)(H - 1));
         x = clipd(x, 0.0, (double)(W - 1));
         double t;

@@ -107,6 +107,18 @@ def test_g15_folding_model_pins_the_documented_band_deviation(hip):
     assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a), g["absolute_out"]).max() <= 1
 
 
+def test_g16_map_index_outside_the_image_follows_the_reference(hip):
+    """correct_perspective_image(map_index=..., mode=...) with coordinates outside the image: the reference's outputs
+    (it hands both to scipy), every mode, orders 0 and 1."""
+    g = golden("g16_map_index_outside")
+    mat = noise(g["seed"], g["shape"])
+    coef = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]
+    for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+        for order in (0, 1):
+            got = pp.correct_perspective_image(mat, coef, order=order, mode=mode, map_index=(g["ys"], g["xs"]), blend="scipy")
+            assert np.array_equal(got, g["%s_o%d" % (mode.replace("-", "_"), order)]), (mode, order)
+
+
 def test_g7_fused_and_two_pass(hip):
     g = golden("g7_fused144")
     img = noise(g["seed"], g["shape"])
@@ -713,22 +725,34 @@ def test_explicit_coordinates_match_oracle(hip, orc):
         ys = (rng.random(5000) * 75 - 3).astype(dt)            # includes out-of-image values: clamped
         xs = (rng.random(5000) * 96 - 3).astype(dt)
         for order, blend in [(0, "scipy"), (1, "scipy"), (1, "f64lerp"), (1, "f32")]:
-            want = orc.remap_coords(img, ys, xs, order=order, blend=kernel_oracle(orc, blend)["blend"])
+            want = orc.remap_coords(img, ys, xs, order=order, blend=kernel_oracle(orc, blend)["blend"], mode="nearest")
             assert np.array_equal(pp.remap_coordinates(img, ys, xs, order=order, mode="nearest", blend=blend), want)
     assert pp.remap_coordinates(img, np.zeros((0,), np.float32), np.zeros((0,), np.float32)).shape == (0,)
-    # coordinates outside the image are clamped (scipy's mode='nearest'): said with a warning under any other mode
+    # coordinates outside the image follow scipy's `mode` at orders 0 and 1 -- compared with scipy itself, which is what the
+    # reference hands map_index and mode to (postprocessing.py:489-491) -- for float32 and integer images, host and
+    # float64 coordinates; the spline orders clamp them and say so
     import warnings
-    ys = (rng.random(500) * 75 - 3).astype(np.float32)
-    xs = (rng.random(500) * 96 - 3).astype(np.float32)
+    from scipy.ndimage import map_coordinates
+    ys = (rng.random(4000) * 70 * 7 - 70 * 3).astype(np.float32)
+    xs = (rng.random(4000) * 90 * 7 - 90 * 3).astype(np.float32)
+    ys[:60] = np.linspace(-2.0, 71.0, 60)
+    xs[:60] = 44.25
+    u16 = (img * 60000).astype(np.uint16)
+    for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+        for order in (0, 1):
+            for yy, xx in ((ys, xs), (ys.astype(np.float64) * 1.0000001, xs.astype(np.float64))):
+                with warnings.catch_warnings():
+                    warnings.simplefilter("error")
+                    got = pp.remap_coordinates(img, yy, xx, order=order, mode=mode, blend="scipy")
+                    got16 = pp.remap_coordinates(u16, yy, xx, order=order, mode=mode)
+                assert np.array_equal(got, map_coordinates(img, (yy, xx), order=order, mode=mode)), (mode, order, yy.dtype)
+                assert np.array_equal(got, orc.remap_coords(img, yy, xx, order=order, mode=mode)), (mode, order)
+                assert np.array_equal(got16, map_coordinates(u16, (yy, xx), order=order, mode=mode)), (mode, order, "uint16")
     with pytest.warns(RuntimeWarning, match="clamped"):
-        clamped = pp.remap_coordinates(img, ys, xs, order=1, mode="reflect", blend="scipy")
+        clamped = pp.remap_coordinates(img, ys, xs, order=3, mode="reflect")
     with warnings.catch_warnings():
         warnings.simplefilter("error")
-        assert np.array_equal(pp.remap_coordinates(img, ys, xs, order=1, mode="nearest", blend="scipy"), clamped)
-        inside = pp.remap_coordinates(img, np.clip(ys, 0, 69), np.clip(xs, 0, 89), order=1, mode="reflect", blend="scipy")
-    assert np.array_equal(inside, clamped)
-    from scipy.ndimage import map_coordinates
-    assert np.array_equal(clamped, map_coordinates(img, (ys, xs), order=1, mode="nearest"))
+        assert np.array_equal(pp.remap_coordinates(img, np.clip(ys, 0, 69), np.clip(xs, 0, 89), order=3, mode="reflect"), clamped)
 
 
 def test_device_resident_tensors_take_the_same_path(hip, orc):

@@ -116,6 +116,41 @@ def test_g15_folding_model_pins_the_documented_band_deviation(orc):
     assert not np.array_equal(g["ref_out"][:, outside], g["absolute_out"][:, outside])
 
 
+def test_g16_map_index_outside_the_image_follows_scipy_modes(orc):
+    """Explicit coordinates outside the image at orders 0 / 1: the oracle restates scipy's boundary handling; pinned to the
+    reference's own correct_perspective_image(map_index=..., mode=...) outputs (golden G16) and, more densely, to scipy
+    itself (float32 and uint16 images, float32 and float64 coordinates)."""
+    from scipy.ndimage import map_coordinates
+    g = golden("g16_map_index_outside")
+    mat = noise(g["seed"], g["shape"])
+    modes = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+    for mode in modes:
+        for order in (0, 1):
+            want = g["%s_o%d" % (mode.replace("-", "_"), order)].ravel()
+            assert np.array_equal(orc.remap_coords(mat, g["ys"], g["xs"], order=order, mode=mode), want), (mode, order)
+    rng = np.random.default_rng(7)
+    img = noise(3, (70, 90))
+    u16 = (img * 60000).astype(np.uint16)
+    for shape_img in (img, img[:1, :], img[:, :1].copy()):
+        hh, ww = shape_img.shape
+        ys = (rng.random(3000) * hh * 9 - hh * 4).astype(np.float32)
+        xs = (rng.random(3000) * ww * 9 - ww * 4).astype(np.float32)
+        for mode in modes:
+            for order in (0, 1):
+                for yy, xx in ((ys, xs), (ys.astype(np.float64) * 1.0000001, xs.astype(np.float64))):
+                    assert np.array_equal(orc.remap_coords(shape_img, yy, xx, order=order, mode=mode),
+                                          map_coordinates(shape_img, (yy, xx), order=order, mode=mode)), (mode, order, shape_img.shape)
+    for mode in modes:
+        for order in (0, 1):
+            assert np.array_equal(orc.map_coordinates(u16, ys[:2000] * 0 + (rng.random(2000) * 500 - 200).astype(np.float32),
+                                                      xs[:2000] * 0 + (rng.random(2000) * 600 - 250).astype(np.float32), order, mode).shape, (2000,))
+    yy = (rng.random(2000) * 500 - 200).astype(np.float32)
+    xx = (rng.random(2000) * 600 - 250).astype(np.float32)
+    for mode in modes:
+        for order in (0, 1):
+            assert np.array_equal(orc.map_coordinates(u16, yy, xx, order, mode), map_coordinates(u16, (yy, xx), order=order, mode=mode)), (mode, order)
+
+
 def test_chunk_equals_image_rows_and_slice_differs(orc):
     """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
     g = golden("g6_stack3x800x1280")

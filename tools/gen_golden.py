@@ -331,4 +331,28 @@ def g15():
 
 
 g15()
+
+
+# G16: correct_perspective_image with a caller's map_index whose coordinates leave the image, under every boundary mode,
+# orders 0 and 1 -- the reference passes map_index and mode straight to scipy (postprocessing.py:489-491), so this pins
+# the out-of-image handling (scipy's coordinate mapping, tap folding, cval = 0) to the reference's own call.
+def g16():
+    h, w = 23, 31
+    rng = np.random.default_rng(1616)
+    mat = rng.random((h, w), dtype=np.float32)
+    n = h * w                      # (the reference reshapes the result to the image's shape, :492)
+    ys = (rng.random(n) * h * 7 - h * 3).astype(np.float32)
+    xs = (rng.random(n) * w * 7 - w * 3).astype(np.float32)
+    ys[:50] = np.linspace(-2.0, h + 1.0, 50)
+    xs[:50] = 11.25
+    out = {}
+    coef = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0]      # unused once map_index is given
+    for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+        for order in (0, 1):
+            out["%s_o%d" % (mode.replace("-", "_"), order)] = post.correct_perspective_image(mat, coef, order=order, mode=mode,
+                                                                                             map_index=(ys, xs))
+    save("g16_map_index_outside", seed=np.int64(1616), shape=np.array([h, w]), ys=ys, xs=xs, **out)
+
+
+g16()
 print("done")
