@@ -120,7 +120,8 @@ int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, i
   a.pad = (mode == dcp::kModeNearest || mode == dcp::kModeGridConstant) ? 12 : 0;
   a.Hp = a.H + 2 * a.pad;
   a.Wp = a.W + 2 * a.pad;
-  a.filter_kind = (mode == dcp::kModeReflect || mode == dcp::kModeGridMirror) ? dcp::kSplReflect
+  // ('nearest': scipy prefilters the edge-padded array with the reflect boundary -- see spline_filter_kind() in the oracle)
+  a.filter_kind = (mode == dcp::kModeReflect || mode == dcp::kModeGridMirror || mode == dcp::kModeNearest) ? dcp::kSplReflect
                   : mode == dcp::kModeGridWrap                                 ? dcp::kSplWrap
                                                                                : dcp::kSplMirror;
   a.npoles = spline_poles(order, a.poles);

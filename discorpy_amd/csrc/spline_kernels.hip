@@ -566,8 +566,21 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
       yc = (double)((const float*)ca.ycoord)[i];
       xc = (double)((const float*)ca.xcoord)[i];
     }
-    yc = clip_f64(yc, (double)(a.H - 1));
-    xc = clip_f64(xc, (double)(a.W - 1));
+    // a caller's coordinate outside the image: what scipy does before it evaluates the spline (spline_map_point() in the
+    // oracle) -- 'constant' returns cval = 0, 'nearest' and 'grid-constant' evaluate where the coordinate is (taps outside
+    // the padded plane clamp to its edge / read 0), every other mode moves it into the extended image
+    if (!(yc >= 0.0 && yc <= (double)(a.H - 1) && xc >= 0.0 && xc <= (double)(a.W - 1)) && a.mode != kModeNearest &&
+        a.mode != kModeGridConstant) {
+      yc = mc_map_coordinate(yc, a.H, a.mode);
+      xc = mc_map_coordinate(xc, a.W, a.mode);
+      if (a.mode == kModeConstant && (yc <= -1.0 || xc <= -1.0)) {
+        store_any(dst, a.dst_dtype, (size_t)i, 0.0);
+        return;
+      }
+    }
+    // (tap indices are 32-bit: a coordinate a billion samples out already has every tap outside the plane)
+    yc = yc < -1.0e9 ? -1.0e9 : (yc > 1.0e9 ? 1.0e9 : yc);
+    xc = xc < -1.0e9 ? -1.0e9 : (xc > 1.0e9 ? 1.0e9 : xc);
   } else {
     const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
     double xd, yd;
@@ -582,11 +595,22 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
 #pragma unroll
   for (int k = 0; k <= ORDER; ++k) ix[k] = spline_fold(sx + k, a.Wp, a.mode);
   double t = 0.0;
+  if (MAPKIND == 2 && a.mode == kModeGridConstant) {
+    // explicit coordinates under 'grid-constant' may put taps outside the padded plane: those read cval = 0
 #pragma unroll
-  for (int j = 0; j <= ORDER; ++j) {
-    const double* row = a.coef + (size_t)spline_fold(sy + j, a.Hp, a.mode) * (size_t)a.Wp;
+    for (int j = 0; j <= ORDER; ++j) {
+      const bool yout = sy + j < 0 || sy + j >= a.Hp;
+      const double* row = a.coef + (size_t)spline_fold(sy + j, a.Hp, a.mode) * (size_t)a.Wp;
 #pragma unroll
-    for (int k = 0; k <= ORDER; ++k) t += (row[ix[k]] * wy[j]) * wx[k];
+      for (int k = 0; k <= ORDER; ++k) t += (((yout || sx + k < 0 || sx + k >= a.Wp) ? 0.0 : row[ix[k]]) * wy[j]) * wx[k];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j <= ORDER; ++j) {
+      const double* row = a.coef + (size_t)spline_fold(sy + j, a.Hp, a.mode) * (size_t)a.Wp;
+#pragma unroll
+      for (int k = 0; k <= ORDER; ++k) t += (row[ix[k]] * wy[j]) * wx[k];
+    }
   }
   store_any(dst, a.dst_dtype, (size_t)i, t);
 }

@@ -630,26 +630,12 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
     return out
 
 
-def _warn_clamped(ymin, ymax, xmin, xmax, height, width, mode):
-    """Spline orders (2..5): explicit coordinates outside the image are clamped to it -- scipy's ``mode='nearest'``; the
-    reference hands ``map_index`` to scipy, where any other ``mode`` extends the image differently.  Say so instead of
-    differing silently (the reference's own maps are clipped into the image, postprocessing.py:455-457, and never get
-    here).  Orders 0 and 1 follow scipy's ``mode`` for such coordinates."""
-    if ymin < 0.0 or xmin < 0.0 or ymax > height - 1 or xmax > width - 1 or ymin != ymin or xmin != xmin:
-        import warnings
-        warnings.warn("coordinates outside the image (y in [%g, %g], x in [%g, %g] for a %d x %d image) are clamped to it, "
-                      "i.e. treated as mode='nearest', not mode=%r" % (ymin, ymax, xmin, xmax, height, width, mode),
-                      RuntimeWarning, stacklevel=3)
-
-
 def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=None):
     """
     ``scipy.ndimage.map_coordinates(mat, (ycoords, xcoords), order, mode)`` for coordinates that lie
     inside the image (the ``map_index=`` path of ``correct_perspective_image`` :489-491 and
-    ``_mapping`` :250-251).  Coordinates outside the image: orders 0 and 1 treat them as scipy does under ``mode``
-    (coordinate mapping, tap folding, ``cval = 0`` for the two constant modes); the spline orders clamp them to the image,
-    with a ``RuntimeWarning`` unless ``mode`` is ``'nearest'`` (host and torch coordinates; other device arrays are not
-    inspected).  Returns an array shaped like ``ycoords``.
+    ``_mapping`` :250-251).  Coordinates outside the image are treated as scipy treats them under ``mode`` at every order
+    (coordinate mapping, tap folding, ``cval = 0`` for the two constant modes).  Returns an array shaped like ``ycoords``.
     """
     (height, width) = mat.shape
     order = _check_order_mode(order, mode)
@@ -667,8 +653,6 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
             raise RuntimeError("invalid shape for coordinate array")
         cdt = F.COORD_F32 if dt == torch.float32 else F.COORD_F64
         npts, yptr, xptr, shape = yc.numel(), yc.data_ptr(), xc.data_ptr(), tuple(yc.shape)
-        if mode != "nearest" and npts and order >= 2:
-            _warn_clamped(float(yc.min()), float(yc.max()), float(xc.min()), float(xc.max()), height, width, mode)
     elif img.cai and _is_device_coords(ycoords) and _is_device_coords(xcoords) and \
             _cai_dtype(ycoords) == _cai_dtype(xcoords):
         # device image, device coordinates (CuPy / Numba arrays, or the DeviceArray maps of _generate_perspective_map):
@@ -695,8 +679,6 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
             raise RuntimeError("invalid shape for coordinate array")
         cdt = F.COORD_F32 if dt == np.float32 else F.COORD_F64
         npts, yptr, xptr, shape = yc.size, yc.ctypes.data, xc.ctypes.data, yc.shape
-        if mode != "nearest" and npts and order >= 2:
-            _warn_clamped(float(yc.min()), float(yc.max()), float(xc.min()), float(xc.max()), height, width, mode)
         if img.mem == F.MEM_DEVICE:
             # device image (a __cuda_array_interface__ array), host coordinates: the kernel reads the coordinates on the
             # device, so they are uploaded first (the buffers live until the call has been enqueued and are freed -- which

@@ -524,7 +524,10 @@ static int spline_poles(int order, double *z)
 
 static int spline_filter_kind(int mode)
 {
-    if (mode == ORC_MODE_REFLECT || mode == ORC_MODE_GRID_MIRROR) return SPL_REFLECT;
+    /* ('nearest' prefilters its edge-padded array with the reflect boundary too: scipy.ndimage.spline_filter1d(x,
+       mode='nearest') == (x, mode='reflect') to the last bit; invisible inside the image -- twelve samples of constant
+       padding away -- but it is what coordinates outside the image see) */
+    if (mode == ORC_MODE_REFLECT || mode == ORC_MODE_GRID_MIRROR || mode == ORC_MODE_NEAREST) return SPL_REFLECT;
     if (mode == ORC_MODE_GRID_WRAP) return SPL_WRAP;
     return SPL_MIRROR;
 }
@@ -765,12 +768,31 @@ static inline double spline_sample_d(const double *coef, int64_t Hp, int64_t Wp,
     double t = 0.0;
     for (int j = 0; j <= order; ++j) {
         const int64_t iy = spline_fold(sy + j, Hp, mode);
+        /* 'grid-constant': a tap outside the padded plane reads cval = 0 (only reachable from coordinates outside the image) */
+        const int yout = mode == ORC_MODE_GRID_CONSTANT && (sy + j < 0 || sy + j >= Hp);
         for (int i = 0; i <= order; ++i) {
             const int64_t ix = spline_fold(sx + i, Wp, mode);
-            t += (coef[iy * Wp + ix] * wy[j]) * wx[i];
+            const int out = yout || (mode == ORC_MODE_GRID_CONSTANT && (sx + i < 0 || sx + i >= Wp));
+            t += ((out ? 0.0 : coef[iy * Wp + ix]) * wy[j]) * wx[i];
         }
     }
     return t;
+}
+
+/* Spline orders, a caller's coordinate that may lie OUTSIDE the image: what scipy does before it evaluates the spline.
+   'constant' returns cval, 'nearest' and 'grid-constant' evaluate where the coordinate is (taps outside the padded plane
+   clamp to its edge / read cval), every other mode moves the coordinate into the extended image with map_coordinate()
+   of the order 0/1 section.  Returns 1 when the result is cval. */
+static inline int spline_map_point(double *y, double *x, int64_t H, int64_t W, int pad, int mode)
+{
+    if (*y >= 0.0 && *y <= (double)(H - 1) && *x >= 0.0 && *x <= (double)(W - 1)) return 0;
+    (void)pad;
+    /* 'nearest' and 'grid-constant' evaluate where the coordinate is: their taps outside the padded plane clamp to its
+       edge / read cval (scipy does not move the coordinate for these two at the spline orders -- checked against it) */
+    if (mode == ORC_MODE_NEAREST || mode == ORC_MODE_GRID_CONSTANT) return 0;
+    *y = mc_map_coordinate(*y, H, mode);
+    *x = mc_map_coordinate(*x, W, mode);
+    return mode == ORC_MODE_CONSTANT && (*y <= -1.0 || *x <= -1.0);
 }
 
 static inline float spline_sample(const double *coef, int64_t Hp, int64_t Wp, int pad, double y, double x,
@@ -795,9 +817,7 @@ int orc_remap_spline_f32(const float *src, float *dst, int64_t H, int64_t W, int
         for (int64_t i = 0; i < npts; ++i) {
             double y = coord_is_f64 ? ((const double *)ycoord)[i] : (double)((const float *)ycoord)[i];
             double x = coord_is_f64 ? ((const double *)xcoord)[i] : (double)((const float *)xcoord)[i];
-            y = clipd(y, 0.0, (double)(H - 1));
-            x = clipd(x, 0.0, (double)(W - 1));
-            dst[i] = spline_sample(workspace, Hp, Wp, pad, y, x, order, mode);
+            dst[i] = spline_map_point(&y, &x, H, W, pad, mode) ? 0.0f : spline_sample(workspace, Hp, Wp, pad, y, x, order, mode);
         }
         return 0;
     }
@@ -835,6 +855,10 @@ int orc_map_coordinates_typed(const void *src, void *dst, int dtype, int64_t H, 
         double x = coord_is_f64 ? ((const double *)xcoord)[i] : (double)((const float *)xcoord)[i];
         if (order <= 1 && mode != 4 && (y < 0.0 || y > (double)(H - 1) || x < 0.0 || x > (double)(W - 1))) {
             store_typed(dst, dtype, i, mc_sample_outside(src, dtype, H, W, src_row_stride, y, x, order, mode));
+            continue;
+        }
+        if (order >= 2) {
+            store_typed(dst, dtype, i, spline_map_point(&y, &x, H, W, pad, mode) ? 0.0 : spline_sample_d(workspace, Hp, Wp, pad, y, x, order, mode));
             continue;
         }
         y = clipd(y, 0.0, (double)(H - 1));

@@ -748,11 +748,18 @@ def test_explicit_coordinates_match_oracle(hip, orc):
                 assert np.array_equal(got, map_coordinates(img, (yy, xx), order=order, mode=mode)), (mode, order, yy.dtype)
                 assert np.array_equal(got, orc.remap_coords(img, yy, xx, order=order, mode=mode)), (mode, order)
                 assert np.array_equal(got16, map_coordinates(u16, (yy, xx), order=order, mode=mode)), (mode, order, "uint16")
-    with pytest.warns(RuntimeWarning, match="clamped"):
-        clamped = pp.remap_coordinates(img, ys, xs, order=3, mode="reflect")
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")
-        assert np.array_equal(pp.remap_coordinates(img, np.clip(ys, 0, 69), np.clip(xs, 0, 89), order=3, mode="reflect"), clamped)
+    # ... and at the spline orders (scipy's pre-padding for 'nearest' / 'grid-constant' included): equal to the oracle bit for
+    # bit, which is equal to scipy (tests/test_oracle_golden.py)
+    for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+        for order in (2, 3, 4, 5):
+            with warnings.catch_warnings():
+                warnings.simplefilter("error")
+                got = pp.remap_coordinates(img, ys, xs, order=order, mode=mode)
+                got16 = pp.remap_coordinates(u16, ys, xs, order=order, mode=mode)
+            assert np.array_equal(got, orc.remap_coords(img, ys, xs, order=order, mode=mode)), (mode, order)
+            ref = map_coordinates(img, (ys, xs), order=order, mode=mode)
+            assert np.count_nonzero(got != ref) <= 2 and np.max(np.abs(got - ref)) <= 1e-6, (mode, order)
+            assert np.array_equal(got16, orc.map_coordinates(u16, ys, xs, order, mode)), (mode, order, "uint16")
 
 
 def test_device_resident_tensors_take_the_same_path(hip, orc):

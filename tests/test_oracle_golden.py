@@ -151,6 +151,30 @@ def test_g16_map_index_outside_the_image_follows_scipy_modes(orc):
             assert np.array_equal(orc.map_coordinates(u16, yy, xx, order, mode), map_coordinates(u16, (yy, xx), order=order, mode=mode)), (mode, order)
 
 
+def test_explicit_coordinates_outside_the_image_at_spline_orders_follow_scipy(orc):
+    """Orders 2..5: scipy moves a coordinate outside the image into the extended image (or returns cval / evaluates in the
+    padded plane for 'constant', 'nearest', 'grid-constant') before it evaluates the spline; the oracle restates that --
+    compared with scipy itself, float32 and uint16 images, all eight modes."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(11)
+    for shape in ((37, 41), (64, 20)):
+        img = noise(shape[0], shape)
+        u16 = (img * 60000).astype(np.uint16)
+        h, w = shape
+        ys = (rng.random(2500) * h * 7 - h * 3).astype(np.float32)
+        xs = (rng.random(2500) * w * 7 - w * 3).astype(np.float32)
+        ys[:80] = np.linspace(-14.0, h + 13.0, 80)
+        xs[:80] = 17.3
+        for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+            for order in (2, 3, 4, 5):
+                ref = map_coordinates(img, (ys, xs), order=order, mode=mode)
+                got = orc.remap_coords(img, ys, xs, order=order, mode=mode)
+                assert np.count_nonzero(ref != got) <= 2 and np.max(np.abs(ref - got)) <= 1e-6, (shape, mode, order)
+                ref16 = map_coordinates(u16, (ys, xs), order=order, mode=mode).astype(np.int64)
+                got16 = orc.map_coordinates(u16, ys, xs, order, mode).astype(np.int64)
+                assert np.count_nonzero(ref16 != got16) <= 2 and np.max(np.abs(ref16 - got16)) <= 1, (shape, mode, order, "uint16")
+
+
 def test_chunk_equals_image_rows_and_slice_differs(orc):
     """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
     g = golden("g6_stack3x800x1280")
