@@ -108,7 +108,10 @@ __global__ void __launch_bounds__(kSplBlock) spline_causal_kernel(const FilterPa
       double acc = x0 + z_n * (ld(n - 1) * lam);
       const int m = min(n - 1, kHorizon);
       for (int k = 1; k <= m; ++k) {
-        acc += z_i * (ld(k) * lam + z_n * (ld(n - 1 - k) * lam));
+        // (scipy accumulates this sum in c[0], so its last term reads the partial sum where the formula wants sample 0:
+        // see spline_filter_line() in the oracle)
+        const double far = n - 1 - k == 0 ? acc : ld(n - 1 - k) * lam;
+        acc += z_i * (ld(k) * lam + z_n * far);
         z_i *= z;
       }
       t = acc * z / (1.0 - z_i * z_i) + x0;

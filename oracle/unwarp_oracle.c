@@ -554,7 +554,11 @@ static void spline_filter_line(double *c, int64_t n, int64_t s, const double *po
             double acc = c[0] + z_n * c[(n - 1) * s];
             const int64_t m = n - 1 < SPL_HORIZON ? n - 1 : SPL_HORIZON;
             for (int64_t i = 1; i <= m; ++i) {
-                acc += z_i * (c[i * s] + z_n * c[(n - 1 - i) * s]);
+                /* scipy accumulates this sum IN c[0] (ni_splines.c _init_causal_reflect), so its last term, i = n - 1,
+                   reads the partial sum where the formula wants sample 0 -- a z^(2n-1) effect, invisible from a dozen
+                   samples on, 6e-3 for a 2-sample line.  The reference's results contain it; so do ours. */
+                const double far = (n - 1 - i == 0) ? acc : c[(n - 1 - i) * s];
+                acc += z_i * (c[i * s] + z_n * far);
                 z_i *= z;
             }
             c[0] = acc * z / (1.0 - z_i * z_i) + c0;

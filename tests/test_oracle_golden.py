@@ -175,6 +175,26 @@ def test_explicit_coordinates_outside_the_image_at_spline_orders_follow_scipy(or
                 assert np.count_nonzero(ref16 != got16) <= 2 and np.max(np.abs(ref16 - got16)) <= 1, (shape, mode, order, "uint16")
 
 
+def test_spline_orders_on_tiny_images_equal_scipy(orc):
+    """Images of 1 x n, n x 1, 2 x 2 ... 12 x 12 pixels, orders 2..5, eight modes, coordinates inside and outside: the
+    oracle equals scipy to the last bit -- including scipy's reflect-prefilter initialisation, which reads a partial sum
+    where the closed form wants sample 0 (visible only on lines of a few samples)."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(5)
+    for shape in ((2, 2), (3, 5), (5, 64), (1, 30), (33, 1), (8, 9), (12, 12), (2, 40)):
+        img = rng.random(shape, dtype=np.float32)
+        h, w = shape
+        ys = (rng.random(1200) * h * 7 - h * 3).astype(np.float32)
+        xs = (rng.random(1200) * w * 7 - w * 3).astype(np.float32)
+        ys[:400] = (rng.random(400) * (h - 1)).astype(np.float32)
+        xs[:400] = (rng.random(400) * (w - 1)).astype(np.float32)
+        for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+            for order in (2, 3, 4, 5):
+                ref = map_coordinates(img, (ys, xs), order=order, mode=mode)
+                got = orc.remap_coords(img, ys, xs, order=order, mode=mode)
+                assert np.count_nonzero(ref != got) <= 1 and np.max(np.abs(ref - got)) <= 1e-6, (shape, mode, order)
+
+
 def test_chunk_equals_image_rows_and_slice_differs(orc):
     """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
     g = golden("g6_stack3x800x1280")
