@@ -195,6 +195,34 @@ def test_spline_orders_on_tiny_images_equal_scipy(orc):
                 assert np.count_nonzero(ref != got) <= 1 and np.max(np.abs(ref - got)) <= 1e-6, (shape, mode, order)
 
 
+def test_every_element_type_order_and_mode_against_scipy_inside_and_outside(orc):
+    """orc.map_coordinates against scipy.ndimage.map_coordinates itself: eight element types, orders 0..5, eight modes,
+    degenerate shapes, coordinates inside and up to three image sizes outside."""
+    from scipy.ndimage import map_coordinates
+    rng = np.random.default_rng(9)
+    for shape in ((1, 1), (1, 7), (2, 1), (3, 3), (4, 17), (16, 16)):
+        h, w = shape
+        ys = (rng.random(300) * h * 7 - h * 3).astype(np.float32)
+        xs = (rng.random(300) * w * 7 - w * 3).astype(np.float32)
+        ys[:100] = (rng.random(100) * (h - 1)).astype(np.float32)
+        xs[:100] = (rng.random(100) * (w - 1)).astype(np.float32)
+        for dt in (np.float32, np.float64, np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32):
+            if np.dtype(dt).kind == "f":
+                img = (rng.random(shape) * 2000 - 700).astype(dt)
+            else:
+                ii = np.iinfo(dt)
+                img = rng.integers(ii.min, ii.max, size=shape, endpoint=True).astype(dt)
+            for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+                for order in range(6):
+                    ref = map_coordinates(img, (ys, xs), order=order, mode=mode)
+                    got = orc.map_coordinates(img, ys, xs, order, mode)
+                    if np.dtype(dt).kind == "f":
+                        ok = np.allclose(ref, got, rtol=2e-6 if dt == np.float32 else 1e-11, atol=1e-4 if dt == np.float32 else 1e-9)
+                    else:
+                        ok = np.max(np.abs(ref.astype(np.int64) - got.astype(np.int64))) <= (0 if order <= 1 else 1)
+                    assert ok, (shape, np.dtype(dt).name, mode, order)
+
+
 def test_chunk_equals_image_rows_and_slice_differs(orc):
     """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
     g = golden("g6_stack3x800x1280")
