@@ -762,6 +762,30 @@ def test_explicit_coordinates_match_oracle(hip, orc):
             assert np.array_equal(got16, orc.map_coordinates(u16, ys, xs, order, mode)), (mode, order, "uint16")
 
 
+def test_explicit_coordinates_every_type_order_mode_on_degenerate_shapes(hip, orc):
+    """remap_coordinates against the oracle (itself held to scipy in the CPU suite): eight element types, orders 0..5, eight
+    modes, shapes down to 1 x 1, coordinates inside and up to three image sizes outside."""
+    rng = np.random.default_rng(9)
+    for shape in ((1, 1), (1, 7), (2, 1), (3, 3), (4, 17), (16, 16)):
+        h, w = shape
+        ys = (rng.random(300) * h * 7 - h * 3).astype(np.float32)
+        xs = (rng.random(300) * w * 7 - w * 3).astype(np.float32)
+        ys[:100] = (rng.random(100) * (h - 1)).astype(np.float32)
+        xs[:100] = (rng.random(100) * (w - 1)).astype(np.float32)
+        for dt in (np.float32, np.float64, np.uint8, np.int8, np.uint16, np.int16, np.uint32, np.int32):
+            if np.dtype(dt).kind == "f":
+                img = (rng.random(shape) * 2000 - 700).astype(dt)
+            else:
+                ii = np.iinfo(dt)
+                img = rng.integers(ii.min, ii.max, size=shape, endpoint=True).astype(dt)
+            for mode in ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap"):
+                for order in range(6):
+                    got = pp.remap_coordinates(img, ys, xs, order=order, mode=mode, blend="scipy")
+                    want = orc.map_coordinates(img, ys, xs, order, mode) if dt != np.float32 else \
+                        orc.remap_coords(img, ys, xs, order=order, mode=mode)
+                    assert got.dtype == want.dtype and np.array_equal(got, want), (shape, np.dtype(dt).name, mode, order)
+
+
 def test_device_resident_tensors_take_the_same_path(hip, orc):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
