@@ -119,6 +119,15 @@ def test_g16_map_index_outside_the_image_follows_the_reference(hip):
             assert np.array_equal(got, g["%s_o%d" % (mode.replace("-", "_"), order)]), (mode, order)
 
 
+def test_g17_small_frames_every_order_and_mode_equal_the_reference(hip):
+    """Golden G17 through the HIP path: bit-equal to the reference's outputs (scipy's exact blend at order 1)."""
+    from test_oracle_golden import g17_cases
+    g = golden("g17_small_frames_orders_modes")
+    for k, img, xc, yc, fact, order, mode, coef in g17_cases():
+        assert np.array_equal(pp.unwarp_image_backward(img, xc, yc, fact, order=order, mode=mode, blend="scipy"), g["radial_%02d" % k]), (k, order, mode)
+        assert np.array_equal(pp.correct_perspective_image(img, coef, order=order, mode=mode, blend="scipy"), g["persp_%02d" % k]), (k, order, mode)
+
+
 def test_g7_fused_and_two_pass(hip):
     g = golden("g7_fused144")
     img = noise(g["seed"], g["shape"])

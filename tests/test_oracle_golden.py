@@ -223,6 +223,31 @@ def test_every_element_type_order_and_mode_against_scipy_inside_and_outside(orc)
                     assert ok, (shape, np.dtype(dt).name, mode, order)
 
 
+def g17_cases():
+    """The inputs of golden G17 (tools/gen_golden.py g17_case, same draws in the same order)."""
+    modes = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+    rng = np.random.default_rng(1717)
+    for k in range(60):
+        h, w = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+        img = rng.random((h, w), dtype=np.float32)
+        xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
+        fact = [1.0, float(rng.uniform(-2e-3, 2e-3)), float(rng.uniform(-3e-5, 3e-5))]
+        order = int(rng.integers(0, 6))
+        mode = modes[int(rng.integers(0, 8))]
+        coef = [1 + rng.uniform(-.05, .05), rng.uniform(-.05, .05), rng.uniform(-3, 3), rng.uniform(-.05, .05),
+                1 + rng.uniform(-.05, .05), rng.uniform(-3, 3), rng.uniform(-1e-4, 1e-4), rng.uniform(-1e-4, 1e-4)]
+        yield k, img, xc, yc, fact, order, mode, [float(c) for c in coef]
+
+
+def test_g17_small_frames_every_order_and_mode_equal_the_reference(orc):
+    """60 random frames of 2..69 pixels a side, random order 0..5 and boundary mode, radial and perspective: the oracle
+    reproduces the reference's outputs bit for bit (the spline prefilter's boundary handling shows in every pixel here)."""
+    g = golden("g17_small_frames_orders_modes")
+    for k, img, xc, yc, fact, order, mode, coef in g17_cases():
+        assert np.array_equal(orc.unwarp_image_backward(img, xc, yc, fact, order=order, mode=mode), g["radial_%02d" % k]), (k, order, mode)
+        assert np.array_equal(orc.correct_perspective_image(img, coef, order=order, mode=mode), g["persp_%02d" % k]), (k, order, mode)
+
+
 def test_chunk_equals_image_rows_and_slice_differs(orc):
     """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
     g = golden("g6_stack3x800x1280")

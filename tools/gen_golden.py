@@ -355,4 +355,35 @@ def g16():
 
 
 g16()
+
+
+# G17: small random frames (2..69 pixels a side) through unwarp_image_backward and correct_perspective_image at a random
+# order 0..5 and boundary mode -- the regime where the spline prefilter's boundary handling (and scipy's quirks in it) is
+# visible in every pixel.  60 cases; inputs regenerate from the seed.
+def g17_case(rng):
+    h, w = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+    img = rng.random((h, w), dtype=np.float32)
+    xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
+    fact = [1.0, float(rng.uniform(-2e-3, 2e-3)), float(rng.uniform(-3e-5, 3e-5))]
+    order = int(rng.integers(0, 6))
+    mode = MODES_ALL[int(rng.integers(0, 8))]
+    coef = [1 + rng.uniform(-.05, .05), rng.uniform(-.05, .05), rng.uniform(-3, 3), rng.uniform(-.05, .05),
+            1 + rng.uniform(-.05, .05), rng.uniform(-3, 3), rng.uniform(-1e-4, 1e-4), rng.uniform(-1e-4, 1e-4)]
+    return img, xc, yc, fact, order, mode, [float(c) for c in coef]
+
+
+MODES_ALL = ("reflect", "grid-mirror", "constant", "grid-constant", "nearest", "mirror", "grid-wrap", "wrap")
+
+
+def g17():
+    rng = np.random.default_rng(1717)
+    out = {}
+    for k in range(60):
+        img, xc, yc, fact, order, mode, coef = g17_case(rng)
+        out["radial_%02d" % k] = post.unwarp_image_backward(img, xc, yc, fact, order=order, mode=mode)
+        out["persp_%02d" % k] = post.correct_perspective_image(img, coef, order=order, mode=mode)
+    save("g17_small_frames_orders_modes", seed=np.int64(1717), ncases=np.int64(60), **out)
+
+
+g17()
 print("done")
