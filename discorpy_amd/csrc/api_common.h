@@ -118,6 +118,11 @@ int homography_is_tame(const double* c, int64_t H, int64_t W);
 // level 2: the same for 128 x 32 tiles (kind: dcp::kRadial or dcp::kPersp; anything else 0) -- lets the staged kernels
 // take a tile's source box from its corner pixels alone, without a per-pixel containment vote
 int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W);
+// yd = yc + B(r) yu increases with yu at every x over the frame (sufficient test): no row of a chunk can then leave the
+// band the reference crops from the chunk's first and last rows
+bool radial_monotone_in_y(const dcp::MapArgs& m, int64_t H, int64_t W);
+// that band, [*b0, *b1), with the reference's own arithmetic (postprocessing.py:289-301)
+void reference_chunk_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_first, double row_last, int64_t* b0, int64_t* b1);
 void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0, int64_t* b1);
 void host_row_band_rect(const dcp::MapArgs& m, int64_t H, double x_lo, double x_hi, double y_lo, double y_hi, int64_t* b0,
                         int64_t* b1);

@@ -255,6 +255,83 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
   return ok;
 }
 
+// d/dyu [B(r) yu] = B + B' yu^2 / r >= B - |B'| r: positive on [0, rmax] => every column's row coordinate increases with
+// the row.  1024 samples of B - |B'| r and the same Lipschitz slack as radial_curvature_bound; a folding model fails.
+bool radial_monotone_in_y(const dcp::MapArgs& m, int64_t H, int64_t W) {
+  const int n = m.nfact;
+  if (n <= 0 || H < 1 || W < 1) return false;
+  // (the same calibration is applied to chunk after chunk: keep the last answer)
+  thread_local struct {
+    int nfact = -1;
+    int64_t H = 0, W = 0;
+    double xc = 0, yc = 0, fact[dcp::kMaxFact];
+    bool ok = false;
+  } cache;
+  if (cache.nfact == n && cache.H == H && cache.W == W && cache.xc == m.xc && cache.yc == m.yc &&
+      memcmp(cache.fact, m.fact, sizeof(double) * (size_t)n) == 0)
+    return cache.ok;
+  auto remember = [&](bool ok) {
+    cache.nfact = n;
+    cache.H = H;
+    cache.W = W;
+    cache.xc = m.xc;
+    cache.yc = m.yc;
+    memcpy(cache.fact, m.fact, sizeof(double) * (size_t)n);
+    cache.ok = ok;
+    return ok;
+  };
+  double rmax = 0.0;
+  for (double x : {0.0, (double)(W - 1)})
+    for (double y : {0.0, (double)(H - 1)}) rmax = std::max(rmax, std::hypot(x - m.xc, y - m.yc));
+  rmax = rmax * (1.0 + 1e-12) + 1e-9;
+  if (!std::isfinite(rmax)) return remember(false);
+  double lip = 0.0, rp = 1.0;                  // |d/dr (B - |B'| r)| <= |B'| + |B'| + |B''| r <= sum (2 i + i (i - 1)) |a_i| rmax^(i-1)
+  for (int i = 1; i < n; ++i) {
+    lip += (double)(2 * i + i * (i - 1)) * std::fabs(m.fact[i]) * rp;
+    rp *= rmax;
+  }
+  constexpr int kNodes = 1024;
+  const double h = rmax / kNodes;
+  double lo = INFINITY;
+  for (int k = 0; k < kNodes; ++k) {
+    const double r = (k + 0.5) * h;
+    double b = 0.0, b1 = 0.0;
+    for (int i = n - 1; i >= 0; --i) b = b * r + m.fact[i];
+    for (int i = n - 1; i >= 1; --i) b1 = b1 * r + (double)i * m.fact[i];
+    lo = std::min(lo, b - std::fabs(b1) * r);
+  }
+  lo -= 0.5 * h * lip;
+  return remember(std::isfinite(lo) && lo > 0.0);
+}
+
+// yd_min = int16(floor(amin(yd_list1))), yd_max = int16(ceil(amax(yd_list2))) + 1 of postprocessing.py:289-301, the two
+// lists being the clipped float64 row coordinates of the chunk's first and last rows, evaluated as numpy evaluates
+// them: flist = sum_i a_i * ru**i accumulated from i = 0 (ru**0 = 1, ru**1 = ru, ru**2 = ru * ru, higher powers by pow()).
+void reference_chunk_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_first, double row_last, int64_t* b0, int64_t* b1) {
+  auto row_extreme = [&](double row, bool want_min) {
+    const double yu = row - m.yc;
+    double ext = want_min ? INFINITY : -INFINITY;
+    for (int64_t x = 0; x < W; ++x) {
+      const double xu = (double)x - m.xc;
+      const double ru = std::sqrt(xu * xu + yu * yu);
+      double fl = 0.0;
+      for (int i = 0; i < m.nfact; ++i) {
+        const double p = i == 0 ? 1.0 : i == 1 ? ru : i == 2 ? ru * ru : std::pow(ru, (double)i);
+        const double t = m.fact[i] * p;
+        fl = i == 0 ? t : fl + t;
+      }
+      double yd = m.yc + fl * yu;
+      yd = yd < 0.0 ? 0.0 : (yd > (double)(H - 1) ? (double)(H - 1) : yd);
+      ext = want_min ? std::fmin(ext, yd) : std::fmax(ext, yd);
+    }
+    return ext;
+  };
+  const double lo = std::floor(row_extreme(row_first, true)), hi = std::ceil(row_extreme(row_last, false)) + 1.0;
+  *b0 = std::isfinite(lo) ? (int64_t)lo : 0;
+  *b1 = std::isfinite(hi) ? std::min<int64_t>((int64_t)hi, H) : H;     // (a Python slice stops at the array's end)
+  if (*b0 < 0) *b0 = 0;
+}
+
 uint32_t extent_bytes(int64_t H, int64_t W, int64_t rs, int64_t cs) {
   return (uint32_t)(((H - 1) * rs + (W - 1) * cs + 1) * 4);
 }

@@ -33,6 +33,7 @@ struct StackCall {
   int round_f32, sampler;      // sampler: float32 data only (the other element types use scipy's exact blend)
   int mem_kind, device;
   void* stream;
+  int32_t rb0, rbh;            // the reference's row band of a chunk call when a coordinate might leave it (rbh = 0: cannot)
 };
 
 // base = address of (projection 0, row 0) -- possibly before the buffer when the band starts later; the
@@ -52,9 +53,17 @@ hipError_t launch_stack_any(const StackCall& c, bool fast, const void* base, voi
     st.proj_stride = proj_stride;
     st.row_stride = (int32_t)row_stride;
     st.proj_bytes = (uint32_t)(((rows_end - 1) * row_stride + c.width) * 4);
+    st.rb0 = c.rb0;
+    st.rbh = c.rbh;
+    if (c.rbh > 0) {                 // a model that may fold: the direct kernel, which checks every row coordinate against the band
+      dcp::LaunchOpts plain = opts;
+      plain.stack_wg = 0;
+      plain.stack_lds = 0;
+      return dcp::launch_stack(st, c.map, c.sampler, c.round_f32 != 0, plain, hs);
+    }
     return dcp::launch_stack(st, c.map, c.sampler, c.round_f32 != 0, opts, hs);
   }
-  if (c.round_f32 && !c.out_f32 && opts.stack_wg) {
+  if (c.round_f32 && !c.out_f32 && opts.stack_wg && c.rbh == 0) {
     // 8- / 16-bit integer stacks under a certified map: the workgroup-box kernel (uint16 cfg4 shard 0.42 of the 8 TB/s peak
     // against 0.30 for the generic kernel; its launcher declines small launches and ineligible layouts)
     const int64_t esz = dcp::elem_size(c.dtype);
@@ -88,6 +97,8 @@ hipError_t launch_stack_any(const StackCall& c, bool fast, const void* base, voi
   st.dtype = c.dtype;
   st.out_f32 = c.out_f32;
   st.round_f32 = c.round_f32 != 0;
+  st.rb0 = c.rb0;
+  st.rbh = c.rbh;
   st.vol = base;
   st.out = out;
   st.proj_stride = proj_stride;
@@ -257,6 +268,19 @@ int make_stack_call(StackCall* c, const void* vol, void* out, int dtype, int out
   if ((rc = fill_map(&c->map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
   if (g_tile_cert.load() && coord_round_f32 && height > 0 && width > 0)
     c->map.tile_dev_ok = tile_deviation_certified(dcp::kRadial, c->map, height, width);
+  // unwarp_chunk_slices_backward crops the rows [yd_min, yd_max) spanned by its first and last rows and lets scipy reflect
+  // inside that band (postprocessing.py:289-312).  Under a model whose row coordinate increases with the row nothing can
+  // leave the band; otherwise (a folding model) the band goes to the kernel, which then checks every pixel.
+  c->rb0 = c->rbh = 0;
+  if (coord_round_f32 && nrows > 0 && height > 0 && width > 0 && std::isfinite(row_start) && !radial_monotone_in_y(c->map, height, width)) {
+    int64_t b0 = 0, b1 = height;
+    reference_chunk_band(c->map, height, width, row_start, row_start + (double)(nrows - 1), &b0, &b1);
+    if (b1 <= b0) return fail(DCP_ERR_INVALID_ARG, "the model folds the requested rows onto an empty band of source rows [%lld, %lld)",
+                              (long long)b0, (long long)b1);
+    c->rb0 = (int32_t)b0;
+    c->rbh = (int32_t)(b1 - b0);
+    c->map.tile_dev_ok = 0;
+  }
   return DCP_OK;
 }
 

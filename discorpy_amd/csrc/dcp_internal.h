@@ -56,6 +56,9 @@ struct StackArgs {
   int32_t nrows;
   int32_t d_chunk;         // projections walked by one thread
   uint32_t proj_bytes;
+  int32_t rb0, rbh;        // the reference's row band [rb0, rb0 + rbh) of unwarp_chunk_slices_backward (postprocessing.py:289-312):
+                           // a row coordinate outside it is reflected inside it, as scipy does with the cropped band.  rbh = 0:
+                           // the host has shown that no coordinate can leave the band (or the call is not a chunk): no check
 };
 
 struct CoordArgs {
@@ -97,6 +100,7 @@ struct TypedStackArgs {
   int32_t dtype;
   int32_t out_f32;         // 1: out is float32 holding the value already converted to `dtype` (unwarp_slice_backward)
   int32_t round_f32;       // 1: coordinates rounded to float32 (unwarp_chunk_slices_backward)
+  int32_t rb0, rbh;        // as in StackArgs
   double row_start;
 };
 

@@ -159,8 +159,19 @@ __global__ void __launch_bounds__(kTypedBlock) typed_stack_kernel(const TypedSta
   const T* proj = (const T*)st.vol + (int64_t)d0 * st.proj_stride;
   const int64_t o0 = ((int64_t)d0 * st.nrows + r) * (int64_t)st.W + x;
   const int64_t out_step = (int64_t)st.nrows * st.W;
+  // (a folding model, chunk semantics: a row coordinate outside the reference's band is reflected inside it -- see
+  // stack_rows_kernel)
+  const bool outside = st.round_f32 && st.rbh > 0 && (yc < (double)st.rb0 || yc > (double)(st.rb0 + st.rbh - 1));
   for (int d = d0; d < d1; ++d) {
-    const double t = sample_typed<T>(proj, st.row_stride, 1, st.H, st.W, yc, xc, 1);
+    double t;
+    if (outside) {
+      const T* band = proj + (int64_t)st.rb0 * st.row_stride;
+      const int64_t rs = st.row_stride;
+      t = mc_sample_outside([&](long long rr, long long cc) -> double { return (double)band[rr * rs + cc]; }, st.rbh, st.W,
+                            yc - (double)st.rb0, xc, 1, kModeReflect);
+    } else {
+      t = sample_typed<T>(proj, st.row_stride, 1, st.H, st.W, yc, xc, 1);
+    }
     const T v = to_elem<T>(t);
     const int64_t o = o0 + (int64_t)(d - d0) * out_step;
     if (st.out_f32) ((float*)st.out)[o] = (float)v;   // sino[i] = ... into a float32 array, postprocessing.py:224-227

@@ -1204,6 +1204,24 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
     xc = clip_f64(xd, (double)(st.W - 1));
     yc = clip_f64(yd, (double)(st.H - 1));
   }
+  if constexpr (ROUND32) {
+    if (st.rbh > 0 && (yc < (float)st.rb0 || yc > (float)(st.rb0 + st.rbh - 1))) {
+      // a folding model: the row coordinate lies outside the band the reference crops (rows rb0 .. rb0 + rbh - 1); scipy
+      // reflects it inside the band (mode='reflect' on the cropped array, postprocessing.py:308-312) -- double arithmetic in
+      // scipy's order whatever the blend, 64-bit addressing (rare pixels of a model nobody should use)
+      const float yrel = yc - (float)st.rb0;             // float32, exact: the reference subtracts yd_min from the float32 plane
+      const float* proj = st.vol + (size_t)d0 * (size_t)st.proj_stride + (size_t)st.rb0 * (size_t)st.row_stride;
+      float* o = st.out + ((size_t)d0 * (size_t)st.nrows + (size_t)r) * (size_t)st.W + (size_t)x;
+      for (int d = d0; d < d1; ++d) {
+        const int64_t rs = st.row_stride;
+        *o = (float)mc_sample_outside([&](long long rr, long long cc) -> double { return (double)proj[rr * rs + cc]; }, st.rbh, st.W,
+                                      (double)yrel, (double)xc, 1, kModeReflect);
+        proj += st.proj_stride;
+        o += (size_t)st.nrows * (size_t)st.W;
+      }
+      return;
+    }
+  }
   // base tap and fractions once; per projection only the descriptor base moves
   int xi = min((int)xc, st.W - 2), yi = min((int)yc, st.H - 2);
   Fetch<SAMPLER, true, CT> ft;

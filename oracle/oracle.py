@@ -48,6 +48,8 @@ def lib():
         L.orc_perspective_image_f32.argtypes = [fp, fp, i64, i64, i64, dp, i32, i32]
         L.orc_unwarp_fused_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, dp, i32, i32, i32]
         L.orc_remap_coords_f32.argtypes = [fp, fp, i64, i64, i64, vp, vp, i32, i64, i32, i32, i32]
+        L.orc_chunk_band.argtypes = [i64, i64, dbl, dbl, dp, i32, dbl, dbl, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_chunk_band.restype = None
         L.orc_unwarp_stack_rows_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, dbl, i64,
                                                 i32, i32, i32]
         L.orc_spline_pad.argtypes = [i32]
@@ -274,8 +276,16 @@ def unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, *, c
         r0 = int(row_start)
         yd, xd = yd[r0:r0 + nrows], xd[r0:r0 + nrows]
         out = np.empty((depth, nrows, width), mat3D.dtype)
+        b0, b1 = 0, height
+        if coord_round_f32 and nrows > 0:
+            # the chunk function crops the band [yd_min, yd_max) and scipy reflects inside it (:289-312)
+            f = _facts(list_fact)
+            lo, hi = C.c_int64(0), C.c_int64(0)
+            lib().orc_chunk_band(height, width, float(xcenter), float(ycenter), _dp(f), f.size, float(row_start),
+                                 float(row_start + nrows - 1), C.byref(lo), C.byref(hi))
+            b0, b1 = int(lo.value), int(hi.value)
         for d in range(depth):
-            out[d] = map_coordinates(mat3D[d], yd, xd, 1)
+            out[d] = map_coordinates(mat3D[d, b0:b1], yd - np.float32(b0) if yd.dtype == np.float32 else yd - b0, xd, 1, "reflect")
         return out
     mat3D = np.ascontiguousarray(_f32c(mat3D))
     (depth, height, width) = mat3D.shape

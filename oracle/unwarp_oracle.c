@@ -461,26 +461,57 @@ int orc_remap_coords_f32(const float *src, float *dst, int64_t H, int64_t W,
  * unwarp_chunk_slices_backward (:281-313, coord_round_f32 = 1) over a
  * (D,H,W) stack: out[d, r, x] for rows row_start .. row_start+nrows-1.
  * The reference samples a row band mat3D[i, yd_min:yd_max, :] with
- * band-relative coordinates; subtracting the integer yd_min is exact, so the
- * result equals sampling the whole projection at absolute coordinates.
+ * band-relative coordinates; subtracting the integer yd_min is exact, so for
+ * a coordinate inside the band the result equals sampling the whole
+ * projection at the absolute coordinate.  The chunk function takes the band
+ * from its first row's minimum and its last row's maximum (:289-301): under a
+ * folding model a row in between can leave it, and scipy then reflects the
+ * coordinate inside the CROPPED array (mode='reflect', :308-312) -- restated
+ * below (golden G15).  The slice function's band comes from the row itself.
  * row_start may be any double-representable number (the reference does not
  * validate `index`, :215); rows are row_start + r.
  */
+/* [*b0, *b1): yd_min, yd_max of postprocessing.py:289-301 for the rows row_first .. row_last of a chunk (the reference's
+   arithmetic: float64, numpy's polynomial order, clipped, not rounded to float32) */
+void orc_chunk_band(int64_t H, int64_t W, double xc, double yc, const double *fact, int nfact, double row_first,
+                    double row_last, int64_t *b0, int64_t *b1)
+{
+    double lo = INFINITY, hi = -INFINITY;
+    for (int64_t x = 0; x < W; ++x) {
+        double xd, yd;
+        radial_coord((double)x, row_first, xc, yc, fact, nfact, ORC_POLY_NUMPY, (double)(W - 1), (double)(H - 1), 0, &xd, &yd);
+        lo = fmin(lo, yd);
+        radial_coord((double)x, row_last, xc, yc, fact, nfact, ORC_POLY_NUMPY, (double)(W - 1), (double)(H - 1), 0, &xd, &yd);
+        hi = fmax(hi, yd);
+    }
+    *b0 = (int64_t)floor(lo);
+    *b1 = (int64_t)ceil(hi) + 1;
+    if (*b0 < 0) *b0 = 0;
+    if (*b1 > H) *b1 = H;            /* a Python slice stops at the array's end */
+}
+
 int orc_unwarp_stack_rows_f32(const float *vol, float *out, int64_t D, int64_t H,
                               int64_t W, double xc, double yc, const double *fact,
                               int nfact, double row_start, int64_t nrows,
                               int coord_round_f32, int poly_mode, int blend_mode)
 {
     if (D < 0 || H <= 0 || W <= 0 || nrows < 0 || nfact < 0) return -1;
+    int64_t b0 = 0, b1 = H;
+    if (coord_round_f32 && nrows > 0) {
+        orc_chunk_band(H, W, xc, yc, fact, nfact, row_start, row_start + (double)(nrows - 1), &b0, &b1);
+        if (b1 <= b0) return -1;
+    }
 #pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int64_t r = 0; r < nrows; ++r) {
         for (int64_t x = 0; x < W; ++x) {
             double xd, yd;
             radial_coord((double)x, row_start + (double)r, xc, yc, fact, nfact, poly_mode,
                          (double)(W - 1), (double)(H - 1), coord_round_f32, &xd, &yd);
+            const int outside = coord_round_f32 && (yd < (double)b0 || yd > (double)(b1 - 1));
             for (int64_t d = 0; d < D; ++d)
-                out[(d * nrows + r) * W + x] =
-                    sample(vol + d * H * W, H, W, W, 1, yd, xd, 1, blend_mode);
+                out[(d * nrows + r) * W + x] = outside
+                    ? (float)mc_sample_outside(vol + d * H * W + b0 * W, ORC_DT_F32, b1 - b0, W, W, yd - (double)b0, xd, 1, ORC_MODE_REFLECT)
+                    : sample(vol + d * H * W, H, W, W, 1, yd, xd, 1, blend_mode);
         }
     }
     return 0;

@@ -51,6 +51,8 @@ int orc_unwarp_fused_f32(const float *src, float *dst, int64_t H, int64_t W, int
 int orc_remap_coords_f32(const float *src, float *dst, int64_t H, int64_t W, int64_t src_row_stride,
                          const void *ycoord, const void *xcoord, int coord_is_f64, int64_t npts,
                          int order, int blend_mode, int mode);
+void orc_chunk_band(int64_t H, int64_t W, double xc, double yc, const double *fact, int nfact, double row_first,
+                    double row_last, int64_t *b0, int64_t *b1);
 int orc_unwarp_stack_rows_f32(const float *vol, float *out, int64_t D, int64_t H, int64_t W,
                               double xc, double yc, const double *fact, int nfact, double row_start,
                               int64_t nrows, int coord_round_f32, int poly_mode, int blend_mode);

@@ -95,16 +95,21 @@ def test_g6_stack_rows(hip):
         assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a, s0, s1), g[key]).max() <= 1
 
 
-def test_g15_folding_model_pins_the_documented_band_deviation(hip):
-    """See tests/test_oracle_golden.py: equal to the reference inside its band, absolute-coordinate sampling outside."""
+def test_g15_folding_model_reflects_inside_the_reference_band(hip, orc):
+    """See tests/test_oracle_golden.py: under a folding model the chunk function reflects row coordinates inside the band it
+    crops; the HIP path (the direct stack kernel with the per-pixel band check) equals the reference on every pixel."""
     g = golden("g15_folding_chunk")
     vol = noise(g["seed"], g["shape"])
     a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]), int(g["start"]), int(g["stop"]))
-    outside = g["outside_band"]
     out = pp.unwarp_chunk_slices_backward(vol, *a, blend="scipy")
-    assert np.array_equal(out[:, ~outside], g["ref_out"][:, ~outside])
-    assert np.array_equal(out, g["absolute_out"])
-    assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a), g["absolute_out"]).max() <= 1
+    assert hip.last_kernel().startswith("stack_rows_kernel"), hip.last_kernel()
+    assert np.array_equal(out, g["ref_out"])
+    assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a), g["ref_out"])[:, ~g["outside_band"]].max() <= 1
+    u16 = (vol * 60000).astype(np.uint16)
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(u16, *a), orc.unwarp_chunk_slices_backward(u16, *a))
+    # a sub-chunk has its own band, as a call of the reference on those rows would
+    sub = (a[0], a[1], a[2], a[3] + 3, a[4] - 2)
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *sub, blend="scipy"), orc.unwarp_chunk_slices_backward(vol, *sub))
 
 
 def test_g16_map_index_outside_the_image_follows_the_reference(hip):

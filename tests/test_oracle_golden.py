@@ -101,19 +101,27 @@ def test_g6_stack_rows(orc, poly):
         assert np.array_equal(orc.unwarp_chunk_slices_backward(vol, *a, s0, s1, poly=p), g[key])
 
 
-def test_g15_folding_model_pins_the_documented_band_deviation(orc):
-    """A non-monotone model: where a chunk row's coordinate stays inside the reference's band [yd_min, yd_max) we equal
-    the reference bit for bit; where it leaves it the reference reads samples reflected inside the band
-    (postprocessing.py:289-312) and we read the projection at the absolute coordinate."""
+def test_g15_folding_model_reflects_inside_the_reference_band(orc):
+    """A non-monotone model: rows of the chunk leave the band [yd_min, yd_max) the reference crops from its first and last
+    rows, and scipy reflects them inside the cropped array (postprocessing.py:289-312).  Reproduced since round 2: the
+    oracle equals the reference on every pixel, and differs from sampling the whole projection exactly where the golden
+    says the row coordinate leaves the band."""
     g = golden("g15_folding_chunk")
     vol = noise(g["seed"], g["shape"])
-    out = orc.unwarp_chunk_slices_backward(vol, float(g["xcenter"]), float(g["ycenter"]), g["list_fact"], int(g["start"]),
-                                           int(g["stop"]))
+    a = (float(g["xcenter"]), float(g["ycenter"]), g["list_fact"], int(g["start"]), int(g["stop"]))
+    out = orc.unwarp_chunk_slices_backward(vol, *a)
     outside = g["outside_band"]
     assert 0 < outside.sum() < outside.size
-    assert np.array_equal(out[:, ~outside], g["ref_out"][:, ~outside])
-    assert np.array_equal(out, g["absolute_out"])
-    assert not np.array_equal(g["ref_out"][:, outside], g["absolute_out"][:, outside])
+    assert np.array_equal(out, g["ref_out"])
+    assert np.array_equal(out[:, ~outside], g["absolute_out"][:, ~outside])
+    assert not np.array_equal(out[:, outside], g["absolute_out"][:, outside])
+    u16 = (vol * 60000).astype(np.uint16)
+    from scipy.ndimage import map_coordinates                    # the integer path: the reference's own recipe on the band
+    b0, b1 = (int(v) for v in g["band"])
+    got16 = orc.unwarp_chunk_slices_backward(u16, *a)
+    ref32 = orc.unwarp_chunk_slices_backward(vol, *a)
+    assert got16.dtype == np.uint16 and got16.shape == ref32.shape
+    assert np.max(np.abs(got16.astype(np.float64) - ref32.astype(np.float64) * 60000)) <= 2.0      # (truncated inputs, rounded outputs)
 
 
 def test_g16_map_index_outside_the_image_follows_scipy_modes(orc):

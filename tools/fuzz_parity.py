@@ -135,8 +135,20 @@ def one_case(rng, k):
         xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
         fact = rand_fact(rng, h, w)[:8]
         tag += " rows %d..%d depth %d xc=%r yc=%r fact=%r" % (r0, r1, d, xc, yc, fact)
-        same(pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **kw),
-             orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **okw), 1, tag + " chunk")
+        try:
+            got = pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **kw)
+        except ValueError as e:
+            # a model that folds the chunk's rows onto an EMPTY band of source rows (yd_min >= yd_max): the reference would
+            # hand scipy a zero-row array; library and oracle both refuse
+            assert "empty band" in str(e), tag
+            try:
+                orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **okw)
+            except Exception:      # noqa: BLE001
+                got = None
+            else:
+                raise AssertionError(tag + ": the library refused an empty band the oracle accepts")
+        if got is not None:
+            same(got, orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **okw), 1, tag + " chunk")
         same(pp.unwarp_slice_backward(vol, xc, yc, fact, r0, **kw),
              orc.unwarp_slice_backward(vol, xc, yc, fact, r0, **okw), 1, tag + " slice")
     elif kind == "coords":
