@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(kTypedBlock) typed_stack_kernel(const TypedSta
       const T* band = proj + (int64_t)st.rb0 * st.row_stride;
       const int64_t rs = st.row_stride;
       t = mc_sample_outside([&](long long rr, long long cc) -> double { return (double)band[rr * rs + cc]; }, st.rbh, st.W,
-                            yc - (double)st.rb0, xc, 1, kModeReflect);
+                            (double)((float)yc - (float)st.rb0), xc, 1, kModeReflect);      // (a float32 subtraction in the reference)
     } else {
       t = sample_typed<T>(proj, st.row_stride, 1, st.H, st.W, yc, xc, 1);
     }

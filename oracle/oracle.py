@@ -284,8 +284,10 @@ def unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, *, c
             lib().orc_chunk_band(height, width, float(xcenter), float(ycenter), _dp(f), f.size, float(row_start),
                                  float(row_start + nrows - 1), C.byref(lo), C.byref(hi))
             b0, b1 = int(lo.value), int(hi.value)
+        # (yd_mat - yd_min is a float32 subtraction in the chunk function, :305-307; the slice function subtracts in float64)
+        yrel = (yd.astype(np.float32) - np.float32(b0)) if coord_round_f32 else yd - b0
         for d in range(depth):
-            out[d] = map_coordinates(mat3D[d, b0:b1], yd - np.float32(b0) if yd.dtype == np.float32 else yd - b0, xd, 1, "reflect")
+            out[d] = map_coordinates(mat3D[d, b0:b1], yrel, xd.astype(np.float32) if coord_round_f32 else xd, 1, "reflect")
         return out
     mat3D = np.ascontiguousarray(_f32c(mat3D))
     (depth, height, width) = mat3D.shape

@@ -510,7 +510,9 @@ int orc_unwarp_stack_rows_f32(const float *vol, float *out, int64_t D, int64_t H
             const int outside = coord_round_f32 && (yd < (double)b0 || yd > (double)(b1 - 1));
             for (int64_t d = 0; d < D; ++d)
                 out[(d * nrows + r) * W + x] = outside
-                    ? (float)mc_sample_outside(vol + d * H * W + b0 * W, ORC_DT_F32, b1 - b0, W, W, yd - (double)b0, xd, 1, ORC_MODE_REFLECT)
+                    /* (yd_mat - yd_min is a float32 subtraction in the reference, :305-307: exact inside the band, rounded
+                       when the difference is larger in magnitude than the coordinate) */
+                    ? (float)mc_sample_outside(vol + d * H * W + b0 * W, ORC_DT_F32, b1 - b0, W, W, (double)((float)yd - (float)b0), xd, 1, ORC_MODE_REFLECT)
                     : sample(vol + d * H * W, H, W, W, 1, yd, xd, 1, blend_mode);
         }
     }

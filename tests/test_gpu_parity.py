@@ -105,8 +105,12 @@ def test_g15_folding_model_reflects_inside_the_reference_band(hip, orc):
     assert hip.last_kernel().startswith("stack_rows_kernel"), hip.last_kernel()
     assert np.array_equal(out, g["ref_out"])
     assert ulp_diff(pp.unwarp_chunk_slices_backward(vol, *a), g["ref_out"])[:, ~g["outside_band"]].max() <= 1
-    u16 = (vol * 60000).astype(np.uint16)
-    assert np.array_equal(pp.unwarp_chunk_slices_backward(u16, *a), orc.unwarp_chunk_slices_backward(u16, *a))
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(vol.astype(np.float64), *a), g["ref_out_f64"])
+    assert np.array_equal(pp.unwarp_chunk_slices_backward((vol * 60000).astype(np.uint16), *a), g["ref_out_u16"])
+    vol2 = noise(g["case2_seed"], g["case2_shape"])
+    a2 = (float(g["case2_xcenter"]), float(g["case2_ycenter"]), list(g["case2_list_fact"]), int(g["case2_rows"][0]), int(g["case2_rows"][1]))
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(vol2, *a2, blend="scipy"), g["case2_ref_out"])
+    assert np.array_equal(pp.unwarp_chunk_slices_backward(vol2.astype(np.float64), *a2), g["case2_ref_out_f64"])
     # a sub-chunk has its own band, as a call of the reference on those rows would
     sub = (a[0], a[1], a[2], a[3] + 3, a[4] - 2)
     assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *sub, blend="scipy"), orc.unwarp_chunk_slices_backward(vol, *sub))

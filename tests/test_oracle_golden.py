@@ -115,13 +115,14 @@ def test_g15_folding_model_reflects_inside_the_reference_band(orc):
     assert np.array_equal(out, g["ref_out"])
     assert np.array_equal(out[:, ~outside], g["absolute_out"][:, ~outside])
     assert not np.array_equal(out[:, outside], g["absolute_out"][:, outside])
-    u16 = (vol * 60000).astype(np.uint16)
-    from scipy.ndimage import map_coordinates                    # the integer path: the reference's own recipe on the band
-    b0, b1 = (int(v) for v in g["band"])
-    got16 = orc.unwarp_chunk_slices_backward(u16, *a)
-    ref32 = orc.unwarp_chunk_slices_backward(vol, *a)
-    assert got16.dtype == np.uint16 and got16.shape == ref32.shape
-    assert np.max(np.abs(got16.astype(np.float64) - ref32.astype(np.float64) * 60000)) <= 2.0      # (truncated inputs, rounded outputs)
+    # other element types (output dtype = input dtype), and a geometry whose rows leave the band far on the low side, where
+    # the reference's float32 subtraction yd_mat - yd_min rounds
+    assert np.array_equal(orc.unwarp_chunk_slices_backward(vol.astype(np.float64), *a), g["ref_out_f64"])
+    assert np.array_equal(orc.unwarp_chunk_slices_backward((vol * 60000).astype(np.uint16), *a), g["ref_out_u16"])
+    vol2 = noise(g["case2_seed"], g["case2_shape"])
+    a2 = (float(g["case2_xcenter"]), float(g["case2_ycenter"]), g["case2_list_fact"], int(g["case2_rows"][0]), int(g["case2_rows"][1]))
+    assert np.array_equal(orc.unwarp_chunk_slices_backward(vol2, *a2), g["case2_ref_out"])
+    assert np.array_equal(orc.unwarp_chunk_slices_backward(vol2.astype(np.float64), *a2), g["case2_ref_out_f64"])
 
 
 def test_g16_map_index_outside_the_image_follows_scipy_modes(orc):

@@ -325,9 +325,20 @@ def g15():
     assert outside.any() and not outside.all()
     assert np.array_equal(ref[:, ~outside], absolute[:, ~outside])
     assert not np.array_equal(ref[:, outside], absolute[:, outside])
+    # the same chunk of a float64 and a uint16 stack (output dtype = input dtype): rows BELOW the band get a band-relative
+    # coordinate larger in magnitude than the absolute one, where the reference's float32 subtraction yd_mat - yd_min rounds
+    ref_f64 = post.unwarp_chunk_slices_backward(vol.astype(np.float64), xc, yc, fact, start, stop)
+    ref_u16 = post.unwarp_chunk_slices_backward((vol * 60000).astype(np.uint16), xc, yc, fact, start, stop)
+    # a second geometry whose rows leave the band on the low side by more than the coordinate itself
+    vol2 = np.random.default_rng(1516).random((2, 55, 58), dtype=np.float32)
+    case2 = (29.3, 8.4, [0.9105341112829652, -0.011490848185174918, -0.0006863296016646205], 46, 52)
+    ref2 = post.unwarp_chunk_slices_backward(vol2, *case2)
+    ref2_f64 = post.unwarp_chunk_slices_backward(vol2.astype(np.float64), *case2)
     save("g15_folding_chunk", seed=np.int64(1515), shape=np.array([d, h, w]), xcenter=f64(xc), ycenter=f64(yc),
          list_fact=f64(fact), start=np.int64(start), stop=np.int64(stop), ref_out=ref, outside_band=outside,
-         absolute_out=absolute.astype(np.float32), band=np.array([yd_min, yd_max]))
+         absolute_out=absolute.astype(np.float32), band=np.array([yd_min, yd_max]), ref_out_f64=ref_f64, ref_out_u16=ref_u16,
+         case2_seed=np.int64(1516), case2_shape=np.array([2, 55, 58]), case2_xcenter=f64(case2[0]), case2_ycenter=f64(case2[1]),
+         case2_list_fact=f64(case2[2]), case2_rows=np.array(case2[3:]), case2_ref_out=ref2, case2_ref_out_f64=ref2_f64)
 
 
 g15()
