@@ -67,6 +67,8 @@ def test_abi_rejects_bad_arguments_before_any_gpu_work():
         L.dcp_unwarp_image_f32(p, p, 4, 4, 4, 1, 0.0, 0.0, fa, n, 1, 1, 7, F.MEM_HOST, -1, None),
         L.dcp_perspective_image_f32(p, p, 4, 4, 4, 1, None, 1, 0, F.MEM_HOST, -1, None),
         L.dcp_remap_coords_f32(p, p, 4, 4, 4, 1, p, p, 5, 16, 1, 0, F.MEM_HOST, -1, None),
+        L.dcp_remap_coords_mode_f32(p, p, 4, 4, 4, 1, p, p, 0, 16, 1, 8, 0, F.MEM_HOST, -1, None),     # boundary mode 8
+        L.dcp_remap_coords_mode_f32(p, p, 4, 4, 4, 1, p, p, 0, -1, 1, 0, 0, F.MEM_HOST, -1, None),     # npts < 0
         L.dcp_unwarp_stack_rows_f32(p, p, 1, 4, 4, 16, 2, 0.0, 0.0, fa, n, 0.0, 1, 1, 0, F.MEM_HOST, -1, None),
     ]
     assert all(rc == F.ERR_INVALID_ARG for rc in bad), bad
