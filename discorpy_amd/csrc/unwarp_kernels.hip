@@ -114,14 +114,30 @@ __device__ __forceinline__ Fetch<SAMPLER, PAIR, CT> fetch(const SrcView& s, CT x
 }
 
 // The three order-1 arithmetics (same as sample() in oracle/unwarp_oracle.c).
-template <int SAMPLER, bool PAIR, typename CT>
+// EDGE = false: the caller knows both fractions are below 1 (tiles strictly inside the image)
+template <int SAMPLER, bool PAIR, typename CT, bool EDGE = true>
 __device__ __forceinline__ float finish(const Fetch<SAMPLER, PAIR, CT>& f) {
   const float v00 = __uint_as_float(f.a.x), v01 = __uint_as_float(f.a.y);
   const float v10 = __uint_as_float(f.b.x), v11 = __uint_as_float(f.b.y);
   if constexpr (SAMPLER == kNearest) {
     return v00;
   } else if constexpr (SAMPLER == kScipy) {
-    // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right
+    // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right.
+    // At the far edge the gather holds the base tap at len - 2 and the fraction is 1, where scipy's taps are (len - 1,
+    // len - 1 folded) with fraction 0: the same value for finite data, but scipy's zero-weight tap is the edge pixel itself.
+    // Take it too, so that a non-finite pixel at len - 2 does not reach a clipped coordinate (0 * NaN).
+    float v00 = __uint_as_float(f.a.x), v01 = __uint_as_float(f.a.y);
+    float v10 = __uint_as_float(f.b.x), v11 = __uint_as_float(f.b.y);
+    if constexpr (EDGE) {
+      if (f.fx == (CT)1) {
+        v00 = v01;
+        v10 = v11;
+      }
+      if (f.fy == (CT)1) {
+        v00 = v10;
+        v01 = v11;
+      }
+    }
     const double fx = (double)f.fx, fy = (double)f.fy;
     const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
     const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
@@ -688,7 +704,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, (KIND == kFused && NF < 0) ? 3 : 
           f.a.y = __float_as_uint(t[1]);
           f.b.x = __float_as_uint(t[kBoxW]);
           f.b.y = __float_as_uint(t[kBoxW + 1]);
-          v = finish<SAMPLER, true, float>(f);
+          v = finish<SAMPLER, true, float, !decltype(inner)::value>(f);
         }
 #if defined(DCP_EXPERIMENT_NO_STORE)     // timing experiment only: the value is computed, the store (practically) never happens
         if (__float_as_uint(v) == 0x7fc12345u)
@@ -1017,7 +1033,7 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
             f.a.y = __float_as_uint(t[1]);
             f.b.x = __float_as_uint(t[kBoxWEl]);
             f.b.y = __float_as_uint(t[kBoxWEl + 1]);
-            v = finish<SAMPLER, true, float>(f);
+            v = finish<SAMPLER, true, float, !decltype(inner)::value>(f);
           }
           if (decltype(full)::value || k < rows)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);

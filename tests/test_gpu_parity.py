@@ -804,6 +804,35 @@ def test_explicit_coordinates_every_type_order_mode_on_degenerate_shapes(hip, or
                     assert got.dtype == want.dtype and np.array_equal(got, want), (shape, np.dtype(dt).name, mode, order)
 
 
+def test_non_finite_pixels_next_to_a_clipped_edge_scipy_blend(hip, orc):
+    """Coordinates clipped to the last column / row read (len - 1, len - 1 folded) in scipy: a NaN or Inf at len - 2 must not
+    reach them through a zero weight.  The scipy blend reproduces that (staged and direct kernels, frames and stacks); compared
+    with the oracle, which is scipy's arithmetic."""
+    from scipy.ndimage import map_coordinates
+    for shape in ((300, 517), (64, 4096)):
+        h, w = shape
+        img = noise(5, shape)
+        img[:, w - 2] = np.nan
+        img[h - 2, :] = np.inf
+        img[7, 9] = -np.inf
+        a = (img, 0.75 * w, 0.7 * h, [1.08, 2.0e-4])            # magnifying model: a band of pixels clips to the right / bottom edge
+        want = orc.unwarp_image_backward(*a, poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY)
+        assert np.isfinite(want[:, -1]).sum() > h // 4              # (clipped pixels stay finite in scipy's arithmetic)
+        for opts in ({}, {"wg_box": 0}, {"lds_gather": 0}):
+            try:
+                for k, v in opts.items():
+                    hip.set_option(k, v)
+                got = pp.unwarp_image_backward(*a, blend="scipy")
+            finally:
+                for k in opts:
+                    hip.set_option(k, 1)
+            assert np.array_equal(got, want, equal_nan=True), (shape, opts, hip.last_kernel())
+        vol = np.stack([img, img[::-1].copy()])
+        got = pp.unwarp_chunk_slices_backward(vol, a[1], a[2], a[3], h // 2, h - 1, blend="scipy")
+        want = orc.unwarp_chunk_slices_backward(vol, a[1], a[2], a[3], h // 2, h - 1, poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY)
+        assert np.array_equal(got, want, equal_nan=True), shape
+
+
 def test_device_resident_tensors_take_the_same_path(hip, orc):
     torch = pytest.importorskip("torch")
     if not torch.cuda.is_available():
