@@ -114,17 +114,20 @@ __device__ __forceinline__ Fetch<SAMPLER, PAIR, CT> fetch(const SrcView& s, CT x
 }
 
 // The three order-1 arithmetics (same as sample() in oracle/unwarp_oracle.c).
-// EDGE = false: the caller knows both fractions are below 1 (tiles strictly inside the image).
-// At the far edge the gather holds the base tap at len - 2 and the fraction is 1, where scipy's taps are (len - 1,
-// len - 1 folded) with fraction 0: the same value for finite data, but scipy's zero-weight tap is the edge pixel itself.
-// Every blend takes that tap too, so that a non-finite pixel at len - 2 does not reach a clipped coordinate (0 * NaN).
+// EDGE = false: the caller knows both fractions are below 1 (tiles strictly inside the image)
 template <int SAMPLER, bool PAIR, typename CT, bool EDGE = true>
 __device__ __forceinline__ float finish(const Fetch<SAMPLER, PAIR, CT>& f) {
-  float v00 = __uint_as_float(f.a.x), v01 = __uint_as_float(f.a.y);
-  float v10 = __uint_as_float(f.b.x), v11 = __uint_as_float(f.b.y);
+  const float v00 = __uint_as_float(f.a.x), v01 = __uint_as_float(f.a.y);
+  const float v10 = __uint_as_float(f.b.x), v11 = __uint_as_float(f.b.y);
   if constexpr (SAMPLER == kNearest) {
     return v00;
-  } else {
+  } else if constexpr (SAMPLER == kScipy) {
+    // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right.
+    // At the far edge the gather holds the base tap at len - 2 and the fraction is 1, where scipy's taps are (len - 1,
+    // len - 1 folded) with fraction 0: the same value for finite data, but scipy's zero-weight tap is the edge pixel itself.
+    // Take it too, so that a non-finite pixel at len - 2 does not reach a clipped coordinate (0 * NaN).
+    float v00 = __uint_as_float(f.a.x), v01 = __uint_as_float(f.a.y);
+    float v10 = __uint_as_float(f.b.x), v11 = __uint_as_float(f.b.y);
     if constexpr (EDGE) {
       if (f.fx == (CT)1) {
         v00 = v01;
@@ -135,28 +138,25 @@ __device__ __forceinline__ float finish(const Fetch<SAMPLER, PAIR, CT>& f) {
         v01 = v11;
       }
     }
-    if constexpr (SAMPLER == kScipy) {
-      // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right
-      const double fx = (double)f.fx, fy = (double)f.fy;
-      const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
-      const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
-      double acc = ((double)v00 * wy0) * wx0;
-      acc += ((double)v01 * wy0) * wx1;
-      acc += ((double)v10 * wy1) * wx0;
-      acc += ((double)v11 * wy1) * wx1;
-      return (float)acc;
-    } else if constexpr (SAMPLER == kF64Lerp) {
-      const double fx = (double)f.fx, fy = (double)f.fy;
-      const double a = (double)v00, b = (double)v01, c = (double)v10, d = (double)v11;
-      const double top = __builtin_fma(fx, b - a, a);
-      const double bot = __builtin_fma(fx, d - c, c);
-      return (float)__builtin_fma(fy, bot - top, top);
-    } else {
-      const float fx = (float)f.fx, fy = (float)f.fy;
-      const float top = __builtin_fmaf(fx, v01 - v00, v00);
-      const float bot = __builtin_fmaf(fx, v11 - v10, v10);
-      return __builtin_fmaf(fy, bot - top, top);
-    }
+    const double fx = (double)f.fx, fy = (double)f.fy;
+    const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
+    const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
+    double acc = ((double)v00 * wy0) * wx0;
+    acc += ((double)v01 * wy0) * wx1;
+    acc += ((double)v10 * wy1) * wx0;
+    acc += ((double)v11 * wy1) * wx1;
+    return (float)acc;
+  } else if constexpr (SAMPLER == kF64Lerp) {
+    const double fx = (double)f.fx, fy = (double)f.fy;
+    const double a = (double)v00, b = (double)v01, c = (double)v10, d = (double)v11;
+    const double top = __builtin_fma(fx, b - a, a);
+    const double bot = __builtin_fma(fx, d - c, c);
+    return (float)__builtin_fma(fy, bot - top, top);
+  } else {
+    const float fx = (float)f.fx, fy = (float)f.fy;
+    const float top = __builtin_fmaf(fx, v01 - v00, v00);
+    const float bot = __builtin_fmaf(fx, v11 - v10, v10);
+    return __builtin_fmaf(fy, bot - top, top);
   }
 }
 

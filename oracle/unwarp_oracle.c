@@ -188,8 +188,13 @@ static inline float sample(const float *src, int64_t H, int64_t W,
     int64_t iy1 = fold_edge(iy0 + 1, H), ix1 = fold_edge(ix0 + 1, W);
     iy0 = fold_edge(iy0, H);
     ix0 = fold_edge(ix0, W);
-    /* (every blend reads scipy's taps: at the far edge (len-1, folded len-1) with fraction 0 -- the HIP gather holds its
-       base tap at len-2 with fraction 1 and substitutes the edge pixel for the zero-weight tap, the same value) */
+    if (blend_mode != ORC_BLEND_SCIPY) {
+        /* the factorised forms are defined on the base tap the HIP gather uses: x0 <= W-2,
+           y0 <= H-2, so that at the far edge the fraction is 1 on (len-2, len-1) rather than
+           0 on (len-1, folded len-1) */
+        if (W >= 2 && ix0 > W - 2) { ix0 = W - 2; ix1 = W - 1; fx = x - (double)ix0; }
+        if (H >= 2 && iy0 > H - 2) { iy0 = H - 2; iy1 = H - 1; fy = y - (double)iy0; }
+    }
     float v00 = src[iy0 * rs + ix0 * cs], v01 = src[iy0 * rs + ix1 * cs];
     float v10 = src[iy1 * rs + ix0 * cs], v11 = src[iy1 * rs + ix1 * cs];
     if (blend_mode == ORC_BLEND_SCIPY) {
