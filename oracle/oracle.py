@@ -43,6 +43,7 @@ def lib():
         L.orc_max_threads.restype = i32
         L.orc_get_threads.restype = i32
         L.orc_radial_coords.argtypes = [i64, i64, dbl, dbl, dp, i32, i32, i32, dp, dp]
+        L.orc_radial_coords_rows.argtypes = [i64, i64, dbl, dbl, dp, i32, i32, i32, dbl, i64, dp, dp]
         L.orc_perspective_coords.argtypes = [i64, i64, dp, i32, dp, dp]
         L.orc_unwarp_image_f32.argtypes = [fp, fp, i64, i64, i64, dbl, dbl, dp, i32, i32, i32, i32, i32]
         L.orc_perspective_image_f32.argtypes = [fp, fp, i64, i64, i64, dp, i32, i32]
@@ -272,9 +273,11 @@ def unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, *, c
         # :303-309 build them), then one map_coordinates per projection in the input's dtype (:226-228, :310-312)
         mat3D = np.asarray(mat3D)
         (depth, height, width) = mat3D.shape
-        yd, xd = radial_coords(height, width, xcenter, ycenter, list_fact, poly=poly, round_f32=coord_round_f32)
-        r0 = int(row_start)
-        yd, xd = yd[r0:r0 + nrows], xd[r0:r0 + nrows]
+        f = _facts(list_fact)
+        yd = np.empty((nrows, width), np.float64)
+        xd = np.empty((nrows, width), np.float64)
+        _check(lib().orc_radial_coords_rows(height, width, float(xcenter), float(ycenter), _dp(f), f.size, poly,
+                                            int(coord_round_f32), float(row_start), nrows, _dp(yd), _dp(xd)))
         out = np.empty((depth, nrows, width), mat3D.dtype)
         b0, b1 = 0, height
         if coord_round_f32 and nrows > 0:

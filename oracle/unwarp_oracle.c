@@ -235,6 +235,19 @@ int orc_radial_coords(int64_t H, int64_t W, double xc, double yc,
     return 0;
 }
 
+/* the same for nrows output rows row_start, row_start + 1, ... of an (H, W) frame -- row_start any real number, as the
+   slice function's `index` (not validated by the reference, postprocessing.py:215) */
+int orc_radial_coords_rows(int64_t H, int64_t W, double xc, double yc, const double *fact, int nfact, int poly_mode,
+                           int round_f32, double row_start, int64_t nrows, double *yd, double *xd)
+{
+    if (H < 0 || W < 0 || nfact < 0 || nrows < 0) return -1;
+    for (int64_t r = 0; r < nrows; ++r)
+        for (int64_t x = 0; x < W; ++x)
+            radial_coord((double)x, row_start + (double)r, xc, yc, fact, nfact, poly_mode,
+                         (double)(W - 1), (double)(H - 1), round_f32, &xd[r * W + x], &yd[r * W + x]);
+    return 0;
+}
+
 int orc_perspective_coords(int64_t H, int64_t W, const double *coef,
                            int round_f32, double *yd, double *xd)
 {

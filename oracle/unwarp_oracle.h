@@ -37,6 +37,8 @@ void orc_set_threads(int n);
 int orc_get_threads(void);
 int orc_max_threads(void);
 
+int orc_radial_coords_rows(int64_t H, int64_t W, double xc, double yc, const double *fact, int nfact, int poly_mode,
+                           int round_f32, double row_start, int64_t nrows, double *yd, double *xd);
 int orc_radial_coords(int64_t H, int64_t W, double xc, double yc, const double *fact, int nfact,
                       int poly_mode, int round_f32, double *yd, double *xd);
 int orc_perspective_coords(int64_t H, int64_t W, const double *coef, int round_f32, double *yd, double *xd);

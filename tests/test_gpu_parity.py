@@ -137,6 +137,14 @@ def test_g17_small_frames_every_order_and_mode_equal_the_reference(hip):
         assert np.array_equal(pp.correct_perspective_image(img, coef, order=order, mode=mode, blend="scipy"), g["persp_%02d" % k]), (k, order, mode)
 
 
+def test_g18_slice_with_any_index_equals_the_reference(hip):
+    from test_oracle_golden import g18_cases
+    g = golden("g18_slice_any_index")
+    for t, vol, xc, yc, fact, idx in g18_cases():
+        out = pp.unwarp_slice_backward(vol, xc, yc, fact, idx, blend="scipy")
+        assert out.dtype == np.float32 and np.array_equal(out, g["slice_%02d" % t]), (t, vol.dtype, idx)
+
+
 def test_g7_fused_and_two_pass(hip):
     g = golden("g7_fused144")
     img = noise(g["seed"], g["shape"])
@@ -831,6 +839,24 @@ def test_non_finite_pixels_next_to_a_clipped_edge_scipy_blend(hip, orc):
         got = pp.unwarp_chunk_slices_backward(vol, a[1], a[2], a[3], h // 2, h - 1, blend="scipy")
         want = orc.unwarp_chunk_slices_backward(vol, a[1], a[2], a[3], h // 2, h - 1, poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY)
         assert np.array_equal(got, want, equal_nan=True), shape
+
+
+def test_slice_index_fractional_and_outside_for_every_element_type(hip, orc):
+    """unwarp_slice_backward does not validate `index` (postprocessing.py:215): fractional and out-of-range values go through
+    the same arithmetic.  Every element type against the oracle (held to the reference on 1000 such cases when it was fixed)."""
+    rng = np.random.default_rng(55)
+    for t in range(60):
+        d, h, w = int(rng.integers(1, 3)), int(rng.integers(3, 70)), int(rng.integers(3, 70))
+        dt = [np.float32, np.uint16, np.float64, np.uint8, np.int16][t % 5]
+        vol = rng.random((d, h, w))
+        vol = (vol * 60000).astype(dt) if dt == np.uint16 else (vol * 250).astype(dt) if dt == np.uint8 else \
+            (vol * 60000 - 30000).astype(dt) if dt == np.int16 else vol.astype(dt)
+        xc, yc = float(rng.uniform(-0.2 * w, 1.2 * w)), float(rng.uniform(-0.2 * h, 1.2 * h))
+        fact = [1.0 + float(rng.uniform(-.1, .1)), float(rng.uniform(-3e-3, 3e-3)), float(rng.uniform(-1e-4, 1e-4))]
+        idx = [float(rng.uniform(-5, h + 5)), int(rng.integers(-3, h + 3)), float(rng.integers(0, h)) + 0.5][t % 3]
+        got = pp.unwarp_slice_backward(vol, xc, yc, fact, idx, blend="scipy")
+        want = orc.unwarp_slice_backward(vol, xc, yc, fact, idx)
+        assert got.dtype == np.float32 and np.array_equal(got, want), (t, np.dtype(dt).name, (d, h, w), idx)
 
 
 def test_device_resident_tensors_take_the_same_path(hip, orc):

@@ -257,6 +257,29 @@ def test_g17_small_frames_every_order_and_mode_equal_the_reference(orc):
         assert np.array_equal(orc.correct_perspective_image(img, coef, order=order, mode=mode), g["persp_%02d" % k]), (k, order, mode)
 
 
+def g18_cases():
+    """The inputs of golden G18 (tools/gen_golden.py g18_case, same draws in the same order)."""
+    rng = np.random.default_rng(1818)
+    for t in range(40):
+        d, h, w = int(rng.integers(1, 3)), int(rng.integers(3, 70)), int(rng.integers(3, 70))
+        dt = [np.float32, np.uint16, np.float64][t % 3]
+        vol = rng.random((d, h, w))
+        vol = (vol * 60000).astype(dt) if dt == np.uint16 else vol.astype(dt)
+        xc, yc = float(rng.uniform(-0.2 * w, 1.2 * w)), float(rng.uniform(-0.2 * h, 1.2 * h))
+        fact = [1.0 + float(rng.uniform(-.1, .1)), float(rng.uniform(-3e-3, 3e-3)), float(rng.uniform(-1e-4, 1e-4))]
+        idx = [float(rng.uniform(-5, h + 5)), int(rng.integers(-3, h + 3)), float(rng.integers(0, h)) + 0.5][(t // 3) % 3]
+        yield t, vol, xc, yc, fact, idx
+
+
+def test_g18_slice_with_any_index_equals_the_reference(orc):
+    """unwarp_slice_backward with a fractional, negative or too large `index` (the reference does not validate it), float32 /
+    uint16 / float64 stacks: bit-equal to the reference."""
+    g = golden("g18_slice_any_index")
+    for t, vol, xc, yc, fact, idx in g18_cases():
+        out = orc.unwarp_slice_backward(vol, xc, yc, fact, idx)
+        assert out.dtype == np.float32 and np.array_equal(out, g["slice_%02d" % t]), (t, vol.dtype, idx)
+
+
 def test_chunk_equals_image_rows_and_slice_differs(orc):
     """chunk rows == image rows (float32 coordinates); slice keeps float64 ones."""
     g = golden("g6_stack3x800x1280")

@@ -397,4 +397,29 @@ def g17():
 
 
 g17()
+
+
+# G18: unwarp_slice_backward with an `index` the reference does not validate (:215) -- fractional, negative, past the last row --
+# on float32, uint16 and float64 stacks.  40 cases; inputs regenerate from the seed.
+def g18_case(rng, t):
+    d, h, w = int(rng.integers(1, 3)), int(rng.integers(3, 70)), int(rng.integers(3, 70))
+    dt = [np.float32, np.uint16, np.float64][t % 3]
+    vol = rng.random((d, h, w))
+    vol = (vol * 60000).astype(dt) if dt == np.uint16 else vol.astype(dt)
+    xc, yc = float(rng.uniform(-0.2 * w, 1.2 * w)), float(rng.uniform(-0.2 * h, 1.2 * h))
+    fact = [1.0 + float(rng.uniform(-.1, .1)), float(rng.uniform(-3e-3, 3e-3)), float(rng.uniform(-1e-4, 1e-4))]
+    idx = [float(rng.uniform(-5, h + 5)), int(rng.integers(-3, h + 3)), float(rng.integers(0, h)) + 0.5][(t // 3) % 3]
+    return vol, xc, yc, fact, idx
+
+
+def g18():
+    rng = np.random.default_rng(1818)
+    out = {}
+    for t in range(40):
+        vol, xc, yc, fact, idx = g18_case(rng, t)
+        out["slice_%02d" % t] = post.unwarp_slice_backward(vol, xc, yc, fact, idx)
+    save("g18_slice_any_index", seed=np.int64(1818), ncases=np.int64(40), **out)
+
+
+g18()
 print("done")
