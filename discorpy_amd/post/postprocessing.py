@@ -382,8 +382,15 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
         raise ValueError("Selected index is out of the range")
     nrows = int(stop_index) - int(start_index) + 1
     if nrows < 1:
-        # np.arange(start, stop + 1) is empty in the reference and map_coordinates then fails
-        raise ValueError("Selected index is out of the range")
+        # np.arange(start, stop + 1) is empty in the reference: scipy maps zero coordinates and the result is an empty
+        # (depth, 0, width) array of the input's type
+        if out is not None:
+            if tuple(out.shape) != (depth, 0, width):
+                raise ValueError("out must have shape %s" % ((depth, 0, width),))
+            return out
+        if hasattr(mat3D, "new_empty"):                       # torch tensor
+            return mat3D.new_empty((depth, 0, width))
+        return np.empty((depth, 0, width), dtype=np.dtype(mat3D.dtype))
     return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices,
                        out=out)
 

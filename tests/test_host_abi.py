@@ -102,6 +102,10 @@ def test_chunk_index_validation_matches_the_reference():
     for start, stop in [(-1, 3), (0, 8), (3, 99), (0, -1), (2.5, 4)]:
         with pytest.raises(ValueError, match="Selected index is out of the range"):
             pp.unwarp_chunk_slices_backward(vol, 4, 4, [1.0], start, stop)
+    # start beyond stop: the reference maps zero rows and returns an empty (depth, 0, width) array of the input's type
+    for dt in (np.float32, np.uint16):
+        empty = pp.unwarp_chunk_slices_backward(vol.astype(dt), 4, 4, [1.0], 5, 0)
+        assert empty.shape == (2, 0, 8) and empty.dtype == dt
 
 
 def test_image_shape_errors_surface_like_the_reference():
