@@ -27,8 +27,8 @@ What differs from the reference, on purpose:
 
 * float32 data (what ``discorpy.losa.load_image`` / ``load_hdf_file`` produce) takes the tuned kernels;
   float64, (u)int8, (u)int16 and (u)int32 data run the generic kernels with scipy's exact arithmetic and
-  its integer rounding, output dtype = input dtype as in the reference; other dtypes (64-bit
-  integers, bool, complex, float16) raise ``NotImplementedError``;
+  its integer rounding, output dtype = input dtype as in the reference; 64-bit integers, bool and complex data (which
+  scipy handles) raise ``NotImplementedError``, float16 raises scipy's own ``RuntimeError("data type not supported")``;
 * for spline ``order`` 0 and 1 ``mode`` cannot influence the result because every coordinate is
   clipped into the image first; it is validated and otherwise ignored.
   Orders 2..5 run scipy's prefiltered B-spline interpolation on the GPU with all eight modes
@@ -118,7 +118,8 @@ def _check_order_mode(order, mode):
     if mode not in _MODES:
         # scipy's own message for an unknown boundary mode
         raise RuntimeError("boundary mode not supported")
-    order = int(order)
+    import operator
+    order = operator.index(order)          # scipy takes an integer: order=1.0 is a TypeError there too
     if order < 0 or order > 5:
         raise RuntimeError("spline order not supported")
     return order
@@ -130,6 +131,8 @@ def _dtype_code(dtype):
     try:
         return F.DTYPE_BY_NAME[name]
     except KeyError:
+        if name in ("float16", "longdouble", "float128", "object", "bfloat16") or name.startswith(("str", "bytes", "void", "datetime", "timedelta")):
+            raise RuntimeError("data type not supported")     # scipy's own refusal (the reference passes the array to it)
         raise NotImplementedError("element type %s is not implemented on the GPU path (supported: %s)"
                                   % (dtype, ", ".join(sorted(F.DTYPE_BY_NAME))))
 
@@ -358,6 +361,7 @@ def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=No
         if tuple(out.shape) != (depth, width):
             raise ValueError("out must have shape (depth, width)")
         out = out.reshape((depth, 1, width))
+    index = index - 0.0                  # (the reference computes index - ycenter: a str or None is a TypeError)
     res = _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True,
                       devices=devices, out=out)
     return res.reshape((depth, width)) if isinstance(res, F.DeviceArray) else res[:, 0, :]
@@ -657,7 +661,7 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
         yc = yc.to(dt).contiguous()
         xc = xc.to(dt).contiguous()
         if yc.numel() != xc.numel():
-            raise RuntimeError("invalid shape for coordinate array")
+            raise ValueError("the two coordinate arrays differ in size (numpy cannot stack them: inhomogeneous shape)")
         cdt = F.COORD_F32 if dt == torch.float32 else F.COORD_F64
         npts, yptr, xptr, shape = yc.numel(), yc.data_ptr(), xc.data_ptr(), tuple(yc.shape)
     elif img.cai and _is_device_coords(ycoords) and _is_device_coords(xcoords) and \
@@ -669,7 +673,7 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
         shape = tuple(int(v) for v in yci["shape"])
         npts = int(np.prod(shape, dtype=np.int64))
         if npts != int(np.prod(xci["shape"], dtype=np.int64)):
-            raise RuntimeError("invalid shape for coordinate array")
+            raise ValueError("the two coordinate arrays differ in size (numpy cannot stack them: inhomogeneous shape)")
         cdt = F.COORD_F32 if dt == np.float32 else F.COORD_F64
         yptr, xptr = int(yci["data"][0]), int(xci["data"][0])
         staged = (ycoords, xcoords)
@@ -683,7 +687,7 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
         yc = np.ascontiguousarray(yc, dtype=dt)
         xc = np.ascontiguousarray(xc, dtype=dt)
         if yc.size != xc.size:
-            raise RuntimeError("invalid shape for coordinate array")
+            raise ValueError("the two coordinate arrays differ in size (numpy cannot stack them: inhomogeneous shape)")
         cdt = F.COORD_F32 if dt == np.float32 else F.COORD_F64
         npts, yptr, xptr, shape = yc.size, yc.ctypes.data, xc.ctypes.data, yc.shape
         if img.mem == F.MEM_DEVICE:

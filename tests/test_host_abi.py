@@ -119,11 +119,19 @@ def test_unsupported_inputs_fail_loudly_instead_of_falling_back():
     img = np.zeros((4, 4), np.float32)
     with pytest.raises(RuntimeError, match="spline order not supported"):
         pp.unwarp_image_backward(img, 1, 1, [1.0], order=6)
-    for dt in (np.int64, np.uint64, np.float16, np.bool_, np.complex64):
+    for dt in (np.int64, np.uint64, np.bool_, np.complex64):      # scipy handles these; this path does not, and says so
         with pytest.raises(NotImplementedError, match="element type"):
             pp.unwarp_image_backward(img.astype(dt), 1, 1, [1.0])
         with pytest.raises(NotImplementedError, match="element type"):
             pp.unwarp_chunk_slices_backward(np.zeros((2, 4, 4), dt), 1, 1, [1.0], 0, 1)
+    with pytest.raises(RuntimeError, match="data type not supported"):      # scipy's own refusal of float16, word for word
+        pp.unwarp_image_backward(img.astype(np.float16), 1, 1, [1.0])
+    with pytest.raises(TypeError):                                           # scipy wants an integer order
+        pp.unwarp_image_backward(img, 1, 1, [1.0], order=1.0)
+    with pytest.raises(TypeError):                                           # index - ycenter in the reference
+        pp.unwarp_slice_backward(np.zeros((2, 4, 4), np.float32), 1, 1, [1.0], "a")
+    with pytest.raises(ValueError):                                          # map_index arrays of different sizes
+        pp.correct_perspective_image(img, [1, 0, 0, 0, 1, 0, 0, 0], map_index=(np.zeros(16, np.float32), np.zeros(12, np.float32)))
     with pytest.raises(RuntimeError, match="boundary mode not supported"):
         pp.unwarp_image_backward(img, 1, 1, [1.0], mode="bogus")
     with pytest.raises(ValueError, match="unknown blend"):
