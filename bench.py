@@ -62,6 +62,7 @@ def parse(argv=None):
     ap.add_argument("--depth", type=int, default=2048, help="stack: total number of projections")
     ap.add_argument("--rows", type=int, default=2560, help="stack: output rows per step (2560 = whole stack)")
     ap.add_argument("--no-gather", action="store_true", help="stack workload: skip the all-gather")
+    ap.add_argument("--e2e-child", action="store_true", help=argparse.SUPPRESS)   # internal: the NumPy -> NumPy timings, in a process of their own
     ap.add_argument("--shard", default="depth", choices=["depth", "rows"],
                     help="stack workload: depth = projections split over the ranks (+ all-gather); rows = every rank owns "
                          "output rows of every projection (the whole stack on every rank, no collective)")
@@ -118,7 +119,9 @@ def cpu_baseline(cfg, img, blend, threads):
     return {"value": round(mpix, 2), "unit": "Mpixels/s", "cores": t, "kind": "port",
             "sample": "%d full %dx%d frames of the bench workload, reference arithmetic order "
                       "(numpy-order polynomial, scipy blend), %d OpenMP threads (%d logical CPUs visible, %d usable "
-                      "under the affinity mask / cgroup quota), %.2f s wall"
+                      "under the affinity mask / cgroup quota), %.2f s wall.  The reference itself (Python: numpy + scipy, it "
+                      "cannot use more than one core and may not travel to this box) measured on one core of the build container: "
+                      "1.97 s per frame = 8.5 Mpixels/s (profiles/r01c_reference_cpu_build_container.txt, tools/time_reference.py)"
                       % (frames, img.shape[0], img.shape[1], t, ncores, usable_cpus(), dt)}
 
 
@@ -143,6 +146,86 @@ def timed_launches(fn, reps, dev, settle_ms=120.0):
     e1.record()
     e1.synchronize()
     return e0.elapsed_ms(e1) * 1e3 / reps
+
+
+def launch_distribution(fn, n, dev):
+    """Device time of each of n consecutive fn(i) launches (one HIP event between every two): median, mean and tail.  The
+    intervals include the gap to the next launch, as the headline's average does."""
+    L = F.lib()
+    ev = [F.Event(dev) for _ in range(n + 1)]
+    for i in range(8):
+        fn(i)
+    F.check(L.dcp_stream_synchronize(dev, None))
+    for i in range(n):
+        ev[i].record()
+        fn(i)
+    ev[n].record()
+    ev[n].synchronize()
+    us = np.array([ev[i].elapsed_ms(ev[i + 1]) * 1e3 for i in range(n)])
+    return {"launches": n, "median_us": round(float(np.median(us)), 3), "mean_us": round(float(us.mean()), 3),
+            "p10_us": round(float(np.percentile(us, 10)), 3), "p90_us": round(float(np.percentile(us, 90)), 3),
+            "max_us": round(float(us.max()), 3)}
+
+
+def hip_runtime_path():
+    try:
+        for ln in open("/proc/self/maps"):
+            if "libamdhip64" in ln:
+                return ln.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+def e2e_child():
+    """NumPy in -> NumPy out through the drop-in functions (what a caller of discorpy.post.postprocessing with host arrays
+    sees: PCIe-inclusive, SURVEY.md section 8(d) "secondary").  Runs in a process of its own so that the parent can time both
+    HIP runtimes (the one bundled with PyTorch-ROCm, which the library shares with torch by default, and /opt/rocm's)."""
+    from discorpy_amd.post import postprocessing as pp
+    F.require_device()
+    res = {"hip_runtime": hip_runtime_path()}
+    c2 = configs.cfg2()
+    img = np.random.default_rng(c2["seed"]).random(c2["shape"], dtype=np.float32)
+
+    def med(fn, reps):
+        fn()
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)) * 1e3
+    ms = med(lambda: pp.unwarp_image_backward(img, c2["xcenter"], c2["ycenter"], c2["list_fact"]), 12)
+    res["cfg2_unwarp_image_backward_4096"] = {"ms": round(ms, 3), "Mpixels_per_s": round(img.size / ms / 1e3, 1)}
+    c4 = configs.cfg4(32)
+    D, H, W = c4["shape"]
+    vol = np.random.default_rng(c4["seed"]).random((D, H, W), dtype=np.float32)
+    ms = med(lambda: pp.unwarp_slice_backward(vol, c4["xcenter"], c4["ycenter"], c4["list_fact"], 1277), 12)
+    res["cfg4_unwarp_slice_backward_depth32"] = {"ms": round(ms, 3), "Mpixels_per_s": round(D * W / ms / 1e3, 2)}
+    ms = med(lambda: pp.unwarp_chunk_slices_backward(vol, c4["xcenter"], c4["ycenter"], c4["list_fact"], 1248, 1311), 6)
+    res["cfg4_unwarp_chunk_slices_64rows_depth32"] = {"ms": round(ms, 3), "Mpixels_per_s": round(D * 64 * W / ms / 1e3, 1)}
+    print(json.dumps(res), flush=True)
+
+
+def end_to_end_numpy():
+    """The e2e child under both HIP runtimes (when torch is installed its bundled runtime is the library's default)."""
+    import subprocess
+    out = {"what": "NumPy in -> NumPy out through discorpy_amd.post.postprocessing (host arrays: H2D + kernel + D2H, median of "
+                   "repeated calls); the reference on one core: cfg2 1965 ms, slice of a depth-64 stack 6.7 ms "
+                   "(profiles/r01c_reference_cpu_build_container.txt)"}
+    for label, env in (("default_runtime", {}), ("system_rocm_runtime", {"DISCORPY_AMD_SYSTEM_HIP": "1"})):
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-child"], capture_output=True, text=True, timeout=300,
+                               env=dict(os.environ, **env), cwd=ROOT)
+            lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+            out[label] = json.loads(lines[-1]) if (r.returncode == 0 and lines) else {"error": (r.stderr or r.stdout)[-400:]}
+        except Exception as e:      # noqa: BLE001 -- context only
+            out[label] = {"error": repr(e)}
+    a_, b_ = out.get("default_runtime", {}), out.get("system_rocm_runtime", {})
+    if a_.get("hip_runtime") and a_.get("hip_runtime") == b_.get("hip_runtime"):
+        out["note"] = "both runs loaded the same libamdhip64.so (no second runtime on this box)"
+    return out
 
 
 def entry(us, pixels, bytes_per_pixel, kernel, verified, **more):
@@ -191,6 +274,51 @@ def clocks_under_load(step, sync):
     if not samples:
         return None
     return {"sclk_MHz_under_this_kernel": [s_[0] for s_ in samples], "package_power_W": [s_[1] for s_ in samples]}
+
+
+def distinct_calibrations(cfg, n):
+    """n calibrations around BASELINE config 2's (centre moved by up to ~100 px, coefficients rescaled by up to 4 %): all hold the
+    level-2 tile certificate on 4096^2 frames."""
+    cals = []
+    for i in range(n):
+        t = (i - 0.5 * (n - 1)) / max(n - 1, 1)
+        cals.append((cfg["xcenter"] + 200.0 * t, cfg["ycenter"] - 120.0 * t,
+                     [v * (1.0 + 0.04 * t * k) for k, v in enumerate(cfg["list_fact"])]))
+    return cals
+
+
+def batched_distinct_calibrations(a, dev, srcs, dsts, img0, cfg, blend):
+    import ctypes as C
+    L = F.lib()
+    H, W = cfg["shape"]
+    n = len(srcs)
+    cals = distinct_calibrations(cfg, n)
+    nf = len(cfg["list_fact"])
+    table = np.ascontiguousarray([c[2] for c in cals], dtype=np.float64)
+    sp = (C.c_void_p * n)(*[b.ptr for b in srcs])
+    dp = (C.c_void_p * n)(*[b.ptr for b in dsts])
+    xa, ya = (C.c_double * n)(*[c[0] for c in cals]), (C.c_double * n)(*[c[1] for c in cals])
+    tp = table.ctypes.data_as(C.POINTER(C.c_double))
+
+    def run(_i):
+        F.check(L.dcp_unwarp_images_f32(sp, dp, n, H, W, W, 1, xa, ya, tp, nf, a.order, 1, blend, F.MEM_DEVICE, dev, None))
+    per_frame_us = timed_launches(run, max(6, a.steps // 2), dev) / n
+    kernel = F.last_kernel()
+    run(0)
+    orc = oracle_module(a.cpu_threads)
+    ob = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32lerp": orc.BLEND_F32LERP}[a.blend]
+    ok = True
+    host = {0: img0}
+    for i in sorted({0, n // 2, n - 1}):       # three frames with three different calibrations, every pixel
+        if i not in host:
+            host[i] = download(srcs[i].ptr, (H, W), dev)
+        want = orc.unwarp_image_backward(host[i], cals[i][0], cals[i][1], cals[i][2], order=a.order, poly=orc.POLY_KERNEL, blend=ob)
+        ok = ok and bool(np.array_equal(download(dsts[i].ptr, (H, W), dev), want))
+    return {"what": "the %d frames of a step in ONE dcp_unwarp_images_f32 call, every frame with its own centre and coefficients "
+                    "(blockIdx.z = frame)" % n,
+            "us_per_frame": round(per_frame_us, 3), "Mpixels_per_s": round(H * W / per_frame_us, 1),
+            "frac_of_hbm_peak": round(configs.BYTES_PER_PIXEL * H * W / (per_frame_us * 1e-6) / 1e9 / configs.HBM_PEAK_GBPS, 4),
+            "kernel": kernel, "verified_vs_oracle": ok, "frames_checked": sorted({0, n // 2, n - 1})}
 
 
 # ----------------------------------------------------------------------------------------- other configurations (N = 1)
@@ -669,6 +797,9 @@ def stack_main(a, world, rank, dev, dist, backend):
 
 def main(argv=None):
     a = parse(argv)
+    if a.e2e_child:
+        e2e_child()
+        return
     world, rank, dev_index, dist, backend = init_dist()
     n_gpus = world
     if a.gpus != world and rank == 0:
@@ -774,6 +905,16 @@ def main(argv=None):
         except Exception:      # noqa: BLE001
             copy_gbps = None
 
+    dist_launch = None
+    if rank == 0:
+        try:          # per-launch distribution of the headline call (outside the timed region): the mean hides a few slow launches
+            def one(i):
+                F.check(L.dcp_unwarp_image_f32(srcs[i % a.batch].ptr, dsts[i % a.batch].ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"], fa, nf,
+                                               a.order, 1, blend, F.MEM_DEVICE, dev, None))
+            dist_launch = launch_distribution(one, max(96, 4 * a.batch), dev)
+        except Exception as e:      # noqa: BLE001 -- context only
+            dist_launch = {"error": repr(e)}
+
     box = clocks_under_load(step, sync) if (rank == 0 and n_gpus == 1 and not a.no_extras) else None
 
     batched = None
@@ -803,36 +944,15 @@ def main(argv=None):
         except Exception as e:      # noqa: BLE001 -- context only, never fails the bench
             batched = {"error": repr(e)}
 
-    overlapped = None
+    batched_distinct = None
     if rank == 0 and n_gpus == 1 and not a.no_extras:
-        # context, not the metric: the same frames alternated over two streams, so that the drain of one launch
-        # overlaps the ramp of the next (per-launch durations are then not meaningful; only throughput is)
+        # beside the per-launch headline, not instead of it: the frames of a step through ONE dcp_unwarp_images_f32 call, every
+        # frame with its OWN calibration (centre shifted, coefficients rescaled per frame) -- remap_wg_batch_kernel, the frame in
+        # blockIdx.z, so that the drain of one frame runs under the ramp of the next
         try:
-            s2 = [F.Stream(dev), F.Stream(dev)]
-
-            def step2():
-                for i, (s_, d_) in enumerate(zip(srcs, dsts)):
-                    rc = L.dcp_unwarp_image_f32(s_.ptr, d_.ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"], fa, nf,
-                                                a.order, 1, blend, F.MEM_DEVICE, dev, s2[i & 1].ptr)
-                    if rc:
-                        F.check(rc)
-            for _ in range(3):
-                step2()
-            for st_ in s2:
-                st_.synchronize()
-            t2 = time.perf_counter()
-            n2 = max(10, a.steps // 4)
-            for _ in range(n2):
-                step2()
-            for st_ in s2:
-                st_.synchronize()
-            dt2 = time.perf_counter() - t2
-            overlapped = {"what": "the same step with its frames alternated over two HIP streams (throughput only: the drain of "
-                                  "one launch overlaps the ramp of the next)",
-                          "Mpixels_per_s": round(n2 * a.batch * H * W / dt2 / 1e6, 1),
-                          "us_per_frame": round(dt2 * 1e6 / (n2 * a.batch), 3)}
-        except Exception as e:      # noqa: BLE001 -- context only
-            overlapped = {"error": repr(e)}
+            batched_distinct = batched_distinct_calibrations(a, dev, srcs, dsts, img0, cfg, blend)
+        except Exception as e:      # noqa: BLE001 -- context only, never fails the bench
+            batched_distinct = {"error": repr(e)}
 
     others = None
     if rank == 0 and n_gpus == 1 and not a.no_extras:
@@ -903,7 +1023,7 @@ def main(argv=None):
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "traffic_source": traffic_source, "kernel": headline_kernel, "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch),
-                         "d2d_copy_same_frames_GBps": copy_gbps},
+                         "d2d_copy_same_frames_GBps": copy_gbps, "per_launch_distribution": dist_launch},
             "verified_vs_oracle": verified,
         }
         if box is not None:
@@ -914,8 +1034,10 @@ def main(argv=None):
             out["stack_scaling"] = scaling
         if batched is not None:
             out["batched_same_calibration"] = batched
-        if overlapped is not None:
-            out["two_streams"] = overlapped
+        if batched_distinct is not None:
+            out["batched_distinct_calibrations"] = batched_distinct
+        if n_gpus == 1 and not a.no_extras:
+            out["end_to_end_numpy"] = end_to_end_numpy()
         if n_gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, img0, blend, a.cpu_threads)
         print(json.dumps(out), flush=True)

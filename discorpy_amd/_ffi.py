@@ -47,6 +47,8 @@ SIGNATURES = {
     "dcp_get_option": (_int, [C.c_char_p, C.POINTER(_int)]),
     "dcp_unwarp_image_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int,
                                     _int, _int, _int, _vp]),
+    "dcp_unwarp_images_f32": (_int, [C.POINTER(_vp), C.POINTER(_vp), _int, _i64, _i64, _i64, _i64, _dp, _dp, _dp, _int, _int, _int,
+                                     _int, _int, _int, _vp]),
     "dcp_perspective_image_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),
     "dcp_unwarp_fused_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dp, _int, _int,
                                     _int, _int, _vp]),
@@ -84,6 +86,7 @@ SIGNATURES = {
     "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_debug_last_kernel": (C.c_char_p, []),
+    "dcp_debug_tile_certificate": (_int, [_int, _i64, _i64, _dbl, _dbl, _dp, _int, _dp]),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
     "dcp_free": (_int, [_vp, _int]),
     "dcp_memcpy": (_int, [_vp, _vp, _sz, _int, _int, _vp]),
@@ -198,6 +201,19 @@ def last_kernel():
     """Name of the float32 image / stack kernel this thread launched last, e.g. 'remap_wg_kernel<Radial,NF=5,f64lerp>'."""
     v = lib().dcp_debug_last_kernel()
     return v.decode() if v else ""
+
+
+def tile_certificate(height, width, xcenter, ycenter, list_fact=None, list_coef=None):
+    """Level of the host's tile-deviation certificate (0, 1 or 2) for a radial (list_fact) or perspective (list_coef) map."""
+    if list_coef is not None:
+        ca, _ = fact_array(list_coef)
+        rc = lib().dcp_debug_tile_certificate(MAP_PERSPECTIVE, int(height), int(width), 0.0, 0.0, None, 0, ca)
+    else:
+        fa, nf = fact_array(list_fact)
+        rc = lib().dcp_debug_tile_certificate(MAP_RADIAL, int(height), int(width), float(xcenter), float(ycenter), fa, nf, None)
+    if rc < 0:
+        check(rc)
+    return rc
 
 
 def stack_row_band(height, width, xcenter, ycenter, list_fact, row_start, nrows):

@@ -196,20 +196,34 @@ bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) 
   return bad * 50 <= sx * sy;          // at most 2 % of the sampled tiles
 }
 
-thread_local struct {
+// the same calibrations are applied to frame after frame (one per camera / channel / grid-search candidate): keep the
+// answers of the last kCertSlots distinct ones, replaced round-robin
+constexpr int kCertSlots = 64;
+struct CertEntry {
   int kind = -1, nfact = -1;
   int64_t H = 0, W = 0;
   double xc = 0, yc = 0, fact[dcp::kMaxFact], coef[8];
   int ok = 0;
-} g_cert_cache;
+};
+thread_local CertEntry g_cert_cache[kCertSlots];
+thread_local int g_cert_next = 0, g_cert_last = 0;
 }  // namespace
 
 int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) {
   if (H < 1 || W < 1) return 0;
-  auto& c = g_cert_cache;        // the same calibration is applied to frame after frame: keep the last answer
-  if (c.kind == kind && c.nfact == m.nfact && c.H == H && c.W == W && c.xc == m.xc && c.yc == m.yc &&
-      memcmp(c.fact, m.fact, sizeof(double) * (size_t)(m.nfact > 0 ? m.nfact : 0)) == 0 && memcmp(c.coef, m.coef, sizeof(c.coef)) == 0)
-    return c.ok;
+  auto same = [&](const CertEntry& c) {
+    return c.kind == kind && c.nfact == m.nfact && c.H == H && c.W == W && c.xc == m.xc && c.yc == m.yc &&
+           memcmp(c.fact, m.fact, sizeof(double) * (size_t)(m.nfact > 0 ? m.nfact : 0)) == 0 && memcmp(c.coef, m.coef, sizeof(c.coef)) == 0;
+  };
+  if (same(g_cert_cache[g_cert_last])) return g_cert_cache[g_cert_last].ok;      // the common case: the calibration of the previous call
+  for (int i = 0; i < kCertSlots; ++i)
+    if (same(g_cert_cache[i])) {
+      g_cert_last = i;
+      return g_cert_cache[i].ok;
+    }
+  CertEntry& c = g_cert_cache[g_cert_next];
+  g_cert_last = g_cert_next;
+  g_cert_next = (g_cert_next + 1) % kCertSlots;
   int ok = 0;
   if (kind == dcp::kRadial) {
     double rmax = 0.0;
@@ -529,6 +543,18 @@ int dcp_debug_counters(uint64_t* out, int n, int reset) {
 }
 
 const char* dcp_debug_last_kernel(void) { return dcp::last_kernel_name(); }
+
+int dcp_debug_tile_certificate(int map_kind, int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact,
+                               int nfact, const double* list_coef) {
+  if (map_kind != DCP_MAP_RADIAL && map_kind != DCP_MAP_PERSPECTIVE) return fail(DCP_ERR_INVALID_ARG, "map_kind must be radial or perspective");
+  if (map_kind == DCP_MAP_PERSPECTIVE && !list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  int rc;
+  if ((rc = fill_map(&map, xcenter, ycenter, map_kind == DCP_MAP_RADIAL ? list_fact : nullptr, map_kind == DCP_MAP_RADIAL ? nfact : 0,
+                     map_kind == DCP_MAP_PERSPECTIVE ? list_coef : nullptr)) != DCP_OK)
+    return rc;
+  return tile_deviation_certified(map_kind == DCP_MAP_RADIAL ? dcp::kRadial : dcp::kPersp, map, height, width);
+}
 
 int dcp_malloc(void** ptr, size_t bytes, int device) {
   if (!ptr) return fail(DCP_ERR_INVALID_ARG, "null out pointer");

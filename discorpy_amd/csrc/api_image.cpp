@@ -388,6 +388,58 @@ int dcp_unwarp_image_f32(const float* src, float* dst, int64_t height, int64_t w
                    coord_round_f32 != 0, mem_kind, device, stream);
 }
 
+int dcp_unwarp_images_f32(const float* const* srcs, float* const* dsts, int nframes, int64_t height, int64_t width,
+                          int64_t src_row_stride, int64_t src_col_stride, const double* xcenters, const double* ycenters,
+                          const double* list_facts, int nfact, int order, int coord_round_f32, int blend_mode, int mem_kind,
+                          int device, void* stream) {
+  int rc, sampler;
+  if (nframes < 0) return fail(DCP_ERR_INVALID_ARG, "nframes < 0");
+  if (nframes == 0) return DCP_OK;
+  if (!srcs || !dsts || !xcenters || !ycenters) return fail(DCP_ERR_INVALID_ARG, "null frame / centre array");
+  if (nfact < 0 || nfact > dcp::kMaxFact) return fail(DCP_ERR_INVALID_ARG, "nfact = %d outside [0, %d]", nfact, dcp::kMaxFact);
+  if (nfact > 0 && !list_facts) return fail(DCP_ERR_INVALID_ARG, "null coefficient pointer");
+  if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
+  auto one_by_one = [&](int first) {      // frames first .. nframes-1 through the single-frame entry point
+    for (int i = first; i < nframes; ++i) {
+      const int r = dcp_unwarp_image_f32(srcs[i], dsts[i], height, width, src_row_stride, src_col_stride, xcenters[i], ycenters[i],
+                                         list_facts ? list_facts + (size_t)i * (size_t)nfact : nullptr, nfact, order, coord_round_f32,
+                                         blend_mode, mem_kind, device, stream);
+      if (r != DCP_OK) return r;
+    }
+    return DCP_OK;
+  };
+  // host frames are bound by PCIe: each goes through the single-frame host path (bands of rows, uploads and downloads
+  // overlapped); float64 coordinates and sources beyond 32-bit offsets have no multi-frame kernel either
+  if (mem_kind != DCP_MEM_DEVICE || !coord_round_f32 || nframes == 1 || nfact > 10 ||
+      beyond_32bit_offsets(height, width, src_row_stride, src_col_stride))
+    return one_by_one(0);
+  for (int i = 0; i < nframes; ++i)
+    if ((rc = check_image(srcs[i], dsts[i], height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  // every frame's calibration must hold the level-2 tile certificate (one box per 128 x 32 workgroup tile)
+  std::vector<dcp::BatchFrame> fr((size_t)nframes);
+  bool all_certified = g_tile_cert.load() != 0;
+  for (int i = 0; i < nframes && all_certified; ++i) {
+    dcp::MapArgs map;
+    const double* f = list_facts ? list_facts + (size_t)i * (size_t)nfact : nullptr;
+    if ((rc = fill_map(&map, xcenters[i], ycenters[i], f, nfact, nullptr)) != DCP_OK) return rc;
+    all_certified = tile_deviation_certified(dcp::kRadial, map, height, width) >= 2;
+    fr[(size_t)i] = dcp::BatchFrame{srcs[i], dsts[i], xcenters[i], ycenters[i], f};
+  }
+  if (!all_certified) return one_by_one(0);
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  dcp::ImageArgs img;
+  memset(&img, 0, sizeof(img));
+  img.H = (int32_t)height;
+  img.W = (int32_t)width;
+  img.src_stride = (int32_t)src_row_stride;
+  img.src_col_stride = (int32_t)src_col_stride;
+  img.src_bytes = extent_bytes(height, width, src_row_stride, src_col_stride);
+  bool taken = false;
+  DCP_HIP(dcp::launch_image_batch(img, fr.data(), nframes, nfact, sampler, current_opts(), (hipStream_t)stream, &taken));
+  return taken ? DCP_OK : one_by_one(0);
+}
+
 int dcp_perspective_image_f32(const float* src, float* dst, int64_t height, int64_t width,
                               int64_t src_row_stride, int64_t src_col_stride, const double* list_coef,
                               int order, int blend_mode, int mem_kind, int device, void* stream) {

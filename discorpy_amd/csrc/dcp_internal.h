@@ -133,6 +133,19 @@ struct LaunchOpts {
 // launchers (unwarp_kernels.hip)
 hipError_t launch_image(MapKind kind, const ImageArgs& img, const MapArgs& map, int sampler,
                         bool round_f32, const LaunchOpts& opts, hipStream_t stream);
+// one frame of launch_image_batch (host side): its own source, destination, centre and coefficient vector
+struct BatchFrame {
+  const float* src;
+  float* dst;
+  double xc, yc;
+  const double* fact;
+};
+// n dense float32 frames of ONE shape (img: H, W, src_stride, src_bytes; src / dst ignored), radial map, float32 coordinates, every
+// frame with its own calibration of `nfact` <= 10 coefficients, through remap_wg_batch_kernel (blockIdx.z = frame) in
+// ceil(n / 55) launches (35 per launch above 5 coefficients).  The caller has certified every frame at level 2
+// (tile_deviation_certified).  *taken = false: the shape / options do not qualify, launch the frames one by one
+hipError_t launch_image_batch(const ImageArgs& img, const BatchFrame* frames, int n, int nfact, int sampler, const LaunchOpts& opts,
+                              hipStream_t stream, bool* taken);
 // 8- and 16-bit integer images on remap_wg_kernel (img.src / dst reinterpreted, src_stride in elements, src_bytes the extent
 // in bytes); *taken = false: the call does not qualify, use launch_typed_image
 hipError_t launch_wg_typed(MapKind kind, const ImageArgs& img, const MapArgs& map, int order, int dtype, const LaunchOpts& opts,

@@ -39,6 +39,7 @@
 #include "dcp_device.h"
 #include <type_traits>
 #include <cstdio>
+#include <cstring>
 
 namespace dcp {
 
@@ -773,8 +774,9 @@ static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wav
 // taps with ds_read_u16 / _i16 / _u8 / _i8, blend in scipy's exact float64 operation order (SAMPLER = kScipy; the
 // integer result depends on it at rounding ties) and convert as scipy does: round half away from zero, saturate.
 // ImageArgs::src / dst / src_stride / src_bytes keep their meaning (pointers reinterpreted, stride in ELEMENTS, extent in bytes).
-template <int KIND, int NF, int SAMPLER, typename T = float>
-__global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
+// (the body is a device function: the single-frame kernel and the multi-frame kernel remap_wg_batch_kernel share it)
+template <int KIND, int NF, int SAMPLER, typename T>
+__device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArgs& map) {
   constexpr bool kIsF32 = std::is_same<T, float>::value;
   constexpr int ES = (int)sizeof(T);                           // element size in bytes
   constexpr int CH = ES == 4 ? 36 : (ES == 2 ? 20 : 10);       // 16-byte chunks per slab row
@@ -794,7 +796,7 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
   const int lane = (int)threadIdx.x & 63;
   const int wx = wave & 1, wy = wave >> 1;
 #ifdef DCP_EXPERIMENT_TRACE
-  const unsigned trace_id = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
+  const unsigned trace_id = (((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
   const bool trace_on = trace_id < 65536u;
   DCP_TRACE(0);
   if (trace_on && lane == 0) {
@@ -1117,6 +1119,51 @@ __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const Image
       }
     }
   }
+}
+
+template <int KIND, int NF, int SAMPLER, typename T = float>
+__global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
+  remap_wg_body<KIND, NF, SAMPLER, T>(img, map);
+}
+
+// ------------------------------------------------------------------ K1, many frames in one launch
+
+// remap_wg_kernel over a batch of frames of one shape, each with its OWN source, destination, centre and coefficient
+// vector: blockIdx.z = frame.  A per-frame launch spends ~3.5 us before its first tile completes and ~9 us draining
+// its last workgroups (profiles/r02b_phase_timeline_wg_f64lerp.txt: a third of a 4096^2 launch); here the tail of
+// frame z runs under the head of frame z + 1.  The per-frame arguments travel in the KERNEL ARGUMENTS (a table of
+// BatchEntry<NF>, indexed by the workgroup's frame: scalar loads from the kernarg segment, no device-side table whose
+// lifetime would have to outlast the launch), which bounds a launch to BatchTable<NF>::kMax frames; longer batches are
+// cut into several launches by the host.  Radial map, float32, certified at level 2 for EVERY frame (the host checks).
+template <int NF>
+struct BatchEntry {
+  const float* src;
+  float* dst;
+  double xc, yc;
+  double fact[NF];
+};
+template <int NF>
+struct BatchTable {
+  // kernel arguments are limited to 4 KB: ImageArgs (72 B) + the table
+  static constexpr int kMax = (4096 - 128) / (int)sizeof(BatchEntry<NF>) > 64 ? 64 : (4096 - 128) / (int)sizeof(BatchEntry<NF>);
+  BatchEntry<NF> e[kMax];
+};
+
+template <int NF, int SAMPLER>
+__global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_batch_kernel(const ImageArgs img0, const BatchTable<NF> tab) {
+  const BatchEntry<NF>& e = tab.e[blockIdx.z];
+  ImageArgs img = img0;
+  img.src = e.src;
+  img.dst = e.dst;
+  MapArgs map;
+  map.xc = e.xc;
+  map.yc = e.yc;
+#pragma unroll
+  for (int i = 0; i < NF; ++i) map.fact[i] = e.fact[i];
+  map.nfact = NF;
+  map.fast_div = 0;
+  map.tile_dev_ok = 2;
+  remap_wg_body<kRadial, NF, SAMPLER, float>(img, map);
 }
 
 // ------------------------------------------------------------------ K5: explicit coordinates
@@ -1694,6 +1741,68 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
   note_kernel("remap_wg_kernel", KIND, NF, SAMPLER);
   hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), pad, stream, img, map);
   return hipGetLastError();
+}
+
+// Many frames of one shape, each with its own calibration, in as few launches as the 4 KB of kernel arguments allow
+// (55 frames of <= 5 coefficients, 35 of <= 10).  Coefficient vectors shorter than the instantiated length are padded with
+// zeros: fma(r2, 0, a) = a exactly, so every intermediate of the even / odd Horner chains is unchanged.
+template <int NF, int SAMPLER>
+static hipError_t launch_wg_batch_t(const ImageArgs& img_in, const BatchFrame* fr, int n, int nfact, hipStream_t stream) {
+  using Tab = BatchTable<NF>;
+  static_assert(sizeof(ImageArgs) + sizeof(Tab) + 16 <= 4096, "kernel arguments are limited to 4 KB");
+  ImageArgs img = img_in;
+  img.tiles_x = (img.W + kWgTW - 1) / kWgTW;
+  img.tiles_y = (img.rows_out + kWgTH - 1) / kWgTH;
+  if (img.xcd_remap == 2 && 8 * ((img.tiles_x + 7) / 8) * 100 > img.tiles_x * 107) img.xcd_remap = 0;       // see launch_wg
+  note_kernel("remap_wg_batch_kernel", kRadial, NF, SAMPLER);
+  for (int f0 = 0; f0 < n; f0 += Tab::kMax) {
+    const int m = n - f0 < Tab::kMax ? n - f0 : Tab::kMax;
+    Tab tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int i = 0; i < m; ++i) {
+      const BatchFrame& f = fr[f0 + i];
+      tab.e[i].src = f.src;
+      tab.e[i].dst = f.dst;
+      tab.e[i].xc = f.xc;
+      tab.e[i].yc = f.yc;
+      for (int k = 0; k < nfact; ++k) tab.e[i].fact[k] = f.fact[k];
+    }
+    const dim3 grid(img.xcd_remap == 2 ? 8 * ((img.tiles_x + 7) / 8) : img.tiles_x, img.tiles_y, m);
+    hipLaunchKernelGGL((remap_wg_batch_kernel<NF, SAMPLER>), grid, dim3(256), 0, stream, img, tab);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+template <int NF>
+static hipError_t launch_wg_batch_s(const ImageArgs& img, const BatchFrame* fr, int n, int nfact, int sampler, hipStream_t stream) {
+  switch (sampler) {
+    case kNearest: return launch_wg_batch_t<NF, kNearest>(img, fr, n, nfact, stream);
+    case kScipy: return launch_wg_batch_t<NF, kScipy>(img, fr, n, nfact, stream);
+    case kF64Lerp: return launch_wg_batch_t<NF, kF64Lerp>(img, fr, n, nfact, stream);
+    default: return launch_wg_batch_t<NF, kF32Lerp>(img, fr, n, nfact, stream);
+  }
+}
+
+hipError_t launch_image_batch(const ImageArgs& img_in, const BatchFrame* frames, int n, int nfact, int sampler, const LaunchOpts& opts,
+                              hipStream_t stream, bool* taken) {
+  *taken = false;
+  ImageArgs img = img_in;
+  if (img.rows_out <= 0) {
+    img.y_origin = 0;
+    img.rows_out = img.H;
+  }
+  img.xcd_remap = opts.xcd_remap;
+  img.wg_box = opts.wg_box;
+  img.wg_per_cu = 0;
+  // what remap_wg_kernel needs (launch_image / launch_lds_vote): the LDS-staged pair gather with one box per workgroup
+  if (n <= 0 || nfact < 0 || nfact > 10 || !opts.wg_box || !opts.lds_gather || opts.coef_lds || opts.xcd_remap == 1 || img.src_col_stride != 1 ||
+      img.W < 2 || img.H < 2 || img.src_stride >= (1 << 22) || img.H >= (1 << 24) || !lds_addressable(img))
+    return hipSuccess;
+  *taken = true;
+  if (nfact <= 5) return launch_wg_batch_s<5>(img, frames, n, nfact, sampler, stream);
+  return launch_wg_batch_s<10>(img, frames, n, nfact, sampler, stream);
 }
 
 // Narrow integer element types on remap_wg_kernel (typed entry points of the C ABI, orders 0 / 1): taken = false when the

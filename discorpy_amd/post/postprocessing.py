@@ -47,7 +47,7 @@ import numpy as np
 from .. import _ffi as F
 from .. import _pool
 
-__all__ = ["unwarp_line_forward", "unwarp_image_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
+__all__ = ["unwarp_line_forward", "unwarp_image_backward", "unwarp_images_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
            "correct_perspective_image", "unwarp_perspective_fused", "remap_coordinates",
            "generate_radial_map", "generate_fused_map"]
 
@@ -345,6 +345,104 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
                                          float(xcenter), float(ycenter), fa, nf, order, 1, bcode,
                                          img.mem, img.device, img.stream))
     return out
+
+
+def _per_frame(value, n, what):
+    """`value` as n floats: a number is shared by all frames, a sequence must hold one number per frame."""
+    if np.ndim(value) == 0:
+        return [float(value)] * n
+    vals = [float(v) for v in value]
+    if len(vals) != n:
+        raise ValueError("%s: expected one value or %d (one per image), got %d" % (what, n, len(vals)))
+    return vals
+
+
+def unwarp_images_backward(mats, xcenter, ycenter, list_fact, order=1, mode="reflect", *, blend=None, out=None):
+    """
+    :func:`unwarp_image_backward` (reference ``postprocessing.py:111-148``) over a batch of images of one shape in ONE
+    call -- the loops the reference's users write around it: per colour channel
+    (``examples/readthedocs_demo/demo_06.py:111-113``, ``demo_07.py:58-60``), per camera, per candidate calibration.
+
+    Parameters
+    ----------
+    mats : sequence of 2D arrays, or one 3D array (n, height, width)
+        The images (NumPy arrays or ROCm torch tensors), all of one shape.
+    xcenter, ycenter : float or sequence of n floats
+        Center of distortion, shared or one per image.
+    list_fact : list of float, or sequence of n such lists
+        Polynomial coefficients of the backward model, shared or one vector per image (lengths may differ).
+    order, mode : as :func:`unwarp_image_backward`.
+
+    Returns
+    -------
+    list of 2D arrays (a sequence was given) or one 3D array (a 3D array was given); every image is bit-identical to what
+    :func:`unwarp_image_backward` returns for it.  Device-resident float32 images at order 0 / 1 whose calibrations all
+    hold the tile certificate go through ONE kernel launch per 55 images (``dcp_unwarp_images_f32``: the drain of one
+    frame overlaps the ramp of the next); anything else is processed image by image.
+    """
+    stacked = hasattr(mats, "shape") and len(mats.shape) == 3
+    if hasattr(mats, "shape") and len(mats.shape) != 3:
+        raise ValueError("expected a sequence of 2-D images or one 3-D array (n, height, width)")
+    frames = [mats[i] for i in range(mats.shape[0])] if stacked else list(mats)
+    n = len(frames)
+    order = _check_order_mode(order, mode)
+    bcode = _blend_code(blend)
+    xcs, ycs = _per_frame(xcenter, n, "xcenter"), _per_frame(ycenter, n, "ycenter")
+    per_frame_fact = len(list_fact) > 0 and np.ndim(list_fact[0]) > 0
+    if per_frame_fact and len(list_fact) != n:
+        raise ValueError("list_fact: expected one coefficient vector or %d (one per image), got %d" % (n, len(list_fact)))
+    facts = [_coefs(list_fact[i] if per_frame_fact else list_fact, "list_fact") for i in range(n)]
+    outs = None
+    if out is not None:
+        outs = [out[i] for i in range(n)] if (hasattr(out, "shape") and len(out.shape) == 3) else list(out)
+        if len(outs) != n:
+            raise ValueError("out must hold one array per image")
+    if n == 0:
+        return mats if stacked else []
+    imgs = [_Image(f, 2).dense_rows() for f in frames]
+    first = imgs[0]
+    uniform = all(im.f32 and im.shape == first.shape and im.strides == first.strides and im.mem == first.mem and
+                  im.device == first.device and im.stream == first.stream and im.torch == first.torch for im in imgs)
+    nf = max(len(f) for f in facts)
+    if not (uniform and order <= 1 and nf <= F.MAX_FACT):
+        res = [unwarp_image_backward(frames[i], xcs[i], ycs[i], facts[i], order=order, mode=mode, blend=blend,
+                                     out=None if outs is None else outs[i]) for i in range(n)]
+    else:
+        (height, width) = first.shape
+        res, optrs = [], []
+        if stacked and outs is None and first.torch:
+            import torch
+            whole = torch.empty((n, height, width), dtype=torch.float32, device=first.keep.device)
+            res = [whole[i] for i in range(n)]
+            optrs = [whole.data_ptr() + i * height * width * 4 for i in range(n)]
+        else:
+            whole = None
+            for i, im in enumerate(imgs):
+                o, optr = im.empty((height, width), out=None if outs is None else outs[i])
+                res.append(o)
+                optrs.append(optr)
+        table = np.zeros((n, max(nf, 1)), np.float64)             # shorter vectors padded with zeros (the result does not change)
+        for i, f in enumerate(facts):
+            table[i, :len(f)] = f
+        sp = (C.c_void_p * n)(*[im.ptr for im in imgs])
+        dp = (C.c_void_p * n)(*optrs)
+        xa, ya = (C.c_double * n)(*xcs), (C.c_double * n)(*ycs)
+        F.require_device()
+        F.check(F.lib().dcp_unwarp_images_f32(sp, dp, n, height, width, first.strides[0], first.strides[1], xa, ya,
+                                              table.ctypes.data_as(C.POINTER(C.c_double)), nf, order, 1, bcode, first.mem,
+                                              first.device, first.stream))
+        if whole is not None:
+            return whole
+    if not stacked:
+        return res
+    if out is not None and hasattr(out, "shape") and len(out.shape) == 3:
+        return out
+    if _is_torch(res[0]):
+        import torch
+        return torch.stack(res)
+    if isinstance(res[0], F.DeviceArray):
+        return res
+    return np.stack(res)
 
 
 def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=None, devices=None, out=None):

@@ -180,14 +180,12 @@ def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode=
     order = _pp._check_order_mode(order, mode)
     if order <= 1 and blend in (None, "scipy", "exact", "f64lerp", "f64") and 1 <= mat_pad.shape[2] <= 64:
         return _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order)
-    # channels as dense planes: one coordinate map, C gathers
+    # channels as dense planes through the batched entry point (the reference's loop over mat_pad[:, :, i], utility.py:320-341):
+    # device-resident float32 planes at order 0 / 1 share ONE launch, the other cases go plane by plane inside it
     if is_torch:
-        import torch
         planes = mat_pad.permute(2, 0, 1).contiguous()
-        out = torch.stack([_pp.unwarp_image_backward(planes[i], xcenter, ycenter, list_fact, order=order, mode=mode,
-                                                     blend=blend) for i in range(planes.shape[0])])
+        out = _pp.unwarp_images_backward(planes, xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
         return out.permute(1, 2, 0)
     planes = np.ascontiguousarray(np.moveaxis(mat_pad, 2, 0))
-    mat_corr = [_pp.unwarp_image_backward(planes[i], xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
-                for i in range(planes.shape[0])]
+    mat_corr = _pp.unwarp_images_backward(planes, xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
     return np.moveaxis(np.asarray(mat_corr), 0, 2)

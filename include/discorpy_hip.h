@@ -86,6 +86,20 @@ int dcp_unwarp_image_f32(const float* src, float* dst, int64_t height, int64_t w
                          const double* list_fact, int nfact, int order, int coord_round_f32, int blend_mode,
                          int mem_kind, int device, void* stream);
 
+/* unwarp_image_backward (discorpy/post/postprocessing.py:111-148) over `nframes` images of ONE shape in one call, every
+ * frame with its own source, destination, centre and coefficient vector -- the reference's callers loop over channels
+ * (examples/readthedocs_demo/demo_06.py:111-113, demo_07.py:58-60), cameras or candidate calibrations (example_05.py:62-65),
+ * one call per image.  srcs[i] / dsts[i]: the frames (all with the strides given); xcenters[i], ycenters[i]; list_facts:
+ * nframes x nfact, row-major (pad shorter vectors with zeros: the result does not change).  Device-resident dense
+ * float32 frames (unit column stride, coord_round_f32 = 1, nfact <= 10) whose calibrations all hold the tile certificate
+ * run as ONE launch per 55 frames (35 above 5 coefficients) with the workgroup's frame in blockIdx.z, so that the drain of
+ * one frame overlaps the ramp of the next (a 4096 x 4096 frame: ~25 us instead of ~31 us per frame); anything else is
+ * processed frame by frame through dcp_unwarp_image_f32.  Results are bit-identical to nframes separate calls. */
+int dcp_unwarp_images_f32(const float* const* srcs, float* const* dsts, int nframes, int64_t height, int64_t width,
+                          int64_t src_row_stride, int64_t src_col_stride, const double* xcenters, const double* ycenters,
+                          const double* list_facts, int nfact, int order, int coord_round_f32, int blend_mode, int mem_kind,
+                          int device, void* stream);
+
 /* discorpy/post/postprocessing.py:444-459 (_generate_perspective_map) + :486-492
  * (correct_perspective_image, map_index=None).  list_coef = c1..c8 of the backward homography in
  * (x, y) convention (discorpy/proc/processing.py:1254-1270). */
@@ -272,6 +286,13 @@ int dcp_debug_counters(uint64_t* out, int n, int reset);
  * "remap_wg_kernel<Radial,NF=5,f64lerp>" (empty before the first launch).  For tests and benchmarks that must say
  * -- and assert -- which kernel a call took; the reference has no counterpart. */
 const char* dcp_debug_last_kernel(void);
+
+/* The host's tile-deviation certificate for a calibration on a height x width frame (needs no GPU): 0 = none (the staged
+ * kernels verify every pixel), 1 = holds for 64 x 16 wave tiles, 2 = also for 128 x 32 workgroup tiles (remap_wg_kernel,
+ * stack_wg_kernel, remap_wg_batch_kernel).  map_kind DCP_MAP_RADIAL (list_fact) or DCP_MAP_PERSPECTIVE (list_coef).
+ * Negative: a DCP_ERR_* code.  For tests and for callers that want to know which kernel their calibration will take. */
+int dcp_debug_tile_certificate(int map_kind, int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact,
+                               int nfact, const double* list_coef);
 
 /* ---- device memory / stream / event helpers (so a host language needs no other GPU runtime) ---- */
 int dcp_malloc(void** ptr, size_t bytes, int device);

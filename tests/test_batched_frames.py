@@ -1,0 +1,187 @@
+"""Many frames in one launch: dcp_unwarp_images_f32 / post.unwarp_images_backward (remap_wg_batch_kernel, blockIdx.z = frame)
+-- every frame with its OWN calibration must equal the oracle, and the single-frame entry point, bit for bit.
+Reference behaviour restated: one call of unwarp_image_backward per image (postprocessing.py:111-148), looped over channels in
+examples/readthedocs_demo/demo_06.py:111-113."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import noise
+
+from discorpy_amd import _ffi as F
+from discorpy_amd import configs
+from discorpy_amd.post import postprocessing as pp
+from discorpy_amd.util import utility as ut
+
+ORC_BLEND = {"scipy": "BLEND_SCIPY", "f64lerp": "BLEND_F64LERP", "f32": "BLEND_F32LERP"}
+
+
+def _calibrations(n, H, W, seed):
+    """n distinct mild calibrations (all certified at level 2 on frames of this size), with coefficient vectors of 3..5 terms."""
+    rng = np.random.default_rng(seed)
+    c2 = configs.cfg2()
+    s = min(4096.0 / max(H, W), 1.5)
+    out = []
+    for i in range(n):
+        nf = 3 + i % 3
+        fact = [c2["list_fact"][k] * (s ** k) * (1.0 + 0.1 * rng.standard_normal()) for k in range(nf)]
+        fact[0] = 1.0 + 0.01 * rng.standard_normal()
+        out.append((W * (0.3 + 0.4 * rng.random()), H * (0.3 + 0.4 * rng.random()), fact))
+    return out
+
+
+def _device_batch(hip, frames, cals, order, blend_code, dev=-1):
+    """The C ABI on device pointers, exactly as bench.py calls it; returns the downloaded outputs and the kernel that ran."""
+    L = hip.lib()
+    n = len(frames)
+    H, W = frames[0].shape
+    src = [hip.DeviceBuffer(f.nbytes, dev).upload(f) for f in frames]
+    dst = [hip.DeviceBuffer(f.nbytes, dev) for f in frames]
+    nf = max(len(c[2]) for c in cals)
+    table = np.zeros((n, nf))
+    for i, c in enumerate(cals):
+        table[i, :len(c[2])] = c[2]
+    sp = (C.c_void_p * n)(*[b.ptr for b in src])
+    dp = (C.c_void_p * n)(*[b.ptr for b in dst])
+    xa = (C.c_double * n)(*[c[0] for c in cals])
+    ya = (C.c_double * n)(*[c[1] for c in cals])
+    hip.check(L.dcp_unwarp_images_f32(sp, dp, n, H, W, W, 1, xa, ya, table.ctypes.data_as(C.POINTER(C.c_double)), nf, order, 1, blend_code,
+                                      hip.MEM_DEVICE, dev, None))
+    kernel = hip.last_kernel()
+    outs = [b.download((H, W), np.float32) for b in dst]
+    for b in src + dst:
+        b.free()
+    return outs, kernel
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blend", ["f64lerp", "scipy", "f32"])
+def test_batch_of_distinct_calibrations_equals_the_oracle_per_frame(hip, orc, blend):
+    H, W, n = 700, 1000, 7
+    frames = [noise(100 + i, (H, W)) for i in range(n)]
+    cals = _calibrations(n, H, W, 5)
+    outs, kernel = _device_batch(hip, frames, cals, 1, hip.BLEND_BY_NAME[blend])
+    assert kernel.startswith("remap_wg_batch_kernel<Radial,NF=5"), kernel
+    for f, (xc, yc, fact), got in zip(frames, cals, outs):
+        want = orc.unwarp_image_backward(f, xc, yc, fact, poly=orc.POLY_KERNEL, blend=getattr(orc, ORC_BLEND[blend]))
+        assert np.array_equal(got, want)
+        assert np.array_equal(got, pp.unwarp_image_backward(f, xc, yc, fact, blend=blend))     # == one call per image
+
+
+@pytest.mark.gpu
+def test_batch_order0_and_long_coefficient_vectors(hip, orc):
+    H, W, n = 300, 520, 4
+    frames = [noise(200 + i, (H, W)) for i in range(n)]
+    cals = _calibrations(n, H, W, 6)
+    outs, kernel = _device_batch(hip, frames, cals, 0, hip.BLEND_SCIPY)
+    assert kernel.startswith("remap_wg_batch_kernel<Radial,NF=5,nearest"), kernel
+    for f, (xc, yc, fact), got in zip(frames, cals, outs):
+        assert np.array_equal(got, orc.unwarp_image_backward(f, xc, yc, fact, order=0, poly=orc.POLY_KERNEL))
+    # 6..10 coefficients: the NF = 10 instantiation (shorter vectors padded with zeros -- bit-identical)
+    c5 = configs.cfg5()
+    long_fact = [a * 2.0 ** k for k, a in enumerate(c5["list_fact"])]
+    cals = [(W * 0.5, H * 0.5, long_fact), (W * 0.45, H * 0.52, long_fact[:7]), (W * 0.4, H * 0.6, long_fact[:2])]
+    outs, kernel = _device_batch(hip, frames[:3], cals, 1, hip.BLEND_F64LERP)
+    assert kernel.startswith("remap_wg_batch_kernel<Radial,NF=10"), kernel
+    for f, (xc, yc, fact), got in zip(frames, cals, outs):
+        assert np.array_equal(got, orc.unwarp_image_backward(f, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+
+
+@pytest.mark.gpu
+def test_batch_longer_than_one_launch_and_uncertified_frames_fall_back(hip, orc):
+    # 60 frames > the 55 one launch carries: two launches, every frame still its own calibration
+    H, W, n = 96, 200, 60
+    frames = [noise(300 + i, (H, W)) for i in range(n)]
+    cals = _calibrations(n, H, W, 7)
+    outs, kernel = _device_batch(hip, frames, cals, 1, hip.BLEND_F64LERP)
+    assert kernel.startswith("remap_wg_batch_kernel"), kernel
+    for i in (0, 1, 54, 55, 56, 59):
+        xc, yc, fact = cals[i]
+        assert np.array_equal(outs[i], orc.unwarp_image_backward(frames[i], xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+    # one strongly curved (uncertified) calibration in the batch: the whole call goes frame by frame, results unchanged
+    cals2 = list(cals[:4])
+    cals2[2] = (W * 0.5, H * 0.5, [1.0, 4e-3, 3e-5])
+    outs, kernel = _device_batch(hip, frames[:4], cals2, 1, hip.BLEND_F64LERP)
+    assert not kernel.startswith("remap_wg_batch_kernel"), kernel
+    for f, (xc, yc, fact), got in zip(frames, cals2, outs):
+        assert np.array_equal(got, orc.unwarp_image_backward(f, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+
+
+@pytest.mark.gpu
+def test_full_size_batch_three_calibrations_4096(hip, orc):
+    """BASELINE config 2 frames, three calibrations, through the call bench.py times (`batched_distinct_calibrations`)."""
+    c2 = configs.cfg2()
+    H, W = c2["shape"]
+    frames = [noise(c2["seed"] + i, (H, W)) for i in range(3)]
+    cals = [(c2["xcenter"], c2["ycenter"], c2["list_fact"]),
+            (c2["xcenter"] + 37.25, c2["ycenter"] - 11.5, [v * (1.0 + 0.05 * k) for k, v in enumerate(c2["list_fact"])]),
+            (c2["xcenter"] - 150.0, c2["ycenter"] + 80.0, [c2["list_fact"][0] * 0.99, c2["list_fact"][1] * 0.5, c2["list_fact"][2] * 0.7])]
+    outs, kernel = _device_batch(hip, frames, cals, 1, hip.BLEND_F64LERP)
+    assert kernel == "remap_wg_batch_kernel<Radial,NF=5,f64lerp>", kernel
+    for f, (xc, yc, fact), got in zip(frames, cals, outs):
+        assert np.array_equal(got, orc.unwarp_image_backward(f, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+
+
+@pytest.mark.gpu
+def test_python_front_end_numpy_torch_and_colour_planes(hip, orc):
+    H, W, n = 260, 390, 3
+    frames = [noise(400 + i, (H, W)) for i in range(n)]
+    cals = _calibrations(n, H, W, 8)
+    xcs, ycs, facts = [c[0] for c in cals], [c[1] for c in cals], [c[2] for c in cals]
+    want = [orc.unwarp_image_backward(f, *c, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP) for f, c in zip(frames, cals)]
+    # NumPy frames (host path: frame by frame inside the C call), per-frame calibrations of different lengths
+    got = pp.unwarp_images_backward(frames, xcs, ycs, facts)
+    assert isinstance(got, list) and all(np.array_equal(g, w) for g, w in zip(got, want))
+    # one 3-D array, one shared calibration
+    got = pp.unwarp_images_backward(np.stack(frames), xcs[0], ycs[0], facts[0])
+    assert got.shape == (n, H, W)
+    for i in range(n):
+        assert np.array_equal(got[i], orc.unwarp_image_backward(frames[i], *cals[0], poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+    # other element types and spline orders go image by image, same results as the single calls
+    u16 = [(f * 60000).astype(np.uint16) for f in frames]
+    got = pp.unwarp_images_backward(u16, xcs, ycs, facts)
+    assert all(np.array_equal(g, pp.unwarp_image_backward(u, *c)) for g, u, c in zip(got, u16, cals))
+    got = pp.unwarp_images_backward(frames, xcs, ycs, facts, order=3, mode="mirror")
+    assert all(np.array_equal(g, pp.unwarp_image_backward(f, *c, order=3, mode="mirror")) for g, f, c in zip(got, frames, cals))
+    with pytest.raises(ValueError):
+        pp.unwarp_images_backward(frames, xcs[:2], ycs, facts)
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        t = torch.from_numpy(np.stack(frames)).cuda()
+        got = pp.unwarp_images_backward(t, xcs, ycs, facts)
+        torch.cuda.synchronize()
+        assert F.last_kernel().startswith("remap_wg_batch_kernel") and tuple(got.shape) == (n, H, W)
+        assert all(np.array_equal(got[i].cpu().numpy(), want[i]) for i in range(n))
+        got = pp.unwarp_images_backward([t[i] for i in range(n)], xcs, ycs, facts, blend="scipy")
+        torch.cuda.synchronize()
+        for i in range(n):
+            assert np.array_equal(got[i].cpu().numpy(), orc.unwarp_image_backward(frames[i], *cals[i], poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY))
+        # the colour image's plane-by-plane path (blend="f32" is not offered by the interleaved kernel): one launch for the 3 planes
+        rgb = torch.from_numpy(np.stack(frames, axis=2)).cuda()
+        got = ut.unwarp_color_image_backward(rgb, xcs[0], ycs[0], facts[0], blend="f32")
+        torch.cuda.synchronize()
+        assert F.last_kernel().startswith("remap_wg_batch_kernel<Radial,NF=5,f32lerp"), F.last_kernel()
+        for i in range(n):
+            assert np.array_equal(got[:, :, i].cpu().numpy(),
+                                  orc.unwarp_image_backward(frames[i], *cals[0], poly=orc.POLY_KERNEL, blend=orc.BLEND_F32LERP))
+
+
+def test_front_end_validation_needs_no_gpu():
+    a = np.zeros((4, 5), np.float32)
+    with pytest.raises(ValueError):
+        pp.unwarp_images_backward(a, 1.0, 1.0, [1.0])                       # a single 2-D image is not a batch
+    with pytest.raises(ValueError):
+        pp.unwarp_images_backward([a, a], [1.0, 2.0, 3.0], 1.0, [1.0])      # three centres for two images
+    with pytest.raises(ValueError):
+        pp.unwarp_images_backward([a, a], 1.0, 1.0, [[1.0], [1.0], [1.0]])  # three coefficient vectors for two images
+    with pytest.raises(RuntimeError):
+        pp.unwarp_images_backward([a], 1.0, 1.0, [1.0], mode="bogus")       # scipy's message for an unknown mode
+    assert pp.unwarp_images_backward([], 1.0, 1.0, [1.0]) == []
+    L = F.lib()
+    one = (C.c_double * 1)(1.0)
+    ptr = (C.c_void_p * 1)(a.ctypes.data)
+    assert L.dcp_unwarp_images_f32(ptr, ptr, -1, 4, 5, 5, 1, one, one, one, 1, 1, 1, F.BLEND_F64LERP, F.MEM_HOST, -1, None) == F.ERR_INVALID_ARG
+    assert L.dcp_unwarp_images_f32(None, ptr, 1, 4, 5, 5, 1, one, one, one, 1, 1, 1, F.BLEND_F64LERP, F.MEM_HOST, -1, None) == F.ERR_INVALID_ARG
+    assert L.dcp_unwarp_images_f32(ptr, ptr, 1, 4, 5, 5, 1, one, one, one, 40, 1, 1, F.BLEND_F64LERP, F.MEM_HOST, -1, None) == F.ERR_INVALID_ARG
+    assert L.dcp_unwarp_images_f32(ptr, ptr, 0, 4, 5, 5, 1, one, one, one, 1, 1, 1, F.BLEND_F64LERP, F.MEM_HOST, -1, None) == F.OK

@@ -38,7 +38,16 @@ def test_bench_line_carries_every_config_verified(hip):
     assert "stack_wg_kernel" in oc["cfg4_stack_one_gpu"]["kernel"]          # the workgroup-box stack kernel, auto-selected
     ss = j["stack_scaling"]
     assert ss["compute_plus_allgather"] is None and ss["verified_vs_oracle"] is True and ss["compute_only"]["ms_per_step"] > 0
-    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and "profiles/r01c_reference_cpu" in j["cpu_baseline"]["sample"]
+    # the multi-frame launch (every frame its own calibration) beside the per-launch headline, checked against the oracle
+    bd = j["batched_distinct_calibrations"]
+    assert bd["verified_vs_oracle"] is True and bd["kernel"].startswith("remap_wg_batch_kernel<Radial,NF=5,f64lerp") and bd["us_per_frame"] > 0
+    assert j["batched_same_calibration"]["identical_to_per_frame_launches"] is True and "two_streams" not in j
+    pl = roof["per_launch_distribution"]
+    assert pl["launches"] >= 50 and 0 < pl["p10_us"] <= pl["median_us"] <= pl["p90_us"] <= pl["max_us"]
+    # the drop-in caller's number: NumPy in -> NumPy out, PCIe-inclusive
+    e2e = j["end_to_end_numpy"]
+    assert e2e["default_runtime"]["cfg2_unwarp_image_backward_4096"]["ms"] > 0 and e2e["default_runtime"]["cfg4_unwarp_slice_backward_depth32"]["ms"] > 0
 
 
 def test_bench_two_ranks_share_the_gpu_through_gloo(hip):
