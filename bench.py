@@ -162,9 +162,22 @@ def launch_distribution(fn, n, dev):
     ev[n].record()
     ev[n].synchronize()
     us = np.array([ev[i].elapsed_ms(ev[i + 1]) * 1e3 for i in range(n)])
+    # what the event between two launches costs by itself (a marker packet with a cache release: the next kernel starts later
+    # than it would behind another kernel): the same kernel in pairs, one event per pair -- (pair - 2 x back-to-back) is not
+    # observable directly, so report the back-to-back average beside the per-interval figures and let the reader subtract
+    e0, e1 = F.Event(dev), F.Event(dev)
+    e0.record()
+    for i in range(n):
+        fn(i)
+    e1.record()
+    e1.synchronize()
+    b2b = e0.elapsed_ms(e1) * 1e3 / n
     return {"launches": n, "median_us": round(float(np.median(us)), 3), "mean_us": round(float(us.mean()), 3),
             "p10_us": round(float(np.percentile(us, 10)), 3), "p90_us": round(float(np.percentile(us, 90)), 3),
-            "max_us": round(float(us.max()), 3)}
+            "max_us": round(float(us.max()), 3), "back_to_back_mean_us": round(b2b, 3),
+            "event_overhead_us": round(float(np.median(us)) - b2b, 3),
+            "note": "each interval = one launch + one HIP event record between launches; back_to_back_mean_us is the same n launches with "
+                    "no events in between, event_overhead_us = median_us - back_to_back_mean_us"}
 
 
 def hip_runtime_path():

@@ -266,13 +266,17 @@ int make_stack_call(StackCall* c, const void* vol, void* out, int dtype, int out
   c->sampler = dcp::kScipy;
   if (dtype == dcp::kF32 && !out_f32 && (rc = sampler_of(1, blend_mode, &c->sampler)) != DCP_OK) return rc;
   if ((rc = fill_map(&c->map, xcenter, ycenter, list_fact, nfact, nullptr)) != DCP_OK) return rc;
-  if (g_tile_cert.load() && coord_round_f32 && height > 0 && width > 0)
+  // the certificate (and the monotonicity test below) bound the model over the radii of the FRAME [0, W-1] x [0, H-1]: rows
+  // requested outside it are evaluated beyond the proven radius and take the per-pixel-checked kernels
+  const bool rows_inside = std::isfinite(row_start) && row_start >= 0.0 && nrows >= 1 && row_start + (double)(nrows - 1) <= (double)(height - 1);
+  if (g_tile_cert.load() && coord_round_f32 && height > 0 && width > 0 && rows_inside)
     c->map.tile_dev_ok = tile_deviation_certified(dcp::kRadial, c->map, height, width);
   // unwarp_chunk_slices_backward crops the rows [yd_min, yd_max) spanned by its first and last rows and lets scipy reflect
   // inside that band (postprocessing.py:289-312).  Under a model whose row coordinate increases with the row nothing can
   // leave the band; otherwise (a folding model) the band goes to the kernel, which then checks every pixel.
   c->rb0 = c->rbh = 0;
-  if (coord_round_f32 && nrows > 0 && height > 0 && width > 0 && std::isfinite(row_start) && !radial_monotone_in_y(c->map, height, width)) {
+  if (coord_round_f32 && nrows > 0 && height > 0 && width > 0 && std::isfinite(row_start) &&
+      (!rows_inside || !radial_monotone_in_y(c->map, height, width))) {
     int64_t b0 = 0, b1 = height;
     reference_chunk_band(c->map, height, width, row_start, row_start + (double)(nrows - 1), &b0, &b1);
     if (b1 <= b0) return fail(DCP_ERR_INVALID_ARG, "the model folds the requested rows onto an empty band of source rows [%lld, %lld)",
@@ -410,14 +414,26 @@ int dcp_unwarp_stack_rows_peer_f32(const float* const* vol, float* const* out, i
   DCP_HIP(hipGetDevice(&prev));
   std::vector<hipStream_t> streams((size_t)ndev, nullptr);
   int rc = DCP_OK;
+  // drains and destroys every stream; an asynchronous fault of a kernel or a peer copy surfaces here and must not be
+  // reported as success (the caller would read a partly written gather)
   auto finish = [&](int code) {
+    hipError_t first = hipSuccess;
+    int first_dev = -1;
     for (int i = 0; i < ndev; ++i)
       if (streams[(size_t)i]) {
-        (void)hipSetDevice(devices[i]);
-        (void)hipStreamSynchronize(streams[(size_t)i]);
+        hipError_t e = hipSetDevice(devices[i]);
+        if (e == hipSuccess) e = hipStreamSynchronize(streams[(size_t)i]);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess && first == hipSuccess) {
+          first = e;
+          first_dev = devices[i];
+        }
         (void)hipStreamDestroy(streams[(size_t)i]);
+        (void)hipGetLastError();
       }
     (void)hipSetDevice(prev);
+    if (code == DCP_OK && first != hipSuccess)
+      return fail(DCP_ERR_HIP, "stack kernel / peer copy on device %d failed: %s", first_dev, hipGetErrorString(first));
     return code;
   };
   const size_t block = (size_t)nrows * (size_t)width;           // floats per projection of the result
@@ -428,9 +444,14 @@ int dcp_unwarp_stack_rows_peer_f32(const float* const* vol, float* const* out, i
       break;
     }
     if (gather)
-      for (int h = 0; h < ndev; ++h)
-        if (devices[h] != devices[i]) (void)hipDeviceEnablePeerAccess(devices[h], 0);     // already enabled: an error we ignore
-    (void)hipGetLastError();
+      for (int h = 0; h < ndev && rc == DCP_OK; ++h)
+        if (devices[h] != devices[i]) {
+          const hipError_t e = hipDeviceEnablePeerAccess(devices[h], 0);
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+            rc = fail(DCP_ERR_HIP, "device %d cannot access device %d: %s", devices[i], devices[h], hipGetErrorString(e));
+          (void)hipGetLastError();
+        }
+    if (rc != DCP_OK) break;
     const int64_t n = d0[(size_t)i + 1] - d0[(size_t)i];
     if (n == 0) continue;
     float* mine = out[i] + (gather ? (size_t)d0[(size_t)i] * block : 0);

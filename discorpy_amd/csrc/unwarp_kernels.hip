@@ -1739,6 +1739,10 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
   unsigned pad = 0;
   if (img.wg_per_cu >= 1 && img.wg_per_cu <= 5) pad = (unsigned)(160 * 1024 / img.wg_per_cu - 24 * 1024) & ~255u;
   note_kernel("remap_wg_kernel", KIND, NF, SAMPLER);
+  if (pad > 32768u) {        // beyond the 64 KB a launch may ask for by default (static 24.6 KB + the padding)
+    const hipError_t e = hipFuncSetAttribute((const void*)remap_wg_kernel<KIND, NF, SAMPLER, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
+    if (e != hipSuccess) return e;
+  }
   hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), pad, stream, img, map);
   return hipGetLastError();
 }

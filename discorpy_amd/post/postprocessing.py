@@ -88,6 +88,20 @@ def _is_device_coords(a):
     return True
 
 
+def _cai_is_contiguous(a):
+    """C-contiguous ``__cuda_array_interface__`` array of any element type (no strides, or the strides of C order)."""
+    cai = a.__cuda_array_interface__
+    st = cai.get("strides")
+    if st is None:
+        return True
+    acc = np.dtype(cai["typestr"]).itemsize
+    for n, v in zip(reversed(cai["shape"]), reversed(st)):
+        if int(n) > 1 and int(v) != acc:
+            return False
+        acc *= max(int(n), 1)
+    return True
+
+
 def _cai_to_host(a):
     """Host copy of a ``__cuda_array_interface__`` array (C-contiguous ones only; anything else should be copied by its owner)."""
     if hasattr(a, "copy_to_host"):
@@ -95,7 +109,7 @@ def _cai_to_host(a):
     if hasattr(a, "get"):
         return a.get()
     cai = a.__cuda_array_interface__
-    if cai.get("strides") is not None and not _is_device_coords(a):
+    if not _cai_is_contiguous(a):
         raise ValueError("a strided device coordinate array cannot be read back; pass a contiguous one")
     out = np.empty(tuple(int(v) for v in cai["shape"]), np.dtype(cai["typestr"]))
     F.check(F.lib().dcp_memcpy(out.ctypes.data, int(cai["data"][0]), out.nbytes, F.COPY_D2H, -1, None))

@@ -113,7 +113,15 @@ def unwarp_stack_row_sharded(vol, xcenter, ycenter, list_fact, row_start, nrows,
     reach are touched (the reference's band, ``postprocessing.py:289-301``; the library computes it per call).
 
     Returns ``(local, (r0, r1))`` with ``local`` of shape ``(depth, r1 - r0, width)``; rows are relative to ``row_start``.
+
+    With ``coord_round_f32=True`` every rank's call is an ``unwarp_chunk_slices_backward`` over ITS rows, so the reference's
+    row band (``:289-301``: spanned by the call's first and last rows) is that of the sub-chunk -- what calling the
+    reference on the sub-chunk gives.  Under a model whose row coordinate increases with the row (every usable calibration)
+    the band is never left and the union of the ranks' rows equals the single call; under a FOLDING model the single
+    call reflects inside the whole chunk's band and the two differ, as they do in the reference.
     """
+    if world_size is not None and rank is None:
+        raise ValueError("rank is required when world_size is given")
     if world_size is None:
         import torch.distributed as dist
         world_size = dist.get_world_size(group) if dist.is_initialized() else 1

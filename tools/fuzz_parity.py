@@ -162,7 +162,7 @@ def one_case(rng, k):
             xs[:5] = [w - 1, 0, 0.5, w - 1.5 if w > 1 else 0, (w - 1) / 2.0]
         ok2 = {k_: v for k_, v in okw.items() if k_ != "poly"}
         import warnings
-        with warnings.catch_warnings():      # (coordinates 10 % outside the image on purpose: clamped, with a warning)
+        with warnings.catch_warnings():      # (coordinates 10 % outside the image on purpose: treated as scipy treats them under the mode)
             warnings.simplefilter("ignore", RuntimeWarning)
             got = pp.remap_coordinates(img, ys, xs, order=order, **kw)
         same(got, orc.remap_coords(img, ys, xs, order=order, **ok2), order, tag)
