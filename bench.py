@@ -63,6 +63,13 @@ def parse(argv=None):
     ap.add_argument("--rows", type=int, default=2560, help="stack: output rows per step (2560 = whole stack)")
     ap.add_argument("--no-gather", action="store_true", help="stack workload: skip the all-gather")
     ap.add_argument("--e2e-child", action="store_true", help=argparse.SUPPRESS)   # internal: the NumPy -> NumPy timings, in a process of their own
+    # internal: the torch-free exchange variants of config 4 (C ABI only), each in processes of their own (native_exchange_variants)
+    ap.add_argument("--native-child", default=None, choices=["rccl", "peer"], help=argparse.SUPPRESS)
+    ap.add_argument("--child-world", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--child-rank", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--idfile", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--no-spawn", action="store_true",
+                    help="--gpus N > 1 without WORLD_SIZE in the environment normally re-launches itself as N ranks; this keeps one process")
     ap.add_argument("--shard", default="depth", choices=["depth", "rows"],
                     help="stack workload: depth = projections split over the ranks (+ all-gather); rows = every rank owns "
                          "output rows of every projection (the whole stack on every rank, no collective)")
@@ -494,6 +501,16 @@ class DevBlock:
         self.tensor = None
 
 
+class SubBlock:
+    """Projections [s0, s1) of a block (a view: same allocation)."""
+
+    def __init__(self, block, s0, s1):
+        per = int(np.prod(block.shape[1:], dtype=np.int64))
+        self.shape = (s1 - s0,) + tuple(block.shape[1:])
+        self.ptr = block.ptr + s0 * per * 4
+        self.tensor = block.tensor[s0:s1] if getattr(block, "tensor", None) is not None else None
+
+
 def fill_projections(block, dev, seed, upload=None):
     """Synthetic projections: one host chunk of noise replicated over the block (53.7 GB do not pass through PCIe)."""
     D, H, W = block.shape
@@ -526,7 +543,7 @@ def hip_stack_launch(cfg, nrows, blend, dev, stream=None, row_start=0.0):
 
 
 def stack_scaling(cfg, world, rank, dist, steps, warmup, nrows, make_block, launch, sync, fill, barrier_device="cuda",
-                  verify=None, collective_name="all_gather_into_tensor"):
+                  verify=None, collective_name="all_gather_into_tensor", pipeline_blocks=4):
     """BASELINE config 4 with the projections sharded by depth over `world` ranks (discorpy_amd.stack.shard_bounds): time
     `steps` passes of (a) the local kernel alone and (b) the kernel followed by the all-gather that reassembles the
     (depth, nrows, width) block on every rank.  The max over ranks is what counts.  `make_block(shape)`, `launch(vol, out,
@@ -572,6 +589,20 @@ def stack_scaling(cfg, world, rank, dist, steps, warmup, nrows, make_block, laun
         launch(vol, out, dl)
         dist.all_gather_into_tensor(full.tensor, out.tensor)
 
+    nsub = min(pipeline_blocks, dl)
+
+    def compute_and_gather_pipelined():
+        # the shard in `nsub` depth sub-blocks: the (asynchronous) all-gather of sub-block s, every rank's piece landing in its place
+        # of the depth-outer result, runs while the kernel of sub-block s + 1 computes (discorpy_amd.stack, pipeline=)
+        pending = []
+        for s_ in range(nsub):
+            s0, s1 = st.shard_bounds(dl, nsub, s_)
+            launch(SubBlock(vol, s0, s1), SubBlock(out, s0, s1), s1 - s0)
+            pieces = [full.tensor[r * dl + s0:r * dl + s1] for r in range(world)]
+            pending.append(dist.all_gather(pieces, out.tensor[s0:s1], async_op=True))
+        for w in pending:
+            w.wait()
+
     ms_compute = timed(compute_only)
     try:
         kernel = F.last_kernel()
@@ -581,6 +612,15 @@ def stack_scaling(cfg, world, rank, dist, steps, warmup, nrows, make_block, laun
     verified = None
     if verify is not None:
         verified = bool(verify(chunk, out, full if gather else None, d0, dl))
+    ms_pipe, verified_pipe = None, None
+    if gather and nsub > 1:
+        try:
+            full.tensor.zero_()
+            ms_pipe = timed(compute_and_gather_pipelined)
+            if verify is not None:
+                verified_pipe = bool(verify(chunk, out, full, d0, dl))
+        except Exception as e:      # noqa: BLE001 -- a variant beside the plain all-gather: never fails the run
+            ms_pipe, verified_pipe = None, "error: %r" % (e,)
     vox = float(D) * nrows * W
     res = {"what": "config 4: (%d, %d, %d) float32 stack, %d output rows of every projection, projections sharded by depth over "
                    "%d rank(s)" % (D, H, W, nrows, world),
@@ -590,6 +630,10 @@ def stack_scaling(cfg, world, rank, dist, steps, warmup, nrows, make_block, laun
            "compute_plus_allgather": None if ms_gather is None else {
                "ms_per_step": round(ms_gather, 4), "Mpixels_per_s": round(vox / ms_gather / 1e3, 1),
                "gathered_bytes_received_per_gpu": int((D - dl) * nrows * W * 4), "collective": collective_name},
+           "compute_plus_allgather_pipelined": None if ms_pipe is None else {
+               "ms_per_step": round(ms_pipe, 4), "Mpixels_per_s": round(vox / ms_pipe / 1e3, 1), "depth_sub_blocks": nsub,
+               "collective": "all_gather (list form, async_op) per sub-block under the next sub-block's kernel",
+               "verified_vs_oracle": verified_pipe},
            "kernel": kernel, "verified_vs_oracle": verified}
     if world > 1 and not even:
         res["note"] = "depth does not divide evenly over the ranks: the timed all-gather needs even shards (discorpy_amd.stack pads ragged ones)"
@@ -715,6 +759,196 @@ def stack_one_gpu_cases(a, dev):
                                             "source rows (12 B per voxel); 2.6 MB per launch -- launch-bound")
 
 
+# ----------------------------------------------------------------------------------------- exchange without torch (C ABI only)
+
+def native_rccl_child(a):
+    """One rank of config 4 with the exchange done by dcp_unwarp_stack_rows_rccl_f32 (dlopen'ed librccl: ncclAllGather in place on
+    the kernel's stream; pipelined: grouped ncclBroadcasts of depth sub-blocks on a side stream) -- no torch in this process.
+    The ncclUniqueId travels through --idfile (rank 0 writes it, the others poll)."""
+    import ctypes as C
+    L = F.lib()
+    F.require_device()
+    world, rank = a.child_world, a.child_rank
+    dev = int(os.environ.get("DCP_BENCH_DEVICE", rank))
+    idbuf = (C.c_char * 128)()
+    if rank == 0:
+        F.check(L.dcp_rccl_unique_id(idbuf, 128))
+        tmp = a.idfile + ".tmp"
+        open(tmp, "wb").write(bytes(idbuf))
+        os.replace(tmp, a.idfile)
+    else:
+        t0 = time.perf_counter()
+        while not os.path.exists(a.idfile):
+            if time.perf_counter() - t0 > 90:
+                raise RuntimeError("no RCCL unique id from rank 0 after 90 s")
+            time.sleep(0.05)
+        idbuf = (C.c_char * 128).from_buffer_copy(open(a.idfile, "rb").read())
+    comm = C.c_void_p()
+    F.check(L.dcp_rccl_comm_create(C.byref(comm), world, rank, idbuf, dev))
+    cfg = configs.cfg4(a.depth)
+    D, H, W = cfg["shape"]
+    if D % world:
+        raise RuntimeError("depth %d does not divide over %d ranks" % (D, world))
+    dl, nrows = D // world, a.rows
+    vol = DevBlock((dl, H, W), dev, False)
+    full = DevBlock((D, nrows, W), dev, False)
+    chunk = fill_projections(vol, dev, cfg["seed"] + rank)
+    fa, nf = F.fact_array(cfg["list_fact"])
+    res = {"rank": rank, "world": world, "device": dev, "depth_per_gpu": dl}
+
+    def run(pipeline):
+        F.check(L.dcp_unwarp_stack_rows_rccl_f32(vol.ptr, full.ptr, dl, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf, 0.0, nrows, 1,
+                                                 F.BLEND_F64LERP, comm, pipeline, None))
+
+    def check():
+        orc = oracle_module(a.cpu_threads)
+        ok = True
+        for r, d in ((rank, 0), ((rank + 1) % world, dl - 1)):        # one projection of this rank's block, one of a neighbour's
+            src = chunk if r == rank else np.random.default_rng(cfg["seed"] + r).random((min(dl, 8), H, W), dtype=np.float32)
+            want = orc.unwarp_stack_rows(src[d % src.shape[0]][None], cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], 0, nrows,
+                                         coord_round_f32=True, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+            got = download(full.ptr, (1, nrows, W), dev, offset=(r * dl + d) * nrows * W * 4)
+            ok = ok and bool(np.array_equal(got, want))
+        return ok
+    zeros = np.zeros((nrows, W), np.float32)
+    for name, pipeline in (("allgather", 1), ("allgather_pipelined", 4)):
+        for r, d in ((rank, 0), ((rank + 1) % world, dl - 1)):      # the projections check() reads must come from THIS variant
+            F.check(L.dcp_memcpy(full.ptr + (r * dl + d) * nrows * W * 4, zeros.ctypes.data, zeros.nbytes, F.COPY_H2D, dev, None))
+        run(pipeline)                                   # warm-up; its collective also lines the ranks up
+        F.check(L.dcp_stream_synchronize(dev, None))
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            run(pipeline)
+        F.check(L.dcp_stream_synchronize(dev, None))
+        res[name + "_ms"] = (time.perf_counter() - t0) * 1e3 / a.steps
+        res[name + "_verified"] = check()
+    F.check(L.dcp_rccl_comm_destroy(comm))
+    vol.free()
+    full.free()
+    print(json.dumps(res), flush=True)
+
+
+def native_peer_child(a):
+    """Config 4 with every GPU driven from THIS one process and the exchange done by peer copies (dcp_unwarp_stack_rows_peer_f32:
+    hipMemcpyPeerAsync pushes, one per xGMI link and device) -- no torch, no RCCL."""
+    import ctypes as C
+    L = F.lib()
+    F.require_device()
+    world = a.child_world
+    cfg = configs.cfg4(a.depth)
+    D, H, W = cfg["shape"]
+    if D % world:
+        raise RuntimeError("depth %d does not divide over %d devices" % (D, world))
+    dl, nrows = D // world, a.rows
+    share = os.environ.get("DCP_BENCH_DEVICE")              # test hook: every slot on one GPU
+    devices = [int(share) if share is not None else g for g in range(world)]
+    vols = [DevBlock((dl, H, W), d, False) for d in devices]
+    outs = [DevBlock((D, nrows, W), d, False) for d in devices]
+    chunks = [fill_projections(v, d, cfg["seed"] + g) for g, (v, d) in enumerate(zip(vols, devices))]
+    fa, nf = F.fact_array(cfg["list_fact"])
+    vp = (C.c_void_p * world)(*[v.ptr for v in vols])
+    op = (C.c_void_p * world)(*[o.ptr for o in outs])
+    da = (C.c_int * world)(*devices)
+
+    def run():
+        F.check(L.dcp_unwarp_stack_rows_peer_f32(vp, op, D, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf, 0.0, nrows, 1, F.BLEND_F64LERP,
+                                                 da, world, 1))
+    run()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()                                           # (returns after every stream has drained)
+    ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    orc = oracle_module(a.cpu_threads)
+    ok = True
+    for g, r in ((0, 0), (0, world - 1), (world - 1, 0)):   # slot g's result, the block that slot r computed
+        want = orc.unwarp_stack_rows(chunks[r][0][None], cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], 0, nrows, coord_round_f32=True,
+                                     poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+        got = download(outs[g].ptr, (1, nrows, W), devices[g], offset=r * dl * nrows * W * 4)
+        ok = ok and bool(np.array_equal(got, want))
+    for b in vols + outs:
+        b.free()
+    print(json.dumps({"world": world, "devices": devices, "peer_copies_ms": ms, "verified": ok}), flush=True)
+
+
+def native_exchange_variants(a, world, depth, steps=3, timeout=150):
+    """Rank 0 of the torch job calls this after stack_scaling (the other ranks wait at a barrier, their blocks freed): the same
+    workload with the exchange done WITHOUT torch -- (a) one C-ABI process per GPU and a native RCCL all-gather, plain and
+    pipelined, (b) one process driving every GPU with peer copies.  Child processes with a timeout each: a hang or a crash in a
+    path that no single-GPU box can exercise at world > 1 must not cost the run its JSON line."""
+    import subprocess
+    import tempfile
+    D = depth
+    vox = float(D) * 2560 * 2560
+    out = {}
+    base = [sys.executable, os.path.abspath(__file__), "--depth", str(D), "--rows", "2560", "--steps", str(steps), "--child-world", str(world)]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+
+    def last_json(text):
+        lines = [ln for ln in (text or "").strip().split("\n") if ln.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    # (a) native RCCL, one process per GPU
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            idfile = os.path.join(td, "rccl_id")
+            procs = [subprocess.Popen(base + ["--native-child", "rccl", "--child-rank", str(r), "--idfile", idfile], stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT) for r in range(world)]
+            t_end = time.perf_counter() + timeout
+            res, errs = [], []
+            for p_ in procs:
+                try:
+                    so, se = p_.communicate(timeout=max(1.0, t_end - time.perf_counter()))
+                    j = last_json(so) if p_.returncode == 0 else None
+                    (res if j else errs).append(j or (se or so)[-300:])
+                except subprocess.TimeoutExpired:
+                    p_.kill()
+                    p_.communicate()
+                    errs.append("timeout after %d s" % timeout)
+        if errs or len(res) != world:
+            out["native_rccl"] = {"error": errs[:2]}
+        else:
+            for name in ("allgather", "allgather_pipelined"):
+                ms = max(r[name + "_ms"] for r in res)
+                out["native_rccl_" + name] = {"ms_per_step": round(ms, 4), "Mpixels_per_s": round(vox / ms / 1e3, 1),
+                                              "verified_vs_oracle": all(r[name + "_verified"] for r in res),
+                                              "how": "dcp_unwarp_stack_rows_rccl_f32, one C-ABI process per GPU (no torch), max over ranks of "
+                                                     "wall time per step incl. the kernel"}
+    except Exception as e:      # noqa: BLE001
+        out["native_rccl"] = {"error": repr(e)}
+    # (b) peer copies, one process for all GPUs
+    try:
+        r = subprocess.run(base + ["--native-child", "peer"], capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+        j = last_json(r.stdout) if r.returncode == 0 else None
+        if j:
+            out["peer_copies"] = {"ms_per_step": round(j["peer_copies_ms"], 4), "Mpixels_per_s": round(vox / j["peer_copies_ms"] / 1e3, 1),
+                                  "verified_vs_oracle": j["verified"],
+                                  "how": "dcp_unwarp_stack_rows_peer_f32: one process drives every GPU, hipMemcpyPeerAsync pushes; wall time per "
+                                         "call incl. stream creation and the final synchronisation"}
+        else:
+            out["peer_copies"] = {"error": (r.stderr or r.stdout)[-300:]}
+    except Exception as e:      # noqa: BLE001
+        out["peer_copies"] = {"error": repr(e)}
+    return out
+
+
+def spawn_ranks(a, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: re-launch as N ranks through torch.distributed.run (one
+    process per GPU, rendezvous on 127.0.0.1) and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    args = [x for x in (sys.argv[1:] if argv is None else list(argv))]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env, cwd=os.getcwd()).returncode
+
+
 # ----------------------------------------------------------------------------------------- main
 
 def init_dist():
@@ -813,6 +1047,14 @@ def main(argv=None):
     if a.e2e_child:
         e2e_child()
         return
+    if a.native_child == "rccl":
+        native_rccl_child(a)
+        return
+    if a.native_child == "peer":
+        native_peer_child(a)
+        return
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and not a.no_spawn:
+        sys.exit(spawn_ranks(a, argv))
     world, rank, dev_index, dist, backend = init_dist()
     n_gpus = world
     if a.gpus != world and rank == 0:
@@ -999,6 +1241,16 @@ def main(argv=None):
                                                      shape=[D_, 2560, W_], note="every row of every projection in one launch")
         except Exception as e:      # noqa: BLE001
             scaling = {"error": repr(e)}
+        # the exchange without torch (native RCCL through the C ABI; peer copies): child processes of rank 0, the other ranks wait
+        if world > 1 and os.environ.get("DCP_BENCH_DEVICE") is None and isinstance(scaling, dict) and "error" not in scaling:
+            sync()
+            if rank == 0:
+                try:
+                    scaling["without_torch"] = native_exchange_variants(a, world, a.depth)
+                except Exception as e:      # noqa: BLE001
+                    scaling["without_torch"] = {"error": repr(e)}
+            if dist is not None:
+                dist.barrier()
 
     if rank == 0:
         launches = a.steps * a.batch

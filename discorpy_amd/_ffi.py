@@ -61,6 +61,12 @@ SIGNATURES = {
                                                _i64, _int, _int, C.POINTER(_int), _int]),
     "dcp_unwarp_stack_rows_peer_f32": (_int, [C.POINTER(_vp), C.POINTER(_vp), _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,
                                               _i64, _int, _int, C.POINTER(_int), _int, _int]),
+    "dcp_rccl_available": (_int, []),
+    "dcp_rccl_unique_id": (_int, [_vp, _sz]),
+    "dcp_rccl_comm_create": (_int, [C.POINTER(_vp), _int, _int, _vp, _int]),
+    "dcp_rccl_comm_destroy": (_int, [_vp]),
+    "dcp_unwarp_stack_rows_rccl_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl, _i64, _int, _int, _vp,
+                                              _int, _vp]),
     "dcp_unwarp_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int, _int,
                                            _int, _vp]),
     "dcp_perspective_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dp, _int, _int, _int, _int, _vp]),

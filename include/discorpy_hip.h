@@ -165,6 +165,30 @@ int dcp_unwarp_stack_rows_peer_f32(const float* const* vol, float* const* out, i
                                    const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
                                    int blend_mode, const int* devices, int ndev, int gather);
 
+/* ---- one process per GPU: the depth-sharded stack and ONE RCCL all-gather over xGMI, without torch ----
+ * (north star / SURVEY.md section 8(e); the reference has no multi-device code: its loops over depth,
+ * discorpy/post/postprocessing.py:226-228 and 310-312, carry no state, so the projections may be split anywhere.)
+ * librccl.so is loaded on first use from the directory of the HIP runtime the process runs on (DCP_RCCL_PATH overrides);
+ * every function below returns DCP_ERR_UNSUPPORTED when it cannot be loaded.
+ *   dcp_rccl_unique_id      ncclGetUniqueId: 128 bytes that ONE rank creates and the caller ships to the others (MPI, a file, a socket)
+ *   dcp_rccl_comm_create    ncclCommInitRank on `device` (collective: every rank of the world calls it), plus the side stream of the
+ *                           pipelined exchange; dcp_rccl_comm_destroy releases both
+ *   dcp_unwarp_stack_rows_rccl_f32
+ *       this rank holds `depth_local` projections at `vol` (EVERY rank the same number: pad the last shard) and a result buffer
+ *       `out` of (world_size * depth_local, nrows, width) floats on the communicator's device.  The stack kernel
+ *       (dcp_unwarp_stack_rows_f32) writes this rank's block in place at depth offset rank * depth_local, then ncclAllGather (in
+ *       place, on `stream`, behind the kernel) fills in the other ranks' blocks -- depth is the outer axis of the result, so every
+ *       contribution is one contiguous block.  pipeline > 1: the shard is cut into that many depth sub-blocks and the exchange of
+ *       sub-block s (grouped ncclBroadcasts on a side stream) overlaps the kernel of sub-block s + 1.  Stream-ordered: returns
+ *       without synchronising, `stream` is complete when the whole (depth, nrows, width) result is. */
+int dcp_rccl_available(void);
+int dcp_rccl_unique_id(void* id, size_t bytes);
+int dcp_rccl_comm_create(void** comm, int world_size, int rank, const void* id, int device);
+int dcp_rccl_comm_destroy(void* comm);
+int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_local, int64_t height, int64_t width, int64_t proj_stride,
+                                   int64_t row_stride, double xcenter, double ycenter, const double* list_fact, int nfact, double row_start,
+                                   int64_t nrows, int coord_round_f32, int blend_mode, void* comm, int pipeline, void* stream);
+
 /* ---- spline orders 2..5 (scipy.ndimage.map_coordinates with its B-spline prefilter) ----
  * The same maps as dcp_unwarp_image_f32 / dcp_perspective_image_f32 / dcp_remap_coords_f32 for
  * `order` in 2..5 -- what the reference computes when a caller passes order >= 2

@@ -63,3 +63,20 @@ def test_bench_two_ranks_share_the_gpu_through_gloo(hip):
     assert ss["depth_per_gpu"] == 8 and ss["verified_vs_oracle"] is True
     assert ss["compute_plus_allgather"]["ms_per_step"] >= ss["compute_only"]["ms_per_step"] > 0
     assert ss["compute_plus_allgather"]["gathered_bytes_received_per_gpu"] == 8 * 2560 * 2560 * 4
+
+
+def test_bench_gpus_n_without_torchrun_spawns_its_own_ranks(hip):
+    """`python bench.py --gpus 2` -- the command form the driver uses at N = 1 -- must become two ranks by itself (it
+    used to warn and measure one GPU) and print ONE line with n_gpus: 2."""
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DCP_BENCH_BACKEND="gloo", DCP_BENCH_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4", "--depth", "16"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified_vs_oracle"] is True
+    ss = j["stack_scaling"]
+    assert ss["compute_plus_allgather"]["ms_per_step"] > 0 and ss["compute_plus_allgather_pipelined"]["verified_vs_oracle"] is True

@@ -84,6 +84,9 @@ def test_stack_scaling_two_ranks_gloo(tmp_path):
         assert r["depth_per_gpu"] == 3 and r["compute_plus_allgather"] is not None
         assert r["compute_plus_allgather"]["gathered_bytes_received_per_gpu"] == 3 * NROWS * 56 * 4
         assert r["compute_only"]["ms_per_step"] > 0 and r["compute_plus_allgather"]["ms_per_step"] > 0
+        # the pipelined exchange (depth sub-blocks, asynchronous all-gathers under the next kernel) fills the same result
+        pp_ = r["compute_plus_allgather_pipelined"]
+        assert pp_["verified_vs_oracle"] is True and pp_["depth_sub_blocks"] == 3 and pp_["ms_per_step"] > 0
     # max over ranks: both ranks report the same times
     assert res[0]["compute_only"]["ms_per_step"] == pytest.approx(res[1]["compute_only"]["ms_per_step"])
 
