@@ -949,6 +949,50 @@ def spawn_ranks(a, argv):
     return subprocess.run(cmd, env=env, cwd=os.getcwd()).returncode
 
 
+def grid_search_centres(a, dev):
+    """other_configs entry: the grid search of examples/example_05.py:62-65 -- unwarp_slice_backward for 11 x 11 candidate centres
+    on a device-resident depth-256 shard of config 4 -- as ONE dcp_unwarp_stack_rows_centres_f32 call, against 121 single calls."""
+    import ctypes as C
+    L = F.lib()
+    orc = oracle_module(a.cpu_threads)
+    cfg = configs.cfg4(256)
+    D, H, W = cfg["shape"]
+    fa, nf = F.fact_array(cfg["list_fact"])
+    vol = DevBlock((D, H, W), dev, False)
+    chunk = fill_projections(vol, dev, cfg["seed"])
+    cents = [(cfg["xcenter"] + dx, cfg["ycenter"] + dy) for dx in range(-100, 120, 20) for dy in range(-100, 120, 20)]
+    K = len(cents)
+    out = DevBlock((K, D, 1, W), dev, False)
+    xa, ya = (C.c_double * K)(*[c[0] for c in cents]), (C.c_double * K)(*[c[1] for c in cents])
+    row = 1277.0
+
+    def batched(_i):
+        F.check(L.dcp_unwarp_stack_rows_centres_f32(vol.ptr, out.ptr, D, H, W, H * W, W, xa, ya, K, fa, nf, row, 1, 0, F.BLEND_F64LERP, F.MEM_DEVICE,
+                                                    dev, None))
+
+    def single(i):
+        k = i % K
+        F.check(L.dcp_unwarp_stack_rows_f32(vol.ptr, out.ptr + k * D * W * 4, D, H, W, H * W, W, cents[k][0], cents[k][1], fa, nf, row, 1, 0,
+                                            F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+    us = timed_launches(batched, 40, dev, settle_ms=60.0)
+    kernel = F.last_kernel()
+    us_single = timed_launches(single, 2 * K, dev, settle_ms=60.0) * K
+    batched(0)
+    ok = True
+    for k in (0, K // 2, K - 1):
+        want = orc.unwarp_stack_rows(chunk, cents[k][0], cents[k][1], cfg["list_fact"], row, 1, coord_round_f32=False, poly=orc.POLY_KERNEL,
+                                     blend=orc.BLEND_F64LERP)
+        got = download(out.ptr, (chunk.shape[0], 1, W), dev, offset=k * D * W * 4)
+        ok = ok and bool(np.array_equal(got, want))
+    vol.free()
+    out.free()
+    return entry(us, K * D * W, 12, kernel, ok, centres=K, depth=D,
+                 the_same_as_single_calls_us=round(us_single, 2),
+                 note="%d candidate centres x one sinogram of a depth-%d shard in one launch; 12 B per voxel is the single-call figure (two source "
+                      "rows read per output row) -- here every centre reads the same rows, so HBM sees them once and the fraction may exceed "
+                      "what a single call could reach" % (K, D))
+
+
 # ----------------------------------------------------------------------------------------- main
 
 def init_dist():
@@ -1219,6 +1263,7 @@ def main(argv=None):
         b.free()
     if others is not None and "error" not in others:
         for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev)),
+                         ("cfg4_grid_search_121_centres", lambda: grid_search_centres(a, dev)),
                          ("cfg4_uint16_shard64", lambda: stack_uint16_shard(a, dev))):
             try:
                 others[name] = fn()

@@ -57,6 +57,8 @@ SIGNATURES = {
                                     _int, _vp]),
     "dcp_unwarp_stack_rows_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,
                                          _i64, _int, _int, _int, _int, _vp]),
+    "dcp_unwarp_stack_rows_centres_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dp, _dp, _int, _dp, _int, _dbl, _i64, _int, _int,
+                                                 _int, _int, _vp]),
     "dcp_unwarp_stack_rows_multi_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,
                                                _i64, _int, _int, C.POINTER(_int), _int]),
     "dcp_unwarp_stack_rows_peer_f32": (_int, [C.POINTER(_vp), C.POINTER(_vp), _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl,

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include <algorithm>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -316,6 +317,103 @@ int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_f
                             device, stream)) != DCP_OK)
     return rc;
   return run_stack(c);
+}
+
+int dcp_unwarp_stack_rows_centres_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width, int64_t proj_stride,
+                                      int64_t row_stride, const double* xcenters, const double* ycenters, int ncentres,
+                                      const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
+                                      int blend_mode, int mem_kind, int device, void* stream) {
+  int rc, sampler;
+  if (ncentres < 0) return fail(DCP_ERR_INVALID_ARG, "ncentres < 0");
+  if (ncentres == 0) return DCP_OK;
+  if (!xcenters || !ycenters) return fail(DCP_ERR_INVALID_ARG, "null centre array");
+  if (depth < 0 || nrows < 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows");
+  if (height <= 0 || width <= 0) return fail(DCP_ERR_INVALID_ARG, "projections must be non-empty");
+  if ((rc = sampler_of(1, blend_mode, &sampler)) != DCP_OK) return rc;
+  const size_t per_centre = (size_t)depth * (size_t)nrows * (size_t)width;
+  auto one_by_one = [&]() {
+    for (int k = 0; k < ncentres; ++k) {
+      const int r = dcp_unwarp_stack_rows_f32(vol, out + (size_t)k * per_centre, depth, height, width, proj_stride, row_stride, xcenters[k],
+                                              ycenters[k], list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode, mem_kind, device, stream);
+      if (r != DCP_OK) return r;
+    }
+    return DCP_OK;
+  };
+  // what the batched kernel covers: the tuned float32 gather (32-bit offsets inside a projection), no row-band check
+  bool batched = ncentres > 1 && height >= 2 && width >= 2 && (double)height * (double)row_stride * 4.0 <= 4294967040.0 && nrows <= 65535 &&
+                 depth <= 2147483647LL && std::isfinite(row_start) && row_stride >= width && proj_stride >= (height - 1) * row_stride + width &&
+                 (mem_kind == DCP_MEM_DEVICE || mem_kind == DCP_MEM_HOST) && nfact >= 0 && nfact <= dcp::kMaxFact && (nfact == 0 || list_fact);
+  dcp::MapArgs map;
+  int64_t band0 = height, band1 = 0;
+  if (batched) {
+    const bool rows_inside = row_start >= 0.0 && nrows >= 1 && row_start + (double)(nrows - 1) <= (double)(height - 1);
+    for (int k = 0; k < ncentres && batched; ++k) {
+      if ((rc = fill_map(&map, xcenters[k], ycenters[k], list_fact, nfact, nullptr)) != DCP_OK) return rc;
+      // unwarp_chunk_slices_backward semantics: a model that may fold its rows out of the reference's band goes call by call
+      // (the direct kernel then checks every pixel against that centre's band, postprocessing.py:289-312)
+      if (coord_round_f32 && nrows > 0 && (!rows_inside || !radial_monotone_in_y(map, height, width))) batched = false;
+      if (batched && mem_kind == DCP_MEM_HOST && nrows > 0) {
+        int64_t b0 = 0, b1 = height;
+        host_row_band(map, height, width, row_start, nrows, &b0, &b1);
+        band0 = std::min(band0, b0);
+        band1 = std::max(band1, b1);
+      }
+    }
+  }
+  if (!batched) return one_by_one();
+  if (depth == 0 || nrows == 0) return DCP_OK;
+  if (!vol || !out) return fail(DCP_ERR_INVALID_ARG, "null volume pointer");
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  const dcp::LaunchOpts opts = current_opts();
+  dcp::StackArgs st;
+  memset(&st, 0, sizeof(st));
+  st.H = (int32_t)height;
+  st.W = (int32_t)width;
+  st.row_start = row_start;
+  st.nrows = (int32_t)nrows;
+  hipStream_t hs = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    st.D = (int32_t)depth;
+    st.vol = vol;
+    st.out = out;
+    st.proj_stride = proj_stride;
+    st.row_stride = (int32_t)row_stride;
+    st.proj_bytes = (uint32_t)(((height - 1) * row_stride + width) * 4);
+    DCP_HIP(dcp::launch_stack_centres(st, map, xcenters, ycenters, ncentres, sampler, coord_round_f32 != 0, opts, hs));
+    return DCP_OK;
+  }
+  // host stack: the union of the centres' row bands of a chunk of projections goes up, every centre's rows of that chunk come
+  // back (one 2-D copy: `ncentres` runs, one per centre block of the (ncentres, depth, nrows, width) result)
+  const int64_t bh = band1 - band0;
+  const size_t pbytes = (size_t)bh * (size_t)width * 4, obytes = (size_t)nrows * (size_t)width * 4;
+  int64_t dc = (int64_t)(((size_t)g_stack_chunk_kb.load() << 10) / std::max(pbytes, obytes * (size_t)ncentres));
+  dc = dc < 1 ? 1 : (dc > depth ? depth : dc);
+  void *din = nullptr, *dout = nullptr;
+  DCP_HIP(g_staging.get(0, pbytes * (size_t)dc, &din));
+  DCP_HIP(g_staging.get(2, obytes * (size_t)ncentres * (size_t)dc, &dout));
+  for (int64_t d0 = 0; d0 < depth; d0 += dc) {
+    const int64_t n = d0 + dc > depth ? depth - d0 : dc;
+    const char* hsrc = (const char*)(vol + (size_t)d0 * (size_t)proj_stride + (size_t)band0 * (size_t)row_stride);
+    if (row_stride == width) {
+      DCP_HIP(hipMemcpy2DAsync(din, pbytes, hsrc, (size_t)proj_stride * 4, pbytes, (size_t)n, hipMemcpyHostToDevice, hs));
+    } else {
+      for (int64_t d = 0; d < n; ++d)
+        DCP_HIP(hipMemcpy2DAsync((char*)din + (size_t)d * pbytes, (size_t)width * 4, hsrc + (size_t)d * (size_t)proj_stride * 4, (size_t)row_stride * 4,
+                                 (size_t)width * 4, (size_t)bh, hipMemcpyHostToDevice, hs));
+    }
+    st.D = (int32_t)n;
+    st.vol = (const float*)((const char*)din - (size_t)band0 * (size_t)width * 4);     // absolute row indexing; rows below band0 are never touched
+    st.out = (float*)dout;
+    st.proj_stride = bh * width;
+    st.row_stride = (int32_t)width;
+    st.proj_bytes = (uint32_t)((size_t)band1 * (size_t)width * 4);
+    DCP_HIP(dcp::launch_stack_centres(st, map, xcenters, ycenters, ncentres, sampler, coord_round_f32 != 0, opts, hs));
+    DCP_HIP(hipMemcpy2DAsync(out + (size_t)d0 * (size_t)nrows * (size_t)width, per_centre * 4, dout, obytes * (size_t)n, obytes * (size_t)n,
+                             (size_t)ncentres, hipMemcpyDeviceToHost, hs));
+    DCP_HIP(hipStreamSynchronize(hs));
+  }
+  return DCP_OK;
 }
 
 int dcp_stack_row_band(int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact, int nfact,

@@ -157,6 +157,11 @@ hipError_t launch_coord_map(MapKind kind, const ImageArgs& img, const MapArgs& m
 hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream);
 
+// the rows of `st` under `ncentres` calibrations that differ in the centre only (map.xc / map.yc ignored), one launch per 224
+// centres; st.out = (ncentres, D, nrows, W).  st.rbh must be 0 (no band check: the caller sends folding models call by call)
+hipError_t launch_stack_centres(const StackArgs& st, const MapArgs& map, const double* xcs, const double* ycs, int ncentres, int sampler,
+                                bool round_f32, const LaunchOpts& opts, hipStream_t stream);
+
 hipError_t read_lds_stats(unsigned long long* out, bool reset);
 void set_last_kernel_name(const char* name);   // for the launchers of the other translation units
 const char* last_kernel_name();   // unwarp_kernels.hip: the kernel the calling thread launched last (float32 image / stack launchers)

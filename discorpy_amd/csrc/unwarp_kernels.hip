@@ -1230,21 +1230,23 @@ __global__ void __launch_bounds__(kBlock) coord_map_kernel(const ImageArgs img, 
 // out[d, r, x] = projection d sampled at the radial source coordinate of (row_start + r, x).
 // The coordinate and the tap weights are computed once per (r, x) and reused for d_chunk
 // projections; the per-projection work is two 8-byte gathers, the blend and a 4-byte store.
+// (body shared by stack_rows_kernel -- one centre, from the kernel arguments -- and stack_centres_kernel -- the centre of
+// the workgroup's calibration from a table: xc / yc and the output block of that centre are parameters)
 template <int NF, int SAMPLER, bool ROUND32>
-__global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, const MapArgs map) {
+__device__ __forceinline__ void stack_rows_body(const StackArgs& st, const MapArgs& map, const double xc_, const double yc_, const int r,
+                                                float* __restrict__ out_block) {
   __shared__ double s_coef[kMaxFact];
   if constexpr (NF < 0) {
     if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
     __syncthreads();
   }
   const int x = blockIdx.x * kBlock + (int)threadIdx.x;
-  const int r = blockIdx.y;
   const int d0 = blockIdx.z * st.d_chunk;
   const int d1 = min(st.D, d0 + st.d_chunk);
   if (x >= st.W) return;
 
-  const double xu = (double)x - map.xc;
-  const double yu = (st.row_start + (double)r) - map.yc;
+  const double xu = (double)x - xc_;
+  const double yu = (st.row_start + (double)r) - yc_;
   const double r2 = xu * xu + yu * yu;
   const double ru = sqrt_rn(r2);
   double f;
@@ -1255,8 +1257,8 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
   } else {
     f = poly_lds(s_coef, map.nfact, r2, ru);
   }
-  const double xd = __builtin_fma(f, xu, map.xc);
-  const double yd = __builtin_fma(f, yu, map.yc);
+  const double xd = __builtin_fma(f, xu, xc_);
+  const double yd = __builtin_fma(f, yu, yc_);
 
   using CT = typename std::conditional<ROUND32, float, double>::type;
   CT xc, yc;
@@ -1274,7 +1276,7 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
       // scipy's order whatever the blend, 64-bit addressing (rare pixels of a model nobody should use)
       const float yrel = yc - (float)st.rb0;             // float32, exact: the reference subtracts yd_min from the float32 plane
       const float* proj = st.vol + (size_t)d0 * (size_t)st.proj_stride + (size_t)st.rb0 * (size_t)st.row_stride;
-      float* o = st.out + ((size_t)d0 * (size_t)st.nrows + (size_t)r) * (size_t)st.W + (size_t)x;
+      float* o = out_block + ((size_t)d0 * (size_t)st.nrows + (size_t)r) * (size_t)st.W + (size_t)x;
       for (int d = d0; d < d1; ++d) {
         const int64_t rs = st.row_stride;
         *o = (float)mc_sample_outside([&](long long rr, long long cc) -> double { return (double)proj[rr * rs + cc]; }, st.rbh, st.W,
@@ -1293,7 +1295,7 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
   const uint32_t off = ((uint32_t)yi * (uint32_t)st.row_stride + (uint32_t)xi) << 2;   // full 32-bit product: a row stride may exceed 2^24
   const int row_bytes = st.row_stride * 4;
   const float* base = st.vol + (size_t)d0 * (size_t)st.proj_stride;
-  float* out = st.out + ((size_t)d0 * (size_t)st.nrows + (size_t)r) * (size_t)st.W + (size_t)x;
+  float* out = out_block + ((size_t)d0 * (size_t)st.nrows + (size_t)r) * (size_t)st.W + (size_t)x;
   const size_t out_step = (size_t)st.nrows * (size_t)st.W;
 #pragma unroll 4
   for (int d = d0; d < d1; ++d) {
@@ -1305,6 +1307,29 @@ __global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, 
     base += st.proj_stride;
     out += out_step;
   }
+}
+
+template <int NF, int SAMPLER, bool ROUND32>
+__global__ void __launch_bounds__(kBlock) stack_rows_kernel(const StackArgs st, const MapArgs map) {
+  stack_rows_body<NF, SAMPLER, ROUND32>(st, map, map.xc, map.yc, (int)blockIdx.y, st.out);
+}
+
+// K4 for a grid search over the centre of distortion (examples/example_05.py:62-65 calls unwarp_slice_backward 121 times on
+// one stack, each time with another centre): the same rows of the same stack under `ncentres` calibrations that differ in
+// (xcenter, ycenter) only, in ONE launch.  blockIdx.y = centre * nrows + row; the centres travel in the kernel arguments
+// (scalar loads indexed by the workgroup's centre); out = (ncentres, depth, nrows, width).  The workgroups of one depth chunk
+// run back to back over all centres (x fastest, then y), so the two or three source rows every centre needs of each of
+// its projections are fetched from HBM once and then served by the L2.
+struct CentreTable {
+  static constexpr int kMax = 224;                  // 224 x 16 B = 3.5 KB of the 4 KB of kernel arguments
+  double xc[kMax], yc[kMax];
+};
+
+template <int NF, int SAMPLER, bool ROUND32>
+__global__ void __launch_bounds__(kBlock) stack_centres_kernel(const StackArgs st, const MapArgs map, const CentreTable tab, const int k0) {
+  const int k = (int)blockIdx.y / st.nrows, r = (int)blockIdx.y - k * st.nrows;
+  float* out_block = st.out + (size_t)(k0 + k) * (size_t)st.D * (size_t)st.nrows * (size_t)st.W;
+  stack_rows_body<NF, SAMPLER, ROUND32>(st, map, tab.xc[k], tab.yc[k], r, out_block);
 }
 
 // K4 with the LDS-staged gather of K1: a wave owns a 64 x 16 tile of (x, row) positions; the coordinates, the
@@ -2038,6 +2063,54 @@ static hipError_t launch_stack_t(const StackArgs& st, const MapArgs& map, int sa
       break;
   }
   return hipGetLastError();
+}
+
+template <int NF, bool ROUND32>
+static hipError_t launch_centres_t(const StackArgs& st, const MapArgs& map, const double* xcs, const double* ycs, int ncentres, int sampler,
+                                   hipStream_t stream) {
+  static_assert(sizeof(StackArgs) + sizeof(MapArgs) + sizeof(CentreTable) + 16 <= 4096, "kernel arguments are limited to 4 KB");
+  note_kernel("stack_centres_kernel", -1, NF, sampler, ROUND32 ? "" : ",f64coords");
+  // blockIdx.y = centre * nrows + row stays below 65536
+  const int per_launch = st.nrows >= 65535 ? 1 : (65535 / st.nrows < CentreTable::kMax ? 65535 / st.nrows : CentreTable::kMax);
+  for (int k0 = 0; k0 < ncentres; k0 += per_launch) {
+    const int m = ncentres - k0 < per_launch ? ncentres - k0 : per_launch;
+    CentreTable tab;
+    memset(&tab, 0, sizeof(tab));
+    for (int i = 0; i < m; ++i) {
+      tab.xc[i] = xcs[k0 + i];
+      tab.yc[i] = ycs[k0 + i];
+    }
+    const dim3 grid((st.W + kBlock - 1) / kBlock, (unsigned)(m * st.nrows), (st.D + st.d_chunk - 1) / st.d_chunk);
+    switch (sampler) {
+      case kScipy: hipLaunchKernelGGL((stack_centres_kernel<NF, kScipy, ROUND32>), grid, dim3(kBlock), 0, stream, st, map, tab, k0); break;
+      case kF64Lerp: hipLaunchKernelGGL((stack_centres_kernel<NF, kF64Lerp, ROUND32>), grid, dim3(kBlock), 0, stream, st, map, tab, k0); break;
+      default: hipLaunchKernelGGL((stack_centres_kernel<NF, kF32Lerp, ROUND32>), grid, dim3(kBlock), 0, stream, st, map, tab, k0); break;
+    }
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t launch_stack_centres(const StackArgs& st_in, const MapArgs& map, const double* xcs, const double* ycs, int ncentres, int sampler,
+                                bool round_f32, const LaunchOpts& opts, hipStream_t stream) {
+  StackArgs st = st_in;
+  if (st.D == 0 || st.nrows == 0 || ncentres == 0) return hipSuccess;
+  // one thread keeps its coordinate for d_chunk projections; with many centres the launch is large whatever the chunk
+  st.d_chunk = opts.d_chunk < 1 ? 1 : opts.d_chunk;
+  while (st.d_chunk < 64 && (int64_t)((st.W + kBlock - 1) / kBlock) * st.nrows * ncentres * ((st.D + 2 * st.d_chunk - 1) / (2 * st.d_chunk)) >= 4096)
+    st.d_chunk *= 2;
+  if ((st.D + st.d_chunk - 1) / st.d_chunk > 65535) st.d_chunk = (st.D + 65534) / 65535;
+  if (!opts.coef_lds) {
+    if (map.nfact == 5)
+      return round_f32 ? launch_centres_t<5, true>(st, map, xcs, ycs, ncentres, sampler, stream)
+                       : launch_centres_t<5, false>(st, map, xcs, ycs, ncentres, sampler, stream);
+    if (map.nfact == 4)
+      return round_f32 ? launch_centres_t<4, true>(st, map, xcs, ycs, ncentres, sampler, stream)
+                       : launch_centres_t<4, false>(st, map, xcs, ycs, ncentres, sampler, stream);
+  }
+  return round_f32 ? launch_centres_t<-1, true>(st, map, xcs, ycs, ncentres, sampler, stream)
+                   : launch_centres_t<-1, false>(st, map, xcs, ycs, ncentres, sampler, stream);
 }
 
 #ifdef DCP_EXPERIMENT_TRACE

@@ -48,6 +48,7 @@ from .. import _ffi as F
 from .. import _pool
 
 __all__ = ["unwarp_line_forward", "unwarp_image_backward", "unwarp_images_backward", "unwarp_slice_backward", "unwarp_chunk_slices_backward",
+           "unwarp_slice_backward_centres", "unwarp_chunk_slices_backward_centres",
            "correct_perspective_image", "unwarp_perspective_fused", "remap_coordinates",
            "generate_radial_map", "generate_fused_map"]
 
@@ -509,6 +510,85 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
         return np.empty((depth, 0, width), dtype=np.dtype(mat3D.dtype))
     return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices,
                        out=out)
+
+
+def _stack_rows_centres(mat3D, xcenters, ycenters, list_fact, row_start, nrows, round_f32, blend, out_float32, out):
+    """Rows of a stack under K candidate centres: ``(K, depth, nrows, width)``.  float32 stacks in memory (NumPy, torch, device
+    arrays) go through ONE call of ``dcp_unwarp_stack_rows_centres_f32``; other element types, out-of-core datasets: centre by centre."""
+    xcs = [float(v) for v in xcenters]
+    ycs = [float(v) for v in ycenters]
+    if len(xcs) != len(ycs):
+        raise ValueError("xcenters and ycenters must have the same length")
+    k = len(xcs)
+    lazy = _is_lazy_stack(mat3D)
+    vol = None if lazy else _Image(mat3D, 3)
+    if not lazy and vol.f32 and k > 0:
+        depth, height, width = vol.shape
+        ps, rs, cs = vol.strides
+        if cs != 1 or rs < width or (depth > 1 and ps < (height - 1) * rs + width):
+            if vol.cai:
+                raise ValueError("a device stack must have unit column stride and non-overlapping rows / projections")
+            vol = _Image(vol.keep.contiguous() if vol.torch else np.ascontiguousarray(vol.keep), 3)
+            ps, rs, cs = vol.strides
+        fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
+        res, optr = vol.empty((k, depth, nrows, width), True, out=out)
+        if depth > 0:
+            F.require_device()
+            xa, ya = (C.c_double * k)(*xcs), (C.c_double * k)(*ycs)
+            F.check(F.lib().dcp_unwarp_stack_rows_centres_f32(vol.ptr, optr, depth, height, width, ps if depth > 1 else height * rs, rs, xa, ya, k,
+                                                              fa, nf, float(row_start), int(nrows), int(round_f32), _blend_code(blend), vol.mem,
+                                                              vol.device, vol.stream))
+        return res
+    blocks = [_stack_rows(mat3D, xcs[i], ycs[i], list_fact, row_start, nrows, round_f32, blend, out_float32=out_float32) for i in range(k)]
+    if k and _is_torch(blocks[0]):
+        import torch
+        res = torch.stack(blocks)
+    else:
+        res = np.stack(blocks) if k else np.empty((0,) + tuple(mat3D.shape[:1]) + (nrows, mat3D.shape[2]), np.float32 if out_float32 else np.dtype(mat3D.dtype))
+    if out is not None:
+        out[...] = res
+        return out
+    return res
+
+
+def unwarp_slice_backward_centres(mat3D, xcenters, ycenters, list_fact, index, *, blend=None, out=None):
+    """
+    :func:`unwarp_slice_backward` (reference ``postprocessing.py:188-229``) for K candidate centres of distortion in ONE call:
+    the grid search of ``examples/example_05.py:62-65``, which calls the reference 11 x 11 = 121 times on the same
+    600-projection stack.  ``xcenters[k], ycenters[k]``: the candidates; returns float32 ``(K, depth, width)``, block ``k``
+    bit-identical to ``unwarp_slice_backward(mat3D, xcenters[k], ycenters[k], list_fact, index)``.  A float32 stack is read
+    once for all centres (device-resident: one kernel launch per 224 centres; NumPy: one upload of the union of the row bands).
+    """
+    if len(mat3D.shape) < 3:
+        raise ValueError("Input must be a 3D data")
+    (depth, height, width) = mat3D.shape
+    k = len(xcenters)
+    if out is not None:
+        if tuple(out.shape) != (k, depth, width):
+            raise ValueError("out must have shape (centres, depth, width)")
+        out = out.reshape((k, depth, 1, width))
+    index = index - 0.0
+    res = _stack_rows_centres(mat3D, xcenters, ycenters, list_fact, float(index), 1, False, blend, True, out)
+    return res.reshape((k, depth, width)) if isinstance(res, F.DeviceArray) else res[:, :, 0, :]
+
+
+def unwarp_chunk_slices_backward_centres(mat3D, xcenters, ycenters, list_fact, start_index, stop_index, *, blend=None, out=None):
+    """
+    :func:`unwarp_chunk_slices_backward` (reference ``postprocessing.py:255-313``) for K candidate centres in one call: rows
+    ``start_index .. stop_index`` inclusive, float32 coordinates as the reference; returns ``(K, depth, rows, width)``.
+    """
+    if (len(mat3D.shape) < 3):
+        raise ValueError("Input must be a 3D data")
+    (depth, height, width) = mat3D.shape
+    index_list = np.arange(height, dtype=np.int16)
+    if stop_index == -1:
+        stop_index = height
+    if (start_index not in index_list) or (stop_index not in index_list):
+        raise ValueError("Selected index is out of the range")
+    nrows = int(stop_index) - int(start_index) + 1
+    if nrows < 1:
+        raise ValueError("Selected index is out of the range")
+    return _stack_rows_centres(mat3D, xcenters, ycenters, list_fact, float(start_index), nrows, True, blend, False, out)
 
 
 def _is_lazy_stack(a):

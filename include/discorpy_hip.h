@@ -142,6 +142,18 @@ int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64
                               const double* list_fact, int nfact, double row_start, int64_t nrows,
                               int coord_round_f32, int blend_mode, int mem_kind, int device, void* stream);
 
+/* dcp_unwarp_stack_rows_f32 under `ncentres` calibrations that differ in the centre of distortion only, in one call -- the grid
+ * search of examples/example_05.py:62-65 (unwarp_slice_backward 11 x 11 = 121 times on one stack of 600 projections, one call per
+ * candidate centre).  out = (ncentres, depth, nrows, width), dense; block k is what dcp_unwarp_stack_rows_f32 returns for
+ * (xcenters[k], ycenters[k]), bit for bit.  One launch per 224 centres: the two or three source rows a sinogram needs of each
+ * projection are fetched from HBM once and served to every centre by the L2 (device-resident stacks); a host stack is shipped
+ * once -- the union of the centres' row bands -- instead of once per centre.  coord_round_f32 = 1 under a model that may fold
+ * rows out of the reference's band is processed centre by centre. */
+int dcp_unwarp_stack_rows_centres_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width, int64_t proj_stride,
+                                      int64_t row_stride, const double* xcenters, const double* ycenters, int ncentres,
+                                      const double* list_fact, int nfact, double row_start, int64_t nrows, int coord_round_f32,
+                                      int blend_mode, int mem_kind, int device, void* stream);
+
 /* The same over a HOST-resident stack sharded across `ndev` GPUs of this process (SURVEY.md section
  * 8(e): projections are independent).  devices[i] takes the i-th contiguous depth shard (sizes as
  * numpy.array_split), stages it, runs the kernel and copies its block of `out` (depth x nrows x width,

@@ -31,7 +31,7 @@ def test_bench_line_carries_every_config_verified(hip):
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     oc = j["other_configs"]
     for key in ("cfg2_scipy_exact_blend", "cfg2_order0_nearest", "cfg3_fused", "cfg3_perspective_only",
-                "cfg3_two_pass_reference_semantics", "cfg5_frame8192_radial9", "cfg4_one_sinogram", "cfg4_stack_one_gpu", "cfg2_uint16_frame",
+                "cfg3_two_pass_reference_semantics", "cfg5_frame8192_radial9", "cfg4_one_sinogram", "cfg4_grid_search_121_centres", "cfg4_stack_one_gpu", "cfg2_uint16_frame",
                 "cfg4_uint16_shard64"):
         assert key in oc and oc[key].get("verified_vs_oracle") is True, (key, oc.get(key))
         assert oc[key]["launch_us"] > 0 and oc[key]["kernel"]
