@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -35,6 +35,7 @@ dcp::LaunchOpts current_opts() {
   o.wg_box = g_wg_box.load();
   o.wg_per_cu = g_wg_per_cu.load();
   o.stack_wg = g_stack_wg.load();
+  o.int_exact = g_int_exact.load();
   return o;
 }
 
@@ -486,6 +487,8 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "wg_per_cu")) {
     if (value < 0 || value > 6) return fail(DCP_ERR_INVALID_ARG, "wg_per_cu must be in [0, 6]");
     g_wg_per_cu = value;
+  } else if (!strcmp(key, "int_exact")) {
+    g_int_exact = value ? 1 : 0;      // 0: integer element types blend in scipy's operation order everywhere (A/B and parity runs)
   } else if (!strcmp(key, "wg_box")) {
     g_wg_box = value ? 1 : 0;         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
   } else if (!strcmp(key, "spline_wg")) {
@@ -521,6 +524,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "spline_tiled")) *value = dcp::get_spline_tiled();
   else if (!strcmp(key, "spline_wg")) *value = dcp::get_spline_wg();
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
+  else if (!strcmp(key, "int_exact")) *value = g_int_exact;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }

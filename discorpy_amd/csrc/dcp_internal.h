@@ -33,6 +33,7 @@ struct ImageArgs {
   int32_t wg_per_cu;       // remap_wg_kernel: workgroups resident per CU (0 = as many as fit: 6)
   int32_t y_origin;        // a launch may cover only output rows [y_origin, y_origin + rows_out) of the H x W map;
   int32_t rows_out;        // dst then points at row y_origin (0 / 0 = the whole image)
+  int32_t int_exact;       // integer element types: 1 = tiles at coordinates >= 32 take the exact factorised blend (exact_lerp_pairs)
 };
 
 struct MapArgs {
@@ -59,6 +60,7 @@ struct StackArgs {
   int32_t rb0, rbh;        // the reference's row band [rb0, rb0 + rbh) of unwarp_chunk_slices_backward (postprocessing.py:289-312):
                            // a row coordinate outside it is reflected inside it, as scipy does with the cropped band.  rbh = 0:
                            // the host has shown that no coordinate can leave the band (or the call is not a chunk): no check
+  int32_t int_exact;       // as ImageArgs::int_exact (stack_wg_kernel on integer element types)
 };
 
 struct CoordArgs {
@@ -126,6 +128,7 @@ struct LaunchOpts {
   int stack_lds = 1;       // LDS-staged stack kernel: 0 never, 1 when the launch has enough wave tiles, 2 always
   int wg_box = 1;          // 1: remap_wg_kernel (one source box per 128 x 32 workgroup tile) for certified maps
   int wg_per_cu = 0;       // remap_wg_kernel: cap on resident workgroups per CU (0 = none)
+  int int_exact = 1;       // integer element types: the exact factorised blend where it is provably exact (0: scipy's operation order everywhere)
   int stack_wg = 1;        // stack_wg_kernel (one box per workgroup, two slabs) for chunks of rows under a certified map: 0 never,
                            // 1 when the launch has enough workgroups (float32 and 8- / 16-bit integers), 2 whenever eligible
 };

@@ -737,6 +737,41 @@ __global__ void __launch_bounds__(64 * kLdsBW, (KIND == kFused && NF < 0) ? 3 : 
   }
 }
 
+// ------------------------------------------------------------------ integer element types: the exact lerp
+
+// Bilinear blend of 8- / 16-bit integer taps when BOTH coordinates are >= 32: a float32 coordinate in [32, 2^24) is a multiple of
+// 2^-18, so the fractions carry at most 18 bits, a tap (or a difference of taps) at most 17, and every product and sum of
+// scipy's ((v * wy) * wx) accumulation -- and of the factorised form below -- is EXACTLY representable in a double (<= 53
+// bits: 16 + 18 + 18 + 1).  No operation rounds, so the two forms agree bit for bit (and with the true bilinear value), and the
+// factorised one costs 13 float64 operations fewer per pixel.  `top` / `bot`: the tap pairs (x0, x0 + 1) of rows y0 / y0 + 1 in
+// the low bits of a dword (element 0 in the low half); fx, fy: the fractions.  Tiles whose source box reaches a coordinate
+// below 32 keep scipy's operation order (where roundings do occur it is their order that has to be reproduced).
+constexpr float kExactLerpMinCoord = 32.0f;
+template <typename T>
+__device__ __forceinline__ double exact_lerp_pairs(uint32_t top, uint32_t bot, double fx, double fy) {
+  constexpr int B = (int)sizeof(T) * 8;
+  int a, b, c, d;
+  if constexpr (std::is_signed<T>::value) {
+    a = __builtin_amdgcn_sbfe(top, 0, B);
+    b = __builtin_amdgcn_sbfe(top, B, B);
+    c = __builtin_amdgcn_sbfe(bot, 0, B);
+    d = __builtin_amdgcn_sbfe(bot, B, B);
+  } else {
+    a = (int)(top & ((1u << B) - 1u));
+    c = (int)(bot & ((1u << B) - 1u));
+    if constexpr (B == 16) {
+      b = (int)(top >> 16);
+      d = (int)(bot >> 16);
+    } else {
+      b = (int)__builtin_amdgcn_ubfe(top, B, B);
+      d = (int)__builtin_amdgcn_ubfe(bot, B, B);
+    }
+  }
+  const double tp = __builtin_fma(fx, (double)(b - a), (double)a);
+  const double bt = __builtin_fma(fx, (double)(d - c), (double)c);
+  return __builtin_fma(fy, bt - tp, tp);
+}
+
 // ------------------------------------------------------------------ K1 / K2, workgroup-shared source box
 
 // The per-CU rate at which streamed source data can be brought in (vector L1 misses served by the L2: ~10 B/clk per
@@ -892,7 +927,11 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
   const int nchunk = bh * CH;
   auto issue_fill = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
+#if defined(DCP_EXPERIMENT_NO_FILL)       // timing experiment only (results are then garbage)
+    if constexpr (false) {
+#else
     if constexpr (j < NJ) {
+#endif
       if (fits && (j * 4 + wave) * 64 < nchunk) {             // wave-uniform: does any chunk of this load lie inside the box?
         // 256 j chunks further on: (256 j) / CH whole rows, and the column wraps into the next row at most once
         constexpr int qrow = (256 * j) / CH, rem = (256 * j) % CH;
@@ -1001,7 +1040,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
       asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(a_) : "v"(yi), "s"(PB), "v"(xa));
       return a_;
     };
-    auto tile_rows_loop = [&](auto full, auto inner) {
+    auto tile_rows_loop = [&](auto full, auto inner, auto exact) {
 #pragma unroll
       for (int k = 0; k < kLdsTH; ++k) {
         FetchT f;
@@ -1037,34 +1076,47 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
             f.b.y = __float_as_uint(t[kBoxWEl + 1]);
             v = finish<SAMPLER, true, float, !decltype(inner)::value>(f);
           }
+#if defined(DCP_EXPERIMENT_NO_STORE)
+          if (__float_as_uint(v) == 0x7fc12345u)
+#else
           if (decltype(full)::value || k < rows)
+#endif
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
         } else {
           T v;
           if constexpr (SAMPLER == kNearest) {
             v = t[0];
           } else {
-            // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right, then its integer store
             const double fx = (double)f.fx, fy = (double)f.fy;
-            const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
-            const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
             // The tap pair (x0, x0 + 1) of a row starts at any multiple of the element size: read the two ALIGNED dwords
             // around it (one ds_read2_b32) and shift the pair down -- a dword read at a 2- or 1-byte boundary works on this
             // hardware but costs 40 us per frame.
             const uint32_t* q = (const uint32_t*)(boxb + (addr & ~3u));
             const uint32_t sh = (addr & 3u) * 8u;
             const uint32_t top = __builtin_amdgcn_alignbit(q[1], q[0], sh), bot = __builtin_amdgcn_alignbit(q[PB / 4 + 1], q[PB / 4], sh);
-            auto tap = [](uint32_t w, int i) -> double {            // element i (0 / 1) of the pair, as scipy reads it: a double
-              if constexpr (std::is_signed<T>::value) return (double)(int32_t)__builtin_amdgcn_sbfe(w, i * ES * 8, ES * 8);
-              else return (double)__builtin_amdgcn_ubfe(w, i * ES * 8, ES * 8);
-            };
-            double acc = (tap(top, 0) * wy0) * wx0;
-            acc += (tap(top, 1) * wy0) * wx1;
-            acc += (tap(bot, 0) * wy1) * wx0;
-            acc += (tap(bot, 1) * wy1) * wx1;
+            double acc;
+            if constexpr (decltype(exact)::value) {
+              acc = exact_lerp_pairs<T>(top, bot, fx, fy);        // every coordinate of the tile >= 32: no operation rounds
+            } else {
+              // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0; ((v*wy)*wx) summed left to right, then its integer store
+              const double wy0 = 1.0 - fy, wy1 = 1.0 - wy0;
+              const double wx0 = 1.0 - fx, wx1 = 1.0 - wx0;
+              auto tap = [](uint32_t w, int i) -> double {            // element i (0 / 1) of the pair, as scipy reads it: a double
+                if constexpr (std::is_signed<T>::value) return (double)(int32_t)__builtin_amdgcn_sbfe(w, i * ES * 8, ES * 8);
+                else return (double)__builtin_amdgcn_ubfe(w, i * ES * 8, ES * 8);
+              };
+              acc = (tap(top, 0) * wy0) * wx0;
+              acc += (tap(top, 1) * wy0) * wx1;
+              acc += (tap(bot, 0) * wy1) * wx0;
+              acc += (tap(bot, 1) * wy1) * wx1;
+            }
             v = to_elem<T>(acc);
           }
+#if defined(DCP_EXPERIMENT_NO_STORE)     // timing experiment only: the value is computed, the store (practically) never happens
+          if ((uint32_t)v + 0x10000u == img.src_bytes) {         // (cannot be proven false: the blend stays)
+#else
           if (decltype(full)::value || k < rows) {
+#endif
             if constexpr (ES == 2)
               __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
             else
@@ -1073,9 +1125,17 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
         }
       }
     };
-    if (rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{});
-    else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
-    else tile_rows_loop(std::false_type{}, std::false_type{});
+    if constexpr (kIsF32 || SAMPLER == kNearest) {
+      if (rows == kLdsTH && interior) tile_rows_loop(std::true_type{}, std::true_type{}, std::false_type{});
+      else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{}, std::false_type{});
+      else tile_rows_loop(std::false_type{}, std::false_type{}, std::false_type{});
+    } else {
+      // integer elements, order 1: whole interior tiles whose box lies at coordinates >= 32 take the exact factorised blend
+      // (every coordinate of the tile is >= its box origin); the others scipy's operation order
+      if (rows == kLdsTH && interior && img.int_exact && bx0 >= (int)kExactLerpMinCoord && by0 >= (int)kExactLerpMinCoord)
+        tile_rows_loop(std::true_type{}, std::true_type{}, std::true_type{});
+      else tile_rows_loop(std::false_type{}, std::false_type{}, std::false_type{});
+    }
     DCP_TRACE(6);
 #ifdef DCP_EXPERIMENT_TRACE
     if (trace_on && lane == 0) g_trace[trace_id * 12 + 9] = __builtin_amdgcn_s_memrealtime();
@@ -1546,6 +1606,8 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   const bool fits = bw <= kBoxWEl && bh <= kWgBoxH;          // workgroup-uniform
   if (!fits && lane == 0 && wave == 0) atomicAdd(&g_lds_stats[0], 1ull);
+  // integer elements: the tile's coordinates are all >= its box origin; at >= 32 the factorised blend is exact (exact_lerp_pairs)
+  const bool exact = !kIsF32 && SAMPLER != kNearest && fits && st.int_exact && bx0 >= (int)kExactLerpMinCoord && by0 >= (int)kExactLerpMinCoord;
 
   // ---- coordinates of this wave's 16 rows, once for all projections: slab address (or byte offset inside a projection
   // when the box does not fit) and fractions
@@ -1657,6 +1719,25 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
       if (active) {
         const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((uint32_t)rows * out_row), 0x00020000);
         const char* boxb = (const char*)s_box[cur];
+        if constexpr (!kIsF32) {
+          if (exact) {
+            // every coordinate of the tile >= 32: the factorised blend is exact (exact_lerp_pairs), wx1 / wy1 ARE the fractions
+#pragma unroll
+            for (int k = 0; k < kLdsTH; ++k) {
+              const uint32_t* q = (const uint32_t*)(boxb + (addr[k] & ~3u));
+              const uint32_t sh = (addr[k] & 3u) * 8u;
+              const uint32_t top = __builtin_amdgcn_alignbit(q[1], q[0], sh), bot = __builtin_amdgcn_alignbit(q[PB / 4 + 1], q[PB / 4], sh);
+              const T v = to_elem<T>(exact_lerp_pairs<T>(top, bot, wx1[k], wy1[k]));
+              if (k < rows) {
+                if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+                else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+              }
+            }
+            proj += st.proj_stride;
+            out += out_step;
+            continue;
+          }
+        }
 #pragma unroll
         for (int k = 0; k < kLdsTH; ++k) {
           if constexpr (kIsF32) {
@@ -1875,6 +1956,7 @@ hipError_t launch_wg_typed(MapKind kind, const ImageArgs& img_in, const MapArgs&
     img.y_origin = 0;
     img.rows_out = img.H;
   }
+  img.int_exact = opts.int_exact;
   // unit column stride, at least 2 x 2, 4-byte aligned rows (the 16-byte LDS-DMA copies), 24-bit products, float32 LDS addresses
   if (img.src_col_stride != 1 || img.W < 2 || img.H < 2 || ((uintptr_t)img.src & 3u) || (((int64_t)img.src_stride * es) & 3) ||
       img.src_stride >= (1 << 22) || img.H >= (1 << 24) || !lds_addressable(img))
@@ -2192,6 +2274,7 @@ hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int
   StackArgs st = st_in;
   st.d_chunk = wg_stack_chunk(st, opts.d_chunk, opts.stack_wg >= 2);
   if (st.d_chunk == 0) return hipSuccess;
+  st.int_exact = opts.int_exact;
   *taken = true;
   switch (dtype) {
     case kU8: return launch_stack_wg_n<uint8_t>(st, map, kScipy, stream);

@@ -70,7 +70,8 @@ int dcp_release_scratch(void);
  * "tile_cert" (0: never use the host's tile-deviation certificate), "wg_box" (0: one source box per wave tile),
  * "wg_per_cu", "stack_wg" (0 never / 1 when the launch is large enough / 2 whenever eligible: the workgroup-box stack
  * kernel), "spline_tiled" (0: chunked spline prefilter passes + transposes instead of the one-pass LDS tiles),
- * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box).  Returns
+ * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box), "int_exact" (0: 8- / 16-bit integer
+ * data blend in scipy's operation order everywhere instead of the factorised form where that form is provably exact).  Returns
  * DCP_ERR_INVALID_ARG for an unknown key. */
 int dcp_set_option(const char* key, int value);
 int dcp_get_option(const char* key, int* value);
