@@ -234,6 +234,7 @@ struct TileFilter {
   int64_t in_ls, in_ss;      // input strides in elements: between lines, between samples of a line
   int64_t out_ls, out_ss;
   int32_t n, nlines, kind, npoles, halo, core;
+  int32_t hp[2];             // per pole: samples after which a recursion restarted from zero has decayed below 2^-64 (halo = their sum)
   double z[2];
   double lam;
 };
@@ -320,118 +321,104 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
     nxt = geo_of(next);
     issue_loads(nxt);
   }
-  // ---- the recursions, lane = line.  The LDS reads of the next eight samples are issued before the dependent chain
-  // of the current eight (different addresses; said explicitly because the compiler cannot know it).
-  if (wave == 0) {
+  // ---- the recursions, lane = line.  EVERY wave owns a segment of SEG consecutive samples of the tile's 64 lines: it first
+  // runs the recursion, without storing, over the `hp` samples in front of its segment from a zero state (|z|^hp <= 2^-64: the
+  // restart the tile's own halo already relies on -- or from the exact initial sum when that range reaches the start of the
+  // line), then, after a barrier (nobody has overwritten an input yet), through its segment in place.  16 waves x (hp + 16)
+  // dependent steps instead of one wave x 256: the recursion of a tile is ~5 times shorter and no wave idles through it.
+  {
     double* a = AXIS == 0 ? s_t + lane : s_t + lane * kTfPitch1;
     constexpr int S = AXIS == 0 ? kTfLines : 1;               // LDS distance between consecutive samples of a line
+    constexpr int SEG = (SAMPLES + kTfWaves - 1) / kTfWaves;
+    const int s0 = wave * SEG, e0 = min(R, s0 + SEG);         // this wave's segment [s0, e0); empty when s0 >= R
+    const bool mine = s0 < R;
     for (int p = 0; p < f.npoles; ++p) {
       const double z = f.z[p], lam = p == 0 ? f.lam : 1.0;
-      double t;
-      int i;
-      if (gs == 0) {
-        // exact start of the line, z^n == 0 (the expressions of spline_filter_line() in the oracle with that factor dropped)
-        const double x0 = a[0] * lam;
-        double z_i = z, acc = x0;
-        if (f.kind == kSplReflect) {
-          const int m = min(f.n - 1, kHorizon);
-          for (int k = 1; k <= m; ++k) {
-            acc += z_i * (a[k * S] * lam);
-            z_i *= z;
+      const int hp = f.hp[p];
+      // -- causal: the state in front of the segment
+      double t = 0.0;
+      bool first_exact = false;                               // t is the exact value of sample 0 (wave-uniform)
+      if (mine) {
+        int i = max(0, s0 - hp);
+        if (i == 0 && gs == 0) {
+          // exact start of the line, z^n == 0 (the expressions of spline_filter_line() in the oracle with that factor dropped)
+          const double x0 = a[0] * lam;
+          double z_i = z, acc = x0;
+          if (f.kind == kSplReflect) {
+            const int m = min(f.n - 1, kHorizon);
+            for (int k = 1; k <= m; ++k) {
+              acc += z_i * (a[k * S] * lam);
+              z_i *= z;
+            }
+            t = acc * z / (1.0 - z_i * z_i) + x0;
+          } else {
+            const int m = min(f.n - 2, kHorizon);
+            for (int k = 1; k <= m; ++k) {
+              acc += z_i * (a[k * S] * lam);
+              z_i *= z;
+            }
+            t = acc;
           }
-          t = acc * z / (1.0 - z_i * z_i) + x0;
-        } else {
-          const int m = min(f.n - 2, kHorizon);
-          for (int k = 1; k <= m; ++k) {
-            acc += z_i * (a[k * S] * lam);
-            z_i *= z;
-          }
-          t = acc;
+          first_exact = true;
+          i = 1;
         }
-        a[0] = t;
-        i = 1;
-      } else {
-        t = 0.0;
-        i = 0;
-      }
-      {
-        double v[8], w[8];
-        if (i + 8 <= R) {
+        for (; i + 8 <= s0; i += 8) {
+          double v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = a[(i + j) * S];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t = v[j] * lam + z * t;
         }
-        for (; i + 8 <= R; i += 8) {
-          const bool more = i + 16 <= R;
-          // (the reads go out in the middle of the chain: the compiler waits for ALL LDS traffic at the loop head, so
-          // whatever is issued there is waited for at once; half a batch of arithmetic later it has mostly arrived)
+        for (; i < s0; ++i) t = a[i * S] * lam + z * t;
+      }
+      __syncthreads();
+      if (mine) {
+        double v[SEG];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            t = v[j] * lam + z * t;
-            a[(i + j) * S] = t;
+        for (int j = 0; j < SEG; ++j) v[j] = s0 + j < e0 ? a[(s0 + j) * S] : 0.0;
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+          if (s0 + j < e0) {
+            if (!(first_exact && s0 + j == 0)) t = v[j] * lam + z * t;
+            a[(s0 + j) * S] = t;
           }
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = a[(i + 8 + j) * S];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 4; j < 8; ++j) {
-            t = v[j] * lam + z * t;
-            a[(i + j) * S] = t;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = w[j];
         }
       }
-      for (; i < R; ++i) {
-        t = a[i * S] * lam + z * t;
-        a[i * S] = t;
-      }
-      // anti-causal
-      if (ge == f.n) {
-        if (f.kind == kSplReflect) t = a[(R - 1) * S] * (z / (z - 1.0));
-        else t = (z / (z * z - 1.0)) * (a[(R - 1) * S] + z * a[(R - 2) * S]);
-        a[(R - 1) * S] = t;
-        i = R - 2;
-      } else {
-        t = 0.0;
-        i = R - 1;
-      }
-      {
-        double v[8], w[8];
-        if (i - 7 >= 0) {
+      __syncthreads();
+      // -- anti-causal: the state behind the segment, from the causal values of the following samples
+      t = 0.0;
+      bool last_exact = false;                                // t is the exact value of sample R - 1
+      if (mine) {
+        int i = min(R, e0 + hp) - 1;
+        if (i == R - 1 && ge == f.n) {
+          if (f.kind == kSplReflect) t = a[(R - 1) * S] * (z / (z - 1.0));
+          else t = (z / (z * z - 1.0)) * (a[(R - 1) * S] + z * a[(R - 2) * S]);
+          last_exact = true;
+          i = R - 2;
+        }
+        for (; i - 7 >= e0; i -= 8) {
+          double v[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = a[(i - j) * S];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) t = z * (t - v[j]);
         }
-        for (; i - 7 >= 0; i -= 8) {
-          const bool more = i - 15 >= 0;
+        for (; i >= e0; --i) t = z * (t - a[i * S]);
+      }
+      __syncthreads();
+      if (mine) {
+        double v[SEG];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            t = z * (t - v[j]);
-            a[(i - j) * S] = t;
+        for (int j = 0; j < SEG; ++j) v[j] = s0 + j < e0 ? a[(s0 + j) * S] : 0.0;
+#pragma unroll
+        for (int j = SEG - 1; j >= 0; --j) {
+          if (s0 + j < e0) {
+            if (!(last_exact && s0 + j == R - 1)) t = z * (t - v[j]);
+            a[(s0 + j) * S] = t;
           }
-          __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = a[(i - 8 - j) * S];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 4; j < 8; ++j) {
-            t = z * (t - v[j]);
-            a[(i - j) * S] = t;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = w[j];
         }
       }
-      for (; i >= 0; --i) {
-        t = z * (t - a[i * S]);
-        a[i * S] = t;
-      }
+      __syncthreads();
     }
   }
   __syncthreads();
@@ -800,10 +787,11 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
   }
   // the one-pass tiles when both axes qualify (reflect / mirror kind, z^n underflowed to zero for every pole)
   bool tiled = (a.filter_kind == kSplReflect || a.filter_kind == kSplMirror) && a.Hp >= kTfSamples && a.Wp >= kTfSamples && g_spline_tiled;
-  int halo = 0;
+  int halo = 0, hp[2] = {0, 0};
   for (int p = 0; p < a.npoles; ++p) {
     tiled = tiled && a.zpow[0][p] == 0.0 && a.zpow[1][p] == 0.0;
-    halo += (int)ceil(-64.0 * 0.6931471805599453 / log(fabs(a.poles[p])));      // |z|^h <= 2^-64
+    hp[p] = (int)ceil(-64.0 * 0.6931471805599453 / log(fabs(a.poles[p])));      // |z|^h <= 2^-64
+    halo += hp[p];
   }
   const int samples = kTfSamples;
   if (tiled && samples - 2 * halo >= 32) {
@@ -814,6 +802,8 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.z[1] = a.npoles > 1 ? a.poles[1] : 0.0;
     f.lam = lam;
     f.halo = halo;
+    f.hp[0] = hp[0];
+    f.hp[1] = hp[1];
     f.core = samples - 2 * halo;
     auto launch = [&](auto axis, auto in_f32, auto smp, const dim3& grid) {
       constexpr int AX = decltype(axis)::value, SM = decltype(smp)::value;
