@@ -239,14 +239,46 @@ struct TileFilter {
   double lam;
 };
 
+#ifndef DCP_TF_RW
+#define DCP_TF_RW 16                 // waves that recurse (segments of 256 / DCP_TF_RW samples)
+#endif
 constexpr int kTfBlock = 1024;       // 16 waves move the tile (16 rows of loads in flight each); wave 0 runs the recursions
 constexpr int kTfWaves = kTfBlock / 64;
+
+#ifdef DCP_EXPERIMENT_TF_TRACE      // timing experiment: phase timestamps of every tile (thread 0), read by tools/trace_tf.py
+__device__ unsigned long long g_tf_trace[2][4096][8];
+extern "C" int dcp_experiment_read_tf_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tf_trace), sizeof(g_tf_trace));
+}
+#define TF_TRACE(slot)                                                                       \
+  do {                                                                                       \
+    if (threadIdx.x == 0 && tile < 4096) g_tf_trace[AXIS][tile][slot] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+__device__ unsigned long long g_tf_trace_r[2][4096][8];       // the stages of the recursion as wave 8 sees them
+extern "C" int dcp_experiment_read_tf_trace_r(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tf_trace_r), sizeof(g_tf_trace_r));
+}
+#define TF_TRACE_R(slot)                                                                     \
+  do {                                                                                       \
+    if (threadIdx.x == 512 && tile < 4096) g_tf_trace_r[AXIS][tile][slot] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define TF_TRACE(slot) do { } while (0)
+#define TF_TRACE_R(slot) do { } while (0)
+#endif
+
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also drains the wave's global memory operations; the tile
+// lives in LDS and the prefetched values in registers the compiler tracks itself, so the barriers here need lgkmcnt only and
+// the stores of one tile / the loads of the next stay in flight across them).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int AXIS, bool IN_F32, int SAMPLES>
 __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const TileFilter f) {
   extern __shared__ double s_t[];
   constexpr int kTfPitch1 = SAMPLES + 1;
-  const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+  // (the wave index is wave-uniform by construction; said explicitly, or every segment bound derived from it lives in VGPRs and
+  // the recursion loops run under per-lane predicates)
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
   // The workgroup is persistent (one per CU: the tile takes most of the LDS) and walks tiles blockIdx.x, + gridDim.x, ...;
   // the 16 loads per lane of tile i + 1 are issued into registers before wave 0 starts the recursions of tile i and are
   // written to LDS when tile i has been stored, so the global reads run under the recursions.
@@ -312,8 +344,10 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
   Geo cur = geo_of(tile);
   issue_loads(cur);
   for (;;) {
+  TF_TRACE(0);
   commit(cur);
-  __syncthreads();
+  lds_barrier();
+  TF_TRACE(1);
   const int l0 = cur.l0, g0 = cur.g0, gs = cur.gs, ge = cur.ge, R = cur.R;
   const int next = tile + (int)gridDim.x;
   Geo nxt = cur;
@@ -321,6 +355,7 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
     nxt = geo_of(next);
     issue_loads(nxt);
   }
+  TF_TRACE(2);
   // ---- the recursions, lane = line.  EVERY wave owns a segment of SEG consecutive samples of the tile's 64 lines: it first
   // runs the recursion, without storing, over the `hp` samples in front of its segment from a zero state (|z|^hp <= 2^-64: the
   // restart the tile's own halo already relies on -- or from the exact initial sum when that range reaches the start of the
@@ -329,12 +364,13 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
   {
     double* a = AXIS == 0 ? s_t + lane : s_t + lane * kTfPitch1;
     constexpr int S = AXIS == 0 ? kTfLines : 1;               // LDS distance between consecutive samples of a line
-    constexpr int SEG = (SAMPLES + kTfWaves - 1) / kTfWaves;
+    constexpr int SEG = (SAMPLES + DCP_TF_RW - 1) / DCP_TF_RW;
     const int s0 = wave * SEG, e0 = min(R, s0 + SEG);         // this wave's segment [s0, e0); empty when s0 >= R
-    const bool mine = s0 < R;
+    const bool mine = wave < DCP_TF_RW && s0 < R;
     for (int p = 0; p < f.npoles; ++p) {
       const double z = f.z[p], lam = p == 0 ? f.lam : 1.0;
       const int hp = f.hp[p];
+      TF_TRACE_R(0);
       // -- causal: the state in front of the segment
       double t = 0.0;
       bool first_exact = false;                               // t is the exact value of sample 0 (wave-uniform)
@@ -371,20 +407,27 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
         }
         for (; i < s0; ++i) t = a[i * S] * lam + z * t;
       }
-      __syncthreads();
+      TF_TRACE(6);
+      TF_TRACE_R(1);
+      lds_barrier();
+      TF_TRACE(7);
+      TF_TRACE_R(2);
+      double cs[SEG];                                         // the segment's causal values stay in registers for its anti-causal pass
       if (mine) {
-        double v[SEG];
 #pragma unroll
-        for (int j = 0; j < SEG; ++j) v[j] = s0 + j < e0 ? a[(s0 + j) * S] : 0.0;
+        for (int j = 0; j < SEG; ++j) cs[j] = s0 + j < e0 ? a[(s0 + j) * S] : 0.0;
 #pragma unroll
         for (int j = 0; j < SEG; ++j) {
           if (s0 + j < e0) {
-            if (!(first_exact && s0 + j == 0)) t = v[j] * lam + z * t;
-            a[(s0 + j) * S] = t;
+            if (!(first_exact && s0 + j == 0)) t = cs[j] * lam + z * t;
+            cs[j] = t;
+            a[(s0 + j) * S] = t;                              // (the neighbours' anti-causal warm-up reads it)
           }
         }
       }
-      __syncthreads();
+      TF_TRACE_R(3);
+      lds_barrier();
+      TF_TRACE_R(4);
       // -- anti-causal: the state behind the segment, from the causal values of the following samples
       t = 0.0;
       bool last_exact = false;                                // t is the exact value of sample R - 1
@@ -405,23 +448,24 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
         }
         for (; i >= e0; --i) t = z * (t - a[i * S]);
       }
-      __syncthreads();
+      TF_TRACE_R(5);
+      lds_barrier();
+      TF_TRACE_R(6);
       if (mine) {
-        double v[SEG];
-#pragma unroll
-        for (int j = 0; j < SEG; ++j) v[j] = s0 + j < e0 ? a[(s0 + j) * S] : 0.0;
 #pragma unroll
         for (int j = SEG - 1; j >= 0; --j) {
           if (s0 + j < e0) {
-            if (!(last_exact && s0 + j == R - 1)) t = z * (t - v[j]);
+            if (!(last_exact && s0 + j == R - 1)) t = z * (t - cs[j]);
             a[(s0 + j) * S] = t;
           }
         }
       }
-      __syncthreads();
+      TF_TRACE_R(7);
+      lds_barrier();
     }
   }
-  __syncthreads();
+  lds_barrier();
+  TF_TRACE(3);
   // ---- LDS -> global: the core
   const int c_lo = g0 - gs, c_n = min(f.core, f.n - g0);
   if constexpr (AXIS == 0) {
@@ -436,8 +480,10 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
       for (int sI = lane; sI < c_n; sI += 64) o[(int64_t)sI * f.out_ss] = s_t[li * kTfPitch1 + c_lo + sI];
     }
   }
+  TF_TRACE(4);
   if (next >= ntiles) break;
-  __syncthreads();                                            // the tile has been read out: LDS is free for the next one
+  lds_barrier();                                              // the tile has been read out: LDS is free for the next one
+  TF_TRACE(5);
   tile = next;
   cur = nxt;
   }

@@ -1,9 +1,16 @@
 #!/bin/bash
 # Builds experiment variants of the library: tools/variants.sh name "-DFLAG=.." [name2 "-D.."] ...
+# FILE=spline_kernels.hip tools/variants.sh ...  rebuilds that translation unit instead of unwarp_kernels.hip.
 set -e
 cd "$(dirname "$0")/../discorpy_amd/csrc"
+FILE=${FILE:-unwarp_kernels.hip}
+BASE=${FILE%.hip}
 while [ $# -ge 2 ]; do
   n=$1; f=$2; shift 2
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $f -c unwarp_kernels.hip -o /tmp/uk_$n.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libdcp_var_$n.so /tmp/uk_$n.o ../lib/spline_kernels.o ../lib/typed_kernels.o ../lib/api_core.o ../lib/api_image.o ../lib/api_stack.o ../lib/api_spline.o ../lib/api_rccl.o -pthread -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $f -c $FILE -o /tmp/var_$n.o
+  OBJS=""
+  for o in unwarp_kernels spline_kernels typed_kernels api_core api_image api_stack api_spline api_rccl; do
+    if [ "$o" = "$BASE" ]; then OBJS="$OBJS /tmp/var_$n.o"; else OBJS="$OBJS ../lib/$o.o"; fi
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libdcp_var_$n.so $OBJS -pthread -ldl
 done
