@@ -1180,7 +1180,7 @@ def test_randomised_differential_campaign(hip, orc):
     kinds = set()
     for k in range(600):
         kinds.add(fz.one_case(rng, k))
-    assert kinds == {"radial", "persp", "fused", "stack", "coords", "spline", "color"}
+    assert kinds == {"radial", "persp", "fused", "stack", "coords", "spline", "color", "batch", "centres"}
 
 
 # --------------------------------------------------------------------------- (c) BASELINE sizes

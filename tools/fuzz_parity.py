@@ -84,8 +84,23 @@ def same(a, b, order, what):
         assert d.max() <= 1 and np.count_nonzero(d) <= max(3, a.size // 2000), what
 
 
+def device_tensor(a):
+    """A ROCm torch tensor of a NumPy array (None without torch: the case then runs on host arrays)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    except ImportError:
+        pass
+    return None
+
+
+def to_host(a):
+    return a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+
+
 def one_case(rng, k):
-    kind = ["radial"] * 5 + ["persp", "fused", "stack", "coords", "spline", "color"]
+    kind = ["radial"] * 5 + ["persp", "fused", "stack", "coords", "spline", "color", "batch", "centres"]
     kind = kind[int(rng.integers(0, len(kind)))]
     h, w = rand_shape(rng)
     dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
@@ -101,7 +116,50 @@ def one_case(rng, k):
     kw = dict(blend=blend) if f32 else {}
     if f32:
         okw["blend"] = BLENDS[blend]
-    if kind == "radial":
+    if kind == "batch":
+        # several frames of one shape, every frame its own centre and coefficient vector, in one call (device-resident
+        # float32 frames under certified calibrations share ONE launch; everything else goes frame by frame inside)
+        n = int(rng.integers(1, 7))
+        frames = [rand_image(rng, (h, w), dt) for _ in range(n)]
+        mild = rng.integers(0, 2) == 0
+        cals = []
+        for _ in range(n):
+            fx, fy = float(rng.uniform(0.2, 0.8) * w), float(rng.uniform(0.2, 0.8) * h)
+            ff = [1.0 + float(rng.uniform(-0.02, 0.02)), float(rng.uniform(-2e-5, 2e-5)), float(rng.uniform(-2e-8, 2e-8))][:int(rng.integers(1, 4))] \
+                if mild else rand_fact(rng, h, w)
+            cals.append((fx, fy, ff))
+        dev = [device_tensor(f_) for f_ in frames] if (f32 and rng.integers(0, 3) > 0) else [None]
+        src = dev if dev[0] is not None else frames
+        got = pp.unwarp_images_backward(src, [c_[0] for c_ in cals], [c_[1] for c_ in cals], [c_[2] for c_ in cals], order=order, **kw)
+        for f_, c_, g_ in zip(frames, cals, got):
+            same(to_host(g_), orc.unwarp_image_backward(f_, c_[0], c_[1], c_[2], order=order, **okw), order, tag + " batch frame cal=%r" % (c_,))
+    elif kind == "centres":
+        d = int(rng.integers(1, 6))
+        vol = rand_image(rng, (d, h, w), dt)
+        nk = int(rng.integers(1, 9))
+        xs = [xc + float(rng.uniform(-20, 20)) for _ in range(nk)]
+        ys = [yc + float(rng.uniform(-20, 20)) for _ in range(nk)]
+        src = device_tensor(vol) if (f32 and rng.integers(0, 2)) else None
+        src = vol if src is None else src
+        skw = dict(blend=blend) if (f32 and blend != "f32") else {}
+        sokw = dict(okw, blend=BLENDS[blend]) if (f32 and blend != "f32") else {k_: v for k_, v in okw.items() if k_ != "blend"}
+        if rng.integers(0, 2) or h < 2:
+            idx = float(rng.uniform(-2, h + 1)) if rng.integers(0, 3) == 0 else int(rng.integers(0, h))
+            got = to_host(pp.unwarp_slice_backward_centres(src, xs, ys, fact, idx, **skw))
+            for q in range(nk):
+                same(got[q], orc.unwarp_slice_backward(vol, xs[q], ys[q], fact, idx, **sokw), 1, tag + " centres slice %r centre %d" % (idx, q))
+        else:
+            r0 = int(rng.integers(0, h))
+            r1 = int(rng.integers(r0, min(h, r0 + 40)))
+            try:
+                got = to_host(pp.unwarp_chunk_slices_backward_centres(src, xs, ys, fact, r0, r1, **skw))
+            except ValueError as e:          # a model that folds the rows onto an empty band: refused like the single call
+                if "empty band" not in str(e):
+                    raise
+                return kind
+            for q in range(nk):
+                same(got[q], orc.unwarp_chunk_slices_backward(vol, xs[q], ys[q], fact, r0, r1, **sokw), 1, tag + " centres chunk %d..%d centre %d" % (r0, r1, q))
+    elif kind == "radial":
         img = rand_image(rng, (h, w), dt)
         if rng.integers(0, 4) == 0 and h > 2 and w > 2:       # strided / padded view
             big = rand_image(rng, (h + 3, 2 * w + 5), dt)
@@ -208,19 +266,27 @@ def main():
     rng = np.random.default_rng(seed)
     counts, kernels, t0 = {}, {}, time.time()
     F.debug_counters()
+    # every kernel a case launched, not only its last one: each C-ABI call of the front end passes through F.check
+    launched, plain_check = set(), F.check
+
+    def recording_check(rc):
+        plain_check(rc)
+        launched.add(F.last_kernel().split("<")[0].split(" ")[0] or "(spline / point kernels)")
+    F.check = recording_check
     for k in range(cases):
         F.set_option("stack_lds", (1, 2, 0)[k % 3])       # stack cases: automatic choice / forced staged kernel / direct
         F.set_option("stack_wg", (2, 1, 2, 0)[k % 4])     # workgroup-box stack kernel: whenever eligible / automatic / off
         F.set_option("wg_box", 0 if k % 5 == 4 else 1)    # one box per workgroup, or per wave tile
         F.set_option("tile_cert", 0 if k % 7 == 6 else 1) # the host certificate, or the per-pixel vote
+        launched.clear()
         kind = one_case(rng, k)
         counts[kind] = counts.get(kind, 0) + 1
-        name = F.last_kernel().split("<")[0].split(" ")[0] or "(spline / point kernels)"
-        kernels[name] = kernels.get(name, 0) + 1
+        for name in launched:
+            kernels[name] = kernels.get(name, 0) + 1
     nofit, vote = F.debug_counters()
     for key in ("stack_lds", "stack_wg", "wg_box", "tile_cert"):
         F.set_option(key, 1)
-    print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; last kernel of each case: %s; LDS-kernel fallbacks exercised: "
+    print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; cases in which each kernel ran: %s; LDS-kernel fallbacks exercised: "
           "%d tiles did not fit, %d tiles failed the vote" % (cases, seed, time.time() - t0, dict(sorted(counts.items())),
                                                               dict(sorted(kernels.items())), nofit, vote))
 
