@@ -74,7 +74,8 @@ int fill_map(dcp::MapArgs* m, double xc, double yc, const double* fact, int nfac
   m->xc = xc;
   m->yc = yc;
   if (nfact < 0 || nfact > dcp::kMaxFact)
-    return fail(DCP_ERR_INVALID_ARG, "nfact = %d outside [0, %d]", nfact, dcp::kMaxFact);
+    return fail(DCP_ERR_INVALID_ARG, "nfact = %d outside [0, %d] (DCP_MAX_FACT is a limit of this library: the reference takes a coefficient list of any "
+                "length, discorpy/post/postprocessing.py:142-143, and never ships more than 5)", nfact, dcp::kMaxFact);
   if (nfact > 0 && !fact) return fail(DCP_ERR_INVALID_ARG, "null coefficient pointer");
   for (int i = 0; i < nfact; ++i) m->fact[i] = fact[i];
   m->nfact = nfact;

@@ -396,7 +396,8 @@ int dcp_unwarp_images_f32(const float* const* srcs, float* const* dsts, int nfra
   if (nframes < 0) return fail(DCP_ERR_INVALID_ARG, "nframes < 0");
   if (nframes == 0) return DCP_OK;
   if (!srcs || !dsts || !xcenters || !ycenters) return fail(DCP_ERR_INVALID_ARG, "null frame / centre array");
-  if (nfact < 0 || nfact > dcp::kMaxFact) return fail(DCP_ERR_INVALID_ARG, "nfact = %d outside [0, %d]", nfact, dcp::kMaxFact);
+  if (nfact < 0 || nfact > dcp::kMaxFact)
+    return fail(DCP_ERR_INVALID_ARG, "nfact = %d outside [0, %d] (DCP_MAX_FACT is a limit of this library, not of the reference)", nfact, dcp::kMaxFact);
   if (nfact > 0 && !list_facts) return fail(DCP_ERR_INVALID_ARG, "null coefficient pointer");
   if ((rc = sampler_of(order, blend_mode, &sampler)) != DCP_OK) return rc;
   auto one_by_one = [&](int first) {      // frames first .. nframes-1 through the single-frame entry point

@@ -50,6 +50,9 @@ constexpr int kBlock = 256;
 #define DCP_PIPE_DEPTH 2
 #endif
 constexpr int kPipeDepth = DCP_PIPE_DEPTH;
+#ifndef DCP_FILL_AUX
+#define DCP_FILL_AUX 0   // cache-policy bits of remap_wg_kernel's LDS-DMA fill (2 = nt)
+#endif
 #ifndef DCP_STORE_AUX
 #define DCP_STORE_AUX 2  // cache-policy bits of the output store: 2 = nt (streamed once, never re-read here)
 #endif
@@ -941,7 +944,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
         // zeros into LDS -- past the end of the slab when the box is 40 rows tall)
         if (crow < bh)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16,
-                                                   off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u, 0, 0, 0);
+                                                   off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u, 0, 0, DCP_FILL_AUX);
       }
     }
   };

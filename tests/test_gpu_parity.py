@@ -967,6 +967,14 @@ def test_integration_stub_of_the_docs_runs(hip, orc, monkeypatch):
     assert np.array_equal(got, orc.unwarp_image_backward(img, *a, **kernel_oracle(orc, "f64lerp")))
     with pytest.raises(ValueError):
         ns["_check"](ns["lib"]().dcp_unwarp_image_f32(None, None, 4, 4, 4, 1, 0.0, 0.0, None, 0, 1, 1, 1, 0, -1, None))
+    # the continuation of the stub: many images, every image its own calibration, in one call
+    more = next(b for b in blocks if "def unwarp_images(" in b)
+    exec(compile(more, "INTEGRATION.md", "exec"), ns)
+    frames = [noise(91 + i, (120, 160)) for i in range(3)]
+    cals = [(75.0, 61.0, [1.0, 2e-3, 1e-6]), (80.5, 58.0, [0.99, 1e-3]), (70.0, 66.25, [1.01, -1e-3, 2e-6, 1e-9])]
+    outs = ns["unwarp_images"](frames, [c[0] for c in cals], [c[1] for c in cals], [c[2] for c in cals])
+    for f, c, o in zip(frames, cals, outs):
+        assert np.array_equal(o, orc.unwarp_image_backward(f, *c, **kernel_oracle(orc, "f64lerp")))
 
 
 def test_release_scratch_then_work_again(hip, orc):
