@@ -28,14 +28,26 @@ __device__ __forceinline__ double sqrt_rn(double x) {
   return x == 0.0 ? 0.0 : g;
 }
 
-// The same for x > 0 (no zero select).
+// The same for x > 0 (no zero select) in the per-pixel coordinate loops of the frame and stack kernels, with the refinement of h
+// left out: after the coupled step g is good to ~2^-52 and the exact residual d = x - g^2 is of that relative size, so the
+// correction d * h needs h only to the seed's accuracy.  tools/ubench_sqrt.hip, 4.3e9 operands r^2 of a frame: 0 results differ
+// from the correctly rounded sqrt with h refined, 79 (1.8e-8) differ by one ulp without -- a third of a pixel per 4096^2 frame
+// whose ru is one ulp off, which moves a float32-rounded coordinate with probability < 1e-16 per pixel (ru enters B through
+// ru * O(r^2) ~ 0.1 and the coordinate is rounded to 24 bits): outputs stay equal to the oracle's (correctly rounded sqrt).
+// One float64 instruction of 44 per pixel: 28.8 -> 28.1 us per frame in the multi-frame launch, same box.  DCP_SQRT_REFINE_H=1
+// restores the refinement (A/B builds).
+#ifndef DCP_SQRT_REFINE_H
+#define DCP_SQRT_REFINE_H 0
+#endif
 __device__ __forceinline__ double sqrt_pos(double x) {
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
   double h = 0.5 * y;
   double r = __builtin_fma(-h, g, 0.5);
   g = __builtin_fma(g, r, g);
+#if DCP_SQRT_REFINE_H
   h = __builtin_fma(h, r, h);
+#endif
   double d = __builtin_fma(-g, g, x);
   return __builtin_fma(d, h, g);
 }
