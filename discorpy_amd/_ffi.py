@@ -98,6 +98,8 @@ SIGNATURES = {
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
     "dcp_free": (_int, [_vp, _int]),
     "dcp_memcpy": (_int, [_vp, _vp, _sz, _int, _int, _vp]),
+    "dcp_host_register": (_int, [_vp, _sz, _int]),
+    "dcp_host_unregister": (_int, [_vp]),
     "dcp_stream_create": (_int, [C.POINTER(_vp), _int]),
     "dcp_stream_destroy": (_int, [_vp]),
     "dcp_stream_synchronize": (_int, [_int, _vp]),

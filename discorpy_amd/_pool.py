@@ -18,6 +18,45 @@ import threading
 import numpy as np
 
 _MIN_BYTES = 1 << 20          # smaller outputs are not worth tracking
+_PIN_MIN_BYTES = 16 << 20     # blocks from this size on are registered with the GPU (the library's direct-write path starts there)
+
+
+class _Block:
+    """One block of the pool: a uint8 array, registered with the GPU (hipHostRegister through dcp_host_register) when it is large
+    enough for the library's direct-write path -- the kernels then write a host frame's result straight into it instead of
+    staging it on the device and copying it back (csrc/api_image.cpp: run_host_direct).  The registration costs ~0.8 ms per 64 MiB
+    once per block and is undone before the memory goes away.  DISCORPY_AMD_PIN_OUTPUTS=0 switches it off."""
+
+    __slots__ = ("arr", "registered")
+
+    def __init__(self, nbytes):
+        self.arr = np.empty(nbytes, np.uint8)
+        self.registered = False
+        if nbytes >= _PIN_MIN_BYTES and os.environ.get("DISCORPY_AMD_PIN_OUTPUTS", "1") != "0":
+            try:
+                from . import _ffi as F
+                if F.device_count() > 0:
+                    self.arr[::4096] = 0                      # fault the pages in before they are pinned
+                    dev = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
+                    self.registered = F.lib().dcp_host_register(self.arr.ctypes.data, nbytes, dev) == 0
+            except Exception:      # noqa: BLE001 -- no library / no device: a plain block
+                self.registered = False
+
+    @property
+    def nbytes(self):
+        return self.arr.nbytes
+
+    def release(self):
+        if self.registered:
+            self.registered = False
+            try:
+                from . import _ffi as F
+                F.lib().dcp_host_unregister(self.arr.ctypes.data)
+            except Exception:      # noqa: BLE001 -- interpreter shutdown
+                pass
+
+    def __del__(self):
+        self.release()
 
 
 class _Lease:
@@ -30,7 +69,7 @@ class _Lease:
         self._pool = pool
         self._block = block
         self.__array_interface__ = {"version": 3, "shape": tuple(int(s) for s in shape), "typestr": np.dtype(dtype).str,
-                                    "data": (block.ctypes.data, False), "strides": None}
+                                    "data": (block.arr.ctypes.data, False), "strides": None}
 
     def __del__(self):
         pool, block = self._pool, self._block
@@ -65,29 +104,36 @@ class HostPool:
             else:
                 self.misses += 1
         if block is None:
-            block = np.empty(nbytes, np.uint8)
+            block = _Block(nbytes)
         return np.asarray(_Lease(self, block, shape, dtype))
 
     def _give_back(self, block):
         try:
+            dropped = []
             with self.lock:
                 if block.nbytes > self.cap:
-                    return
-                self.idle.setdefault(block.nbytes, []).append(block)
-                self.age.append(block.nbytes)
-                self.idle_bytes += block.nbytes
-                while self.idle_bytes > self.cap:        # evict the blocks that have been idle the longest
-                    old = self.age.popleft()
-                    self.idle[old].pop(0)
-                    self.idle_bytes -= old
+                    dropped.append(block)
+                else:
+                    self.idle.setdefault(block.nbytes, []).append(block)
+                    self.age.append(block.nbytes)
+                    self.idle_bytes += block.nbytes
+                    while self.idle_bytes > self.cap:        # evict the blocks that have been idle the longest
+                        old = self.age.popleft()
+                        dropped.append(self.idle[old].pop(0))
+                        self.idle_bytes -= old
+            for b in dropped:                                # (unregistered before their memory is freed)
+                b.release()
         except Exception:      # interpreter shutdown: let the block go
             pass
 
     def clear(self):
         with self.lock:
+            blocks = [b for stack in self.idle.values() for b in stack]
             self.idle.clear()
             self.age.clear()
             self.idle_bytes = 0
+        for b in blocks:
+            b.release()
 
 
 _pool = HostPool(int(float(os.environ.get("DISCORPY_AMD_HOST_POOL_MB", "1024")) * (1 << 20)))

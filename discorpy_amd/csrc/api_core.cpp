@@ -21,7 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -488,6 +488,10 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "wg_per_cu")) {
     if (value < 0 || value > 6) return fail(DCP_ERR_INVALID_ARG, "wg_per_cu must be in [0, 6]");
     g_wg_per_cu = value;
+  } else if (!strcmp(key, "host_direct")) {
+    if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "host_direct must be 0, 1 or 2");
+    g_host_direct = value;            // 0: a host frame's result is always staged on the device and copied back; 1: written straight into a
+                                      // registered destination when the runtime cannot overlap an upload with a download; 2: whenever registered
   } else if (!strcmp(key, "int_exact")) {
     g_int_exact = value ? 1 : 0;      // 0: integer element types blend in scipy's operation order everywhere (A/B and parity runs)
   } else if (!strcmp(key, "wg_box")) {
@@ -526,6 +530,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "spline_wg")) *value = dcp::get_spline_wg();
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else if (!strcmp(key, "int_exact")) *value = g_int_exact;
+  else if (!strcmp(key, "host_direct")) *value = g_host_direct;
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }
@@ -588,6 +593,20 @@ int dcp_memcpy(void* dst, const void* src, size_t bytes, int kind, int device, v
   }
   DCP_HIP(hipMemcpyAsync(dst, src, bytes, k, (hipStream_t)stream));
   if (kind != DCP_COPY_D2D) DCP_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return DCP_OK;
+}
+
+int dcp_host_register(void* ptr, size_t bytes, int device) {
+  if (!ptr || bytes == 0) return fail(DCP_ERR_INVALID_ARG, "nothing to register");
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  DCP_HIP(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return DCP_OK;
+}
+
+int dcp_host_unregister(void* ptr) {
+  if (!ptr) return DCP_OK;
+  DCP_HIP(hipHostUnregister(ptr));
   return DCP_OK;
 }
 

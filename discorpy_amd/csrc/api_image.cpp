@@ -153,6 +153,68 @@ int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix
   return DCP_OK;
 }
 
+// Is `p` host memory the GPU can address (hipHostRegister / hipHostMalloc)?  Returns its device-visible address, or nullptr.
+void* registered_host_alias(const void* p) {
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();            // plain pageable memory: not an error
+    return nullptr;
+  }
+  if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return nullptr;
+  return attr.devicePointer;
+}
+
+// Host frame whose DESTINATION is registered host memory (the recycled outputs of the Python front end are; so is anything a C
+// caller got from hipHostMalloc / hipHostRegister): the kernels write their rows straight into it over PCIe -- no device result,
+// no download.  The source goes up in bands on one stream; the kernel of band k, on a second stream behind an event, writes band k
+// of the result while band k + 1 is uploaded: the upload is the copy engine's, the result the shader's stores, and the two
+// directions overlap whatever the runtime does with two copies (the runtime bundled with PyTorch-ROCm serialises those: 2.45 ms
+// per 4096^2 frame; this path: see DESIGN.md section 6, round 3).
+template <typename Hull, typename LaunchBand>
+int run_host_direct(const void* src, void* dst_alias, int64_t H, int64_t W, size_t pix, size_t rs_bytes, Hull&& source_rows,
+                    LaunchBand&& launch_band) {
+  const size_t row_bytes = (size_t)W * pix;
+  void* dsrc = nullptr;
+  DCP_HIP(g_staging.get(0, (size_t)H * row_bytes, &dsrc));
+  hipStream_t s_up = nullptr, s_k = nullptr;
+  DCP_HIP(g_host_streams.get(&s_up, &s_k));
+  thread_local hipEvent_t ev[2] = {nullptr, nullptr};
+  thread_local int ev_dev = -1;
+  int cur = 0;
+  DCP_HIP(hipGetDevice(&cur));
+  if (ev_dev != cur) {
+    for (auto& e : ev) {
+      if (e) (void)hipEventDestroy(e);
+      e = nullptr;
+      DCP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    ev_dev = cur;
+  }
+  const int64_t nbands = g_host_bands.load();
+  int64_t rows_per = ((H + nbands - 1) / nbands + 63) / 64 * 64;
+  if (rows_per > 65535) rows_per = 65535 / 64 * 64;
+  const int64_t nb = (H + rows_per - 1) / rows_per;
+  int64_t uploaded = 0;
+  for (int64_t k = 0; k < nb; ++k) {
+    const int64_t r0 = k * rows_per, n = (r0 + rows_per > H ? H - r0 : rows_per);
+    int64_t b0 = 0, b1 = H;
+    source_rows(r0, n, &b0, &b1);
+    const int64_t need = (k == nb - 1) ? H : b1;
+    if (need > uploaded) {
+      DCP_HIP(hipMemcpy2DAsync((char*)dsrc + (size_t)uploaded * row_bytes, row_bytes, (const char*)src + (size_t)uploaded * rs_bytes, rs_bytes,
+                               row_bytes, (size_t)(need - uploaded), hipMemcpyHostToDevice, s_up));
+      uploaded = need;
+    }
+    if (b0 < 0 || b1 > uploaded) return fail(DCP_ERR_HIP, "band hull outside the uploaded rows");      // cannot happen: need >= b1
+    DCP_HIP(hipEventRecord(ev[k & 1], s_up));
+    DCP_HIP(hipStreamWaitEvent(s_k, ev[k & 1], 0));
+    DCP_HIP(launch_band(dsrc, (char*)dst_alias + (size_t)r0 * row_bytes, r0, n, s_k));
+  }
+  DCP_HIP(hipStreamSynchronize(s_k));
+  return DCP_OK;
+}
+
 // Shared driver of the three whole-image entry points.
 int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_t W, int64_t rs, int64_t cs,
               const dcp::MapArgs& map, int sampler, bool round_f32, int mem_kind, int device, void* stream) {
@@ -173,6 +235,60 @@ int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_
     return DCP_OK;
   }
   if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  // a destination the GPU can address: the kernels write into it directly (run_host_direct)
+  // (taken where the runtime cannot run an upload and a download at once -- the one bundled with PyTorch-ROCm: 2.16 ms against
+  // 2.44 per 4096^2 frame; where it can -- /opt/rocm's -- the two-copy banded path below is the faster one, 1.78 ms against 2.15.
+  // "host_direct" = 2 forces it, 0 forbids it)
+  void* dst_alias = nullptr;
+  if (g_host_direct.load() && cs == 1 && H >= 512 && W >= 2 && (double)H * (double)W * 4.0 >= 16.0 * 1048576.0 &&
+      (double)H * (double)W * 4.0 <= 4294967040.0 && (kind == dcp::kRadial || map.fast_div) &&
+      (g_host_direct.load() == 2 || !g_host_duplex.load() || !runtime_overlaps_directions()))
+    dst_alias = registered_host_alias(dst);
+  if (dst_alias) {
+    auto band_rows = [&](int64_t r0, int64_t n, int64_t* b0, int64_t* b1) {
+      if (kind == dcp::kRadial) {
+        host_row_band(map, H, W, (double)r0, n, b0, b1);
+        return;
+      }
+      // homography with a denominator of one sign over the frame: the extremes of a band of rows are at its four corners
+      double ylo = 1e300, yhi = -1e300, xlo = 1e300, xhi = -1e300;
+      for (double y : {(double)r0, (double)(r0 + n - 1)})
+        for (double x : {0.0, (double)(W - 1)}) {
+          const double den = (map.coef[6] * x + map.coef[7] * y) + 1.0;
+          double yd = ((map.coef[3] * x + map.coef[4] * y) + map.coef[5]) / den;
+          double xd = ((map.coef[0] * x + map.coef[1] * y) + map.coef[2]) / den;
+          if (!(yd >= 0.0)) yd = 0.0;
+          if (yd > (double)(H - 1)) yd = (double)(H - 1);
+          if (!(xd >= 0.0)) xd = 0.0;
+          if (xd > (double)(W - 1)) xd = (double)(W - 1);
+          ylo = std::min(ylo, yd);
+          yhi = std::max(yhi, yd);
+          xlo = std::min(xlo, xd);
+          xhi = std::max(xhi, xd);
+        }
+      if (kind == dcp::kFused) {
+        host_row_band_rect(map, H, xlo - 0.01, xhi + 0.01, ylo - 0.01, yhi + 0.01, b0, b1);
+        return;
+      }
+      *b0 = std::max<int64_t>(0, (int64_t)std::floor(ylo) - 1);
+      *b1 = std::min<int64_t>(H, (int64_t)std::floor(yhi) + 3);
+    };
+    return run_host_direct(src, dst_alias, H, W, sizeof(float), (size_t)rs * sizeof(float), band_rows,
+                           [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {
+                             dcp::ImageArgs b;
+                             memset(&b, 0, sizeof(b));
+                             b.H = (int32_t)H;
+                             b.W = (int32_t)W;
+                             b.src = (const float*)dsrc;
+                             b.dst = (float*)dband;
+                             b.src_stride = (int32_t)W;
+                             b.src_col_stride = 1;
+                             b.src_bytes = (uint32_t)((size_t)H * (size_t)W * 4);
+                             b.y_origin = (int32_t)r0;
+                             b.rows_out = (int32_t)n;
+                             return dcp::launch_image(kind, b, map, sampler, round_f32, opts, s);
+                           });
+  }
   if ((kind == dcp::kPersp || kind == dcp::kFused) && map.fast_div && cs == 1 && H >= 512 && W >= 2 && g_host_duplex.load() &&
       (double)H * (double)W * 4.0 >= 16.0 * 1048576.0 && (double)H * (double)W * 4.0 <= 4294967040.0 &&
       (g_host_duplex.load() == 2 || runtime_overlaps_directions())) {

@@ -70,7 +70,8 @@ int dcp_release_scratch(void);
  * "tile_cert" (0: never use the host's tile-deviation certificate), "wg_box" (0: one source box per wave tile),
  * "wg_per_cu", "stack_wg" (0 never / 1 when the launch is large enough / 2 whenever eligible: the workgroup-box stack
  * kernel), "spline_tiled" (0: chunked spline prefilter passes + transposes instead of the one-pass LDS tiles),
- * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box), "int_exact" (0: 8- / 16-bit integer
+ * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box), "host_direct" (0: never write a host frame's result straight into registered
+ * host memory), "int_exact" (0: 8- / 16-bit integer
  * data blend in scipy's operation order everywhere instead of the factorised form where that form is provably exact).  Returns
  * DCP_ERR_INVALID_ARG for an unknown key. */
 int dcp_set_option(const char* key, int value);
@@ -338,6 +339,12 @@ int dcp_free(void* ptr, int device);
 #define DCP_COPY_D2H 1
 #define DCP_COPY_D2D 2
 int dcp_memcpy(void* dst, const void* src, size_t bytes, int kind, int device, void* stream);
+/* Host memory the GPU can address (hipHostRegister): a DCP_MEM_HOST frame call whose `dst` lies in registered memory -- these, or
+ * anything from hipHostMalloc -- has its result written straight into it by the kernels, band by band while the source is still
+ * uploading (no device copy of the result, no download; option "host_direct" = 0 switches that off).  Registration costs ~0.8 ms
+ * per 64 MiB: for buffers that are reused.  Unregister before the memory is freed. */
+int dcp_host_register(void* ptr, size_t bytes, int device);
+int dcp_host_unregister(void* ptr);
 int dcp_stream_create(void** stream, int device);   /* a non-blocking stream for DCP_MEM_DEVICE calls */
 int dcp_stream_destroy(void* stream);
 int dcp_stream_synchronize(int device, void* stream);

@@ -1,0 +1,68 @@
+"""Host frames whose destination is REGISTERED host memory (the recycled NumPy outputs of the front end are): the kernels write
+the result straight into it over PCIe, band by band, while the source is still uploading (csrc/api_image.cpp: run_host_direct).
+The result must be what the staged path and the oracle give.  Reference: a NumPy array in, a NumPy array out
+(postprocessing.py:111-148, 462-492)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import noise
+
+from discorpy_amd import _ffi as F
+from discorpy_amd import _pool
+from discorpy_amd.post import postprocessing as pp
+
+
+def test_register_entry_points_validate_without_a_gpu():
+    L = F.lib()
+    assert L.dcp_host_register(None, 10, -1) == F.ERR_INVALID_ARG
+    assert L.dcp_host_unregister(None) == F.OK
+    with pytest.raises(ValueError):
+        F.set_option("host_direct", 3)
+    a = _pool.empty((2048, 2048), np.float32)            # 16 MiB: would be registered on a GPU box; a plain block here or there, usable
+    a[...] = 1.0
+    assert float(a.sum()) == 2048.0 * 2048.0
+
+
+@pytest.mark.gpu
+def test_direct_write_into_registered_host_memory_equals_the_staged_path(hip, orc):
+    H, W = 2200, 2100                                     # 18.5 MB: above the 16 MiB threshold of the direct / banded paths
+    img = noise(501, (H, W))
+    xc, yc, fact = 1010.4, 1120.7, [1.0, -8e-6, 6e-9, -2e-12]
+    coef = [0.98, -0.012, 20.5, 0.009, 1.01, -14.0, 4e-6, -3e-6]
+    want = {"radial": orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP),
+            "nearest": orc.unwarp_image_backward(img, xc, yc, fact, order=0, poly=orc.POLY_KERNEL),
+            "persp": orc.correct_perspective_image(img, coef, blend=orc.BLEND_F64LERP),
+            "fused": orc.unwarp_fused(img, xc, yc, fact, coef, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)}
+    L = hip.lib()
+    try:
+        for mode in (2, 0, 1):                            # always direct when registered / never / decided by the runtime probe
+            hip.set_option("host_direct", mode)
+            got = {"radial": pp.unwarp_image_backward(img, xc, yc, fact), "nearest": pp.unwarp_image_backward(img, xc, yc, fact, order=0),
+                   "persp": pp.correct_perspective_image(img, coef), "fused": pp.unwarp_perspective_fused(img, xc, yc, fact, coef)}
+            for k in want:
+                assert np.array_equal(got[k], want[k]), (mode, k)
+        # a caller's own registered buffer through the C ABI (out=): written in place
+        hip.set_option("host_direct", 2)
+        out = np.zeros((H, W), np.float32)
+        hip.check(L.dcp_host_register(out.ctypes.data, out.nbytes, -1))
+        try:
+            res = pp.unwarp_image_backward(img, xc, yc, fact, out=out)
+            assert res is out and np.array_equal(out, want["radial"])
+            strided = np.zeros((H, W + 7), np.float32)
+            strided[:, :W] = img
+            res = pp.unwarp_image_backward(strided[:, :W], xc, yc, fact, out=out)       # padded source rows
+            assert np.array_equal(out, want["radial"])
+        finally:
+            hip.check(L.dcp_host_unregister(out.ctypes.data))
+    finally:
+        hip.set_option("host_direct", 1)
+    # the pool's blocks are registered and survive recycling
+    del got, res
+    a = pp.unwarp_image_backward(img, xc, yc, fact)
+    addr = a.ctypes.data
+    del a
+    b = pp.unwarp_image_backward(img, xc, yc, fact)
+    assert b.ctypes.data == addr and np.array_equal(b, want["radial"])
+    _pool.clear()
