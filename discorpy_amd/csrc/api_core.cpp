@@ -496,6 +496,9 @@ int dcp_set_option(const char* key, int value) {
     g_int_exact = value ? 1 : 0;      // 0: integer element types blend in scipy's operation order everywhere (A/B and parity runs)
   } else if (!strcmp(key, "wg_box")) {
     g_wg_box = value ? 1 : 0;         // 0: one source box per wave tile (remap_lds_kernel) even when the certificate covers 128 x 32 tiles
+  } else if (!strcmp(key, "box_table")) {
+    if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "box_table must be 0, 1 or 2");
+    dcp::set_box_table(value);        // 0: every wave of remap_wg_kernel evaluates its tile's corners; 1: once per tile by box_table_kernel where it pays
   } else if (!strcmp(key, "spline_wg")) {
     dcp::set_spline_wg(value ? 1 : 0);
   } else if (!strcmp(key, "spline_tiled")) {
@@ -528,6 +531,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "wg_per_cu")) *value = g_wg_per_cu;
   else if (!strcmp(key, "spline_tiled")) *value = dcp::get_spline_tiled();
   else if (!strcmp(key, "spline_wg")) *value = dcp::get_spline_wg();
+  else if (!strcmp(key, "box_table")) *value = dcp::get_box_table();
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else if (!strcmp(key, "int_exact")) *value = g_int_exact;
   else if (!strcmp(key, "host_direct")) *value = g_host_direct;

@@ -34,6 +34,8 @@ struct ImageArgs {
   int32_t y_origin;        // a launch may cover only output rows [y_origin, y_origin + rows_out) of the H x W map;
   int32_t rows_out;        // dst then points at row y_origin (0 / 0 = the whole image)
   int32_t int_exact;       // integer element types: 1 = tiles at coordinates >= 32 take the exact factorised blend (exact_lerp_pairs)
+  const int32_t* boxes = nullptr;   // remap_wg_kernel: corner hulls (x0, x1, y0, y1) of every 128 x 32 tile, frame-major, from box_table_kernel
+                                    // (nullptr: every wave evaluates its workgroup's corners itself)
 };
 
 struct MapArgs {
@@ -170,6 +172,8 @@ void set_last_kernel_name(const char* name);   // for the launchers of the other
 const char* last_kernel_name();   // unwarp_kernels.hip: the kernel the calling thread launched last (float32 image / stack launchers)
 // spline_kernels.hip: map_kind 0 radial, 1 perspective, 2 explicit coordinates
 void set_spline_wg(int v);      // 0: spline taps always from global memory (option "spline_wg")
+void set_box_table(int v);      // option "box_table": remap_wg_kernel reads its tile hulls from box_table_kernel's table (0 never, 1 where it pays)
+int get_box_table();
 int get_spline_wg();
 void set_spline_tiled(int v);   // 0: chunked prefilter passes + transposes even where the one-pass tiles qualify (option "spline_tiled")
 int get_spline_tiled();

@@ -834,6 +834,37 @@ static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wav
 #ifndef DCP_WG_WAVES
 #define DCP_WG_WAVES 6      // waves per SIMD the register allocation aims at (six 24 KB workgroups fit a CU's LDS)
 #endif
+// Corner `corner` (bit 0: right, bit 1: bottom) of workgroup tile (tx, yblk / kWgTH): its source pixel, rounded and clipped as the
+// taps are.  Pixels past the image are clamped to the last valid ones, so the corners span exactly the valid part of the tile.
+template <int KIND, int NF>
+__device__ __forceinline__ void wg_corner_tap(const ImageArgs& img, const MapArgs& map, int tx, int yblk, int corner, int* cxi, int* cyi) {
+  const float wmaxf = (float)(img.W - 1), hmaxf = (float)(img.H - 1);
+  const double X = (double)min(tx * kWgTW + (corner & 1) * (kWgTW - 1), img.W - 1);
+  const double Y = (double)(img.y_origin + min(yblk + ((corner >> 1) & 1) * (kWgTH - 1), img.rows_out - 1));
+  double xd, yd;
+  if constexpr (KIND == kRadial) {
+    const double xu = X - map.xc, yu = Y - map.yc;
+    const double r2 = xu * xu + yu * yu;
+    const double ru = sqrt_rn(r2);
+    double f;
+    if constexpr (NF >= 0) {
+      double le, lo;
+      poly_leads<NF>(map.fact, &le, &lo);
+      f = poly_inline<NF>(map.fact, le, lo, r2, ru);
+    } else {
+      f = poly_lds(map.fact, map.nfact, r2, ru);          // straight from the kernel arguments (uniform loads)
+    }
+    xd = __builtin_fma(f, xu, map.xc);
+    yd = __builtin_fma(f, yu, map.yc);
+  } else {
+    const double den = (map.coef[6] * X + map.coef[7] * Y) + 1.0;
+    xd = ((map.coef[0] * X + map.coef[1] * Y) + map.coef[2]) / den;
+    yd = ((map.coef[3] * X + map.coef[4] * Y) + map.coef[5]) / den;
+  }
+  *cxi = (int)round_clip_f32(xd, wmaxf);
+  *cyi = (int)round_clip_f32(yd, hmaxf);
+}
+
 // T: element type of source and result.  float is the tuned float32 path (any blend).  uint8 / int8 / uint16 / int16
 // (what detectors and cameras deliver) run the same kernel on narrower slab rows -- 16-bit: 20 chunks of 16 bytes =
 // 160 elements, 8-bit: 10 chunks = 160 elements, the box's first column rounded down to a 4-byte boundary -- read their
@@ -901,30 +932,18 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
   // last valid ones, so the corners span exactly the valid part of the tile.  The values may differ from the
   // row-hoisted evaluation of phase 1 in the last bits; the certificate leaves 0.05 px for that.
   int cx0, cx1, cy0, cy1;
-  {
-    const double X = (double)min(tx * kWgTW + (lane & 1) * (kWgTW - 1), img.W - 1);
-    const double Y = (double)(img.y_origin + min(yblk + ((lane >> 1) & 1) * (kWgTH - 1), img.rows_out - 1));
-    double xd, yd;
-    if constexpr (KIND == kRadial) {
-      const double xu = X - map.xc, yu = Y - map.yc;
-      const double r2 = xu * xu + yu * yu;
-      const double ru = sqrt_rn(r2);
-      double f;
-      if constexpr (NF >= 0) {
-        double le, lo;
-        poly_leads<NF>(map.fact, &le, &lo);
-        f = poly_inline<NF>(map.fact, le, lo, r2, ru);
-      } else {
-        f = poly_lds(map.fact, map.nfact, r2, ru);          // straight from the kernel arguments (uniform loads)
-      }
-      xd = __builtin_fma(f, xu, map.xc);
-      yd = __builtin_fma(f, yu, map.yc);
-    } else {
-      const double den = (map.coef[6] * X + map.coef[7] * Y) + 1.0;
-      xd = ((map.coef[0] * X + map.coef[1] * Y) + map.coef[2]) / den;
-      yd = ((map.coef[3] * X + map.coef[4] * Y) + map.coef[5]) / den;
-    }
-    const int cxi = (int)round_clip_f32(xd, wmaxf), cyi = (int)round_clip_f32(yd, hmaxf);
+  if (img.boxes != nullptr) {
+    // (the hull was computed once per tile by box_table_kernel with the same code: four scalars from one scalar load,
+    // instead of ~70 vector instructions in each of the four waves)
+    typedef __attribute__((address_space(4))) const int32_t* const_ptr;
+    const const_ptr b = (const_ptr)(img.boxes + 4 * ((size_t)blockIdx.z * img.tiles_y * img.tiles_x + (size_t)ty * img.tiles_x + tx));
+    cx0 = b[0];
+    cx1 = b[1];
+    cy0 = b[2];
+    cy1 = b[3];
+  } else {
+    int cxi, cyi;
+    wg_corner_tap<KIND, NF>(img, map, tx, yblk, lane, &cxi, &cyi);
     const int xa = __builtin_amdgcn_readlane(cxi, 0), xb = __builtin_amdgcn_readlane(cxi, 1);
     const int xc_ = __builtin_amdgcn_readlane(cxi, 2), xd_ = __builtin_amdgcn_readlane(cxi, 3);
     const int ya = __builtin_amdgcn_readlane(cyi, 0), yb = __builtin_amdgcn_readlane(cyi, 1);
@@ -1252,21 +1271,58 @@ struct BatchTable {
   BatchEntry<NF> e[kMax];
 };
 
+template <int NF>
+__device__ __forceinline__ void batch_frame_args(const ImageArgs& img0, const BatchTable<NF>& tab, int frame, ImageArgs* img, MapArgs* map) {
+  const BatchEntry<NF>& e = tab.e[frame];
+  *img = img0;
+  img->src = e.src;
+  img->dst = e.dst;
+  map->xc = e.xc;
+  map->yc = e.yc;
+#pragma unroll
+  for (int i = 0; i < NF; ++i) map->fact[i] = e.fact[i];
+  map->nfact = NF;
+  map->fast_div = 0;
+  map->tile_dev_ok = 2;
+}
+
 template <int NF, int SAMPLER>
 __global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_batch_kernel(const ImageArgs img0, const BatchTable<NF> tab) {
-  const BatchEntry<NF>& e = tab.e[blockIdx.z];
-  ImageArgs img = img0;
-  img.src = e.src;
-  img.dst = e.dst;
+  ImageArgs img;
   MapArgs map;
-  map.xc = e.xc;
-  map.yc = e.yc;
-#pragma unroll
-  for (int i = 0; i < NF; ++i) map.fact[i] = e.fact[i];
-  map.nfact = NF;
-  map.fast_div = 0;
-  map.tile_dev_ok = 2;
+  batch_frame_args<NF>(img0, tab, blockIdx.z, &img, &map);
   remap_wg_body<kRadial, NF, SAMPLER, float>(img, map);
+}
+
+// The corner hulls of every workgroup tile of every frame of a batch, once per tile (one thread each, the four corners in
+// turn) with the code the waves of remap_wg_kernel would otherwise run four times per tile: (x0, x1, y0, y1) of the rounded,
+// clipped corner taps.  ~2 us for 24 frames of 4096 tiles; the table lives in stream-ordered scratch of the batch launch.
+template <int KIND, int NF>
+__device__ __forceinline__ void tile_hull(const ImageArgs& img, const MapArgs& map, int frame, int32_t* boxes) {
+  const int ntiles = img.tiles_x * img.tiles_y;
+  const int t = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if (t >= ntiles) return;
+  const int ty = t / img.tiles_x, tx = t - ty * img.tiles_x;
+  int x0 = INT32_MAX, x1 = INT32_MIN, y0 = INT32_MAX, y1 = INT32_MIN;
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    int cxi, cyi;
+    wg_corner_tap<KIND, NF>(img, map, tx, ty * kWgTH, c, &cxi, &cyi);
+    x0 = min(x0, cxi);
+    x1 = max(x1, cxi);
+    y0 = min(y0, cyi);
+    y1 = max(y1, cyi);
+  }
+  int4* const o = (int4*)(boxes + 4 * ((size_t)frame * ntiles + t));
+  *o = make_int4(x0, x1, y0, y1);
+}
+
+template <int NF>
+__global__ void __launch_bounds__(64) box_table_kernel(const ImageArgs img0, const BatchTable<NF> tab, int32_t* boxes) {
+  ImageArgs img;
+  MapArgs map;
+  batch_frame_args<NF>(img0, tab, blockIdx.z, &img, &map);
+  tile_hull<kRadial, NF>(img, map, blockIdx.z, boxes);
 }
 
 // ------------------------------------------------------------------ K5: explicit coordinates
@@ -1897,6 +1953,10 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
 // Many frames of one shape, each with its own calibration, in as few launches as the 4 KB of kernel arguments allow
 // (55 frames of <= 5 coefficients, 35 of <= 10).  Coefficient vectors shorter than the instantiated length are padded with
 // zeros: fma(r2, 0, a) = a exactly, so every intermediate of the even / odd Horner chains is unchanged.
+static int g_batch_box_table = 1;      // option box_table (A/B switch)
+void set_box_table(int v) { g_batch_box_table = v; }
+int get_box_table() { return g_batch_box_table; }
+
 template <int NF, int SAMPLER>
 static hipError_t launch_wg_batch_t(const ImageArgs& img_in, const BatchFrame* fr, int n, int nfact, hipStream_t stream) {
   using Tab = BatchTable<NF>;
@@ -1919,8 +1979,19 @@ static hipError_t launch_wg_batch_t(const ImageArgs& img_in, const BatchFrame* f
       for (int k = 0; k < nfact; ++k) tab.e[i].fact[k] = f.fact[k];
     }
     const dim3 grid(img.xcd_remap == 2 ? 8 * ((img.tiles_x + 7) / 8) : img.tiles_x, img.tiles_y, m);
+    // the tiles' corner hulls once per tile instead of in every wave, when there are enough frames to pay for the extra launch
+    // (stream-ordered scratch: allocated, written, read and freed in the stream's order; without it the waves evaluate the corners)
+    const int ntiles = img.tiles_x * img.tiles_y;
+    int32_t* boxes = nullptr;
+    if (g_batch_box_table && m >= 4 && hipMallocAsync((void**)&boxes, (size_t)m * ntiles * 16, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      boxes = nullptr;
+    }
+    img.boxes = boxes;
+    if (boxes) hipLaunchKernelGGL((box_table_kernel<NF>), dim3((ntiles + 63) / 64, 1, m), dim3(64), 0, stream, img, tab, boxes);
     hipLaunchKernelGGL((remap_wg_batch_kernel<NF, SAMPLER>), grid, dim3(256), 0, stream, img, tab);
     const hipError_t e = hipGetLastError();
+    if (boxes) (void)hipFreeAsync(boxes, stream);
     if (e != hipSuccess) return e;
   }
   return hipSuccess;
