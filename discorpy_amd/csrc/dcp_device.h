@@ -174,6 +174,124 @@ __device__ __forceinline__ void pixel_coord(const MapArgs& map, double X, double
   *yd_out = __builtin_fma(f, yu, map.yc);
 }
 
+// ------------------------------------------------------------------ the hoisted evaluation (tiled kernels)
+
+// Per-column (thread) invariants of the coordinate map.
+struct ColCtx {
+  double cx0, cx1, cx2;      // radial: xu, xu^2, -.  perspective/fused: c7*x, c1*x, c4*x
+  double lead_e, lead_o;     // leading even / odd polynomial coefficient pinned in VGPRs
+};
+
+template <int KIND, int NF>
+__device__ __forceinline__ ColCtx make_col(const MapArgs& map, int x) {
+  ColCtx c;
+  const double xd_ = (double)x;
+  if constexpr (KIND == kRadial) {
+    c.cx0 = xd_ - map.xc;
+    c.cx1 = c.cx0 * c.cx0;
+    c.cx2 = 0.0;
+  } else {
+    c.cx0 = map.coef[6] * xd_;
+    c.cx1 = map.coef[0] * xd_;
+    c.cx2 = map.coef[3] * xd_;
+  }
+  c.lead_e = c.lead_o = 0.0;
+  if constexpr (NF >= 0 && KIND != kPersp) poly_leads<NF>(map.fact, &c.lead_e, &c.lead_o);
+  return c;
+}
+
+// Per-row invariants written to LDS by one thread per row: radial (yu, max(yu^2, tiny)),
+// perspective (c8*y, c2*y, c5*y).
+template <int KIND, int RW>
+__device__ __forceinline__ void fill_row(const MapArgs& map, double (*row)[RW], int slot, double y) {
+  if constexpr (KIND == kRadial) {
+    const double yu = y - map.yc;
+    const double yu2 = yu * yu;
+    row[slot][0] = yu;
+    // r2 = xu^2 + yu^2 must stay > 0 for rsq; the bias is absorbed by the addition unless
+    // xu == yu == 0, where the coordinate is xc + B*0 whatever B is.
+    row[slot][1] = yu2 > kTinyR2 ? yu2 : kTinyR2;
+  } else {
+    row[slot][0] = map.coef[7] * y;   // c8*y
+    row[slot][1] = map.coef[1] * y;   // c2*y
+    row[slot][2] = map.coef[4] * y;   // c5*y
+  }
+}
+
+// Source coordinate (float64, unclipped) of the pixel in column ctx / LDS row slot k.
+template <int KIND, int NF, int RW, int FASTDIV = -1>   // FASTDIV: 1 / 0 fixed at compile time, -1 = map.fast_div
+__device__ __forceinline__ void map_coord(const MapArgs& map, const double (*s_row)[RW], const double* s_coef,
+                                          const ColCtx& c, int k, float wmaxf, float hmaxf, double* xd_out,
+                                          double* yd_out) {
+  double xd, yd;
+  if constexpr (KIND == kRadial) {
+    const double yu = s_row[k][0];
+    const double r2 = c.cx1 + s_row[k][1];
+    const double g = sqrt_pos(r2);                 // r2 > 0 (row table)
+    double f;
+    if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, c.lead_e, c.lead_o, r2, g);
+    else f = poly_lds(s_coef, map.nfact, r2, g);
+    xd = __builtin_fma(f, c.cx0, map.xc);
+    yd = __builtin_fma(f, yu, map.yc);
+  } else {
+    // postprocessing.py:453-455, numpy order: (c7*x + c8*y) + 1.0 etc., true divisions
+    const double den = (c.cx0 + s_row[k][0]) + 1.0;
+    const double nx = (c.cx1 + s_row[k][1]) + map.coef[2];
+    const double ny = (c.cx2 + s_row[k][2]) + map.coef[5];
+    if (FASTDIV == 1 || (FASTDIV < 0 && map.fast_div)) {
+      div2_rn(nx, ny, den, &xd, &yd);
+    } else {
+      xd = nx / den;
+      yd = ny / den;
+    }
+    if constexpr (KIND == kFused) {
+      // float32-rounded perspective coordinate, then the radial map evaluated there
+      const double xp = (double)round_clip_f32(xd, wmaxf);
+      const double yp = (double)round_clip_f32(yd, hmaxf);
+      const double xu = xp - map.xc;
+      const double yu = yp - map.yc;
+      const double xx = xu * xu;
+      const double yy = yu * yu;
+      // as in the radial branch: keep rsq finite at the centre; there xu == yu == 0 and the
+      // coordinate is xc + B*0 whatever B is
+      const double r2 = __builtin_fmax(xx + yy, kTinyR2);
+      const double ru = sqrt_pos(r2);
+      double f;
+      if constexpr (NF >= 0) f = poly_inline<NF>(map.fact, c.lead_e, c.lead_o, r2, ru);
+      else f = poly_lds(s_coef, map.nfact, r2, ru);
+      xd = __builtin_fma(f, xu, map.xc);
+      yd = __builtin_fma(f, yu, map.yc);
+    }
+  }
+  *xd_out = xd;
+  *yd_out = yd;
+}
+
+// One pixel of the radial or perspective map without hoisting, polynomial length fixed at compile time (NF >= 0: coefficients
+// straight from the kernel arguments) -- the corner pixels of a workgroup tile (remap_wg_kernel, spline_wg_kernel).
+template <int KIND, int NF>
+__device__ __forceinline__ void corner_coord(const MapArgs& map, double X, double Y, double* xd, double* yd) {
+  if constexpr (KIND == kRadial) {
+    const double xu = X - map.xc, yu = Y - map.yc;
+    const double r2 = xu * xu + yu * yu;
+    const double ru = sqrt_rn(r2);
+    double f;
+    if constexpr (NF >= 0) {
+      double le, lo;
+      poly_leads<NF>(map.fact, &le, &lo);
+      f = poly_inline<NF>(map.fact, le, lo, r2, ru);
+    } else {
+      f = poly_lds(map.fact, map.nfact, r2, ru);          // straight from the kernel arguments (uniform loads)
+    }
+    *xd = __builtin_fma(f, xu, map.xc);
+    *yd = __builtin_fma(f, yu, map.yc);
+  } else {
+    const double den = (map.coef[6] * X + map.coef[7] * Y) + 1.0;
+    *xd = ((map.coef[0] * X + map.coef[1] * Y) + map.coef[2]) / den;
+    *yd = ((map.coef[3] * X + map.coef[4] * Y) + map.coef[5]) / den;
+  }
+}
+
 // ------------------------------------------------------------------ explicit coordinates outside the image
 
 // What scipy.ndimage.map_coordinates does with a coordinate outside [0, len - 1] at orders 0 and 1 (the reference hands

@@ -661,13 +661,21 @@ __global__ void __launch_bounds__(kSplBlock) spline_remap_kernel(const SplineArg
 // over the edge of the coefficient plane (there the taps fold according to the boundary mode) takes the global
 // gather of spline_remap_kernel for all its pixels.  Radial and perspective maps.
 constexpr int kSwTW = 128, kSwTH = 32;             // workgroup tile
-constexpr int kSwBoxW = 144, kSwBoxH = 46;         // slab: 144 x 46 float64 = 52 992 B, three workgroups per CU
+constexpr int kSwBoxW = 144, kSwBoxH = 45;         // slab: 144 x 45 float64 = 51 840 B; with the row tables three workgroups per CU
 constexpr int kSwCH = kSwBoxW * 8 / 16;            // 16-byte chunks per slab row
 constexpr int kSwNJ = (kSwBoxH * kSwCH + 255) / 256;   // loads per wave that cover the slab: 13
 
-template <int KIND, int ORDER>
+// NF: length of the radial polynomial (5: coefficients from the kernel arguments, shorter vectors padded with zeros by the
+// launcher -- fma(r2, 0, a) = a exactly; -1: any length, coefficients staged in LDS).  Phase 1 is remap_wg_kernel's: a row table
+// per wave and the hoisted evaluation map_coord (dcp_device.h) -- round 2 walked the coefficient vector with one scalar load and
+// one wait per coefficient and pixel row.
+template <int KIND, int ORDER, int NF>
 __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, const MapArgs map, void* dst) {
+  constexpr int RW = KIND == kRadial ? 2 : 4;
   __shared__ __attribute__((aligned(16))) unsigned char s_box[kSwBoxH * kSwBoxW * 8];
+  __shared__ double s_row[4][16][RW];                                // one row table per wave: no barrier before it is read
+  __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
+  static_assert(sizeof(s_box) + sizeof(s_row) + sizeof(s_coef) <= 160 * 1024 / 3, "three workgroups per CU");
   typedef __attribute__((address_space(3))) void* lds_ptr;
   constexpr int PB = kSwBoxW * 8;
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -683,7 +691,7 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
     const double X = (double)min(tx * kSwTW + (lane & 1) * (kSwTW - 1), a.W - 1);
     const double Y = (double)min(ty * kSwTH + ((lane >> 1) & 1) * (kSwTH - 1), a.H - 1);
     double xd, yd;
-    pixel_coord<KIND>(map, X, Y, wmaxf, hmaxf, &xd, &yd);
+    corner_coord<KIND, NF>(map, X, Y, &xd, &yd);
     const int cxi = (int)round_clip_f32(xd, wmaxf) + a.pad, cyi = (int)round_clip_f32(yd, hmaxf) + a.pad;
     const int xa = __builtin_amdgcn_readlane(cxi, 0), xb = __builtin_amdgcn_readlane(cxi, 1);
     const int xc_ = __builtin_amdgcn_readlane(cxi, 2), xd_ = __builtin_amdgcn_readlane(cxi, 3);
@@ -701,9 +709,12 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
   const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
   // staged: the box fits the slab and lies inside the plane (no tap folds); workgroup-uniform
   const bool staged = bw <= kSwBoxW && bh <= kSwBoxH && bx0 >= 0 && by0 >= 0 && bx1 <= a.Wp - 1 && by1 <= a.Hp - 1;
-  const __amdgpu_buffer_rsrc_t src_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (int)((uint32_t)a.Hp * (uint32_t)a.Wp * 8u), 0x00020000);
+  // the fill's descriptor ends with the box's last row: a chunk of a later row is out of range (zeros, no memory access), which
+  // replaces a per-lane row test in every load (remap_wg_kernel)
   const uint32_t rstep = (uint32_t)a.Wp * 8u;
+  const unsigned long long plane_bytes = (unsigned long long)a.Hp * rstep, rows_end = (unsigned long long)(by1 + 1) * rstep;
+  const __amdgpu_buffer_rsrc_t src_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.coef, 0, (int)(uint32_t)(staged && rows_end < plane_bytes ? rows_end : plane_bytes), 0x00020000);
   const int fc = wave * 64 + lane;
   const int crow0 = fc / kSwCH;
   const int c160 = fc - crow0 * kSwCH;
@@ -715,16 +726,20 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
       if (staged && (j * 4 + wave) * 64 < nchunk) {
         constexpr int qrow = (256 * j) / kSwCH, rem = (256 * j) % kSwCH;
         const bool wrap = c160 >= kSwCH - rem;
-        const int crow = crow0 + qrow + (wrap ? 1 : 0);
-        if (crow < bh)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16,
-                                                   off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u, 0, 0, 0);
+        const uint32_t step_nowrap = (uint32_t)qrow * rstep + (uint32_t)rem * 16u, step_wrap = step_nowrap + rstep - (uint32_t)PB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16, off0 + (wrap ? step_wrap : step_nowrap), 0, 0, 0);
       }
     }
   };
+  // ---- row table of this wave's 16 rows (lanes 0..15; same-wave LDS traffic is ordered, no barrier)
+  if (lane < 16) fill_row<KIND, RW>(map, s_row[wave], lane, (double)min(y0 + lane, a.H - 1));
+  if constexpr (NF < 0 && KIND != kPersp) {
+    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
+    __syncthreads();
+  }
   // ---- phase 1: the float32 coordinates of this wave's 16 rows, a load going out in front of each of the first 13
   const int rows = __builtin_amdgcn_readfirstlane(max(0, min(16, a.H - y0)));
-  const double X = (double)min(x, a.W - 1);
+  const ColCtx col = make_col<KIND, NF>(map, min(x, a.W - 1));
   float xf[16], yf[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -743,7 +758,7 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
     if (k == 12) issue_fill(std::integral_constant<int, 12>{});
     static_assert(kSwNJ <= 13, "one load per coordinate row");
     double xd, yd;
-    pixel_coord<KIND>(map, X, (double)min(y0 + k, a.H - 1), wmaxf, hmaxf, &xd, &yd);
+    map_coord<KIND, NF, RW>(map, s_row[wave], s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
     xf[k] = round_clip_f32(xd, wmaxf);
     yf[k] = round_clip_f32(yd, hmaxf);
   }
@@ -754,9 +769,7 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
   const double padd = (double)a.pad;
   if (staged) {
     const int org = by0 * PB + bx0 * 8;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (k >= rows) continue;
+    auto value = [&](int k) -> double {
       double wyv[6], wxv[6];
       const int sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
       const int sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
@@ -768,15 +781,34 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
 #pragma unroll
         for (int q = 0; q <= ORDER; ++q) t += (row[q] * wyv[j]) * wxv[q];
       }
-      store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, t);
+      return t;
+    };
+    if (a.dst_dtype == kF32 && (uint64_t)a.H * (uint64_t)a.W * 4u < (1ull << 32)) {
+      // float32 results (the common case) through a buffer descriptor: the row offset is a scalar, no 64-bit address per store
+      const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((uint32_t)a.H * (uint32_t)a.W * 4u), 0x00020000);
+      const uint32_t xoff = ((uint32_t)y0 * (uint32_t)a.W + (uint32_t)x) * 4u, row_bytes = (uint32_t)a.W * 4u;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k >= rows) continue;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)value(k)), drs, xoff, (uint32_t)k * row_bytes, 0);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k >= rows) continue;
+        store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, value(k));
+      }
     }
   } else {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (k >= rows) continue;
+    // (rare: a box that reaches over the plane's edge or does not fit.  The coordinates are evaluated again in a rolled loop --
+    // the same values -- instead of sixteen copies of the folding gather)
+#pragma unroll 1
+    for (int k = 0; k < rows; ++k) {
+      double xd, yd;
+      map_coord<KIND, NF, RW>(map, s_row[wave], s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
       double wyv[6], wxv[6];
-      const int sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
-      const int sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+      const int sy = spline_weights<ORDER>((double)round_clip_f32(yd, hmaxf) + padd, wyv);
+      const int sx = spline_weights<ORDER>((double)round_clip_f32(xd, wmaxf) + padd, wxv);
       int ix[ORDER + 1];
 #pragma unroll
       for (int q = 0; q <= ORDER; ++q) ix[q] = spline_fold(sx + q, a.Wp, a.mode);
@@ -792,16 +824,29 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
   }
 }
 
-template <int KIND>
-static hipError_t launch_spline_wg(const SplineArgs& a, const MapArgs& map, void* dst, hipStream_t stream) {
+template <int KIND, int NF>
+static hipError_t launch_spline_wg_nf(const SplineArgs& a, const MapArgs& map, void* dst, hipStream_t stream) {
   const dim3 grid((unsigned)((a.W + kSwTW - 1) / kSwTW), (unsigned)((a.H + kSwTH - 1) / kSwTH));
   switch (a.order) {
-    case 2: hipLaunchKernelGGL((spline_wg_kernel<KIND, 2>), grid, dim3(256), 0, stream, a, map, dst); break;
-    case 3: hipLaunchKernelGGL((spline_wg_kernel<KIND, 3>), grid, dim3(256), 0, stream, a, map, dst); break;
-    case 4: hipLaunchKernelGGL((spline_wg_kernel<KIND, 4>), grid, dim3(256), 0, stream, a, map, dst); break;
-    default: hipLaunchKernelGGL((spline_wg_kernel<KIND, 5>), grid, dim3(256), 0, stream, a, map, dst); break;
+    case 2: hipLaunchKernelGGL((spline_wg_kernel<KIND, 2, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
+    case 3: hipLaunchKernelGGL((spline_wg_kernel<KIND, 3, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
+    case 4: hipLaunchKernelGGL((spline_wg_kernel<KIND, 4, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
+    default: hipLaunchKernelGGL((spline_wg_kernel<KIND, 5, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
   }
   return hipGetLastError();
+}
+
+template <int KIND>
+static hipError_t launch_spline_wg(const SplineArgs& a, const MapArgs& map_in, void* dst, hipStream_t stream) {
+  if constexpr (KIND == kPersp) {
+    return launch_spline_wg_nf<KIND, 0>(a, map_in, dst, stream);          // (no polynomial)
+  } else {
+    if (map_in.nfact > 5) return launch_spline_wg_nf<KIND, -1>(a, map_in, dst, stream);
+    MapArgs map = map_in;                                                 // <= 5 coefficients: the NF = 5 instantiation, zero-padded
+    for (int i = map.nfact < 0 ? 0 : map.nfact; i < 5; ++i) map.fact[i] = 0.0;
+    map.nfact = 5;
+    return launch_spline_wg_nf<KIND, 5>(a, map, dst, stream);
+  }
 }
 
 template <int MAPKIND>
