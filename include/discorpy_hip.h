@@ -72,7 +72,8 @@ int dcp_release_scratch(void);
  * kernel), "spline_tiled" (0: chunked spline prefilter passes + transposes instead of the one-pass LDS tiles),
  * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box), "host_direct" (0: never write a host frame's result straight into registered
  * host memory), "int_exact" (0: 8- / 16-bit integer
- * data blend in scipy's operation order everywhere instead of the factorised form where that form is provably exact).  Returns
+ * data blend in scipy's operation order everywhere instead of the factorised form where that form is provably exact), "box_table"
+ * (0: the waves of a multi-frame launch evaluate their tiles' corner pixels themselves instead of reading them from a table kernel's output).  Returns
  * DCP_ERR_INVALID_ARG for an unknown key. */
 int dcp_set_option(const char* key, int value);
 int dcp_get_option(const char* key, int* value);
