@@ -195,23 +195,39 @@ int run_host_direct(const void* src, void* dst_alias, int64_t H, int64_t W, size
   int64_t rows_per = ((H + nbands - 1) / nbands + 63) / 64 * 64;
   if (rows_per > 65535) rows_per = 65535 / 64 * 64;
   const int64_t nb = (H + rows_per - 1) / rows_per;
-  int64_t uploaded = 0;
-  for (int64_t k = 0; k < nb; ++k) {
-    const int64_t r0 = k * rows_per, n = (r0 + rows_per > H ? H - r0 : rows_per);
-    int64_t b0 = 0, b1 = H;
-    source_rows(r0, n, &b0, &b1);
-    const int64_t need = (k == nb - 1) ? H : b1;
-    if (need > uploaded) {
-      DCP_HIP(hipMemcpy2DAsync((char*)dsrc + (size_t)uploaded * row_bytes, row_bytes, (const char*)src + (size_t)uploaded * rs_bytes, rs_bytes,
-                               row_bytes, (size_t)(need - uploaded), hipMemcpyHostToDevice, s_up));
-      uploaded = need;
+  // (an error in the middle leaves work queued on both streams that reads the staging buffer and writes the caller's memory:
+  // whatever happens, both streams are drained before this function returns)
+  const char* what = "";
+  auto enqueue = [&]() -> hipError_t {
+    int64_t uploaded = 0;
+    for (int64_t k = 0; k < nb; ++k) {
+      const int64_t r0 = k * rows_per, n = (r0 + rows_per > H ? H - r0 : rows_per);
+      int64_t b0 = 0, b1 = H;
+      source_rows(r0, n, &b0, &b1);
+      const int64_t need = (k == nb - 1) ? H : b1;
+      hipError_t e;
+      if (need > uploaded) {
+        what = "upload of a band";
+        e = hipMemcpy2DAsync((char*)dsrc + (size_t)uploaded * row_bytes, row_bytes, (const char*)src + (size_t)uploaded * rs_bytes, rs_bytes, row_bytes,
+                             (size_t)(need - uploaded), hipMemcpyHostToDevice, s_up);
+        if (e != hipSuccess) return e;
+        uploaded = need;
+      }
+      what = "band hull outside the uploaded rows";
+      if (b0 < 0 || b1 > uploaded) return hipErrorInvalidValue;      // cannot happen: need >= b1
+      what = "event between the upload and the kernel of a band";
+      if ((e = hipEventRecord(ev[k & 1], s_up)) != hipSuccess) return e;
+      if ((e = hipStreamWaitEvent(s_k, ev[k & 1], 0)) != hipSuccess) return e;
+      what = "kernel of a band";
+      if ((e = launch_band(dsrc, (char*)dst_alias + (size_t)r0 * row_bytes, r0, n, s_k)) != hipSuccess) return e;
     }
-    if (b0 < 0 || b1 > uploaded) return fail(DCP_ERR_HIP, "band hull outside the uploaded rows");      // cannot happen: need >= b1
-    DCP_HIP(hipEventRecord(ev[k & 1], s_up));
-    DCP_HIP(hipStreamWaitEvent(s_k, ev[k & 1], 0));
-    DCP_HIP(launch_band(dsrc, (char*)dst_alias + (size_t)r0 * row_bytes, r0, n, s_k));
-  }
-  DCP_HIP(hipStreamSynchronize(s_k));
+    return hipSuccess;
+  };
+  const hipError_t e_enq = enqueue();
+  const hipError_t e_up = hipStreamSynchronize(s_up), e_k = hipStreamSynchronize(s_k);
+  if (e_enq != hipSuccess) return fail(DCP_ERR_HIP, "host frame written in place: %s failed: %s", what, hipGetErrorString(e_enq));
+  if (e_up != hipSuccess || e_k != hipSuccess)
+    return fail(DCP_ERR_HIP, "host frame written in place: %s", hipGetErrorString(e_up != hipSuccess ? e_up : e_k));
   return DCP_OK;
 }
 
