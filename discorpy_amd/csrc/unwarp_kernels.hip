@@ -1541,8 +1541,11 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 // copy runs under the arithmetic inside the workgroup) and blend their 1024 pixels each out of the other.  One barrier
 // per projection.  T as in remap_wg_kernel: float (any blend) or an 8- / 16-bit integer type (scipy's blend and integer
 // store) -- tomography detectors deliver uint16.  float32 coordinates only (unwarp_chunk_slices_backward).
+#ifndef DCP_STACK_INT_WAVES
+#define DCP_STACK_INT_WAVES 4   // waves per SIMD the integer instantiations are allocated for (128 VGPRs; at 5 = 96 VGPRs the projection loop spills: 575 us against 435 per uint16 shard)
+#endif
 template <int NF, int SAMPLER, typename T = float>
-__global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, const MapArgs map) {
+__global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_STACK_INT_WAVES)) stack_wg_kernel(const StackArgs st, const MapArgs map) {
   constexpr bool kIsF32 = std::is_same<T, float>::value;
   constexpr int ES = (int)sizeof(T);
   constexpr int CH = ES == 4 ? 36 : (ES == 2 ? 20 : 10);
@@ -1612,10 +1615,10 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
   const int rows = __builtin_amdgcn_readfirstlane(max(0, min(kLdsTH, st.nrows - r0)));
   const ColCtx col = make_col<kRadial, NF>(map, min(x, st.W - 1));
   uint32_t addr[kLdsTH];
-  float fx[kIsF32 ? kLdsTH : 1], fy[kIsF32 ? kLdsTH : 1];
-  // integer element types: scipy's four float64 weights per pixel, kept in registers for all projections (128 VGPRs of the
-  // 170 a wave may use at three waves per SIMD) -- recomputing them per voxel costs 6 of 34 VALU instructions
-  double wy0[kIsF32 ? 1 : kLdsTH], wy1[kIsF32 ? 1 : kLdsTH], wx0[kIsF32 ? 1 : kLdsTH], wx1[kIsF32 ? 1 : kLdsTH];
+  // the two float32 fractions per pixel stay in registers for all projections.  (Integer element types: round 2 kept scipy's four
+  // float64 weights instead -- 128 of 168 VGPRs, three waves per SIMD and spills; the conversions back to float64 cost two
+  // instructions per voxel and buy five waves per SIMD.)
+  float fx[kLdsTH], fy[kLdsTH];
   const uint32_t negorg = (uint32_t)(-(by0 * PB + bx0 * ES));
 #pragma unroll
   for (int k = 0; k < kLdsTH; ++k) {
@@ -1632,16 +1635,8 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
     } else {
       xi = min((int)xc, st.W - 2);
       yi = min((int)yc, st.H - 2);
-      if constexpr (kIsF32) {
-        fx[k] = xc - (float)xi;
-        fy[k] = yc - (float)yi;
-      } else {
-        const double fxd = (double)(xc - (float)xi), fyd = (double)(yc - (float)yi);
-        wy0[k] = 1.0 - fyd;
-        wy1[k] = 1.0 - wy0[k];
-        wx0[k] = 1.0 - fxd;
-        wx1[k] = 1.0 - wx0[k];
-      }
+      fx[k] = xc - (float)xi;
+      fy[k] = yc - (float)yi;
     }
     addr[k] = fits ? (uint32_t)yi * (uint32_t)PB + (uint32_t)xi * (uint32_t)ES + negorg
                    : ((uint32_t)yi * (uint32_t)st.row_stride + (uint32_t)xi) * (uint32_t)ES;
@@ -1690,10 +1685,15 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
       const float v = finish<SAMPLER, true, float>(f);
       if (k < rows) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
     } else {
-      double acc = ((double)t_lo[0] * wy0[k]) * wx0[k];
-      acc += ((double)t_lo[1] * wy0[k]) * wx1[k];
-      acc += ((double)t_hi[0] * wy1[k]) * wx0[k];
-      acc += ((double)t_hi[1] * wy1[k]) * wx1[k];
+      // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0 (not f itself where 1 - f rounds); ((v * wy) * wx) summed left to right
+      // (the empty asm keeps the conversions and the weights inside the projection loop: hoisted, they are 128 registers again)
+      float fy_ = fy[k], fx_ = fx[k];
+      asm volatile("" : "+v"(fy_), "+v"(fx_));
+      const double wy0_ = 1.0 - (double)fy_, wy1_ = 1.0 - wy0_, wx0_ = 1.0 - (double)fx_, wx1_ = 1.0 - wx0_;
+      double acc = ((double)t_lo[0] * wy0_) * wx0_;
+      acc += ((double)t_lo[1] * wy0_) * wx1_;
+      acc += ((double)t_hi[0] * wy1_) * wx0_;
+      acc += ((double)t_hi[1] * wy1_) * wx1_;
       const T v = to_elem<T>(acc);
       if (k < rows) {
         if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
@@ -1714,11 +1714,13 @@ __global__ void __launch_bounds__(256, 3) stack_wg_kernel(const StackArgs st, co
         const char* boxb = (const char*)s_box[cur];
         if constexpr (!kIsF32) {
           if (exact) {
-            // every coordinate of the tile >= 32: the factorised blend is exact (exact_lerp_pairs), wx1 / wy1 ARE the fractions
+            // every coordinate of the tile >= 32: the factorised blend is exact (exact_lerp_pairs) and scipy's w1 = 1 - (1 - f) IS the fraction
 #pragma unroll
             for (int k = 0; k < kLdsTH; ++k) {
               const T* t = (const T*)(boxb + addr[k]);
-              const T v = to_elem_in_range<T>(exact_lerp_taps<T>(t, t + kBoxWEl, wx1[k], wy1[k]));
+              float fy_ = fy[k], fx_ = fx[k];
+              asm volatile("" : "+v"(fy_), "+v"(fx_));            // (see blend_store)
+              const T v = to_elem_in_range<T>(exact_lerp_taps<T>(t, t + kBoxWEl, (double)fx_, (double)fy_));
               if (k < rows) {
                 if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
                 else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
