@@ -1712,6 +1712,9 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
       if (active) {
         const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((uint32_t)rows * out_row), 0x00020000);
         const char* boxb = (const char*)s_box[cur];
+        // (the pointers advance below, in uniform control flow: advanced inside this per-lane branch they -- and the store descriptor built
+        // from them -- become per-lane values and every store a waterfall loop)
+        [[maybe_unused]] bool done = false;
         if constexpr (!kIsF32) {
           if (exact) {
             // every coordinate of the tile >= 32: the factorised blend is exact (exact_lerp_pairs) and scipy's w1 = 1 - (1 - f) IS the fraction
@@ -1726,11 +1729,10 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
                 else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
               }
             }
-            proj += st.proj_stride;
-            out += out_step;
-            continue;
+            done = true;
           }
         }
+        if (!done) {
 #pragma unroll
         for (int k = 0; k < kLdsTH; ++k) {
           if constexpr (kIsF32) {
@@ -1751,6 +1753,7 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
             }
             blend_store(lo, hi, dst, k);
           }
+        }
         }
       }
       proj += st.proj_stride;
