@@ -1676,6 +1676,9 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
       FetchT f;
       f.fx = fx[k];
       f.fy = fy[k];
+      // (scipy's order needs four float64 weights per pixel: hoisted out of the projection loop they are 128 registers and the
+      // kernel spills -- the empty asm keeps their computation inside the loop)
+      if constexpr (SAMPLER == kScipy) asm volatile("" : "+v"(f.fx), "+v"(f.fy));
       f.a.x = __float_as_uint(t_lo[0]);
       if constexpr (SAMPLER != kNearest) {
         f.a.y = __float_as_uint(t_lo[1]);
@@ -1946,11 +1949,21 @@ static hipError_t launch_wg_typed_t(const ImageArgs& img_in, const MapArgs& map,
   return hipGetLastError();
 }
 
+// A coefficient vector of fewer than four terms through the NF = 4 instantiations: padded with zeros -- fma(r2, 0, a) = a exactly, so
+// every intermediate of the even / odd Horner chains, and the result, is unchanged (as in launch_wg_batch_t) -- instead of the
+// run-time-length form (coefficients from LDS, more registers).
+static MapArgs pad4(const MapArgs& m) {
+  MapArgs p = m;
+  for (int i = p.nfact < 0 ? 0 : p.nfact; i < 4; ++i) p.fact[i] = 0.0;
+  if (p.nfact < 4) p.nfact = 4;
+  return p;
+}
+
 template <typename T>
 static hipError_t launch_wg_typed_k(MapKind kind, const ImageArgs& img, const MapArgs& map, int order, hipStream_t stream) {
   if (kind == kPersp) return launch_wg_typed_t<kPersp, -1, T>(img, map, order, stream);
   if (map.nfact == 5) return launch_wg_typed_t<kRadial, 5, T>(img, map, order, stream);
-  if (map.nfact == 4) return launch_wg_typed_t<kRadial, 4, T>(img, map, order, stream);
+  if (map.nfact <= 4) return launch_wg_typed_t<kRadial, 4, T>(img, pad4(map), order, stream);
   return launch_wg_typed_t<kRadial, -1, T>(img, map, order, stream);
 }
 
@@ -2198,9 +2211,9 @@ hipError_t launch_stack_centres(const StackArgs& st_in, const MapArgs& map, cons
     if (map.nfact == 5)
       return round_f32 ? launch_centres_t<5, true>(st, map, xcs, ycs, ncentres, sampler, stream)
                        : launch_centres_t<5, false>(st, map, xcs, ycs, ncentres, sampler, stream);
-    if (map.nfact == 4)
-      return round_f32 ? launch_centres_t<4, true>(st, map, xcs, ycs, ncentres, sampler, stream)
-                       : launch_centres_t<4, false>(st, map, xcs, ycs, ncentres, sampler, stream);
+    if (map.nfact <= 4)
+      return round_f32 ? launch_centres_t<4, true>(st, pad4(map), xcs, ycs, ncentres, sampler, stream)
+                       : launch_centres_t<4, false>(st, pad4(map), xcs, ycs, ncentres, sampler, stream);
   }
   return round_f32 ? launch_centres_t<-1, true>(st, map, xcs, ycs, ncentres, sampler, stream)
                    : launch_centres_t<-1, false>(st, map, xcs, ycs, ncentres, sampler, stream);
@@ -2271,7 +2284,7 @@ static hipError_t launch_stack_wg_t(const StackArgs& st, const MapArgs& map, int
 template <typename T>
 static hipError_t launch_stack_wg_n(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
   if (map.nfact == 5) return launch_stack_wg_t<5, T>(st, map, sampler, stream);
-  if (map.nfact == 4) return launch_stack_wg_t<4, T>(st, map, sampler, stream);
+  if (map.nfact <= 4) return launch_stack_wg_t<4, T>(st, pad4(map), sampler, stream);
   return launch_stack_wg_t<-1, T>(st, map, sampler, stream);
 }
 
@@ -2322,7 +2335,7 @@ hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler,
     if (waves(dc) >= 4096 || opts.stack_lds == 2) {
       st.d_chunk = dc;
       if (map.nfact == 5) return launch_stack_lds<5>(st, map, sampler, stream);
-      if (map.nfact == 4) return launch_stack_lds<4>(st, map, sampler, stream);
+      if (map.nfact <= 4) return launch_stack_lds<4>(st, pad4(map), sampler, stream);
       return launch_stack_lds<-1>(st, map, sampler, stream);
     }
   }
@@ -2330,9 +2343,9 @@ hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler,
     if (map.nfact == 5)
       return round_f32 ? launch_stack_t<5, true>(st, map, sampler, stream)
                        : launch_stack_t<5, false>(st, map, sampler, stream);
-    if (map.nfact == 4)
-      return round_f32 ? launch_stack_t<4, true>(st, map, sampler, stream)
-                       : launch_stack_t<4, false>(st, map, sampler, stream);
+    if (map.nfact <= 4)
+      return round_f32 ? launch_stack_t<4, true>(st, pad4(map), sampler, stream)
+                       : launch_stack_t<4, false>(st, pad4(map), sampler, stream);
   }
   return round_f32 ? launch_stack_t<-1, true>(st, map, sampler, stream)
                    : launch_stack_t<-1, false>(st, map, sampler, stream);
