@@ -36,3 +36,31 @@ def test_integer_frames_and_stacks_exact_blend_equals_scipy_order(hip, orc, dt):
     assert np.array_equal(got[1][0], orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL))
     assert np.array_equal(got[1][1], orc.correct_perspective_image(img, coef))
     assert np.array_equal(got[1][2], orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, 0, H - 1, poly=orc.POLY_KERNEL))
+
+
+@pytest.mark.parametrize("nterms", [1, 2, 3])
+def test_short_coefficient_vectors_run_the_four_term_kernels_zero_padded(hip, orc, nterms):
+    """Fewer than four coefficients on integer data: the NF = 4 instantiations on a zero-padded vector (fma(r2, 0, a) = a exactly),
+    not the run-time-length ones -- frames, stacks and centre grids, all equal to the oracle."""
+    H, W = 300, 700
+    fact = [1.002, -3e-5, 5e-8][:nterms]
+    xc, yc = 330.4, 151.2
+    assert F.tile_certificate(H, W, xc, yc, fact) == 2
+    img = typed_image("uint16", (H, W), 77)
+    got = pp.unwarp_image_backward(img, xc, yc, fact)
+    assert F.last_kernel().startswith("remap_wg_kernel<Radial,NF=4,"), F.last_kernel()
+    assert np.array_equal(got, orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL))
+    vol = typed_image("uint16", (5, H, W), 78)
+    F.set_option("stack_wg", 2)
+    try:
+        got = pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, 0, H - 1)
+        assert "NF=4" in F.last_kernel(), F.last_kernel()
+    finally:
+        F.set_option("stack_wg", 1)
+    assert np.array_equal(got, orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, 0, H - 1, poly=orc.POLY_KERNEL))
+    volf = np.random.default_rng(5).random((4, H, W), dtype=np.float32)
+    cents = [(xc + 3.5 * i, yc - 2.25 * i) for i in range(3)]
+    got = pp.unwarp_slice_backward_centres(volf, [c[0] for c in cents], [c[1] for c in cents], fact, 140)
+    assert "NF=4" in F.last_kernel(), F.last_kernel()
+    for k, (cx, cy) in enumerate(cents):
+        assert np.array_equal(got[k], orc.unwarp_slice_backward(volf, cx, cy, fact, 140, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
