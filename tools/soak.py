@@ -19,6 +19,12 @@ for it in range(3000):
     elif kind == 3: pp.unwarp_chunk_slices_backward(rng.random((3, h, w), dtype=np.float32), *a, 2, min(h - 1, 12))
     elif kind == 4: util.unwarp_color_image_backward((rng.random((h, w, 3)) * 255).astype(np.uint8), *a)
     else: pp.correct_perspective_image(img.astype(np.uint16), [1, 0.01, 1, 0, 1, 2, 1e-5, 0])
+    if it % 50 == 7:        # round 3's paths: a host frame large enough for the registered-output path, a batch (stream-ordered scratch), a centre grid
+        big = rng.random((4096, 2048 + 64 * (it % 3)), dtype=np.float32)
+        pp.unwarp_image_backward(big, big.shape[1] * 0.5, 2048.0, [1.0, 1e-6, 1e-10])
+        fr = [torch.from_numpy(rng.random((300, 520), dtype=np.float32)).cuda() for _ in range(5)]
+        pp.unwarp_images_backward(fr, [260.0 + i for i in range(5)], [150.0] * 5, [[1.0, 2e-5, 1e-9]] * 5)
+        pp.unwarp_slice_backward_centres(rng.random((4, 200, 300), dtype=np.float32), [150.0, 151.0, 152.0], [100.0] * 3, [1.0, 1e-5], 77)
     if it % 500 == 499:
         torch.cuda.synchronize()
         marks.append((it + 1, round(rss()), round(free_gb(), 2), _pool.stats()["idle_bytes"] >> 20))
