@@ -880,13 +880,15 @@ def native_peer_child(a):
     print(json.dumps({"world": world, "devices": devices, "peer_copies_ms": ms, "verified": ok}), flush=True)
 
 
-def native_exchange_variants(a, world, depth, steps=3, timeout=150):
+def native_exchange_variants(a, world, depth, steps=3, timeout=None):
     """Rank 0 of the torch job calls this after stack_scaling (the other ranks wait at a barrier, their blocks freed): the same
     workload with the exchange done WITHOUT torch -- (a) one C-ABI process per GPU and a native RCCL all-gather, plain and
     pipelined, (b) one process driving every GPU with peer copies.  Child processes with a timeout each: a hang or a crash in a
     path that no single-GPU box can exercise at world > 1 must not cost the run its JSON line."""
     import subprocess
     import tempfile
+    if timeout is None:
+        timeout = 150 + 20 * world
     D = depth
     vox = float(D) * 2560 * 2560
     out = {}
@@ -923,6 +925,7 @@ def native_exchange_variants(a, world, depth, steps=3, timeout=150):
                 ms = max(r[name + "_ms"] for r in res)
                 out["native_rccl_" + name] = {"ms_per_step": round(ms, 4), "Mpixels_per_s": round(vox / ms / 1e3, 1),
                                               "verified_vs_oracle": all(r[name + "_verified"] for r in res),
+                                              "librccl": os.environ.get("DCP_RCCL_PATH") or "the one next to the HIP runtime",
                                               "how": "dcp_unwarp_stack_rows_rccl_f32, one C-ABI process per GPU (no torch), max over ranks of "
                                                      "wall time per step incl. the kernel"}
     except Exception as e:      # noqa: BLE001
@@ -1306,7 +1309,10 @@ def main(argv=None):
         except Exception as e:      # noqa: BLE001
             scaling = {"error": repr(e)}
         # the exchange without torch (native RCCL through the C ABI; peer copies): child processes of rank 0, the other ranks wait
-        if world > 1 and os.environ.get("DCP_BENCH_DEVICE") is None and isinstance(scaling, dict) and "error" not in scaling:
+        # (on a one-GPU test box -- DCP_BENCH_DEVICE set -- only when DCP_RCCL_PATH names the tests' stand-in for librccl: RCCL
+        # itself refuses two ranks on one device)
+        if world > 1 and (os.environ.get("DCP_BENCH_DEVICE") is None or os.environ.get("DCP_RCCL_PATH")) and isinstance(scaling, dict) \
+                and "error" not in scaling:
             sync()
             if rank == 0:
                 try:

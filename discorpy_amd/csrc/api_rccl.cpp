@@ -32,6 +32,7 @@ typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, rcclComm, hipS
 typedef int (*fn_group)(void);
 typedef const char* (*fn_error_string)(int);
 constexpr int kRcclFloat = 7;      // ncclFloat32 (rccl.h)
+constexpr int kRcclInt64 = 4;      // ncclInt64
 
 struct Rccl {
   void* handle = nullptr;
@@ -102,13 +103,52 @@ int need_rccl() {
       return fail(DCP_ERR_HIP, "%s failed: %s", #expr, rccl().error_string ? rccl().error_string(r_) : "RCCL error"); \
   } while (0)
 
-// what dcp_rccl_comm_create hands out: the communicator plus the side stream and events of the pipelined exchange
+// what dcp_rccl_comm_create hands out: the communicator, the side stream and events of the pipelined exchange, and the
+// small device / pinned-host tables through which the ranks agree on their shard shapes before every exchange
+constexpr int kMetaWords = 5;      // depth_local, nrows, width, pipeline, 1 if this rank's own arguments are unusable
 struct Comm {
   rcclComm comm = nullptr;
   int world = 0, rank = 0, device = 0;
   hipStream_t side = nullptr;
   hipEvent_t computed = nullptr, gathered = nullptr;
+  int64_t* meta_dev = nullptr;     // world x kMetaWords
+  int64_t* meta_host = nullptr;    // pinned, world x kMetaWords
 };
+
+void release(Comm* c) {
+  if (c->side) {
+    (void)hipStreamSynchronize(c->side);
+    (void)hipStreamDestroy(c->side);
+  }
+  if (c->computed) (void)hipEventDestroy(c->computed);
+  if (c->gathered) (void)hipEventDestroy(c->gathered);
+  if (c->meta_dev) (void)hipFree(c->meta_dev);
+  if (c->meta_host) (void)hipHostFree(c->meta_host);
+}
+
+// Every rank's (depth_local, nrows, width, pipeline, arguments-ok) on every rank: one all-gather of 40 bytes per rank on the SIDE stream (the
+// caller's stream is not waited for), then a wait for that stream only.  Collective: every rank of the world makes this call.
+int agree_on_shards(Comm* c, int64_t depth_local, int64_t nrows, int64_t width, int pipeline, bool local_error) {
+  int64_t* mine = c->meta_host + (size_t)c->rank * kMetaWords;
+  mine[0] = depth_local;
+  mine[1] = nrows;
+  mine[2] = width;
+  mine[3] = pipeline;
+  mine[4] = local_error ? 1 : 0;
+  if (c->world == 1) return DCP_OK;
+  DCP_HIP(hipMemcpyAsync(c->meta_dev + (size_t)c->rank * kMetaWords, mine, kMetaWords * sizeof(int64_t), hipMemcpyHostToDevice, c->side));
+  DCP_RCCL(rccl().all_gather(c->meta_dev + (size_t)c->rank * kMetaWords, c->meta_dev, kMetaWords, kRcclInt64, c->comm, c->side));
+  DCP_HIP(hipMemcpyAsync(c->meta_host, c->meta_dev, (size_t)c->world * kMetaWords * sizeof(int64_t), hipMemcpyDeviceToHost, c->side));
+  DCP_HIP(hipStreamSynchronize(c->side));
+  return DCP_OK;
+}
+
+// sub-block s of `nsub` of a shard of n projections: [first, first + count)
+inline void sub_block(int64_t n, int nsub, int s, int64_t* first, int64_t* count) {
+  const int64_t base = n / nsub, extra = n % nsub;
+  *first = (int64_t)s * base + (s < extra ? s : extra);
+  *count = base + (s < extra ? 1 : 0);
+}
 
 }  // namespace
 
@@ -146,11 +186,14 @@ int dcp_rccl_comm_create(void** comm, int world_size, int rank, const void* id, 
     delete c;
     return fail(DCP_ERR_HIP, "ncclCommInitRank failed: %s", rccl().error_string ? rccl().error_string(r) : "RCCL error");
   }
+  const size_t meta = (size_t)world_size * kMetaWords * sizeof(int64_t);
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->computed, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&c->gathered, hipEventDisableTiming) != hipSuccess) {
+      hipEventCreateWithFlags(&c->gathered, hipEventDisableTiming) != hipSuccess || hipMalloc((void**)&c->meta_dev, meta) != hipSuccess ||
+      hipHostMalloc((void**)&c->meta_host, meta, hipHostMallocDefault) != hipSuccess) {
+    release(c);
     (void)rccl().comm_destroy(c->comm);
     delete c;
-    return fail(DCP_ERR_HIP, "cannot create the exchange stream / events");
+    return fail(DCP_ERR_HIP, "cannot create the exchange stream / events / shard table");
   }
   *comm = c;
   return DCP_OK;
@@ -160,12 +203,7 @@ int dcp_rccl_comm_destroy(void* comm) {
   if (!comm) return DCP_OK;
   Comm* c = (Comm*)comm;
   DeviceScope scope(c->device);
-  if (c->side) {
-    (void)hipStreamSynchronize(c->side);
-    (void)hipStreamDestroy(c->side);
-  }
-  if (c->computed) (void)hipEventDestroy(c->computed);
-  if (c->gathered) (void)hipEventDestroy(c->gathered);
+  release(c);
   const int r = rccl().handle ? rccl().comm_destroy(c->comm) : 0;
   delete c;
   if (r != 0) return fail(DCP_ERR_HIP, "ncclCommDestroy failed");
@@ -179,17 +217,43 @@ int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_l
   if (!comm) return fail(DCP_ERR_INVALID_ARG, "null communicator (dcp_rccl_comm_create)");
   if ((rc = need_rccl()) != DCP_OK) return rc;
   Comm* c = (Comm*)comm;
-  if (depth_local < 0 || nrows < 0 || width <= 0 || height <= 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows or empty projections");
-  if (depth_local > 0 && nrows > 0 && (!vol || !out)) return fail(DCP_ERR_INVALID_ARG, "null volume / result pointer");
-  if (depth_local == 0 || nrows == 0) return DCP_OK;
+  // A rank whose own arguments are unusable still takes part in the agreement and says so there: every rank then returns an
+  // error from THIS call and none is left waiting in a collective its peer never entered.
+  const bool local_error = depth_local < 0 || nrows < 0 || width <= 0 || height <= 0 || (depth_local > 0 && nrows > 0 && !vol) ||
+                           ((depth_local > 0 || c->world > 1) && nrows > 0 && !out);   // a rank without projections still receives
   DeviceScope scope(c->device);
   if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", c->device, hipGetErrorString(scope.status));
-  const size_t block = (size_t)nrows * (size_t)width;                 // floats per projection of the result
-  float* mine = out + (size_t)c->rank * (size_t)depth_local * block;  // depth is the outer axis: this rank's block is contiguous
+  if (pipeline < 1) pipeline = 1;
+  if ((rc = agree_on_shards(c, depth_local, nrows, width, pipeline, local_error)) != DCP_OK) return rc;
+  if (local_error) {
+    if (depth_local < 0 || nrows < 0 || width <= 0 || height <= 0) return fail(DCP_ERR_INVALID_ARG, "negative depth / nrows or empty projections");
+    return fail(DCP_ERR_INVALID_ARG, "null volume / result pointer");
+  }
+  for (int r = 0; r < c->world; ++r)
+    if (c->meta_host[(size_t)r * kMetaWords + 4] != 0)
+      return fail(DCP_ERR_INVALID_ARG, "rank %d was called with unusable arguments (its own error says which); nothing was exchanged", r);
+  int64_t total = 0, deepest = 0, first_of_mine = 0;
+  bool even = true;
+  for (int r = 0; r < c->world; ++r) {
+    const int64_t* m = c->meta_host + (size_t)r * kMetaWords;
+    if (m[1] != nrows || m[2] != width || m[3] != pipeline)
+      return fail(DCP_ERR_INVALID_ARG, "rank %d was called with nrows %lld, width %lld, pipeline %lld; rank %d with %lld, %lld, %d: the ranks must agree",
+                  r, (long long)m[1], (long long)m[2], (long long)m[3], c->rank, (long long)nrows, (long long)width, pipeline);
+    if (m[0] < 0) return fail(DCP_ERR_INVALID_ARG, "rank %d reports a negative shard depth", r);
+    if (r < c->rank) first_of_mine += m[0];
+    if (m[0] != c->meta_host[0]) even = false;
+    if (m[0] > deepest) deepest = m[0];
+    total += m[0];
+  }
+  if (total == 0 || nrows == 0) return DCP_OK;                       // nothing to compute anywhere: every rank returns here
+  const size_t block = (size_t)nrows * (size_t)width;                // floats per projection of the result
+  // depth is the outer axis of the result and the shards are laid down in rank order: rank r's block starts at the sum of the
+  // shards before it and is contiguous
+  float* mine = out + (size_t)first_of_mine * block;
   hipStream_t hs = (hipStream_t)stream;
-  int nsub = pipeline < 1 ? 1 : pipeline;
-  if ((int64_t)nsub > depth_local) nsub = (int)depth_local;
-  if (nsub <= 1 || c->world == 1) {
+  int nsub = (int64_t)pipeline > deepest ? (int)deepest : pipeline;
+  if (c->world == 1) nsub = pipeline > depth_local ? (int)depth_local : pipeline;
+  if (nsub <= 1 && (even || c->world == 1)) {
     // kernel, then the in-place all-gather behind it on the same stream (sendbuff = recvbuff + rank * count)
     if ((rc = dcp_unwarp_stack_rows_f32(vol, mine, depth_local, height, width, proj_stride, row_stride, xcenter, ycenter, list_fact, nfact,
                                         row_start, nrows, coord_round_f32, blend_mode, DCP_MEM_DEVICE, c->device, stream)) != DCP_OK)
@@ -197,35 +261,57 @@ int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_l
     if (c->world > 1) DCP_RCCL(rccl().all_gather(mine, out, (size_t)depth_local * block, kRcclFloat, c->comm, hs));
     return DCP_OK;
   }
-  // pipelined: the shard in `nsub` depth sub-blocks; the exchange of sub-block s (every rank's piece broadcast into its place
-  // of the result, one group on the side stream) runs under the kernel of sub-block s + 1
-  DCP_HIP(hipEventRecord(c->gathered, hs));                       // the side stream starts behind whatever the caller queued
-  DCP_HIP(hipStreamWaitEvent(c->side, c->gathered, 0));
-  const int64_t base = depth_local / nsub, extra = depth_local % nsub;
-  int64_t s0 = 0;
-  for (int s = 0; s < nsub; ++s) {
-    const int64_t n = base + (s < extra ? 1 : 0);
-    if ((rc = dcp_unwarp_stack_rows_f32(vol + (size_t)s0 * (size_t)proj_stride, mine + (size_t)s0 * block, n, height, width, proj_stride,
-                                        row_stride, xcenter, ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode,
-                                        DCP_MEM_DEVICE, c->device, stream)) != DCP_OK)
-      return rc;
-    DCP_HIP(hipEventRecord(c->computed, hs));
-    DCP_HIP(hipStreamWaitEvent(c->side, c->computed, 0));
-    DCP_RCCL(rccl().group_start());
-    for (int r = 0; r < c->world; ++r) {
-      float* piece = out + ((size_t)r * (size_t)depth_local + (size_t)s0) * block;
-      const int e = rccl().broadcast(piece, piece, (size_t)n * block, kRcclFloat, r, c->comm, c->side);
-      if (e != 0) {
-        (void)rccl().group_end();
-        return fail(DCP_ERR_HIP, "ncclBroadcast failed: %s", rccl().error_string ? rccl().error_string(e) : "RCCL error");
-      }
+  if (c->world == 1) {                                               // sub-blocks, no exchange
+    for (int s = 0; s < nsub; ++s) {
+      int64_t s0, n;
+      sub_block(depth_local, nsub, s, &s0, &n);
+      if (n > 0 && (rc = dcp_unwarp_stack_rows_f32(vol + (size_t)s0 * (size_t)proj_stride, mine + (size_t)s0 * block, n, height, width, proj_stride,
+                                                   row_stride, xcenter, ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode,
+                                                   DCP_MEM_DEVICE, c->device, stream)) != DCP_OK)
+        return rc;
     }
-    DCP_RCCL(rccl().group_end());
-    s0 += n;
+    return DCP_OK;
   }
-  DCP_HIP(hipEventRecord(c->gathered, c->side));                  // the caller's stream continues when the last exchange has landed
-  DCP_HIP(hipStreamWaitEvent(hs, c->gathered, 0));
-  return DCP_OK;
+  // Sub-blocks and / or ragged shards: every rank cuts ITS shard into `nsub` depth sub-blocks (a shard shorter than nsub has
+  // empty ones); the exchange of sub-block s -- every rank's piece broadcast into its place of the result, one group on the
+  // side stream, empty pieces skipped by everybody -- runs under the kernel of sub-block s + 1.
+  if (nsub < 1) nsub = 1;
+  DCP_HIP(hipEventRecord(c->gathered, hs));                          // the side stream starts behind whatever the caller queued
+  DCP_HIP(hipStreamWaitEvent(c->side, c->gathered, 0));
+  int status = DCP_OK;
+  for (int s = 0; s < nsub && status == DCP_OK; ++s) {
+    int64_t s0, n;
+    sub_block(depth_local, nsub, s, &s0, &n);
+    if (n > 0)
+      status = dcp_unwarp_stack_rows_f32(vol + (size_t)s0 * (size_t)proj_stride, mine + (size_t)s0 * block, n, height, width, proj_stride,
+                                         row_stride, xcenter, ycenter, list_fact, nfact, row_start, nrows, coord_round_f32, blend_mode,
+                                         DCP_MEM_DEVICE, c->device, stream);
+    if (status != DCP_OK) break;
+    if (hipEventRecord(c->computed, hs) != hipSuccess || hipStreamWaitEvent(c->side, c->computed, 0) != hipSuccess) {
+      status = fail(DCP_ERR_HIP, "cannot chain the exchange stream behind the kernel");
+      break;
+    }
+    int e = rccl().group_start();
+    int64_t first = 0;
+    for (int r = 0; r < c->world && e == 0; ++r) {
+      const int64_t dr = c->meta_host[(size_t)r * kMetaWords];
+      int64_t r0, rn;
+      sub_block(dr, nsub, s, &r0, &rn);
+      float* piece = out + (size_t)(first + r0) * block;
+      if (rn > 0) e = rccl().broadcast(piece, piece, (size_t)rn * block, kRcclFloat, r, c->comm, c->side);
+      first += dr;
+    }
+    const int e2 = rccl().group_end();
+    if (e != 0 || e2 != 0)
+      status = fail(DCP_ERR_HIP, "the exchange of depth sub-block %d failed: %s", s,
+                    rccl().error_string ? rccl().error_string(e != 0 ? e : e2) : "RCCL error");
+  }
+  // on every path, failed ones included, the caller's stream continues behind whatever was queued on the side stream; after a
+  // failure the other ranks may be blocked in their collectives and the communicator must be destroyed (header)
+  if (hipEventRecord(c->gathered, c->side) != hipSuccess || hipStreamWaitEvent(hs, c->gathered, 0) != hipSuccess) {
+    if (status == DCP_OK) status = fail(DCP_ERR_HIP, "cannot re-join the exchange stream");
+  }
+  return status;
 }
 
 }  // extern "C"

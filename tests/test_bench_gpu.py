@@ -80,3 +80,49 @@ def test_bench_gpus_n_without_torchrun_spawns_its_own_ranks(hip):
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["verified_vs_oracle"] is True
     ss = j["stack_scaling"]
     assert ss["compute_plus_allgather"]["ms_per_step"] > 0 and ss["compute_plus_allgather_pipelined"]["verified_vs_oracle"] is True
+
+
+def _fake_rccl():
+    from test_rccl_world import build_fake
+    return build_fake()
+
+
+def test_bench_eight_ranks_on_the_one_gpu_populate_every_exchange_variant(hip):
+    """`python bench.py --gpus 8` as the driver will run it on an 8-GPU node, here with the eight ranks sharing the one GPU: gloo
+    carries torch's collectives (DCP_BENCH_BACKEND), tests/c/libfake_rccl.so stands in for librccl in the torch-free children
+    (DCP_RCCL_PATH).  One JSON line, n_gpus 8, every variant of the config-4 exchange present and checked against the oracle --
+    the first 8-GPU run must not be the first run of this code."""
+    pytest.importorskip("torch")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DCP_BENCH_BACKEND="gloo", DCP_BENCH_DEVICE="0", DCP_RCCL_PATH=_fake_rccl(), FAKE_RCCL_SLOT_MB="16")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--depth", "16"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["verified_vs_oracle"] is True and j["value"] > 0
+    ss = j["stack_scaling"]
+    assert ss["depth_per_gpu"] == 2 and ss["verified_vs_oracle"] is True and ss["compute_only"]["ms_per_step"] > 0
+    assert ss["compute_plus_allgather"]["ms_per_step"] > 0
+    assert ss["compute_plus_allgather"]["gathered_bytes_received_per_gpu"] == 14 * 2560 * 2560 * 4
+    assert ss["compute_plus_allgather_pipelined"]["verified_vs_oracle"] is True and ss["compute_plus_allgather_pipelined"]["depth_sub_blocks"] == 2
+    wt = ss["without_torch"]
+    for key in ("native_rccl_allgather", "native_rccl_allgather_pipelined", "peer_copies"):
+        assert key in wt and wt[key]["verified_vs_oracle"] is True and wt[key]["ms_per_step"] > 0, wt
+    assert "fake_rccl" in wt["native_rccl_allgather"]["librccl"]          # and says so: never mistaken for an RCCL number
+
+
+def test_native_rccl_children_at_world_two(hip, tmp_path):
+    """bench.py's torch-free rank processes (one per GPU on a node) as two processes on the one GPU, the stand-in between them."""
+    env = dict(os.environ, DCP_BENCH_DEVICE="0", DCP_RCCL_PATH=_fake_rccl(), FAKE_RCCL_SLOT_MB="16")
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--native-child", "rccl", "--child-world", "2", "--idfile", str(tmp_path / "id"),
+            "--depth", "8", "--rows", "2560", "--steps", "2"]
+    procs = [subprocess.Popen(base + ["--child-rank", str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+             for r in range(2)]
+    for r, p in enumerate(procs):
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, (se or so)[-2000:]
+        j = _last_json(so)
+        assert j["world"] == 2 and j["rank"] == r and j["depth_per_gpu"] == 4
+        assert j["allgather_verified"] is True and j["allgather_pipelined_verified"] is True and j["allgather_ms"] > 0
