@@ -87,6 +87,8 @@ SIGNATURES = {
                                            _dbl, _i64, _int, _int, _int, _vp]),
     "dcp_unwarp_image_channels": (_int, [_vp, _vp, _int, _i64, _i64, _int, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int,
                                          _int, _vp]),
+    "dcp_unwarp_color_image": (_int, [_vp, _vp, _int, _i64, _i64, _int, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int, _int,
+                                      _int, _vp]),
     "dcp_stack_row_band": (_int, [_i64, _i64, _dbl, _dbl, _dp, _int, _dbl, _i64, C.POINTER(_i64), C.POINTER(_i64)]),
     "dcp_unwarp_stack_band": (_int, [_vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp,
                                      _int, _dbl, _i64, _int, _int, _int, _int, _vp]),

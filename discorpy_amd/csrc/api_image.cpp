@@ -730,9 +730,18 @@ int dcp_remap_coords_typed(const void* src, void* dst, int dtype, int64_t height
 int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t height, int64_t width, int channels,
                               int64_t src_row_stride, int64_t src_pixel_stride, double xcenter, double ycenter,
                               const double* list_fact, int nfact, int order, int mem_kind, int device, void* stream) {
+  return dcp_unwarp_color_image(src, dst, dtype, height, width, channels, src_row_stride, src_pixel_stride, xcenter, ycenter, list_fact, nfact,
+                                order, DCP_BLEND_SCIPY, mem_kind, device, stream);
+}
+
+int dcp_unwarp_color_image(const void* src, void* dst, int dtype, int64_t height, int64_t width, int channels, int64_t src_row_stride,
+                           int64_t src_pixel_stride, double xcenter, double ycenter, const double* list_fact, int nfact, int order,
+                           int blend_mode, int mem_kind, int device, void* stream) {
   int rc;
   if (channels < 1 || channels > 64) return fail(DCP_ERR_INVALID_ARG, "channels = %d outside [1, 64]", channels);
-  if (order < 0 || order > 1) return fail(DCP_ERR_UNSUPPORTED, "the interleaved-channel kernel takes orders 0 and 1 (got %d)", order);
+  if (order < 0 || order > 1) return fail(DCP_ERR_UNSUPPORTED, "the interleaved-channel kernels take orders 0 and 1 (got %d)", order);
+  if (blend_mode != DCP_BLEND_SCIPY && blend_mode != DCP_BLEND_F64LERP)
+    return fail(DCP_ERR_UNSUPPORTED, "interleaved channels blend as scipy does (DCP_BLEND_SCIPY) or within one ulp of it (DCP_BLEND_F64LERP); got %d", blend_mode);
   if (src_pixel_stride < channels) return fail(DCP_ERR_INVALID_ARG, "pixel stride %lld smaller than %d channels", (long long)src_pixel_stride, channels);
   if ((rc = check_image_typed(src, dst, dtype, height, width, src_row_stride, src_pixel_stride)) != DCP_OK) return rc;
   if (src_row_stride < (width - 1) * src_pixel_stride + channels && height > 1)
@@ -742,6 +751,8 @@ int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t hei
   DeviceScope scope(device);
   if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
   hipStream_t st = (hipStream_t)stream;
+  // float32 only: the one-ulp factorisation; integer types always blend in scipy's exact order (their rounding ties depend on it)
+  const int sampler = order == 0 ? dcp::kNearest : (blend_mode == DCP_BLEND_F64LERP && dtype == dcp::kF32 ? dcp::kF64Lerp : dcp::kScipy);
   dcp::TypedImageArgs a;
   memset(&a, 0, sizeof(a));
   a.H = (int32_t)height;
@@ -750,30 +761,53 @@ int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t hei
   a.src_cstride = src_pixel_stride;
   a.order = order;
   a.dtype = dtype;
+  a.blend = sampler;
   a.y0 = 0;
   a.rows = (int32_t)height;
+  const size_t esz = (size_t)dcp::elem_size(dtype);
+  const dcp::LaunchOpts opts = current_opts();
+  map.tile_dev_ok = g_tile_cert.load() ? tile_deviation_certified(dcp::kRadial, map, height, width) : 0;
+  // rows [r0, r0 + n) of the result from the whole-frame source at dsrc: the workgroup-box kernel (remap_wg_color_kernel) where the
+  // call qualifies -- dense pixels of 3 / 4 channels, float32 / uint8 / uint16, certified map --, else one thread per pixel
+  auto launch_rows = [&](const void* dsrc, void* drows, int64_t rs_el, int64_t ps_el, int64_t r0, int64_t n, hipStream_t s) -> hipError_t {
+    const double ext = ((double)(height - 1) * (double)rs_el + (double)(width - 1) * (double)ps_el + (double)channels) * (double)esz;
+    if (ext <= 4294900000.0 && rs_el < (1ll << 31)) {
+      dcp::ImageArgs im;
+      memset(&im, 0, sizeof(im));
+      im.H = (int32_t)height;
+      im.W = (int32_t)width;
+      im.src = (const float*)dsrc;
+      im.dst = (float*)drows;
+      im.src_stride = (int32_t)rs_el;
+      im.src_col_stride = (int32_t)ps_el;
+      im.src_bytes = (uint32_t)ext;
+      im.y_origin = (int32_t)r0;
+      im.rows_out = (int32_t)n;
+      bool taken = false;
+      const hipError_t e = dcp::launch_color(im, map, channels, dtype, sampler, opts, s, &taken);
+      if (e != hipSuccess || taken) return e;
+    }
+    dcp::TypedImageArgs b = a;
+    b.src = dsrc;
+    b.dst = drows;
+    b.src_stride = rs_el;
+    b.src_cstride = ps_el;
+    b.y0 = (int32_t)r0;
+    b.rows = (int32_t)n;
+    return dcp::launch_typed_channels(b, map, channels, s);
+  };
   if (mem_kind == DCP_MEM_DEVICE) {
-    a.src = src;
-    a.dst = dst;
-    DCP_HIP(dcp::launch_typed_channels(a, map, channels, st));
+    DCP_HIP(launch_rows(src, dst, src_row_stride, src_pixel_stride, 0, height, st));
     return DCP_OK;
   }
   if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
-  const size_t esz = (size_t)dcp::elem_size(dtype);
   if (src_pixel_stride == channels && height >= 512 && (double)height * (double)width * (double)channels * (double)esz >= 16.0 * 1048576.0 &&
       g_host_duplex.load() && (g_host_duplex.load() == 2 || runtime_overlaps_directions())) {
     // dense interleaved frame: bands of rows, uploads and downloads overlapped (see run_host_banded)
     return run_host_banded(src, dst, height, width, (size_t)channels * esz, (size_t)src_row_stride * esz,
                                   [&](int64_t r0, int64_t n, int64_t* b0, int64_t* b1) { host_row_band(map, height, width, (double)r0, n, b0, b1); },
                                   [&](void* dsrc, void* dband, int64_t r0, int64_t n, hipStream_t s) {
-                                    dcp::TypedImageArgs b = a;
-                                    b.src = dsrc;
-                                    b.dst = dband;
-                                    b.src_stride = width * channels;
-                                    b.src_cstride = channels;
-                                    b.y0 = (int32_t)r0;
-                                    b.rows = (int32_t)n;
-                                    return dcp::launch_typed_channels(b, map, channels, s);
+                                    return launch_rows(dsrc, dband, width * channels, channels, r0, n, s);
                                   });
   }
   const size_t ext = (size_t)((height - 1) * src_row_stride + (width - 1) * src_pixel_stride + channels) * esz;
@@ -782,9 +816,7 @@ int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t hei
   DCP_HIP(g_staging.get(0, ext, &dsrc));
   DCP_HIP(g_staging.get(1, obytes, &ddst));
   DCP_HIP(hipMemcpyAsync(dsrc, src, ext, hipMemcpyHostToDevice, st));
-  a.src = dsrc;
-  a.dst = ddst;
-  DCP_HIP(dcp::launch_typed_channels(a, map, channels, st));
+  DCP_HIP(launch_rows(dsrc, ddst, src_row_stride, src_pixel_stride, 0, height, st));
   DCP_HIP(hipMemcpyAsync(dst, ddst, obytes, hipMemcpyDeviceToHost, st));
   DCP_HIP(hipStreamSynchronize(st));
   return DCP_OK;

@@ -92,6 +92,7 @@ struct TypedImageArgs {
   int32_t H, W;
   int32_t order;           // 0 or 1
   int32_t dtype;
+  int32_t blend;           // interleaved-channel kernel, float32: kF64Lerp = the one-ulp factorisation (else scipy's exact order)
   int32_t y0, rows;        // interleaved-channel kernel only: output rows [y0, y0 + rows), dst = first row of that band
 };
 
@@ -187,5 +188,9 @@ hipError_t launch_typed_stack(const TypedStackArgs& st, const MapArgs& map, hipS
 hipError_t launch_map_points(const double* yx_in, double* yx_out, int64_t n, const MapArgs& map, hipStream_t stream);
 // interleaved (H, W, C) image, radial map, orders 0 / 1; src_cstride = elements between pixels
 hipError_t launch_typed_channels(const TypedImageArgs& img, const MapArgs& map, int channels, hipStream_t stream);
+// color_kernels.hip: the same on remap_wg_kernel's data path (3 / 4 dense channels of float32 / uint8 / uint16, certified radial map);
+// img as for launch_wg_typed with src_col_stride = channels; *taken = false: does not qualify, use launch_typed_channels
+hipError_t launch_color(const ImageArgs& img, const MapArgs& map, int channels, int dtype, int sampler, const LaunchOpts& opts, hipStream_t stream,
+                        bool* taken);
 
 }  // namespace dcp

@@ -120,6 +120,23 @@ __global__ void __launch_bounds__(kTypedBlock) typed_channels_kernel(const Typed
     for (int c = 0; c < C; ++c) dst[c] = to_elem<T>((double)p[c]);
     return;
   }
+  if constexpr (std::is_same<T, float>::value) {
+    if (a.blend == kF64Lerp && a.W >= 2 && a.H >= 2) {
+      // the one-ulp factorisation with the staged kernels' edge rule (base tap held at len - 2, fraction 1 at the far edge):
+      // bit-equal to remap_wg_color_kernel / remap_wg_kernel under the same blend
+      const float xcf = (float)xc, ycf = (float)yc;
+      const int xi = min((int)xcf, a.W - 2), yi = min((int)ycf, a.H - 2);
+      const double fx = (double)(xcf - (float)xi), fy = (double)(ycf - (float)yi);
+      const T* p = src + (int64_t)yi * rs + (int64_t)xi * cs;
+      for (int c = 0; c < C; ++c) {
+        const double ta = (double)p[c], tb = (double)p[cs + c], tc = (double)p[rs + c], td = (double)p[rs + cs + c];
+        const double top = __builtin_fma(fx, tb - ta, ta);
+        const double bot = __builtin_fma(fx, td - tc, tc);
+        dst[c] = (float)__builtin_fma(fy, bot - top, top);
+      }
+      return;
+    }
+  }
   const double y0 = __builtin_floor(yc), x0 = __builtin_floor(xc);
   const double wy0 = 1.0 - (yc - y0), wy1 = 1.0 - wy0;
   const double wx0 = 1.0 - (xc - x0), wx1 = 1.0 - wx0;

@@ -114,9 +114,11 @@ def _pad_device(t, pad_width, mode):
     return t
 
 
-def _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order):
-    """(H, W, C) interleaved image in one launch of dcp_unwarp_image_channels: one coordinate per pixel, C blends in
-    scipy's exact arithmetic, no per-channel planes on the host."""
+def _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order, blend=None):
+    """(H, W, C) interleaved image in one launch of dcp_unwarp_color_image: one coordinate per pixel, C blends in the
+    arithmetic `blend` names (the default of unwarp_image_backward when None; integer pixels always in scipy's exact order),
+    no per-channel planes on the host.  3 / 4 channels of float32 / uint8 / uint16 under a certified calibration run
+    remap_wg_color_kernel (the source box of a tile staged in LDS once for all channels)."""
     F = _pp.F
     img = _pp._Image(mat_pad, 3)
     h, w, c = img.shape
@@ -127,8 +129,8 @@ def _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order):
     fa, nf = F.fact_array(_pp._coefs(list_fact, "list_fact"))
     out, optr = img.empty((h, w, c))
     F.require_device()
-    F.check(F.lib().dcp_unwarp_image_channels(img.ptr, optr, img.code, h, w, c, rs, ps, float(xcenter), float(ycenter),
-                                              fa, nf, order, img.mem, img.device, img.stream))
+    F.check(F.lib().dcp_unwarp_color_image(img.ptr, optr, img.code, h, w, c, rs, ps, float(xcenter), float(ycenter),
+                                           fa, nf, order, _pp._blend_code(blend), img.mem, img.device, img.stream))
     return out
 
 
@@ -179,7 +181,7 @@ def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode=
         return _pp.unwarp_image_backward(mat_pad, xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
     order = _pp._check_order_mode(order, mode)
     if order <= 1 and blend in (None, "scipy", "exact", "f64lerp", "f64") and 1 <= mat_pad.shape[2] <= 64:
-        return _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order)
+        return _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order, blend)
     # channels as dense planes through the batched entry point (the reference's loop over mat_pad[:, :, i], utility.py:320-341):
     # device-resident float32 planes at order 0 / 1 share ONE launch, the other cases go plane by plane inside it
     if is_torch:

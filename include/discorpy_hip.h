@@ -189,13 +189,20 @@ int dcp_unwarp_stack_rows_peer_f32(const float* const* vol, float* const* out, i
  *   dcp_rccl_comm_create    ncclCommInitRank on `device` (collective: every rank of the world calls it), plus the side stream of the
  *                           pipelined exchange; dcp_rccl_comm_destroy releases both
  *   dcp_unwarp_stack_rows_rccl_f32
- *       this rank holds `depth_local` projections at `vol` (EVERY rank the same number: pad the last shard) and a result buffer
- *       `out` of (world_size * depth_local, nrows, width) floats on the communicator's device.  The stack kernel
- *       (dcp_unwarp_stack_rows_f32) writes this rank's block in place at depth offset rank * depth_local, then ncclAllGather (in
- *       place, on `stream`, behind the kernel) fills in the other ranks' blocks -- depth is the outer axis of the result, so every
- *       contribution is one contiguous block.  pipeline > 1: the shard is cut into that many depth sub-blocks and the exchange of
- *       sub-block s (grouped ncclBroadcasts on a side stream) overlaps the kernel of sub-block s + 1.  Stream-ordered: returns
- *       without synchronising, `stream` is complete when the whole (depth, nrows, width) result is. */
+ *       COLLECTIVE: every rank of the communicator makes the call.  This rank holds `depth_local` projections at `vol` and a
+ *       result buffer `out` of (sum of all ranks' depth_local, nrows, width) floats on the communicator's device.  The ranks first
+ *       agree on their shard shapes (one all-gather of 40 bytes per rank on the communicator's side stream; the caller's stream is
+ *       not waited for): nrows, width and pipeline must be the same everywhere, depth_local may differ from rank to rank and may
+ *       be 0 (the shards are laid down in rank order), and a rank whose own arguments are unusable says so there -- a
+ *       disagreement makes EVERY rank return DCP_ERR_INVALID_ARG from this call, none is left waiting in a collective.  Then the
+ *       stack kernel (dcp_unwarp_stack_rows_f32) writes this rank's block in place at its depth offset and the exchange fills in
+ *       the other ranks' blocks -- depth is the outer axis of the result, so every contribution is one contiguous block: equal
+ *       shards, pipeline <= 1: ONE ncclAllGather in place on `stream` behind the kernel; ragged shards: one group of
+ *       ncclBroadcasts with per-rank counts.  pipeline > 1: every shard is cut into that many depth sub-blocks and the exchange of
+ *       sub-block s (grouped ncclBroadcasts on the side stream) overlaps the kernel of sub-block s + 1.  Stream-ordered: returns
+ *       without waiting for the result, `stream` is complete when the whole (depth, nrows, width) result is.  After a HIP / RCCL
+ *       failure on one rank the others may be blocked in their collectives: destroy the communicator (the caller's stream is
+ *       re-joined to the side stream on every path, so nothing is left running behind the caller's back). */
 int dcp_rccl_available(void);
 int dcp_rccl_unique_id(void* id, size_t bytes);
 int dcp_rccl_comm_create(void** comm, int world_size, int rank, const void* id, int device);
@@ -272,8 +279,18 @@ int dcp_unwarp_stack_rows_typed(const void* vol, void* out, int dtype, int out_f
 /* discorpy/util/utility.py:278-342 (unwarp_color_image_backward), the part after np.pad: an interleaved
  * (height, width, channels) image of `dtype`, every channel sampled at the same radial coordinate
  * (:320-341 loops map_coordinates over mat_pad[:, :, i]) -- one coordinate evaluation and `channels`
- * blends per pixel, scipy's exact arithmetic, orders 0 / 1.  src_pixel_stride = elements between
- * pixels (>= channels); dst is dense (height, width, channels). */
+ * blends per pixel, orders 0 / 1.  src_pixel_stride = elements between pixels (>= channels); dst is dense
+ * (height, width, channels).
+ *   dcp_unwarp_color_image     blend_mode DCP_BLEND_SCIPY (scipy's exact arithmetic: bit-equal to the reference) or, for
+ *                              float32 pixels, DCP_BLEND_F64LERP (within one float32 ulp of it: what dcp_unwarp_image_f32 computes
+ *                              per plane by default); integer element types always blend in scipy's order.  Dense pixels of 3 or 4
+ *                              float32 / uint8 / uint16 channels under a certified calibration take the workgroup-box kernel
+ *                              (remap_wg_color_kernel: the source box of a 128 x 16 tile staged in LDS once for all channels),
+ *                              everything else one thread per pixel -- the same values either way
+ *   dcp_unwarp_image_channels  the same with DCP_BLEND_SCIPY (kept for callers of the earlier ABI) */
+int dcp_unwarp_color_image(const void* src, void* dst, int dtype, int64_t height, int64_t width, int channels, int64_t src_row_stride,
+                           int64_t src_pixel_stride, double xcenter, double ycenter, const double* list_fact, int nfact, int order,
+                           int blend_mode, int mem_kind, int device, void* stream);
 int dcp_unwarp_image_channels(const void* src, void* dst, int dtype, int64_t height, int64_t width, int channels,
                               int64_t src_row_stride, int64_t src_pixel_stride, double xcenter, double ycenter,
                               const double* list_fact, int nfact, int order, int mem_kind, int device, void* stream);

@@ -1,0 +1,117 @@
+"""Interleaved colour images on remap_wg_color_kernel (util.unwarp_color_image_backward, reference
+discorpy/util/utility.py:278-342: map_coordinates channel by channel at ONE set of coordinates, :320-341).
+Every comparison is bit for bit: against the oracle per channel, against golden G10 (the reference's own output), and against
+three single-plane calls of unwarp_image_backward (remap_wg_kernel) under the same blend."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import golden, noise, typed_image
+
+pytestmark = pytest.mark.gpu
+
+FACT5 = [1.00227490554, -9.3601153805625e-06, 8.78436609375e-09, -4.79328802218628e-12, 7.714082828693389e-16]
+
+
+def planes_from_oracle(orc, rgb, xc, yc, fact, order, blend):
+    ob = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP}[blend]
+    if rgb.dtype == np.float32:
+        return np.stack([orc.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, c]), xc, yc, fact, order=order, poly=orc.POLY_KERNEL, blend=ob)
+                         for c in range(rgb.shape[2])], axis=2)
+    yd, xd = orc.radial_coords(rgb.shape[0], rgb.shape[1], xc, yc, fact, poly=orc.POLY_KERNEL)
+    return np.stack([orc.map_coordinates(np.ascontiguousarray(rgb[:, :, c]), yd, xd, order) for c in range(rgb.shape[2])], axis=2)
+
+
+@pytest.mark.parametrize("shape, centre, fact", [
+    ((1000, 1536, 3), (700.3, 480.9), FACT5),
+    ((517, 1031, 4), (500.0, 250.0), [1.0, -2e-5, 3e-8]),           # ragged tiles on both axes, four channels
+    ((40, 56, 3), (27.4, 19.1), [1.0, 4e-3, 5e-5]),                  # golden G10's geometry: one partial tile
+    ((300, 700, 3), (-50.0, 900.0), [0.98, 1e-5, 1e-8, 1e-11, 1e-14, 1e-17, 1e-20]),   # seven terms: the NF = 10 instantiation, centre outside
+])
+def test_float32_colour_equals_the_oracle_and_three_single_plane_calls(hip, orc, shape, centre, fact):
+    from discorpy_amd.post import postprocessing as pp
+    from discorpy_amd.util import utility as util
+    rgb = noise(11, shape) * 255.0
+    xc, yc = centre
+    for order, blend in ((1, None), (1, "scipy"), (0, None)):
+        got = util.unwarp_color_image_backward(rgb, xc, yc, fact, order=order, blend=blend)
+        assert hip.last_kernel().startswith("remap_wg_color_kernel"), hip.last_kernel()
+        assert got.dtype == np.float32 and got.shape == rgb.shape
+        want = planes_from_oracle(orc, rgb, xc, yc, fact, order, blend or "f64lerp")
+        assert np.array_equal(got, want), (order, blend, int((got != want).sum()))
+        for c in range(shape[2]):           # what three K1 calls give
+            assert np.array_equal(got[:, :, c], pp.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, c]), xc, yc, fact, order=order, blend=blend))
+
+
+def test_golden_g10_through_the_colour_kernel(hip):
+    """The reference's own outputs (tools/gen_golden.py imports discorpy.util.utility) -- on the staged kernel now."""
+    from discorpy_amd.util import utility as util
+    g = golden("g10_color40x56x3")
+    rgb = noise(g["seed"], g["shape"])
+    a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    out = util.unwarp_color_image_backward(rgb, *a, blend="scipy")
+    assert hip.last_kernel().startswith("remap_wg_color_kernel"), hip.last_kernel()
+    assert np.array_equal(out, g["nopad"])
+    assert np.array_equal(util.unwarp_color_image_backward(rgb, *a, pad=(3, 5, 2, 7), pad_mode="edge", blend="scipy"), g["pad_3_5_2_7_edge"])
+    assert np.array_equal(util.unwarp_color_image_backward(rgb, *a, order=0, pad=4, pad_mode="reflect"), g["pad_4_reflect_order0"])
+    assert hip.last_kernel().startswith("remap_wg_color_kernel<NF=5,nearest"), hip.last_kernel()
+
+
+@pytest.mark.parametrize("dt, channels, width", [("uint8", 3, 1532), ("uint8", 4, 1001), ("uint16", 3, 1030), ("uint16", 4, 777)])
+def test_integer_colour_blends_and_stores_as_scipy_does(hip, orc, dt, channels, width):
+    from discorpy_amd.util import utility as util
+    rgb = typed_image(dt, (600, width, channels), 5)
+    xc, yc, fact = 610.2, 333.3, [1.0, -3e-5, 4e-8]
+    for order in (1, 0):
+        got = util.unwarp_color_image_backward(rgb, xc, yc, fact, order=order)
+        assert hip.last_kernel().startswith("remap_wg_color_kernel"), hip.last_kernel()
+        assert got.dtype == rgb.dtype
+        assert np.array_equal(got, planes_from_oracle(orc, rgb, xc, yc, fact, order, "scipy")), (dt, channels, order)
+
+
+def test_what_the_staged_kernel_declines_gives_the_same_values(hip, orc):
+    """Rows that are not dword-aligned (uint8 x 3 of odd width), 2 / 5 channels, a pixel stride above the channel count, and an
+    uncertified (folding) model go to the one-thread-per-pixel kernel: same arithmetic, same bits."""
+    from discorpy_amd.util import utility as util
+    xc, yc, fact = 410.2, 233.3, [1.0, -3e-5, 4e-8]
+    odd = typed_image("uint8", (300, 801, 3), 6)
+    got = util.unwarp_color_image_backward(odd, xc, yc, fact)
+    assert hip.last_kernel().startswith("typed_channels_kernel")
+    assert np.array_equal(got, planes_from_oracle(orc, odd, xc, yc, fact, 1, "scipy"))
+    for ch in (2, 5):
+        img = noise(7, (300, 640, ch))
+        for blend in (None, "scipy"):
+            got = util.unwarp_color_image_backward(img, xc, yc, fact, blend=blend)
+            assert hip.last_kernel().startswith("typed_channels_kernel")
+            assert np.array_equal(got, planes_from_oracle(orc, img, xc, yc, fact, 1, blend or "f64lerp")), (ch, blend)
+    rgba = noise(8, (300, 640, 4))
+    view = rgba[:, :, :3]                                    # pixel stride 4, three channels
+    got = util.unwarp_color_image_backward(view, xc, yc, fact)
+    assert np.array_equal(got, planes_from_oracle(orc, np.ascontiguousarray(view), xc, yc, fact, 1, "f64lerp"))
+    fold = [1.0, -4e-3, 6e-6]                                # folds inside the frame: no certificate
+    img = noise(9, (400, 640, 3))
+    got = util.unwarp_color_image_backward(img, 320.0, 200.0, fold)
+    assert hip.last_kernel().startswith("typed_channels_kernel")
+    assert np.array_equal(got, planes_from_oracle(orc, img, 320.0, 200.0, fold, 1, "f64lerp"))
+
+
+def test_device_resident_4096_rgb_and_a_band_of_rows(hip, orc):
+    """BASELINE config 2's geometry with three channels, device-resident through the C ABI; the corner tiles of this model
+    magnify by more than the slab allows and take the kernel's direct gather."""
+    L = hip.lib()
+    H, W, NC = 4096, 4096, 3
+    rgb = noise(21, (H, W, NC))
+    cases = [(1883.8169650464, 1478.6964217312, FACT5),
+             (2048.0, 2048.0, [1.0, 0.0, 5.96e-9])]           # x-magnification 1.10 at the corners: their boxes exceed 144 pixels
+    dsrc = hip.DeviceBuffer(rgb.nbytes).upload(rgb)
+    ddst = hip.DeviceBuffer(rgb.nbytes)
+    for xc, yc, fact in cases:
+        fa, nf = hip.fact_array(fact)
+        for blend, ob in ((hip.BLEND_F64LERP, "f64lerp"), (hip.BLEND_SCIPY, "scipy")):
+            hip.check(L.dcp_unwarp_color_image(dsrc.ptr, ddst.ptr, 0, H, W, NC, W * NC, NC, xc, yc, fa, nf, 1, blend, hip.MEM_DEVICE, -1, None))
+            hip.check(L.dcp_stream_synchronize(-1, None))
+            assert hip.last_kernel().startswith("remap_wg_color_kernel<NF=5,%s,float32 x 3>" % ob), hip.last_kernel()
+            got = ddst.download((H, W, NC), np.float32)
+            want = planes_from_oracle(orc, rgb, xc, yc, fact, 1, ob)
+            assert np.array_equal(got, want), (fact, ob, int((got != want).sum()))
