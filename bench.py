@@ -487,6 +487,37 @@ def config5(a, dev):
     return entry(us, H * W, 8, k, ok, shape=[H, W], nfact=nf)
 
 
+def color_frame(a, dev):
+    """other_configs entry: util.unwarp_color_image_backward's kernel call on a device-resident 4096 x 4096 x 3 float32 image with
+    config 2's calibration (the most-used entry of the fisheye examples) -- 12 B read + 12 B written per
+    pixel, every channel checked against the oracle."""
+    L = F.lib()
+    orc = oracle_module(a.cpu_threads)
+    c2 = configs.cfg2()
+    H, W = c2["shape"]
+    NC = 3
+    fa, nf = F.fact_array(c2["list_fact"])
+    rgb = np.random.default_rng(c2["seed"] + 77).random((H, W, NC), dtype=np.float32)
+    nring = 6                                          # 6 x (201 + 201) MB = 2.4 GB: beyond the Infinity Cache
+    src = [F.DeviceBuffer(rgb.nbytes, dev).upload(rgb) for _ in range(nring)]
+    dst = [F.DeviceBuffer(rgb.nbytes, dev) for _ in range(nring)]
+
+    def run(i):
+        F.check(L.dcp_unwarp_color_image(src[i % nring].ptr, dst[i % nring].ptr, F.DTYPE_F32, H, W, NC, W * NC, NC, c2["xcenter"], c2["ycenter"],
+                                         fa, nf, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+    us = timed_launches(run, max(24, min(240, a.steps * 2)), dev)
+    k = F.last_kernel()
+    run(0)
+    got = np.empty((H, W, NC), np.float32)
+    F.check(L.dcp_memcpy(got.ctypes.data, dst[0].ptr, got.nbytes, F.COPY_D2H, dev, None))
+    ok = all(np.array_equal(got[:, :, c], orc.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, c]), c2["xcenter"], c2["ycenter"], c2["list_fact"],
+                                                                    poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)) for c in range(NC))
+    for b in src + dst:
+        b.free()
+    return entry(us, H * W, 8 * NC, k, ok, shape=[H, W, NC],
+                 note="interleaved float32 RGB, one coordinate and three blends per pixel; 24 algorithmic bytes per pixel")
+
+
 # ----------------------------------------------------------------------------------------- config 4: the stack
 
 class DevBlock:
@@ -1284,7 +1315,7 @@ def main(argv=None):
     for b in srcs + dsts:           # the ring is no longer needed: make room for the 8192^2 frames and the stack
         b.free()
     if others is not None and "error" not in others:
-        for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev)),
+        for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("color_4096x3", lambda: color_frame(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev)),
                          ("cfg4_grid_search_121_centres", lambda: grid_search_centres(a, dev)),
                          ("cfg4_uint16_shard64", lambda: stack_uint16_shard(a, dev))):
             try:

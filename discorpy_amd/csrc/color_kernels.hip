@@ -96,6 +96,20 @@ __device__ __forceinline__ T blend4(T t00, T t01, T t10, T t11, float fxf, float
   }
 }
 
+// A buffer store of MORE than 64 bits whose data registers are overwritten by the very next VALU instruction stored the NEW
+// contents on gfx950 (seen with buffer_store_dwordx3 ... sN offen nt: 500-700 of 4.6e6 values of a frame carried the next row's
+// v_cvt_i32_f32 result, differently from run to run).  LLVM's hazard recognizer pads this case only when soffset is NOT a
+// register (GCNHazardRecognizer::createsVALUHazard), hipcc therefore left no gap behind the stores with an SGPR row offset.
+// The pad keeps the data registers live across one `s_nop 1` (two wait states) behind the store.
+#ifndef DCP_WIDE_STORE_PAD_ON
+#define DCP_WIDE_STORE_PAD_ON 1
+#endif
+#if DCP_WIDE_STORE_PAD_ON
+#define DCP_WIDE_STORE_PAD(p) asm volatile("s_nop 1" : "+v"(p))
+#else
+#define DCP_WIDE_STORE_PAD(p) do { } while (0)
+#endif
+
 // NC elements of type T to dst + voff (bytes) + soff: one store of the pixel where the hardware has one of that width
 template <typename T, int NC>
 __device__ __forceinline__ void store_pixel(const T (&v)[NC], __amdgpu_buffer_rsrc_t dst, uint32_t voff, uint32_t soff) {
@@ -103,9 +117,11 @@ __device__ __forceinline__ void store_pixel(const T (&v)[NC], __amdgpu_buffer_rs
   if constexpr (std::is_same<T, float>::value && NC == 3) {
     u32x3 p = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2])};
     __builtin_amdgcn_raw_buffer_store_b96(p, dst, voff, soff, DCP_COLOR_STORE_AUX);
+    DCP_WIDE_STORE_PAD(p);
   } else if constexpr (std::is_same<T, float>::value && NC == 4) {
     u32x4 p = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
     __builtin_amdgcn_raw_buffer_store_b128(p, dst, voff, soff, DCP_COLOR_STORE_AUX);
+    DCP_WIDE_STORE_PAD(p);
   } else if constexpr (std::is_same<T, float>::value && NC == 2) {
     u32x2c p = {__float_as_uint(v[0]), __float_as_uint(v[1])};
     __builtin_amdgcn_raw_buffer_store_b64(p, dst, voff, soff, DCP_COLOR_STORE_AUX);

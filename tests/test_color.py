@@ -23,20 +23,21 @@ def planes_from_oracle(orc, rgb, xc, yc, fact, order, blend):
     return np.stack([orc.map_coordinates(np.ascontiguousarray(rgb[:, :, c]), yd, xd, order) for c in range(rgb.shape[2])], axis=2)
 
 
-@pytest.mark.parametrize("shape, centre, fact", [
-    ((1000, 1536, 3), (700.3, 480.9), FACT5),
-    ((517, 1031, 4), (500.0, 250.0), [1.0, -2e-5, 3e-8]),           # ragged tiles on both axes, four channels
-    ((40, 56, 3), (27.4, 19.1), [1.0, 4e-3, 5e-5]),                  # golden G10's geometry: one partial tile
-    ((300, 700, 3), (-50.0, 900.0), [0.98, 1e-5, 1e-8, 1e-11, 1e-14, 1e-17, 1e-20]),   # seven terms: the NF = 10 instantiation, centre outside
+@pytest.mark.parametrize("shape, centre, fact, staged", [
+    ((1000, 1536, 3), (700.3, 480.9), FACT5, True),
+    ((517, 1031, 4), (500.0, 250.0), [1.0, -2e-5, 3e-8], True),     # ragged tiles on both axes, four channels
+    ((40, 56, 3), (27.4, 19.1), [1.0, 3e-5, 3e-7], True),            # golden G10's shape: one partial tile
+    ((40, 56, 3), (27.4, 19.1), [1.0, 4e-3, 5e-5], False),           # ... and a model too curved for the tile certificate
+    ((300, 700, 3), (-50.0, 900.0), [0.98, 1e-5, 1e-8, 1e-11, 1e-14, 1e-17, 1e-20], True),   # seven terms: the NF = 10 instantiation, centre outside
 ])
-def test_float32_colour_equals_the_oracle_and_three_single_plane_calls(hip, orc, shape, centre, fact):
+def test_float32_colour_equals_the_oracle_and_three_single_plane_calls(hip, orc, shape, centre, fact, staged):
     from discorpy_amd.post import postprocessing as pp
     from discorpy_amd.util import utility as util
     rgb = noise(11, shape) * 255.0
     xc, yc = centre
     for order, blend in ((1, None), (1, "scipy"), (0, None)):
         got = util.unwarp_color_image_backward(rgb, xc, yc, fact, order=order, blend=blend)
-        assert hip.last_kernel().startswith("remap_wg_color_kernel"), hip.last_kernel()
+        assert hip.last_kernel().startswith("remap_wg_color_kernel" if staged else "typed_channels_kernel"), hip.last_kernel()
         assert got.dtype == np.float32 and got.shape == rgb.shape
         want = planes_from_oracle(orc, rgb, xc, yc, fact, order, blend or "f64lerp")
         assert np.array_equal(got, want), (order, blend, int((got != want).sum()))
@@ -44,18 +45,19 @@ def test_float32_colour_equals_the_oracle_and_three_single_plane_calls(hip, orc,
             assert np.array_equal(got[:, :, c], pp.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, c]), xc, yc, fact, order=order, blend=blend))
 
 
-def test_golden_g10_through_the_colour_kernel(hip):
-    """The reference's own outputs (tools/gen_golden.py imports discorpy.util.utility) -- on the staged kernel now."""
+def test_golden_g10_through_the_colour_entry(hip):
+    """The reference's own outputs (tools/gen_golden.py imports discorpy.util.utility), on whichever kernel the calibration's certificate selects."""
     from discorpy_amd.util import utility as util
     g = golden("g10_color40x56x3")
     rgb = noise(g["seed"], g["shape"])
     a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    fa, nf = hip.fact_array(a[2])
+    level = hip.lib().dcp_debug_tile_certificate(0, 40, 56, a[0], a[1], fa, nf, None)
     out = util.unwarp_color_image_backward(rgb, *a, blend="scipy")
-    assert hip.last_kernel().startswith("remap_wg_color_kernel"), hip.last_kernel()
+    assert hip.last_kernel().startswith("remap_wg_color_kernel" if level >= 2 else "typed_channels_kernel"), (level, hip.last_kernel())
     assert np.array_equal(out, g["nopad"])
     assert np.array_equal(util.unwarp_color_image_backward(rgb, *a, pad=(3, 5, 2, 7), pad_mode="edge", blend="scipy"), g["pad_3_5_2_7_edge"])
     assert np.array_equal(util.unwarp_color_image_backward(rgb, *a, order=0, pad=4, pad_mode="reflect"), g["pad_4_reflect_order0"])
-    assert hip.last_kernel().startswith("remap_wg_color_kernel<NF=5,nearest"), hip.last_kernel()
 
 
 @pytest.mark.parametrize("dt, channels, width", [("uint8", 3, 1532), ("uint8", 4, 1001), ("uint16", 3, 1030), ("uint16", 4, 777)])
