@@ -17,7 +17,8 @@ COORD_F32, COORD_F64 = 0, 1
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
 MAP_RADIAL, MAP_PERSPECTIVE, MAP_FUSED = 0, 1, 2
 # DCP_DTYPE_* by NumPy / torch dtype name
-DTYPE_BY_NAME = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7}
+DTYPE_BY_NAME = {"float32": 0, "float64": 1, "uint8": 2, "int8": 3, "uint16": 4, "int16": 5, "uint32": 6, "int32": 7,
+                 "int64": 8, "uint64": 9, "bool": 10}
 DTYPE_F32 = 0
 MAX_FACT = 32
 

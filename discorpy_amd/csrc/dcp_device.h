@@ -425,12 +425,33 @@ __device__ __forceinline__ double mc_sample_outside(LOAD&& load, int H, int W, d
 // scipy reads every element as a double and converts the double result on the way out
 // (ni_interpolation.c CASE_INTERP_OUT*): floats by a C cast; unsigned integers t > 0 ? t + 0.5 : 0,
 // clamped to the maximum, truncated; signed integers rounded half away from zero, clamped, truncated.
+// 64-bit integers: scipy clamps against NPY_MAX_INT64 / NPY_MAX_UINT64 converted to double -- 2^63 / 2^64, which the C cast
+// behind the clamp cannot represent (undefined behaviour).  The reference's result on x86-64 is what cvttsd2si gives: the
+// "integer indefinite" 0x8000000000000000 for every double outside [-2^63, 2^63); the unsigned cast is cvttsd2si(t) below 2^63,
+// else cvttsd2si(t - 2^63) ^ 2^63, so 2^64 stores 0 (oracle/unwarp_oracle.c x86_cvttsd2si, pinned by golden G12).
+__device__ __forceinline__ long long x86_cvttsd2si(double t) {
+  return (t >= -9223372036854775808.0 && t < 9223372036854775808.0) ? (long long)t : (long long)0x8000000000000000ull;
+}
 template <typename T>
 __device__ __forceinline__ T to_elem(double t) {
   if constexpr (std::is_same<T, float>::value) {
     return (float)t;
   } else if constexpr (std::is_same<T, double>::value) {
     return t;
+  } else if constexpr (std::is_same<T, Bool8>::value) {
+    Bool8 b;
+    b.v = (t >= 0.0 && t < 256.0) ? (uint8_t)(int)t : (uint8_t)0;        // a C cast of the double: truncation
+    return b;
+  } else if constexpr (std::is_same<T, int64_t>::value || std::is_same<T, long long>::value) {
+    double th = t > 0.0 ? t + 0.5 : t - 0.5;
+    th = th > 9223372036854775808.0 ? 9223372036854775808.0 : th;
+    th = th < -9223372036854775808.0 ? -9223372036854775808.0 : th;
+    return (T)x86_cvttsd2si(th);
+  } else if constexpr (std::is_same<T, uint64_t>::value || std::is_same<T, unsigned long long>::value) {
+    double th = t > 0.0 ? t + 0.5 : 0.0;
+    th = th > 18446744073709551616.0 ? 18446744073709551616.0 : th;
+    if (th < 9223372036854775808.0) return (T)(unsigned long long)x86_cvttsd2si(th);
+    return (T)((unsigned long long)x86_cvttsd2si(th - 9223372036854775808.0) ^ 0x8000000000000000ull);
   } else if constexpr (std::is_unsigned<T>::value) {
     // scipy: t > 0 ? t + 0.5 : 0, clamped to the maximum, truncated.  v_cvt_u32_f64 truncates and saturates (negative
     // and NaN -> 0, >= 2^32 -> 0xffffffff), so one add, one conversion and one integer minimum say the same: for
@@ -463,6 +484,9 @@ __device__ __forceinline__ double load_any(const void* p, int dtype, size_t i) {
     case kU16: return (double)((const uint16_t*)p)[i];
     case kI16: return (double)((const int16_t*)p)[i];
     case kU32: return (double)((const uint32_t*)p)[i];
+    case kI64: return (double)((const int64_t*)p)[i];
+    case kU64: return (double)((const uint64_t*)p)[i];
+    case kBool: return (double)((const uint8_t*)p)[i];
     default: return (double)((const int32_t*)p)[i];
   }
 }
@@ -475,6 +499,9 @@ __device__ __forceinline__ void store_any(void* p, int dtype, size_t i, double t
     case kU16: ((uint16_t*)p)[i] = to_elem<uint16_t>(t); break;
     case kI16: ((int16_t*)p)[i] = to_elem<int16_t>(t); break;
     case kU32: ((uint32_t*)p)[i] = to_elem<uint32_t>(t); break;
+    case kI64: ((int64_t*)p)[i] = to_elem<int64_t>(t); break;
+    case kU64: ((uint64_t*)p)[i] = to_elem<uint64_t>(t); break;
+    case kBool: ((Bool8*)p)[i] = to_elem<Bool8>(t); break;
     default: ((int32_t*)p)[i] = to_elem<int32_t>(t); break;
   }
 }

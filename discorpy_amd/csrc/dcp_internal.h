@@ -79,10 +79,15 @@ enum BoundaryMode : int { kModeReflect = 0, kModeGridMirror, kModeConstant, kMod
 enum SplineFilterKind : int { kSplMirror = 0, kSplReflect = 1, kSplWrap = 2 };
 
 // element types of the *_typed entry points (DCP_DTYPE_* of include/discorpy_hip.h)
-enum ElemType : int { kF32 = 0, kF64, kU8, kI8, kU16, kI16, kU32, kI32, kNumElemTypes };
+enum ElemType : int { kF32 = 0, kF64, kU8, kI8, kU16, kI16, kU32, kI32, kI64, kU64, kBool, kNumElemTypes };
 __host__ __device__ inline int elem_size(int dtype) {
-  return dtype == kF64 ? 8 : (dtype == kF32 || dtype == kU32 || dtype == kI32) ? 4 : (dtype == kU16 || dtype == kI16) ? 2 : 1;
+  return (dtype == kF64 || dtype == kI64 || dtype == kU64) ? 8 : (dtype == kF32 || dtype == kU32 || dtype == kI32) ? 4 : (dtype == kU16 || dtype == kI16) ? 2 : 1;
 }
+// numpy's bool_: one byte holding 0 or 1, read as a double and stored by a C cast of the double (scipy CASE_INTERP_OUT(NPY_BOOL))
+struct Bool8 {
+  uint8_t v;
+  __host__ __device__ operator double() const { return (double)v; }
+};
 
 // orders 0 / 1 on any element type (typed_kernels.hip); strides in elements
 struct TypedImageArgs {

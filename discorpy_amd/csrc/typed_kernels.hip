@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(kTypedBlock) typed_stack_kernel(const TypedSta
     }
     const T v = to_elem<T>(t);
     const int64_t o = o0 + (int64_t)(d - d0) * out_step;
-    if (st.out_f32) ((float*)st.out)[o] = (float)v;   // sino[i] = ... into a float32 array, postprocessing.py:224-227
+    if (st.out_f32) ((float*)st.out)[o] = (float)(double)v;   // sino[i] = ... into a float32 array, postprocessing.py:224-227
     else ((T*)st.out)[o] = v;
     proj += st.proj_stride;
   }
@@ -256,6 +256,9 @@ static hipError_t launch_image_t(int map_kind, const TypedImageArgs& a, const Ma
     case kI16: return CALL(int16_t);                \
     case kU32: return CALL(uint32_t);               \
     case kI32: return CALL(int32_t);                \
+    case kI64: return CALL(int64_t);                \
+    case kU64: return CALL(uint64_t);               \
+    case kBool: return CALL(Bool8);                 \
     default: return hipErrorInvalidValue;           \
   }
 

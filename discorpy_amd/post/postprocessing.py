@@ -27,8 +27,9 @@ What differs from the reference, on purpose:
 
 * float32 data (what ``discorpy.losa.load_image`` / ``load_hdf_file`` produce) takes the tuned kernels;
   float64, (u)int8, (u)int16 and (u)int32 data run the generic kernels with scipy's exact arithmetic and
-  its integer rounding, output dtype = input dtype as in the reference; 64-bit integers, bool and complex data (which
-  scipy handles) raise ``NotImplementedError``, float16 raises scipy's own ``RuntimeError("data type not supported")``;
+  its integer rounding, output dtype = input dtype as in the reference -- 64-bit integers (read as doubles, stored as the
+  reference's cast stores them on x86-64) and bool included; complex images and chunks go through as their real and imaginary
+  parts, as scipy treats them; float16 raises scipy's own ``RuntimeError("data type not supported")``;
 * for spline ``order`` 0 and 1 ``mode`` cannot influence the result because every coordinate is
   clipped into the image first; it is validated and otherwise ignored.
   Orders 2..5 run scipy's prefiltered B-spline interpolation on the GPU with all eight modes
@@ -138,6 +139,28 @@ def _check_order_mode(order, mode):
     if order < 0 or order > 5:
         raise RuntimeError("spline order not supported")
     return order
+
+
+def _complex_parts(a):
+    """scipy.ndimage.map_coordinates interpolates a complex array as two real ones (its wrapper calls itself on ``input.real`` and
+    ``input.imag`` and fills ``output.real`` / ``output.imag``); the reference hands whatever it is given to it.  Returns
+    ``(real, imag, join)`` for a complex NumPy array or torch tensor -- strided views, no copies -- and None for real data."""
+    if isinstance(a, np.ndarray):
+        if a.dtype.kind != "c":
+            return None
+        if a.dtype == np.dtype(np.clongdouble) and np.dtype(np.clongdouble) != np.dtype(np.complex128):
+            raise RuntimeError("data type not supported")
+
+        def join(re, im):
+            res = np.empty(np.shape(re), a.dtype)
+            res.real, res.imag = re, im
+            return res
+        return a.real, a.imag, join
+    if _is_torch(a) and a.is_complex():
+        import torch
+        v = torch.view_as_real(a)
+        return v[..., 0], v[..., 1], lambda re, im: torch.complex(re.contiguous(), im.contiguous())
+    return None
 
 
 def _dtype_code(dtype):
@@ -339,6 +362,14 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
         2D array. Distortion-corrected image, same kind and dtype as the input.
     """
     (height, width) = mat.shape
+    parts = _complex_parts(mat)
+    if parts is not None:
+        res = parts[2](unwarp_image_backward(parts[0], xcenter, ycenter, list_fact, order, mode, blend=blend),
+                       unwarp_image_backward(parts[1], xcenter, ycenter, list_fact, order, mode, blend=blend))
+        if out is not None:
+            out[...] = res
+            return out
+        return res
     order = _check_order_mode(order, mode)
     bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
@@ -508,6 +539,15 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
         if hasattr(mat3D, "new_empty"):                       # torch tensor
             return mat3D.new_empty((depth, 0, width))
         return np.empty((depth, 0, width), dtype=np.dtype(mat3D.dtype))
+    parts = _complex_parts(mat3D)
+    if parts is not None:         # (dense copies of the two parts: the stack kernels want unit column stride)
+        dense = (lambda t: t.contiguous()) if _is_torch(mat3D) else np.ascontiguousarray
+        res = parts[2](_stack_rows(dense(parts[0]), xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices),
+                       _stack_rows(dense(parts[1]), xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices))
+        if out is not None:
+            out[...] = res
+            return out
+        return res
     return _stack_rows(mat3D, xcenter, ycenter, list_fact, float(start_index), nrows, True, blend, devices=devices,
                        out=out)
 
@@ -712,6 +752,14 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     if len(list_coef) != 8:
         raise ValueError("!!! Eight coefficients are required !!!")
     (height, width) = mat.shape
+    parts = _complex_parts(mat)
+    if parts is not None:
+        res = parts[2](correct_perspective_image(parts[0], list_coef, order, mode, map_index, blend=blend),
+                       correct_perspective_image(parts[1], list_coef, order, mode, map_index, blend=blend))
+        if out is not None:
+            out[...] = res
+            return out
+        return res
     order = _check_order_mode(order, mode)
     bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()

@@ -180,6 +180,11 @@ def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode=
     if num_dim == 2:
         return _pp.unwarp_image_backward(mat_pad, xcenter, ycenter, list_fact, order=order, mode=mode, blend=blend)
     order = _pp._check_order_mode(order, mode)
+    parts = _pp._complex_parts(mat_pad)
+    if parts is not None:         # scipy interpolates a complex array as its real and imaginary parts
+        dense = (lambda t: t.contiguous()) if is_torch else np.ascontiguousarray
+        return parts[2](unwarp_color_image_backward(dense(parts[0]), xcenter, ycenter, list_fact, order, mode, blend=blend),
+                        unwarp_color_image_backward(dense(parts[1]), xcenter, ycenter, list_fact, order, mode, blend=blend))
     if order <= 1 and blend in (None, "scipy", "exact", "f64lerp", "f64") and 1 <= mat_pad.shape[2] <= 64:
         return _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order, blend)
     # channels as dense planes through the batched entry point (the reference's loop over mat_pad[:, :, i], utility.py:320-341):

@@ -259,6 +259,9 @@ int dcp_unwarp_fused_spline_f32(const float* src, float* dst, int64_t height, in
 #define DCP_DTYPE_I16 5
 #define DCP_DTYPE_U32 6
 #define DCP_DTYPE_I32 7
+#define DCP_DTYPE_I64 8  /* read as a double (rounds above 2^53), stored as scipy's cast does on x86-64: see dcp_device.h to_elem */
+#define DCP_DTYPE_U64 9
+#define DCP_DTYPE_BOOL 10 /* numpy bool_: one byte, 0 / 1; the double result is truncated on the way out */
 int dcp_unwarp_image_typed(const void* src, void* dst, int dtype, int64_t height, int64_t width, int64_t src_row_stride,
                            int64_t src_col_stride, double xcenter, double ycenter, const double* list_fact, int nfact,
                            int order, int boundary_mode, int mem_kind, int device, void* stream);

@@ -103,7 +103,8 @@ def spline_coefficients(mat, order, mode):
 
 # element types of the typed path (codes shared with DCP_DTYPE_* of include/discorpy_hip.h)
 DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.uint8): 2, np.dtype(np.int8): 3,
-          np.dtype(np.uint16): 4, np.dtype(np.int16): 5, np.dtype(np.uint32): 6, np.dtype(np.int32): 7}
+          np.dtype(np.uint16): 4, np.dtype(np.int16): 5, np.dtype(np.uint32): 6, np.dtype(np.int32): 7,
+          np.dtype(np.int64): 8, np.dtype(np.uint64): 9, np.dtype(np.bool_): 10}
 
 
 def map_coordinates(mat, ycoord, xcoord, order=1, mode="reflect"):

@@ -664,6 +664,9 @@ static inline double load_typed(const void *src, int dtype, int64_t i)
     case ORC_DT_U16: return (double)((const uint16_t *)src)[i];
     case ORC_DT_I16: return (double)((const int16_t *)src)[i];
     case ORC_DT_U32: return (double)((const uint32_t *)src)[i];
+    case ORC_DT_I64: return (double)((const int64_t *)src)[i];      /* rounds to nearest above 2^53, as scipy's cast does */
+    case ORC_DT_U64: return (double)((const uint64_t *)src)[i];
+    case ORC_DT_BOOL: return (double)((const uint8_t *)src)[i];     /* npy_bool is an unsigned char */
     default: return (double)((const int32_t *)src)[i];
     }
 }
@@ -686,9 +689,28 @@ static inline double round_signed(double t, double lo, double hi)
     return t < lo ? lo : t;
 }
 
+/* 64-bit integers: scipy's clamps compare against NPY_MAX_INT64 / NPY_MAX_UINT64 converted to double, i.e. 2^63 / 2^64, which
+ * the cast that follows cannot represent -- undefined behaviour in C.  What the reference DOES on x86-64 (scipy 1.15.3 wheels,
+ * probed by tools/gen_golden.py, golden G12): cvttsd2si returns the "integer indefinite" 0x8000000000000000 for every double
+ * outside [-2^63, 2^63), and the unsigned cast is cvttsd2si(t) below 2^63, else cvttsd2si(t - 2^63) ^ 2^63 -- so a result of
+ * 2^63 (any blend of taps near INT64_MAX) stores INT64_MIN and 2^64 stores 0.  Restated with defined operations only. */
+static inline int64_t x86_cvttsd2si(double t)
+{
+    return (t >= -9223372036854775808.0 && t < 9223372036854775808.0) ? (int64_t)t : INT64_MIN;
+}
+
+static inline uint64_t x86_double_to_u64(double t)
+{
+    if (t < 9223372036854775808.0) return (uint64_t)x86_cvttsd2si(t);
+    return (uint64_t)x86_cvttsd2si(t - 9223372036854775808.0) ^ 0x8000000000000000ull;
+}
+
 static inline void store_typed(void *dst, int dtype, int64_t i, double t)
 {
     switch (dtype) {
+    case ORC_DT_I64: ((int64_t *)dst)[i] = x86_cvttsd2si(round_signed(t, -9223372036854775808.0, 9223372036854775808.0)); break;
+    case ORC_DT_U64: ((uint64_t *)dst)[i] = x86_double_to_u64(round_unsigned(t, 18446744073709551616.0)); break;
+    case ORC_DT_BOOL: ((uint8_t *)dst)[i] = (uint8_t)(t >= 0.0 && t < 256.0 ? t : 0.0); break;   /* CASE_INTERP_OUT(NPY_BOOL): a C cast, truncation */
     case ORC_DT_F32: ((float *)dst)[i] = (float)t; break;
     case ORC_DT_F64: ((double *)dst)[i] = t; break;
     case ORC_DT_U8: ((uint8_t *)dst)[i] = (uint8_t)round_unsigned(t, 255.0); break;
@@ -895,7 +917,7 @@ int orc_map_coordinates_typed(const void *src, void *dst, int dtype, int64_t H, 
                               int mode, double *workspace)
 {
     if (H <= 0 || W <= 0 || npts < 0 || order < 0 || order > 5 || mode < 0 || mode > 7) return -1;
-    if (dtype < ORC_DT_F32 || dtype > ORC_DT_I32) return -1;
+    if (dtype < ORC_DT_F32 || dtype > ORC_DT_BOOL) return -1;
     const int pad = orc_spline_pad(mode);
     const int64_t Hp = H + 2 * pad, Wp = W + 2 * pad;
     if (order >= 2 && spline_coefficients_any(src, dtype, H, W, src_row_stride, order, mode, workspace) != 0) return -1;

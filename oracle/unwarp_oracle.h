@@ -32,6 +32,9 @@ extern "C" {
 #define ORC_DT_I16 5
 #define ORC_DT_U32 6
 #define ORC_DT_I32 7
+#define ORC_DT_I64 8
+#define ORC_DT_U64 9
+#define ORC_DT_BOOL 10
 
 void orc_set_threads(int n);
 int orc_get_threads(void);

@@ -66,6 +66,23 @@ def g12_inputs(g, dt):
     return im, typed_image(dt, g["vol_shape"], 900 + k)
 
 
+def wide_image(dt, shape, seed):
+    """The inputs of golden G12b (tools/gen_golden.py): int64 / uint64 over the whole range with the extremes and small values
+    sprinkled in, bool coin flips."""
+    rng = np.random.default_rng(int(seed))
+    shape = tuple(int(v) for v in shape)
+    if np.dtype(dt) == np.bool_:
+        return rng.random(shape) < 0.5
+    info = np.iinfo(dt)
+    im = rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=dt)
+    flat = im.reshape(-1)
+    flat[::7] = rng.integers(0, 1 << 20, size=flat[::7].shape).astype(dt)
+    flat[3::11] = info.max
+    flat[5::13] = info.min
+    return im
+
+
+G12B_DTYPES = ("int64", "uint64", "bool")
 G12_DTYPES = ("uint8", "int8", "uint16", "int16", "uint32", "int32", "float64")
 
 

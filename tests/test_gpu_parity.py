@@ -8,7 +8,7 @@ scipy's arithmetic by at most one float32 ulp (and in these vectors does not dif
 import numpy as np
 import pytest
 
-from conftest import G12_DTYPES, g12_inputs, golden, noise, typed_image, ulp_diff
+from conftest import G12B_DTYPES, G12_DTYPES, g12_inputs, golden, noise, typed_image, ulp_diff, wide_image
 
 pytestmark = pytest.mark.gpu
 
@@ -912,6 +912,51 @@ def test_g12_element_types_against_the_reference(hip, dt):
     sl = pp.unwarp_slice_backward(vol, xc, yc, fact, int(g["index"]))
     assert sl.dtype == np.float32 and np.array_equal(sl, g["slice_" + dt])
     assert typed_close(pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, int(g["start"]), int(g["stop"])), g["chunk_" + dt], 1)
+
+
+@pytest.mark.parametrize("dt", G12B_DTYPES)
+def test_g12b_int64_uint64_bool_against_the_reference(hip, orc, dt):
+    """Inputs the reference accepts because scipy does (postprocessing.py:147, 227, 251, 491): 64-bit integers -- read as doubles,
+    stored as the reference's cast stores them on x86-64, extremes included -- and bool; orders 0 / 1 bit for bit against golden
+    G12b, order 3 within the float64 noise of the recursive filter (test_oracle_golden.wide_close)."""
+    from test_oracle_golden import wide_close
+    g = golden("g12b_wide_types40x52")
+    im = wide_image(dt, g["shape"], g["seed_" + dt])
+    vol = wide_image(dt, g["vol_shape"], int(g["seed_" + dt]) + 100)
+    xc, yc, fact, coef = float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]), list(g["list_coef"])
+    for order in (0, 1, 3):
+        assert wide_close(pp.unwarp_image_backward(im, xc, yc, fact, order=order), g["radial_o%d_%s" % (order, dt)], order), order
+        assert wide_close(pp.remap_coordinates(im, g["pts_y"], g["pts_x"], order=order), g["points_o%d_%s" % (order, dt)], order), order
+    assert wide_close(pp.correct_perspective_image(im, coef), g["persp_o1_" + dt], 1)
+    sl = pp.unwarp_slice_backward(vol, xc, yc, fact, int(g["index"]))
+    assert sl.dtype == np.float32 and np.array_equal(sl, g["slice_" + dt])
+    assert wide_close(pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, int(g["start"]), int(g["stop"])), g["chunk_" + dt], 1)
+    # a larger frame against the oracle (tiles, bands of the host path), and the colour helper
+    from discorpy_amd.util import utility as util
+    big = wide_image(dt, (700, 900), 31)
+    a = (430.5, 333.25, [1.0, -2e-5, 3e-8])
+    yd, xd = orc.radial_coords(700, 900, *a, poly=orc.POLY_KERNEL)
+    for order in (0, 1):
+        assert np.array_equal(pp.unwarp_image_backward(big, *a, order=order), orc.map_coordinates(big, yd, xd, order))
+    rgb = wide_image(dt, (120, 150, 3), 32)
+    got = util.unwarp_color_image_backward(rgb, 70.0, 60.0, [1.0, 1e-4])
+    yd, xd = orc.radial_coords(120, 150, 70.0, 60.0, [1.0, 1e-4], poly=orc.POLY_KERNEL)
+    for c in range(3):
+        assert np.array_equal(got[:, :, c], orc.map_coordinates(np.ascontiguousarray(rgb[:, :, c]), yd, xd, 1))
+
+
+def test_complex_images_go_through_as_real_and_imaginary_parts(hip):
+    g = golden("g12b_wide_types40x52")
+    cim = (np.random.default_rng(861).random((40, 52)) + 1j * np.random.default_rng(862).random((40, 52))).astype(np.complex64)
+    a = (float(g["xcenter"]), float(g["ycenter"]), list(g["list_fact"]))
+    out = pp.unwarp_image_backward(cim, *a, blend="scipy")
+    assert out.dtype == np.complex64 and np.array_equal(out, g["radial_o1_complex64"])
+    out = pp.correct_perspective_image(cim, list(g["list_coef"]), blend="scipy")
+    assert out.dtype == np.complex64 and np.array_equal(out, g["persp_o1_complex64"])
+    vol = np.stack([cim, cim[::-1]]).astype(np.complex128)
+    ch = pp.unwarp_chunk_slices_backward(vol, *a, 3, 9)
+    assert ch.dtype == np.complex128 and ch.shape == (2, 7, 52)
+    assert np.array_equal(ch.real, pp.unwarp_chunk_slices_backward(np.ascontiguousarray(vol.real), *a, 3, 9))
 
 
 @pytest.mark.parametrize("dt", ["uint8", "uint16", "int32", "float64", "float32"])

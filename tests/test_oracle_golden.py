@@ -8,7 +8,7 @@ on the same float32 coordinates.
 import numpy as np
 import pytest
 
-from conftest import G12_DTYPES, g12_inputs, golden, noise, ulp_diff
+from conftest import G12B_DTYPES, G12_DTYPES, g12_inputs, golden, noise, ulp_diff, wide_image
 
 POLYS = ["numpy", "kernel"]
 
@@ -412,3 +412,49 @@ def test_g12_element_types(orc, dt):
     assert sl.dtype == np.float32 and np.array_equal(sl, g["slice_" + dt])
     ch = orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, int(g["start"]), int(g["stop"]))
     assert typed_close(ch, g["chunk_" + dt], 1)
+
+
+def wide_close(out, ref, order):
+    """Golden G12b: orders 0 / 1 bit for bit.  Order 3 on 64-bit integers compares doubles of magnitude ~1e19 after a separable
+    recursive filter: the restatement and scipy agree to a few float64 ulps of the LARGEST values in the filter's support (1e-13
+    of the data's range asserted), which moves the stored integer -- and flips a result that lands within that distance of the
+    2^63 / 2^64 overflow between the type's maximum and what the overflowing cast stores; a bool flips where the float64 result
+    lies that close to 1.0.  At most 5 % of the pixels may fall in those two classes (a ninth of the inputs sit AT the extremes)."""
+    assert out.dtype == ref.dtype and out.shape == ref.shape
+    if order <= 1:
+        return np.array_equal(out, ref)
+    if out.dtype == np.bool_:
+        return np.count_nonzero(out != ref) <= 0.05 * out.size
+    o, r = out.astype(np.float64), ref.astype(np.float64)
+    return np.count_nonzero(np.abs(o - r) > 1e-13 * float(np.max(np.abs(r)))) <= 0.05 * out.size
+
+
+@pytest.mark.parametrize("dt", G12B_DTYPES)
+def test_g12b_int64_uint64_bool(orc, dt):
+    """The element types scipy takes beyond the 32-bit ones: the oracle's restatement of the double read and of
+    what the reference's undefined 64-bit casts store on x86-64, against the reference itself."""
+    g = golden("g12b_wide_types40x52")
+    im = wide_image(dt, g["shape"], g["seed_" + dt])
+    vol = wide_image(dt, g["vol_shape"], int(g["seed_" + dt]) + 100)
+    xc, yc, fact, coef = g["xcenter"], g["ycenter"], g["list_fact"], g["list_coef"]
+    for order in (0, 1, 3):
+        assert wide_close(orc.unwarp_image_backward(im, xc, yc, fact, order=order), g["radial_o%d_%s" % (order, dt)], order), order
+        assert wide_close(orc.map_coordinates(im, g["pts_y"], g["pts_x"], order), g["points_o%d_%s" % (order, dt)], order), order
+    assert wide_close(orc.correct_perspective_image(im, coef), g["persp_o1_" + dt], 1)
+    sl = orc.unwarp_slice_backward(vol, xc, yc, fact, int(g["index"]))
+    assert sl.dtype == np.float32 and np.array_equal(sl, g["slice_" + dt])
+    assert wide_close(orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, int(g["start"]), int(g["stop"])), g["chunk_" + dt], 1)
+    if dt == "int64":       # the extremes really are in play: INT64_MAX reads as 2^63 and comes back as the x86 "integer indefinite"
+        assert np.any(im == np.iinfo(np.int64).max) and not np.any(g["radial_o0_int64"] == np.iinfo(np.int64).max)
+    if dt == "uint64":      # ... and UINT64_MAX reads as 2^64 and comes back as 0
+        assert np.any(im == np.iinfo(np.uint64).max) and not np.any(g["radial_o0_uint64"] == np.iinfo(np.uint64).max)
+
+
+def test_g12b_complex_is_two_real_interpolations(orc):
+    g = golden("g12b_wide_types40x52")
+    cim = (np.random.default_rng(861).random((40, 52)) + 1j * np.random.default_rng(862).random((40, 52))).astype(np.complex64)
+    a = (g["xcenter"], g["ycenter"], g["list_fact"])
+    want = g["radial_o1_complex64"]
+    assert want.dtype == np.complex64
+    assert np.array_equal(orc.unwarp_image_backward(np.ascontiguousarray(cim.real), *a), want.real)
+    assert np.array_equal(orc.unwarp_image_backward(np.ascontiguousarray(cim.imag), *a), want.imag)

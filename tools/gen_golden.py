@@ -266,6 +266,41 @@ for k, dt in enumerate(("uint8", "int8", "uint16", "int16", "uint32", "int32", "
     assert g12["radial_o1_" + dt].dtype == np.dtype(dt) and g12["chunk_" + dt].dtype == np.dtype(dt)
     assert g12["slice_" + dt].dtype == np.float32
 save("g12_dtypes40x52", **g12)
+# ---- G12b: the element types scipy reads as doubles with loss or stores through an undefined cast: int64, uint64 (taps above
+# 2^53 round on the way in; a result of 2^63 / 2^64 -- any blend of taps at the type's maximum -- is stored as the x86-64
+# cvttsd2si sequence stores it: INT64_MIN / 0) and bool (stored by truncating the double).  Inputs: conftest.wide_image.
+def wide_image(dt, shape, seed):
+    rng = np.random.default_rng(seed)
+    if np.dtype(dt) == np.bool_:
+        return rng.random(shape) < 0.5
+    info = np.iinfo(dt)
+    im = rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=dt)
+    flat = im.reshape(-1)
+    flat[::7] = rng.integers(0, 1 << 20, size=flat[::7].shape).astype(dt)           # small values between the huge ones
+    flat[3::11] = info.max
+    flat[5::13] = info.min
+    return im
+
+
+g12b = dict(shape=np.array([40, 52]), xcenter=f64(24.6), ycenter=f64(20.3), list_fact=f64([1.0, 5e-3, 3e-5]),
+            list_coef=g12["list_coef"], vol_shape=np.array([5, 40, 52]), index=np.int64(17), start=np.int64(8), stop=np.int64(21),
+            pts_y=pts_y, pts_x=pts_x)
+for k, dt in enumerate(("int64", "uint64", "bool")):
+    im = wide_image(dt, (40, 52), 850 + k)
+    g12b["seed_" + dt] = np.int64(850 + k)
+    for order in (0, 1, 3):
+        g12b["radial_o%d_%s" % (order, dt)] = post.unwarp_image_backward(im, 24.6, 20.3, g12b["list_fact"], order=order)
+        g12b["points_o%d_%s" % (order, dt)] = map_coordinates(im, (pts_y, pts_x), order=order, mode="reflect")
+    g12b["persp_o1_" + dt] = post.correct_perspective_image(im, g12b["list_coef"])
+    vol = wide_image(dt, (5, 40, 52), 950 + k)
+    g12b["slice_" + dt] = post.unwarp_slice_backward(vol, 24.6, 20.3, g12b["list_fact"], 17)
+    g12b["chunk_" + dt] = post.unwarp_chunk_slices_backward(vol, 24.6, 20.3, g12b["list_fact"], 8, 21)
+    assert g12b["radial_o1_" + dt].dtype == np.dtype(dt) and g12b["chunk_" + dt].dtype == np.dtype(dt) and g12b["slice_" + dt].dtype == np.float32
+# complex data: scipy interpolates the real and the imaginary part separately
+cim = (np.random.default_rng(861).random((40, 52)) + 1j * np.random.default_rng(862).random((40, 52))).astype(np.complex64)
+g12b["radial_o1_complex64"] = post.unwarp_image_backward(cim, 24.6, 20.3, g12b["list_fact"])
+g12b["persp_o1_complex64"] = post.correct_perspective_image(cim, g12b["list_coef"])
+save("g12b_wide_types40x52", **g12b)
 # ---- G13: unwarp_line_forward (postprocessing.py:36-64) on eight jittered dot lines of the 800 x 1280 pattern
 rng13 = np.random.default_rng(5)
 lines13 = [np.column_stack([np.full(12, 40.0 * k) + rng13.uniform(-2, 2, 12), np.linspace(5, 1270, 12) + rng13.uniform(-1, 1, 12)])
