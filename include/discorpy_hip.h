@@ -31,6 +31,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden and an export list (csrc/exports.map): exactly these entry points are visible */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define DCP_OK 0
 #define DCP_ERR_INVALID_ARG (-1)
@@ -375,6 +379,9 @@ int dcp_event_synchronize(void* event);
 int dcp_event_elapsed_ms(void* start, void* stop, float* ms);
 int dcp_event_destroy(void* event);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ def planes_from_oracle(orc, rgb, xc, yc, fact, order, blend):
     ((517, 1031, 4), (500.0, 250.0), [1.0, -2e-5, 3e-8], True),     # ragged tiles on both axes, four channels
     ((40, 56, 3), (27.4, 19.1), [1.0, 3e-5, 3e-7], True),            # golden G10's shape: one partial tile
     ((40, 56, 3), (27.4, 19.1), [1.0, 4e-3, 5e-5], False),           # ... and a model too curved for the tile certificate
-    ((300, 700, 3), (-50.0, 900.0), [0.98, 1e-5, 1e-8, 1e-11, 1e-14, 1e-17, 1e-20], True),   # seven terms: the NF = 10 instantiation, centre outside
+    ((300, 700, 3), (-50.0, 900.0), [0.98, 1e-5, 1e-8, 1e-12, 1e-15, 1e-18, 1e-21], True),   # seven terms: the NF = 10 instantiation, centre outside
 ])
 def test_float32_colour_equals_the_oracle_and_three_single_plane_calls(hip, orc, shape, centre, fact, staged):
     from discorpy_amd.post import postprocessing as pp
