@@ -96,6 +96,7 @@ SIGNATURES = {
     "dcp_map_points_f64": (_int, [_vp, _vp, _i64, _dbl, _dbl, _dp, _int, _int, _int, _vp]),
     "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
+    "dcp_debug_bounds": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_debug_last_kernel": (C.c_char_p, []),
     "dcp_debug_tile_certificate": (_int, [_int, _i64, _i64, _dbl, _dbl, _dp, _int, _dp]),
     "dcp_malloc": (_int, [C.POINTER(_vp), _sz, _int]),
@@ -208,6 +209,13 @@ def debug_counters(reset=True):
     out = (C.c_uint64 * 2)()
     check(lib().dcp_debug_counters(out, 2, int(reset)))
     return int(out[0]), int(out[1])
+
+
+def debug_bounds(reset=True):
+    """(taps outside their LDS slab, first offset, slab bytes, site, is_checking_build) -- see dcp_debug_bounds."""
+    out = (C.c_uint64 * 5)()
+    check(lib().dcp_debug_bounds(out, 5, int(reset)))
+    return tuple(int(v) for v in out)
 
 
 def last_kernel():

@@ -556,6 +556,29 @@ int dcp_debug_counters(uint64_t* out, int n, int reset) {
   return DCP_OK;
 }
 
+int dcp_debug_bounds(uint64_t* out, int n, int reset) {
+  if (!out || n < 5) return fail(DCP_ERR_INVALID_ARG, "need room for 5 values");
+#ifdef DCP_DEBUG_BOUNDS
+  out[4] = 1;
+#else
+  out[4] = 0;
+#endif
+  out[0] = out[1] = out[2] = out[3] = 0;
+  DCP_HIP(hipDeviceSynchronize());
+  hipError_t (*readers[3])(unsigned long long*, bool) = {dcp::read_bounds_unwarp, dcp::read_bounds_color, dcp::read_bounds_spline};
+  for (auto rd : readers) {
+    unsigned long long v[4];
+    DCP_HIP(rd(v, reset != 0));
+    if (v[0] && !out[0]) {
+      out[1] = v[1];
+      out[2] = v[2];
+      out[3] = v[3];
+    }
+    out[0] += v[0];
+  }
+  return DCP_OK;
+}
+
 const char* dcp_debug_last_kernel(void) { return dcp::last_kernel_name(); }
 
 int dcp_debug_tile_certificate(int map_kind, int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact,

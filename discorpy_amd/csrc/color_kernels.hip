@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(256, (ColorGeom<T, NC>::kSlabBytes <= 53 * 102
           const uint32_t xa = (uint32_t)xi * (uint32_t)PS + negorg;
           asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(PB), "v"(xa));
         }
+        DCP_BOUNDS(addr, SAMPLER == kNearest ? PS : PB + 2 * PS, G::kSlabBytes, 6);
         const T* t = (const T*)(boxb + addr);
         T v[NC];
 #pragma unroll
@@ -329,6 +330,8 @@ __global__ void __launch_bounds__(256, (ColorGeom<T, NC>::kSlabBytes <= 53 * 102
 }
 
 // ------------------------------------------------------------------ launchers
+
+DCP_DEFINE_BOUNDS_READER(read_bounds_color)
 
 template <int NF, int SAMPLER, typename T, int NC>
 static hipError_t launch_color_t(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {

@@ -11,6 +11,40 @@
 
 namespace dcp {
 
+// ------------------------------------------------------------------ debug build: every LDS tap checked against its slab
+// `make -C discorpy_amd/csrc bounds` (-DDCP_DEBUG_BOUNDS, a separate library: lib/libdiscorpy_hip_bounds.so) compiles a check
+// in front of every tap the staged kernels read from LDS: DCP_BOUNDS(first byte, bytes spanned, slab bytes, site).  A tap outside
+// its slab is counted (dcp_debug_bounds; the first offender is kept) instead of trapping, so a whole randomised campaign
+// (tools/fuzz_parity.py --bounds) runs through and reports.  The certificate (api_core.cpp tile_deviation_certified) says
+// the count must stay 0.  Nothing of this exists in the product build.
+#ifdef DCP_DEBUG_BOUNDS
+static __device__ unsigned long long g_bounds[4];      // per translation unit: violations, first offset, slab bytes, site
+__device__ __forceinline__ void check_lds_tap(uint32_t first, uint32_t span, uint32_t slab, int site) {
+  if (first > slab || span > slab - first) {
+    if (atomicAdd(&g_bounds[0], 1ull) == 0ull) {
+      g_bounds[1] = first;
+      g_bounds[2] = slab;
+      g_bounds[3] = (unsigned long long)site;
+    }
+  }
+}
+#define DCP_BOUNDS(first, span, slab, site) ::dcp::check_lds_tap((uint32_t)(first), (uint32_t)(span), (uint32_t)(slab), (site))
+#define DCP_DEFINE_BOUNDS_READER(name)                                                                       \
+  hipError_t name(unsigned long long* out, bool reset) {                                                     \
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bounds), sizeof(g_bounds));                         \
+    if (e != hipSuccess || !reset) return e;                                                                 \
+    const unsigned long long zero[4] = {0, 0, 0, 0};                                                         \
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bounds), zero, sizeof(zero));                                      \
+  }
+#else
+#define DCP_BOUNDS(first, span, slab, site) do { } while (0)
+#define DCP_DEFINE_BOUNDS_READER(name)                                     \
+  hipError_t name(unsigned long long* out, bool) {                         \
+    out[0] = out[1] = out[2] = out[3] = 0;                                 \
+    return hipSuccess;                                                     \
+  }
+#endif
+
 // ------------------------------------------------------------------ fp64 helpers
 
 constexpr double kTinyR2 = 1e-300;   // keeps rsq finite at the centre pixel; absorbed everywhere else

@@ -174,6 +174,10 @@ hipError_t launch_stack_centres(const StackArgs& st, const MapArgs& map, const d
                                 bool round_f32, const LaunchOpts& opts, hipStream_t stream);
 
 hipError_t read_lds_stats(unsigned long long* out, bool reset);
+// -DDCP_DEBUG_BOUNDS builds: LDS taps outside their slab (count, first byte offset, slab bytes, site) per translation unit; zeros otherwise
+hipError_t read_bounds_unwarp(unsigned long long* out, bool reset);
+hipError_t read_bounds_color(unsigned long long* out, bool reset);
+hipError_t read_bounds_spline(unsigned long long* out, bool reset);
 void set_last_kernel_name(const char* name);   // for the launchers of the other translation units
 const char* last_kernel_name();   // unwarp_kernels.hip: the kernel the calling thread launched last (float32 image / stack launchers)
 // spline_kernels.hip: map_kind 0 radial, 1 perspective, 2 explicit coordinates

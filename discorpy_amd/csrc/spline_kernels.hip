@@ -773,6 +773,7 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
       double wyv[6], wxv[6];
       const int sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
       const int sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+      DCP_BOUNDS(sy * PB + sx * 8 - org, ORDER * PB + (ORDER + 1) * 8, sizeof(s_box), 7);
       const unsigned char* base = s_box + (sy * PB + sx * 8 - org);
       double t = 0.0;
 #pragma unroll
@@ -863,6 +864,8 @@ static hipError_t launch_remap_order(const SplineArgs& a, const MapArgs& map, co
   }
   return hipGetLastError();
 }
+
+DCP_DEFINE_BOUNDS_READER(read_bounds_spline)
 
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream) {

@@ -611,6 +611,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, (KIND == kFused && NF < 0) ? 3 : 
           asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(xa) : "v"(xi), "s"(negorg4));
           asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(yi), "s"(kBoxW * 4), "v"(xa));
         }
+        DCP_BOUNDS(addr - (uint32_t)wave * (uint32_t)(kBoxH * kBoxW * 4), SAMPLER == kNearest ? 4 : kBoxW * 4 + 8, kBoxH * kBoxW * 4, 1);
         const float* t = (const float*)(boxb + addr);
         float v;
         if constexpr (SAMPLER == kNearest) {
@@ -1014,6 +1015,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
           f.fy = yf[k] - (float)yi;
           addr = tap_addr(xi, yi);
         }
+        DCP_BOUNDS(addr, SAMPLER == kNearest ? ES : PB + 2 * ES, kSlabChunks * 16, 2);
         const T* t = (const T*)(boxb + addr);
         if constexpr (kIsF32) {
           float v;
@@ -1506,6 +1508,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
           FetchT f;
           f.fx = fx[k];
           f.fy = fy[k];
+          DCP_BOUNDS(addr[k], kBoxW * 4 + 8, kBoxH * kBoxW * 4, 3);
           const float* t = (const float*)(boxb + addr[k]);
           f.a.x = __float_as_uint(t[0]);
           f.a.y = __float_as_uint(t[1]);
@@ -1723,6 +1726,7 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
             // every coordinate of the tile >= 32: the factorised blend is exact (exact_lerp_pairs) and scipy's w1 = 1 - (1 - f) IS the fraction
 #pragma unroll
             for (int k = 0; k < kLdsTH; ++k) {
+              DCP_BOUNDS(addr[k], PB + 2 * ES, kWgSlabRows * PB, 4);
               const T* t = (const T*)(boxb + addr[k]);
               float fy_ = fy[k], fx_ = fx[k];
               asm volatile("" : "+v"(fy_), "+v"(fx_));            // (see blend_store)
@@ -1738,6 +1742,7 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
         if (!done) {
 #pragma unroll
         for (int k = 0; k < kLdsTH; ++k) {
+          DCP_BOUNDS(addr[k], PB + 2 * ES, kWgSlabRows * PB, 5);
           if constexpr (kIsF32) {
             const float* t = (const float*)(boxb + addr[k]);
             blend_store(t, t + kBoxWEl, dst, k);
@@ -2224,6 +2229,8 @@ extern "C" int dcp_experiment_read_trace(unsigned long long* out, int nwaves) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 12 * (size_t)nwaves);
 }
 #endif
+
+DCP_DEFINE_BOUNDS_READER(read_bounds_unwarp)
 
 hipError_t read_lds_stats(unsigned long long* out, bool reset) {
   hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lds_stats), sizeof(g_lds_stats));

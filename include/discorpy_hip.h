@@ -345,6 +345,13 @@ int dcp_map_points_f64(const double* yx_in, double* yx_out, int64_t npts, double
  * to the direct gather).  Synchronises the device. */
 int dcp_debug_counters(uint64_t* out, int n, int reset);
 
+/* The bounds-checking debug build (make -C discorpy_amd/csrc bounds -> lib/libdiscorpy_hip_bounds.so, loaded through DCP_LIB_PATH;
+ * SURVEY.md section 5): every tap the staged kernels read from LDS is checked against its slab.  out[0] = taps outside their
+ * slab since the last reset (must be 0: the tile certificate says so), out[1..3] = byte offset, slab size and site number of the
+ * first one, out[4] = 1 if this library IS the checking build (0: the product build, which compiles no check and reports zeros).
+ * n >= 5.  Synchronises the device. */
+int dcp_debug_bounds(uint64_t* out, int n, int reset);
+
 /* Name of the float32 image / stack kernel the calling thread launched last, e.g.
  * "remap_wg_kernel<Radial,NF=5,f64lerp>" (empty before the first launch).  For tests and benchmarks that must say
  * -- and assert -- which kernel a call took; the reference has no counterpart. */

@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libunwarp_oracle.so")
+# ORACLE_LIB_PATH: another build of the same source, e.g. the AddressSanitizer / UBSan one (`make -C oracle asan`, tools/oracle_asan.sh)
+_LIB_PATH = os.environ.get("ORACLE_LIB_PATH") or os.path.join(_HERE, "libunwarp_oracle.so")
 
 POLY_KERNEL, POLY_NUMPY, POLY_KERNEL_MULADD = 0, 1, 2
 BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
@@ -22,6 +23,8 @@ BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
 def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     src = os.path.join(_HERE, "unwarp_oracle.c")
+    if os.environ.get("ORACLE_LIB_PATH"):
+        return _LIB_PATH
     if (force or not os.path.exists(_LIB_PATH)
             or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
         subprocess.run(["make", "-C", _HERE, "-B", "libunwarp_oracle.so"], check=True,

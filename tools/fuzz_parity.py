@@ -1,7 +1,12 @@
 """Randomised differential test: HIP path (through the Python front end and the C ABI) against the CPU oracle in the
 kernels' evaluation order -- bit for bit for orders 0/1, within one ulp on a few pixels for spline orders.
 
-    python tools/fuzz_parity.py [cases] [seed]
+    python tools/fuzz_parity.py [cases] [seed] [--bounds]
+
+--bounds: the run must be on the bounds-checking build (make -C discorpy_amd/csrc bounds; DCP_LIB_PATH=discorpy_amd/lib/
+libdiscorpy_hip_bounds.so) and ends by asserting that no LDS tap of any staged kernel left its slab (dcp_debug_bounds).
+A third of the cases are drawn so that they REACH the staged kernels (certified calibrations, float32 / 8- / 16-bit data, frames of
+at least a few tiles): remap_wg_kernel, remap_wg_batch_kernel, stack_wg_kernel, remap_wg_color_kernel.
 
 Shapes from 1 x 1 to ~1500 x 1500, centres inside and far outside the image, polynomial lengths 0..12 from mild to
 folding maps (which exercise the LDS kernel's "box does not fit" / "vote failed" fallbacks), strong homographies,
@@ -20,7 +25,8 @@ from discorpy_amd.post import postprocessing as pp    # noqa: E402
 
 MODES = orc.MODES
 BLENDS = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32": orc.BLEND_F32LERP}
-DTYPES = ["float32"] * 6 + ["float64", "uint8", "int8", "uint16", "int16", "uint32", "int32"]
+DTYPES = ["float32"] * 6 + ["float64", "uint8", "int8", "uint16", "int16", "uint32", "int32", "int64", "uint64", "bool"]
+WIDE = ("int64", "uint64", "bool")
 
 
 def rand_shape(rng):
@@ -40,8 +46,28 @@ def rand_image(rng, shape, dt):
     dt = np.dtype(dt)
     if dt.kind == "f":
         return (rng.random(shape) * 400.0 - 100.0).astype(dt)
+    if dt.kind == "b":
+        return rng.random(shape) < 0.5
     info = np.iinfo(dt)
+    if dt.itemsize == 8:
+        im = rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=dt)
+        flat = im.reshape(-1)
+        flat[::5] = rng.integers(0, 1 << 30, size=flat[::5].shape).astype(dt)
+        flat[2::9] = info.max
+        return im
     return rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=np.int64).astype(dt)
+
+
+def certified_fact(rng, h, w, xc, yc):
+    """A calibration that holds the level-2 tile certificate (what the staged kernels need): mild coefficients, checked on the host."""
+    R = float(np.hypot(h, w))
+    for _ in range(20):
+        n = int(rng.integers(1, 8))
+        f = [1.0 + float(rng.uniform(-0.03, 0.03))] + [float(rng.uniform(-0.04, 0.04)) / R ** i for i in range(1, n)]
+        fa, nf = F.fact_array(f)
+        if F.lib().dcp_debug_tile_certificate(0, h, w, xc, yc, fa, nf, None) >= 2:
+            return f
+    return [1.0]
 
 
 def rand_fact(rng, h, w):
@@ -110,8 +136,21 @@ def one_case(rng, k):
     if rng.integers(0, 5) == 0:
         xc, yc = float(round(xc)), float(round(yc))
     fact = rand_fact(rng, h, w)
+    staged = rng.integers(0, 3) == 0
+    if staged:
+        # aimed at the staged kernels: a frame of several tiles, a certified calibration, an element type they take
+        kind = ("radial", "radial", "batch", "stack", "color", "persp")[int(rng.integers(0, 6))]
+        h, w = int(rng.integers(40, 900)), int(rng.integers(130, 1400))
+        dt = ("float32", "float32", "float32", "uint8", "uint16", "int16")[int(rng.integers(0, 6))]
+        xc, yc = float(rng.uniform(0.1, 0.9) * w), float(rng.uniform(0.1, 0.9) * h)
+        fact = certified_fact(rng, h, w, xc, yc)
+        if blend == "f32" and kind == "color":
+            blend = "f64lerp"
+        for key in ("wg_box", "tile_cert"):
+            F.set_option(key, 1)
+        F.set_option("stack_wg", 2)
     okw = dict(poly=orc.POLY_KERNEL)
-    tag = "case %d %s %dx%d %s order %d blend %s xc=%r yc=%r fact=%r" % (k, kind, h, w, dt, order, blend, xc, yc, fact)
+    tag = "case %d %s%s %dx%d %s order %d blend %s xc=%r yc=%r fact=%r" % (k, "staged " if staged else "", kind, h, w, dt, order, blend, xc, yc, fact)
     f32 = dt == "float32"
     kw = dict(blend=blend) if f32 else {}
     if f32:
@@ -121,14 +160,14 @@ def one_case(rng, k):
         # float32 frames under certified calibrations share ONE launch; everything else goes frame by frame inside)
         n = int(rng.integers(1, 7))
         frames = [rand_image(rng, (h, w), dt) for _ in range(n)]
-        mild = rng.integers(0, 2) == 0
+        mild = staged or rng.integers(0, 2) == 0
         cals = []
         for _ in range(n):
             fx, fy = float(rng.uniform(0.2, 0.8) * w), float(rng.uniform(0.2, 0.8) * h)
             ff = [1.0 + float(rng.uniform(-0.02, 0.02)), float(rng.uniform(-2e-5, 2e-5)), float(rng.uniform(-2e-8, 2e-8))][:int(rng.integers(1, 4))] \
                 if mild else rand_fact(rng, h, w)
             cals.append((fx, fy, ff))
-        dev = [device_tensor(f_) for f_ in frames] if (f32 and rng.integers(0, 3) > 0) else [None]
+        dev = [device_tensor(f_) for f_ in frames] if (f32 and (staged or rng.integers(0, 3) > 0)) else [None]
         src = dev if dev[0] is not None else frames
         got = pp.unwarp_images_backward(src, [c_[0] for c_ in cals], [c_[1] for c_ in cals], [c_[2] for c_ in cals], order=order, **kw)
         for f_, c_, g_ in zip(frames, cals, got):
@@ -169,6 +208,9 @@ def one_case(rng, k):
     elif kind == "persp":
         img = rand_image(rng, (h, w), dt)
         coef = rand_coef(rng, h, w)
+        if staged:
+            coef = [1.0 + rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), rng.uniform(-0.05, 0.05) * w,
+                    rng.uniform(-0.02, 0.02), 1.0 + rng.uniform(-0.02, 0.02), rng.uniform(-0.05, 0.05) * h, rng.uniform(-1e-5, 1e-5), rng.uniform(-1e-5, 1e-5)]
         ok2 = {k_: v for k_, v in okw.items() if k_ != "poly"}
         want = orc.correct_perspective_image(img, coef, order=order, **ok2)
         same(pp.correct_perspective_image(img, coef, order=order, **kw), want, order, tag + " coef=%r" % coef)
@@ -190,8 +232,14 @@ def one_case(rng, k):
         vol = rand_image(rng, (d, h, w), dt)
         r0 = int(rng.integers(0, h))
         r1 = int(rng.integers(r0, min(h, r0 + 40)))
-        xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
-        fact = rand_fact(rng, h, w)[:8]
+        if staged:      # enough rows and projections for stack_wg_kernel, the calibration kept
+            d = int(rng.integers(2, 9))
+            vol = rand_image(rng, (d, h, w), dt)
+            r0 = int(rng.integers(0, max(1, h - 33)))
+            r1 = int(rng.integers(min(h - 1, r0 + 31), h))
+        else:
+            xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
+            fact = rand_fact(rng, h, w)[:8]
         tag += " rows %d..%d depth %d xc=%r yc=%r fact=%r" % (r0, r1, d, xc, yc, fact)
         try:
             got = pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, r0, r1, **kw)
@@ -230,6 +278,8 @@ def one_case(rng, k):
             h, w = int(rng.integers(900, 1700)), int(rng.integers(900, 1700))
         else:
             h, w = min(h, 300), min(w, 300)
+        if dt in WIDE:                      # (orders >= 2 on 64-bit integers / bool: float64 noise of the recursive filter decides the
+            dt = "int32"                     # stored integer near the overflow and near 1.0 -- tests/test_oracle_golden.py wide_close)
         img = rand_image(rng, (h, w), dt)
         so = int(rng.integers(2, 6))
         mode = MODES[int(rng.integers(0, 8))]
@@ -240,15 +290,17 @@ def one_case(rng, k):
              orc.unwarp_image_backward(img, xc, yc, fact, order=so, mode=mode, poly=orc.POLY_KERNEL), so, tag)
     else:
         from discorpy_amd.util import utility as util
-        h, w = min(max(h, 2), 300), min(max(w, 2), 300)
-        c = int(rng.integers(1, 5))
+        if staged:
+            c = int(rng.integers(3, 5))
+            pad = 0
+        else:
+            h, w = min(max(h, 2), 300), min(max(w, 2), 300)
+            c = int(rng.integers(1, 5))
+            pad = int(rng.integers(0, 6))
+            xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
+            fact = rand_fact(rng, h, w)[:6]
         rgb = rand_image(rng, (h, w, c), dt)
-        pad = int(rng.integers(0, 6))
-        xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
-        fact = rand_fact(rng, h, w)[:6]
         got = util.unwarp_color_image_backward(rgb, xc, yc, fact, order=order, pad=pad, pad_mode="edge", **kw)
-        if f32 and blend != "f32":
-            okw["blend"] = BLENDS["scipy"]      # the interleaved kernel always blends in scipy's exact order
         padded = np.pad(rgb, [(pad, pad), (pad, pad), (0, 0)], mode="edge")
         for ch in range(c):
             want = orc.unwarp_image_backward(np.ascontiguousarray(padded[:, :, ch]), xc + pad, yc + pad, fact, order=order, **okw)
@@ -257,8 +309,10 @@ def one_case(rng, k):
 
 
 def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 400
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20260928
+    argv = [v for v in sys.argv[1:] if not v.startswith("--")]
+    want_bounds = "--bounds" in sys.argv[1:]
+    cases = int(argv[0]) if len(argv) > 0 else 400
+    seed = int(argv[1]) if len(argv) > 1 else 20260928
     orc.build()
     orc.set_threads(min(32, orc.max_threads()))
     F.lib()
@@ -266,6 +320,9 @@ def main():
     rng = np.random.default_rng(seed)
     counts, kernels, t0 = {}, {}, time.time()
     F.debug_counters()
+    checking = F.debug_bounds()[4] == 1
+    if want_bounds and not checking:
+        raise SystemExit("--bounds needs the checking build: make -C discorpy_amd/csrc bounds; DCP_LIB_PATH=discorpy_amd/lib/libdiscorpy_hip_bounds.so")
     # every kernel a case launched, not only its last one: each C-ABI call of the front end passes through F.check
     launched, plain_check = set(), F.check
 
@@ -284,11 +341,16 @@ def main():
         for name in launched:
             kernels[name] = kernels.get(name, 0) + 1
     nofit, vote = F.debug_counters()
+    bounds = F.debug_bounds()
     for key in ("stack_lds", "stack_wg", "wg_box", "tile_cert"):
         F.set_option(key, 1)
     print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; cases in which each kernel ran: %s; LDS-kernel fallbacks exercised: "
           "%d tiles did not fit, %d tiles failed the vote" % (cases, seed, time.time() - t0, dict(sorted(counts.items())),
                                                               dict(sorted(kernels.items())), nofit, vote))
+    if checking:
+        print("bounds-checking build: %d LDS taps outside their slab%s" % (bounds[0], "" if not bounds[0] else
+                                                                            " (first: byte %d of a %d-byte slab, site %d)" % bounds[1:4]))
+        assert bounds[0] == 0, bounds
 
 
 if __name__ == "__main__":
