@@ -76,6 +76,19 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
+def kernel_sources_digest():
+    """SHA-256 over the sources the library is built from (discorpy_amd/csrc): what ties a committed PMC figure
+    (profiles/pmc_latest.json, written by tools/profile.sh on the GPU box) to the code that is being timed."""
+    import hashlib
+    d = os.path.join(ROOT, "discorpy_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp", ".map")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 def usable_cpus():
     """CPUs this process may really use: the smaller of the affinity mask and the cgroup quota (the GPU boxes
     show 256 logical CPUs but grant 16; running 64 threads there is slower than running 16)."""
@@ -1028,13 +1041,22 @@ def grid_search_centres(a, dev):
                                      blend=orc.BLEND_F64LERP)
         got = download(out.ptr, (chunk.shape[0], 1, W), dev, offset=k * D * W * 4)
         ok = ok and bool(np.array_equal(got, want))
+    # algorithmic bytes of the BATCHED call: every voxel of the (K, D, 1, W) result written once, and the source rows any centre reads
+    # (their union over the K centres: dcp_stack_row_band per centre) read once per projection -- not K times the single call's 12 B
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    b0, b1 = H, 0
+    for cx, cy in cents:
+        F.check(L.dcp_stack_row_band(H, W, cx, cy, fa, nf, row, 1, C.byref(lo), C.byref(hi)))
+        b0, b1 = min(b0, lo.value), max(b1, lo.value + hi.value)          # (band_start, band_rows)
+    alg = 4.0 * K * D * W + 4.0 * D * max(b1 - b0, 1) * W
     vol.free()
     out.free()
-    return entry(us, K * D * W, 12, kernel, ok, centres=K, depth=D,
+    return entry(us, K * D * W, round(alg / (K * D * W), 4), kernel, ok, centres=K, depth=D,
+                 source_rows_read_per_projection=int(b1 - b0), algorithmic_bytes_per_launch=int(alg),
                  the_same_as_single_calls_us=round(us_single, 2),
-                 note="%d candidate centres x one sinogram of a depth-%d shard in one launch; 12 B per voxel is the single-call figure (two source "
-                      "rows read per output row) -- here every centre reads the same rows, so HBM sees them once and the fraction may exceed "
-                      "what a single call could reach" % (K, D))
+                 note="%d candidate centres x one sinogram of a depth-%d shard in one launch.  Algorithmic bytes of THIS call: the (K, D, 1, W) "
+                      "result written once + the union of the source rows the centres read, once per projection (a single call moves 12 B per "
+                      "voxel; here the source is shared by all centres)" % (K, D))
 
 
 # ----------------------------------------------------------------------------------------- main
@@ -1064,11 +1086,11 @@ def stack_traffic(a, world, kernel):
     try:
         j = json.load(open(pmc)).get("stack_shard256")
         if j and a.depth // world == 256 and a.rows == 2560 and kernel.split("<")[0] in j.get("rocprof_kernel_name", ""):
-            return {"traffic": j.get("hbm_bytes_per_launch"),
+            return {"traffic": j.get("hbm_bytes_per_launch"), "traffic_stale": json.load(open(pmc)).get("kernel_sources_sha256") != kernel_sources_digest(),
                     "traffic_source": "profiles/pmc_latest.json: rocprofv3 PMC passes of %s on a 256-projection shard, not measured in this run" % j.get("rocprof_kernel_name")}
     except Exception:      # noqa: BLE001
         pass
-    return {"traffic": None, "traffic_source": None}
+    return {"traffic": None, "traffic_source": None, "traffic_stale": None}
 
 
 def stack_main(a, world, rank, dev, dist, backend):
@@ -1360,15 +1382,16 @@ def main(argv=None):
         value = total_pix / wall / 1e6
         launch_us = dev_ms * 1e3 / launches
         achieved = configs.BYTES_PER_PIXEL * pix_per_launch / (launch_us * 1e-6) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_stale = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
                 if j.get("kernel", "").split("<")[0] == headline_kernel.split("<")[0]:
                     traffic = j.get("hbm_bytes_per_launch")
-                    traffic_source = "profiles/pmc_latest.json: rocprofv3 PMC passes of %s over this command (%s), not measured in this run" % (
-                        j.get("kernel"), j.get("collected", "date not recorded"))
+                    traffic_stale = j.get("kernel_sources_sha256") != kernel_sources_digest()
+                    traffic_source = "profiles/pmc_latest.json: rocprofv3 PMC passes of %s over this command (%s, commit %s), not measured in this run" % (
+                        j.get("kernel"), j.get("collected", "date not recorded"), j.get("git_commit", "not recorded"))
                 else:
                     traffic_source = "none: profiles/pmc_latest.json is of %s, this run launched %s" % (j.get("kernel"), headline_kernel)
             except Exception:      # noqa: BLE001
@@ -1387,11 +1410,24 @@ def main(argv=None):
                        "parallelism": "independent frames per GPU (no collective)" if n_gpus > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "traffic_source": traffic_source, "kernel": headline_kernel, "launch_us": round(launch_us, 3),
+                         "traffic_source": traffic_source,
+                         # true: the kernel sources were edited after the counters were collected (SHA-256 over discorpy_amd/csrc)
+                         "traffic_stale": traffic_stale, "kernel": headline_kernel, "launch_us": round(launch_us, 3),
                          "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch),
                          "d2d_copy_same_frames_GBps": copy_gbps, "per_launch_distribution": dist_launch},
             "verified_vs_oracle": verified,
         }
+        # the other BASELINE configurations as top-level scalars too (whatever keeps only part of this line keeps more than one
+        # number): cfg3 fused perspective o radial, cfg4 whole stack on one GPU, cfg5 8192^2 9-term, the colour frame
+        if isinstance(others, dict) and "error" not in others:
+            def pick(name, key, scale=1.0):
+                v = others.get(name)
+                return None if not isinstance(v, dict) or key not in v else round(v[key] * scale, 4)
+            out["cfg3_fused_us"], out["cfg3_fused_frac"] = pick("cfg3_fused", "launch_us"), pick("cfg3_fused", "frac")
+            out["cfg4_stack_ms"], out["cfg4_stack_frac"] = pick("cfg4_stack_one_gpu", "launch_us", 1e-3), pick("cfg4_stack_one_gpu", "frac")
+            out["cfg5_us"], out["cfg5_frac"] = pick("cfg5_frame8192_radial9", "launch_us"), pick("cfg5_frame8192_radial9", "frac")
+            out["color_4096x3_us"], out["color_4096x3_frac"] = pick("color_4096x3", "launch_us"), pick("color_4096x3", "frac")
+            out["cubic_spline_us"] = pick("cfg2_order3_cubic_spline", "launch_us")
         if box is not None:
             out["box"] = box
         if others is not None:

@@ -20,6 +20,52 @@ import numpy as np
 _MIN_BYTES = 1 << 20          # smaller outputs are not worth tracking
 _PIN_MIN_BYTES = 16 << 20     # blocks from this size on are registered with the GPU (the library's direct-write path starts there)
 
+# Registered (pinned, unswappable) host memory is bounded: a caller who keeps many large results alive -- 1800 projections, a centre
+# grid -- must not pin tens of GB through thousands of registrations.  Blocks are registered only while the total stays below the
+# cap (DISCORPY_AMD_PIN_MAX_MB, default: the pool's cap) and only where the library would actually take its direct-write path
+# (dcp_get_option "host_direct_applies": the runtime cannot overlap an upload with a download, or host_direct = 2); beyond that a
+# block is plain memory and the staged path serves it.
+_pin_lock = threading.Lock()
+_pinned_bytes = 0
+_direct_applies = None
+
+
+def _pin_cap():
+    v = os.environ.get("DISCORPY_AMD_PIN_MAX_MB")
+    return int(float(v) * (1 << 20)) if v is not None else int(float(os.environ.get("DISCORPY_AMD_HOST_POOL_MB", "1024")) * (1 << 20))
+
+
+def _may_pin(nbytes):
+    """Reserve `nbytes` of the pinned budget (True) or refuse."""
+    global _pinned_bytes, _direct_applies
+    if nbytes < _PIN_MIN_BYTES or os.environ.get("DISCORPY_AMD_PIN_OUTPUTS", "1") == "0":
+        return False
+    try:
+        from . import _ffi as F
+        if F.device_count() <= 0:
+            return False
+        if _direct_applies is None or F.get_option("host_direct") == 2:
+            _direct_applies = bool(F.get_option("host_direct_applies"))
+        if not _direct_applies:
+            return False
+    except Exception:      # noqa: BLE001 -- no library / no device
+        return False
+    with _pin_lock:
+        if _pinned_bytes + nbytes > _pin_cap():
+            return False
+        _pinned_bytes += nbytes
+        return True
+
+
+def _unpin(nbytes):
+    global _pinned_bytes
+    with _pin_lock:
+        _pinned_bytes = max(0, _pinned_bytes - nbytes)
+
+
+def pinned_bytes():
+    return _pinned_bytes
+
 
 class _Block:
     """One block of the pool: a uint8 array, registered with the GPU (hipHostRegister through dcp_host_register) when it is large
@@ -32,15 +78,16 @@ class _Block:
     def __init__(self, nbytes):
         self.arr = np.empty(nbytes, np.uint8)
         self.registered = False
-        if nbytes >= _PIN_MIN_BYTES and os.environ.get("DISCORPY_AMD_PIN_OUTPUTS", "1") != "0":
+        if _may_pin(nbytes):
             try:
                 from . import _ffi as F
-                if F.device_count() > 0:
-                    self.arr[::4096] = 0                      # fault the pages in before they are pinned
-                    dev = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
-                    self.registered = F.lib().dcp_host_register(self.arr.ctypes.data, nbytes, dev) == 0
-            except Exception:      # noqa: BLE001 -- no library / no device: a plain block
+                self.arr[::4096] = 0                      # fault the pages in before they are pinned
+                dev = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
+                self.registered = F.lib().dcp_host_register(self.arr.ctypes.data, nbytes, dev) == 0
+            except Exception:      # noqa: BLE001 -- a plain block
                 self.registered = False
+            if not self.registered:
+                _unpin(nbytes)
 
     @property
     def nbytes(self):
@@ -49,6 +96,7 @@ class _Block:
     def release(self):
         if self.registered:
             self.registered = False
+            _unpin(self.arr.nbytes)
             try:
                 from . import _ffi as F
                 F.lib().dcp_host_unregister(self.arr.ctypes.data)
@@ -145,7 +193,8 @@ def empty(shape, dtype):
 
 
 def stats():
-    return {"hits": _pool.hits, "misses": _pool.misses, "idle_bytes": _pool.idle_bytes, "cap_bytes": _pool.cap}
+    return {"hits": _pool.hits, "misses": _pool.misses, "idle_bytes": _pool.idle_bytes, "cap_bytes": _pool.cap,
+            "pinned_bytes": _pinned_bytes, "pin_cap_bytes": _pin_cap()}
 
 
 def clear():

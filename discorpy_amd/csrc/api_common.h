@@ -107,6 +107,7 @@ struct HostStreams {
 };
 extern thread_local HostStreams g_host_streams;
 
+bool host_direct_applies();      // api_image.cpp
 int sampler_of(int order, int blend_mode, int* sampler);
 int check_image(const void* src, const void* dst, int64_t H, int64_t W, int64_t rs, int64_t cs);
 int check_image_typed(const void* src, const void* dst, int dtype, int64_t H, int64_t W, int64_t rs, int64_t cs);

@@ -535,6 +535,10 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else if (!strcmp(key, "int_exact")) *value = g_int_exact;
   else if (!strcmp(key, "host_direct")) *value = g_host_direct;
+  else if (!strcmp(key, "host_direct_applies")) {        // read-only: measures the runtime once (needs a device)
+    int n = 0;
+    *value = (hipGetDeviceCount(&n) == hipSuccess && n > 0 && host_direct_applies()) ? 1 : 0;
+  }
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
   return DCP_OK;
 }

@@ -36,6 +36,11 @@ int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, in
 // Does this HIP runtime move pageable data in both PCIe directions at once when two host threads copy on two
 // streams?  ROCm 7.2's does (45 GB/s each way); the runtime bundled with PyTorch-ROCm 2.10 serialises the two
 // directions, and the banded path then only adds overhead.  Measured once per process on 32 MiB buffers.
+// (dcp_get_option("host_direct_applies"): would a registered float32 host destination be written directly?  The Python pool
+// pins its blocks only then)
+bool runtime_overlaps_directions();
+bool host_direct_applies_here() { return g_host_direct.load() && (g_host_direct.load() == 2 || !g_host_duplex.load() || !runtime_overlaps_directions()); }
+
 bool runtime_overlaps_directions() {
   static std::once_flag once;
   static bool overlaps = false;
@@ -153,16 +158,22 @@ int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix
   return DCP_OK;
 }
 
-// Is `p` host memory the GPU can address (hipHostRegister / hipHostMalloc)?  Returns its device-visible address, or nullptr.
-void* registered_host_alias(const void* p) {
-  hipPointerAttribute_t attr;
-  memset(&attr, 0, sizeof(attr));
-  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+// Is [p, p + bytes) host memory the GPU can address (hipHostRegister / hipHostMalloc)?  Returns its device-visible address, or
+// nullptr.  BOTH ends are asked about: a view that starts inside a registered range shorter than the frame (a C caller's partly
+// registered buffer, a NumPy view past a pinned block) must take the staged path, or the kernels would store to unmapped memory.
+void* registered_host_alias(const void* p, size_t bytes) {
+  if (!bytes) return nullptr;
+  hipPointerAttribute_t first, last;
+  memset(&first, 0, sizeof(first));
+  memset(&last, 0, sizeof(last));
+  if (hipPointerGetAttributes(&first, p) != hipSuccess || hipPointerGetAttributes(&last, (const char*)p + (bytes - 1)) != hipSuccess) {
     (void)hipGetLastError();            // plain pageable memory: not an error
     return nullptr;
   }
-  if (attr.type != hipMemoryTypeHost || !attr.devicePointer) return nullptr;
-  return attr.devicePointer;
+  if (first.type != hipMemoryTypeHost || last.type != hipMemoryTypeHost || !first.devicePointer || !last.devicePointer) return nullptr;
+  // one mapping from end to end: the device alias advances exactly as the host pointer does
+  if ((const char*)last.devicePointer - (const char*)first.devicePointer != (ptrdiff_t)(bytes - 1)) return nullptr;
+  return first.devicePointer;
 }
 
 // Host frame whose DESTINATION is registered host memory (the recycled outputs of the Python front end are; so is anything a C
@@ -259,7 +270,7 @@ int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_
   if (g_host_direct.load() && cs == 1 && H >= 512 && W >= 2 && (double)H * (double)W * 4.0 >= 16.0 * 1048576.0 &&
       (double)H * (double)W * 4.0 <= 4294967040.0 && (kind == dcp::kRadial || map.fast_div) &&
       (g_host_direct.load() == 2 || !g_host_duplex.load() || !runtime_overlaps_directions()))
-    dst_alias = registered_host_alias(dst);
+    dst_alias = registered_host_alias(dst, (size_t)H * (size_t)W * sizeof(float));
   if (dst_alias) {
     auto band_rows = [&](int64_t r0, int64_t n, int64_t* b0, int64_t* b1) {
       if (kind == dcp::kRadial) {
@@ -500,6 +511,10 @@ int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, in
 }
 
 }  // namespace
+
+namespace dcpapi {
+bool host_direct_applies() { return host_direct_applies_here(); }
+}  // namespace dcpapi
 
 extern "C" {
 

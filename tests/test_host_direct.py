@@ -66,3 +66,50 @@ def test_direct_write_into_registered_host_memory_equals_the_staged_path(hip, or
     b = pp.unwarp_image_backward(img, xc, yc, fact)
     assert b.ctypes.data == addr and np.array_equal(b, want["radial"])
     _pool.clear()
+
+
+@pytest.mark.gpu
+def test_a_destination_registered_only_in_part_takes_the_staged_path(hip, orc):
+    """the direct path asked about the FIRST byte of the destination only; a frame that starts inside a registered range
+    shorter than itself would have been stored to through an alias that ends early."""
+    H, W = 2200, 2100
+    img = noise(502, (H, W))
+    xc, yc, fact = 1010.4, 1120.7, [1.0, -8e-6, 6e-9, -2e-12]
+    want = orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+    L = hip.lib()
+    out = np.zeros((H, W), np.float32)
+    half = (out.nbytes // 2) & ~4095
+    hip.set_option("host_direct", 2)
+    hip.check(L.dcp_host_register(out.ctypes.data, half, -1))
+    try:
+        res = pp.unwarp_image_backward(img, xc, yc, fact, out=out)
+        assert res is out and np.array_equal(out, want)
+    finally:
+        hip.check(L.dcp_host_unregister(out.ctypes.data))
+        hip.set_option("host_direct", 1)
+
+
+@pytest.mark.gpu
+def test_pinned_output_memory_is_bounded(hip, monkeypatch):
+    """results a caller keeps alive are pinned only up to a cap (default: the pool's), and only where the direct path
+    can be taken at all."""
+    H, W = 2200, 2100                                       # 18.5 MB per result
+    img = noise(503, (H, W))
+    _pool.clear()
+    monkeypatch.setenv("DISCORPY_AMD_PIN_MAX_MB", "40")
+    hip.set_option("host_direct", 2)
+    try:
+        base = _pool.pinned_bytes()
+        keep = [pp.unwarp_image_backward(img, 1000.0, 1100.0, [1.0, -8e-6]) for _ in range(4)]
+        assert _pool.pinned_bytes() - base <= 40 * (1 << 20) and _pool.pinned_bytes() - base >= H * W * 4      # two pinned, two plain
+        assert all(np.array_equal(k, keep[0]) for k in keep)
+        hip.set_option("host_direct", 0)                     # the direct path cannot be taken: nothing new is pinned
+        now = _pool.pinned_bytes()
+        more = pp.unwarp_image_backward(img, 1000.0, 1100.0, [1.0, -8e-6])
+        assert _pool.pinned_bytes() == now and np.array_equal(more, keep[0])
+        del keep, more
+        _pool.clear()
+        assert _pool.pinned_bytes() == base
+    finally:
+        hip.set_option("host_direct", 1)
+        _pool.clear()

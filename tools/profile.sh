@@ -8,6 +8,8 @@ TAG=${1:-run}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+# what the counters belong to: the digest of the kernel sources of THIS tree (bench.py compares it with the tree it times)
+(cd "$ROOT" && python -c "import bench; print(bench.kernel_sources_digest())" > "$OUT/kernel_sources.sha256" 2>/dev/null)
 export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras $*"      # counter passes: the headline kernel only
 BENCH_FULL="python $ROOT/bench.py --no-cpu-baseline $*"    # the timing pass profiles the default command: headline + every other configuration

@@ -24,6 +24,17 @@ if "--latest" in sys.argv:
             best = dict(v, kernel=k.replace("void dcp::", "").split("(")[0].replace("<0, 5, 2, float>", "<Radial,NF=5,f64lerp>"),
                         rocprof_kernel_name=k, source=tag + "_rocprofv3_summary.json", collected=datetime.date.today().isoformat())
     if best:
+        sys.path.insert(0, root)
+        import subprocess
+        import bench
+        dig = os.path.join(src, "kernel_sources.sha256")
+        best["kernel_sources_sha256"] = open(dig).read().strip() if os.path.exists(dig) else None
+        try:      # the commit this tree is at, and whether its kernel sources are still the profiled ones
+            best["git_commit"] = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+            dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--", "discorpy_amd/csrc"], capture_output=True, text=True).stdout.strip()
+            best["git_commit_holds_the_profiled_sources"] = (not dirty) and best["kernel_sources_sha256"] == bench.kernel_sources_digest()
+        except Exception:      # noqa: BLE001
+            best["git_commit"] = None
         for k, v in summ.get("traffic", {}).items():       # the stack kernel's pass: config 4, a 256-projection shard, every row
             if "stack_wg_kernel" in k or "stack_lds_kernel" in k:
                 best["stack_shard256"] = dict(v, rocprof_kernel_name=k, algorithmic_bytes_per_launch=8 * 256 * 2560 * 2560)
