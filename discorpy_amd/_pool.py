@@ -27,7 +27,6 @@ _PIN_MIN_BYTES = 16 << 20     # blocks from this size on are registered with the
 # block is plain memory and the staged path serves it.
 _pin_lock = threading.Lock()
 _pinned_bytes = 0
-_direct_applies = None
 
 
 def _pin_cap():
@@ -37,16 +36,14 @@ def _pin_cap():
 
 def _may_pin(nbytes):
     """Reserve `nbytes` of the pinned budget (True) or refuse."""
-    global _pinned_bytes, _direct_applies
+    global _pinned_bytes
     if nbytes < _PIN_MIN_BYTES or os.environ.get("DISCORPY_AMD_PIN_OUTPUTS", "1") == "0":
         return False
     try:
         from . import _ffi as F
         if F.device_count() <= 0:
             return False
-        if _direct_applies is None or F.get_option("host_direct") == 2:
-            _direct_applies = bool(F.get_option("host_direct_applies"))
-        if not _direct_applies:
+        if not F.get_option("host_direct_applies"):         # (two atomic loads and a once-per-process probe inside the library)
             return False
     except Exception:      # noqa: BLE001 -- no library / no device
         return False
