@@ -472,6 +472,11 @@ int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, in
     im.src_col_stride = 1;
     im.src_bytes = (uint32_t)extent_bytes_typed(H, W, rs_, 1, dtype);
     im.xcd_remap = current_opts().xcd_remap;
+    if (kind == dcp::kRadial && (dtype == dcp::kF64 || dtype == dcp::kI32 || dtype == dcp::kU32)) {
+      // 4- and 8-byte element types: the interleaved-pixel kernel with one channel (color_kernels.hip)
+      im.src_col_stride = 1;
+      return dcp::launch_color(im, mapc, 1, dtype, order == 0 ? dcp::kNearest : dcp::kScipy, current_opts(), st, taken);
+    }
     return dcp::launch_wg_typed(kind, im, mapc, order, dtype, current_opts(), st, taken);
   };
   if (mem_kind == DCP_MEM_DEVICE) {

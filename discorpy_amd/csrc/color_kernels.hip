@@ -125,6 +125,12 @@ __device__ __forceinline__ void store_pixel(const T (&v)[NC], __amdgpu_buffer_rs
   } else if constexpr (std::is_same<T, float>::value && NC == 2) {
     u32x2c p = {__float_as_uint(v[0]), __float_as_uint(v[1])};
     __builtin_amdgcn_raw_buffer_store_b64(p, dst, voff, soff, DCP_COLOR_STORE_AUX);
+  } else if constexpr (std::is_same<T, double>::value && NC == 1) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v[0]);
+    u32x2c p = {(uint32_t)b, (uint32_t)(b >> 32)};
+    __builtin_amdgcn_raw_buffer_store_b64(p, dst, voff, soff, DCP_COLOR_STORE_AUX);
+  } else if constexpr (sizeof(T) == 4 && NC == 1) {                      // int32 / uint32
+    __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v[0], dst, voff, soff, DCP_COLOR_STORE_AUX);
   } else if constexpr (PS == 4) {                                        // 4 x 8-bit, 2 x 16-bit
     uint32_t p = 0;
 #pragma unroll
@@ -343,7 +349,8 @@ static hipError_t launch_color_t(const ImageArgs& img_in, const MapArgs& map, hi
   const dim3 grid(img.xcd_remap == 2 ? 8 * ((img.tiles_x + 7) / 8) : img.tiles_x, img.tiles_y);
   char name[96];
   snprintf(name, sizeof(name), "remap_wg_color_kernel<NF=%d,%s,%s x %d>", NF, SAMPLER == kNearest ? "nearest" : SAMPLER == kScipy ? "scipy" : "f64lerp",
-           std::is_same<T, float>::value ? "float32" : sizeof(T) == 2 ? "uint16" : "uint8", NC);
+           std::is_same<T, float>::value ? "float32" : std::is_same<T, double>::value ? "float64" : std::is_same<T, int32_t>::value ? "int32"
+           : std::is_same<T, uint32_t>::value ? "uint32" : sizeof(T) == 2 ? "uint16" : "uint8", NC);
   set_last_kernel_name(name);
   hipLaunchKernelGGL((remap_wg_color_kernel<NF, SAMPLER, T, NC>), grid, dim3(256), 0, stream, img, map);
   return hipGetLastError();
@@ -379,15 +386,22 @@ static hipError_t launch_color_c(const ImageArgs& img, const MapArgs& map, int c
   if (channels == 3) return launch_color_s<T, 3>(img, map, sampler, stream);
   return launch_color_s<T, 4>(img, map, sampler, stream);
 }
+// single-plane frames of the 4- and 8-byte element types the single-plane kernel (remap_wg_kernel: float32, 8- / 16-bit) does not take
+template <typename T>
+static hipError_t launch_plane(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
+  return launch_color_s<T, 1>(img, map, sampler, stream);
+}
 
-// Interleaved pixels of 3 or 4 channels, float32 / uint8 / uint16, dense (pixel stride = channels), radial map under the level-2
-// certificate, orders 0 / 1.  *taken = false: the call does not qualify and typed_channels_kernel must serve it.
+// Interleaved pixels of 3 or 4 channels, float32 / uint8 / uint16 -- or ONE channel of float64 / int32 / uint32 (the single-plane
+// frames remap_wg_kernel has no instantiation for) --, dense (pixel stride = channels), radial map under the level-2
+// certificate, orders 0 / 1.  *taken = false: the call does not qualify and the one-thread-per-pixel kernels must serve it.
 hipError_t launch_color(const ImageArgs& img_in, const MapArgs& map, int channels, int dtype, int sampler, const LaunchOpts& opts, hipStream_t stream,
                         bool* taken) {
   *taken = false;
   if (map.tile_dev_ok < 2 || !opts.wg_box || !opts.lds_gather || opts.coef_lds || opts.xcd_remap == 1) return hipSuccess;
-  if (channels != 3 && channels != 4) return hipSuccess;
-  if (dtype != kF32 && dtype != kU8 && dtype != kU16) return hipSuccess;
+  const bool colour = (channels == 3 || channels == 4) && (dtype == kF32 || dtype == kU8 || dtype == kU16);
+  const bool plane = channels == 1 && (dtype == kF64 || dtype == kI32 || dtype == kU32);
+  if (!colour && !plane) return hipSuccess;
   if (sampler != kNearest && sampler != kScipy && !(sampler == kF64Lerp && dtype == kF32)) return hipSuccess;
   const int es = elem_size(dtype);
   ImageArgs img = img_in;
@@ -404,7 +418,10 @@ hipError_t launch_color(const ImageArgs& img_in, const MapArgs& map, int channel
   switch (dtype) {
     case kF32: return launch_color_c<float>(img, map, channels, sampler, stream);
     case kU8: return launch_color_c<uint8_t>(img, map, channels, sampler, stream);
-    default: return launch_color_c<uint16_t>(img, map, channels, sampler, stream);
+    case kU16: return launch_color_c<uint16_t>(img, map, channels, sampler, stream);
+    case kF64: return launch_plane<double>(img, map, sampler, stream);
+    case kI32: return launch_plane<int32_t>(img, map, sampler, stream);
+    default: return launch_plane<uint32_t>(img, map, sampler, stream);
   }
 }
 

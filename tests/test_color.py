@@ -117,3 +117,25 @@ def test_device_resident_4096_rgb_and_a_band_of_rows(hip, orc):
             got = ddst.download((H, W, NC), np.float32)
             want = planes_from_oracle(orc, rgb, xc, yc, fact, 1, ob)
             assert np.array_equal(got, want), (fact, ob, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("dt", ["float64", "int32", "uint32"])
+def test_single_plane_frames_of_wide_element_types_on_the_staged_kernel(hip, orc, dt):
+    """float64 / int32 / uint32 frames (they ran on the one-thread-per-pixel kernel): the interleaved-pixel
+    kernel with ONE channel -- scipy's exact blend and store, bit-equal to the oracle; device-resident and host (banded) calls."""
+    from discorpy_amd.post import postprocessing as pp
+    for (h, w), (xc, yc), fact in (((700, 1100), (500.2, 333.3), [1.0, -3e-5, 4e-8]), ((2300, 2048), (1000.5, 1200.0), FACT5), ((33, 150), (70.0, 12.0), [1.01, 1e-5])):
+        im = typed_image(dt, (h, w), 17)
+        yd, xd = orc.radial_coords(h, w, xc, yc, fact, poly=orc.POLY_KERNEL)
+        for order in (1, 0):
+            got = pp.unwarp_image_backward(im, xc, yc, fact, order=order)
+            assert hip.last_kernel().startswith("remap_wg_color_kernel") and (dt + " x 1") in hip.last_kernel(), hip.last_kernel()
+            assert got.dtype == im.dtype and np.array_equal(got, orc.map_coordinates(im, yd, xd, order)), (dt, h, w, order)
+    import torch
+    t = torch.from_numpy(typed_image(dt, (600, 900), 18).astype(np.int64 if dt == "uint32" else dt)) if dt == "uint32" else torch.from_numpy(typed_image(dt, (600, 900), 18))
+    if dt != "uint32":                 # (torch has no uint32 arithmetic type worth the detour)
+        dev = pp.unwarp_image_backward(t.cuda(), 400.0, 300.0, [1.0, 2e-5])
+        torch.cuda.synchronize()
+        assert hip.last_kernel().startswith("remap_wg_color_kernel")
+        yd, xd = orc.radial_coords(600, 900, 400.0, 300.0, [1.0, 2e-5], poly=orc.POLY_KERNEL)
+        assert np.array_equal(dev.cpu().numpy(), orc.map_coordinates(t.numpy(), yd, xd, 1))

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--ring", type=int, default=6)
     ap.add_argument("--reps", type=int, default=60)
-    ap.add_argument("--cases", default="f32x3,f32x4,u8x3,u16x3")
+    ap.add_argument("--cases", default="f32x3,f32x4,u8x3,u16x3,f64x1,i32x1")
     ap.add_argument("--no-generic", action="store_true")
     a = ap.parse_args()
     L = F.lib()
@@ -35,7 +35,7 @@ def main():
     xc, yc = cfg["xcenter"] * s, cfg["ycenter"] * s
     fa, nf = F.fact_array(fact)
     H = W = a.size
-    dt = {"f32": ("float32", 0), "u8": ("uint8", 2), "u16": ("uint16", 4)}
+    dt = {"f32": ("float32", 0), "u8": ("uint8", 2), "u16": ("uint16", 4), "f64": ("float64", 1), "i32": ("int32", 7)}
     rng = np.random.default_rng(3)
     for case in a.cases.split(","):
         tname, nc = case.split("x")
@@ -44,11 +44,23 @@ def main():
         es = np.dtype(npdt).itemsize
         nbytes = H * W * nc * es
         ring = max(2, min(a.ring, int(3e9 // (2 * nbytes)) or 2))
-        img = (rng.random((H, W, nc), dtype=np.float32) * (255 if tname != "f32" else 1)).astype(npdt)
+        img = (rng.random((H, W, nc), dtype=np.float32) * (255 if tname not in ("f32", "f64") else 1)).astype(npdt)
         srcs = [F.DeviceBuffer(nbytes, dev).upload(img) for _ in range(ring)]
         dsts = [F.DeviceBuffer(nbytes, dev) for _ in range(ring)]
         for name, order, blend in (("f64lerp", 1, F.BLEND_F64LERP), ("scipy", 1, F.BLEND_SCIPY), ("nearest", 0, F.BLEND_SCIPY)):
             if tname != "f32" and name == "f64lerp":
+                continue
+
+            if nc == 1:        # single planes go through the typed image entry point
+                def run(i):
+                    F.check(L.dcp_unwarp_image_typed(srcs[i % ring].ptr, dsts[i % ring].ptr, code, H, W, W, 1, xc, yc, fa, nf, order, 0, F.MEM_DEVICE, dev, None))
+                t = bench.timed_launches(run, a.reps, dev, settle_ms=300.0)
+                k = F.last_kernel()
+                F.set_option("wg_box", 0)
+                tg = bench.timed_launches(run, max(4, a.reps // 4), dev, settle_ms=100.0)
+                F.set_option("wg_box", 1)
+                print("%-6s %-8s %8.2f us  %.3f of 8 TB/s (%d B/px)  %s   | one thread per pixel: %.2f us" % (
+                    case, name, t, 2 * nbytes / (t * 1e-6) / 8e12, 2 * es, k, tg), flush=True)
                 continue
 
             def run(i):
