@@ -93,8 +93,8 @@ class _Block:
     def release(self):
         if self.registered:
             self.registered = False
-            _unpin(self.arr.nbytes)
             try:
+                _unpin(self.arr.nbytes)
                 from . import _ffi as F
                 F.lib().dcp_host_unregister(self.arr.ctypes.data)
             except Exception:      # noqa: BLE001 -- interpreter shutdown

@@ -18,7 +18,10 @@ const char* last_error();
 #define DCP_HIP(expr)                                                                                      \
   do {                                                                                                     \
     hipError_t e_ = (expr);                                                                                \
-    if (e_ != hipSuccess) return dcpapi::fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    if (e_ != hipSuccess) {                                                                                \
+      (void)hipGetLastError(); /* reported here: must not resurface as the next launch's hipGetLastError */ \
+      return dcpapi::fail(DCP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                     \
+    }                                                                                                      \
   } while (0)
 
 extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb, g_stack_lds, g_host_duplex, g_host_bands, g_tile_cert, g_wg_box, g_wg_per_cu, g_stack_wg, g_int_exact, g_host_direct;

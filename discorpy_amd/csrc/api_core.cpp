@@ -16,6 +16,9 @@ int fail(int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+  // a HIP failure is reported HERE; the runtime's sticky "last error" must not resurface as the hipGetLastError() of the next,
+  // unrelated launch
+  if (code == DCP_ERR_HIP) (void)hipGetLastError();
   return code;
 }
 

@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(256, (ColorGeom<T, NC>::kSlabBytes <= 53 * 102
     const uint32_t negorg = (uint32_t)(-(by0 * PB + bx0 * PS));
     const char* boxb = (const char*)s_box;
     const bool interior = bx1 < img.W - 1 && by1 < img.H - 1;
-    auto tile_rows_loop = [&](auto inner) {
+    auto tile_rows_loop = [&](auto inner, auto exact) {
 #pragma unroll
       for (int k = 0; k < RPW; ++k) {
         int xi = (int)xf[k], yi = (int)yf[k];
@@ -299,14 +299,34 @@ __global__ void __launch_bounds__(256, (ColorGeom<T, NC>::kSlabBytes <= 53 * 102
         T v[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-          if constexpr (SAMPLER == kNearest) v[c] = t[c];
-          else v[c] = blend4<SAMPLER, T, !decltype(inner)::value>(t[c], t[NC + c], t[PB / ES + c], t[PB / ES + NC + c], fx, fy);
+          if constexpr (SAMPLER == kNearest) {
+            v[c] = t[c];
+          } else if constexpr (decltype(exact)::value) {
+            // 8- / 16-bit taps at coordinates >= 32: no operation of the factorised blend rounds, it equals scipy's (dcp_device.h)
+            const int ta = (int)t[c], tb = (int)t[NC + c], tc = (int)t[PB / ES + c], td = (int)t[PB / ES + NC + c];
+            const double fxd = (double)fx, fyd = (double)fy;
+            const double tp = __builtin_fma(fxd, (double)(tb - ta), (double)ta);
+            const double bt = __builtin_fma(fxd, (double)(td - tc), (double)tc);
+            v[c] = to_elem_in_range<T>(__builtin_fma(fyd, bt - tp, tp));
+          } else {
+            v[c] = blend4<SAMPLER, T, !decltype(inner)::value>(t[c], t[NC + c], t[PB / ES + c], t[PB / ES + NC + c], fx, fy);
+          }
         }
         if (k < rows) store_pixel<T, NC>(v, dst, xoff, (uint32_t)k * row_bytes_out);
       }
     };
-    if (interior) tile_rows_loop(std::true_type{});
-    else tile_rows_loop(std::false_type{});
+    constexpr bool kNarrowInt = std::is_integral<T>::value && sizeof(T) <= 2;
+    bool done = false;
+    if constexpr (kNarrowInt && SAMPLER != kNearest) {
+      if (interior && img.int_exact && bx0 >= (int)kExactLerpMinCoord && by0 >= (int)kExactLerpMinCoord) {
+        tile_rows_loop(std::true_type{}, std::true_type{});
+        done = true;
+      }
+    }
+    if (!done) {
+      if (interior) tile_rows_loop(std::true_type{}, std::false_type{});
+      else tile_rows_loop(std::false_type{}, std::false_type{});
+    }
   } else {
     // ---- box too large for the slab (magnification above ~1.1): direct global gather, same arithmetic
 #pragma unroll
@@ -410,6 +430,7 @@ hipError_t launch_color(const ImageArgs& img_in, const MapArgs& map, int channel
     img.rows_out = img.H;
   }
   img.xcd_remap = opts.xcd_remap;
+  img.int_exact = opts.int_exact;
   // dense pixels, at least 2 x 2, dword-aligned rows (the 16-byte LDS-DMA copies), 24-bit row products, rows of the result below 4 GiB
   if (img.src_col_stride != channels || img.W < 2 || img.H < 2 || ((uintptr_t)img.src & 3u) || (((int64_t)img.src_stride * es) & 3) ||
       (int64_t)img.src_stride * es >= (1ll << 31) || img.H >= (1 << 24) || (int64_t)img.W * channels * es >= (1ll << 28))

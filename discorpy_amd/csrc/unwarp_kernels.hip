@@ -662,7 +662,6 @@ __global__ void __launch_bounds__(64 * kLdsBW, (KIND == kFused && NF < 0) ? 3 : 
 // factorised one costs 13 float64 operations fewer per pixel.  `top` / `bot`: the tap pairs (x0, x0 + 1) of rows y0 / y0 + 1 in
 // the low bits of a dword (element 0 in the low half); fx, fy: the fractions.  Tiles whose source box reaches a coordinate
 // below 32 keep scipy's operation order (where roundings do occur it is their order that has to be reproduced).
-constexpr float kExactLerpMinCoord = 32.0f;
 template <typename T>
 __device__ __forceinline__ double exact_lerp_pairs(uint32_t top, uint32_t bot, double fx, double fy) {
   constexpr int B = (int)sizeof(T) * 8;
@@ -688,33 +687,7 @@ __device__ __forceinline__ double exact_lerp_pairs(uint32_t top, uint32_t bot, d
   return __builtin_fma(fy, bt - tp, tp);
 }
 
-// The same blend with the four taps read as NARROW elements straight from LDS (ds_read_u16 / _i16 / _u8 / _i8: naturally aligned,
-// no pair extraction): 4 LDS reads instead of 2, and 6 VALU instructions fewer per pixel (no aligned-dword address, shift count,
-// two alignbit, two masks) -- the integer kernels are bound by VALU issue (SQ_INSTS_VALU 51 per pixel at 85 % utilisation), not
-// by LDS.  t_lo / t_hi: the tap pairs of rows y0 / y0 + 1.
-template <typename T>
-__device__ __forceinline__ double exact_lerp_taps(const T* t_lo, const T* t_hi, double fx, double fy) {
-  const int a = (int)t_lo[0], b = (int)t_lo[1], c = (int)t_hi[0], d = (int)t_hi[1];
-  const double tp = __builtin_fma(fx, (double)(b - a), (double)a);
-  const double bt = __builtin_fma(fx, (double)(d - c), (double)c);
-  return __builtin_fma(fy, bt - tp, tp);
-}
-// scipy's integer store (to_elem) of a value that is an EXACT convex combination of elements of T: it lies inside T's range, so
-// the clamps cannot act and are left out (v_cvt_u32_f64 / v_cvt_i32_f64 truncate).
-template <typename T>
-__device__ __forceinline__ T to_elem_in_range(double t) {
-  if constexpr (std::is_unsigned<T>::value) {
-    uint32_t r;
-    const double th = t + 0.5;
-    asm("v_cvt_u32_f64 %0, %1" : "=v"(r) : "v"(th));
-    return (T)r;
-  } else {
-    int32_t r;
-    const double th = t + (t > 0.0 ? 0.5 : -0.5);
-    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(th));
-    return (T)r;
-  }
-}
+// (exact_lerp_taps -- the same blend on narrow LDS reads -- and to_elem_in_range live in dcp_device.h: the colour kernel shares them)
 
 // ------------------------------------------------------------------ K1 / K2, workgroup-shared source box
 
