@@ -424,7 +424,8 @@ int run_typed(int map_kind, const void* src, void* dst, int dtype, int64_t H, in
               int mode, int mem_kind, int device, void* stream) {
   int rc;
   if (order < 0 || order > 5) return fail(DCP_ERR_INVALID_ARG, "spline order %d outside [0, 5]", order);
-  if (mode < 0 || mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
+  if (mode < 0 || (mode & ~DCP_SPLINE_SCIPY_SUM) > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
+  if (order < 2) mode &= ~DCP_SPLINE_SCIPY_SUM;        // (orders 0 / 1 of the typed entry points always blend in scipy's order)
   if (order >= 2) {   // run_spline numbers the maps 0 radial, 1 perspective, 2 coordinates, 3 fused
     return run_spline(map_kind == 3 ? 2 : map_kind == 2 ? 3 : map_kind, src, dst, dtype, H, W, rs, cs, map, ycoord, xcoord, coord_dtype, npts,
                       order, mode, mem_kind, device, stream);

@@ -100,6 +100,9 @@ int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, i
                         ? tile_deviation_certified(map_kind == 0 ? dcp::kRadial : dcp::kPersp, map, H, W)
                         : 0;
   if (order < 2 || order > 5) return fail(DCP_ERR_INVALID_ARG, "spline order %d outside [2, 5]", order);
+  // bit 8 of boundary_mode (DCP_SPLINE_SCIPY_SUM): accumulate the taps in scipy's operation order instead of the factorised sum
+  const int exact_sum = (mode >= 0 && (mode & DCP_SPLINE_SCIPY_SUM)) ? 1 : 0;
+  if (mode >= 0) mode &= ~DCP_SPLINE_SCIPY_SUM;
   if (mode < 0 || mode > 7) return fail(DCP_ERR_INVALID_ARG, "unknown boundary mode %d", mode);
   if (map_kind == 2) {
     if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
@@ -117,6 +120,7 @@ int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, i
   a.src_dtype = a.dst_dtype = dtype;
   a.order = order;
   a.mode = mode;
+  a.exact_sum = exact_sum;
   a.pad = (mode == dcp::kModeNearest || mode == dcp::kModeGridConstant) ? 12 : 0;
   a.Hp = a.H + 2 * a.pad;
   a.Wp = a.W + 2 * a.pad;

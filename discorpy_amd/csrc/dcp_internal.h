@@ -124,6 +124,7 @@ struct SplineArgs {
   int32_t order, mode, filter_kind, npoles;
   double poles[2];
   double zpow[2][2];       // [axis][pole]: z^n (reflect) or z^(n-1) (mirror), evaluated on the host
+  int32_t exact_sum;       // 1: the taps are accumulated in scipy's order, t += (c wy) wx; 0: factorised and fused (the LDS-staged gather only)
 };
 
 struct LaunchOpts {

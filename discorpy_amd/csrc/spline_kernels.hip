@@ -26,7 +26,9 @@ constexpr int kSplBlock = 256;
 int g_spline_wg = 1;             // 0: the (order + 1)^2 taps always gathered from global memory (option spline_wg)
 void set_spline_wg(int v) { g_spline_wg = v; }
 int get_spline_wg() { return g_spline_wg; }
-int g_spline_tiled = 1;          // 0: always the chunked passes + transposes (option spline_tiled; A/B runs and tests)
+int g_spline_tiled = 1;          // option spline_tiled (A/B runs and tests): 0 the chunked passes + transposes; 1 the fastest kernels (one pole, float32 source: the LDS-staged
+                                 // register column pass, then the tile kernel along the rows); 2 the LDS tile kernel on both axes; 3 as 1 with the unstaged column
+                                 // stream kernel; 4 tile kernel down the columns, cross-lane scan along the rows
 void set_spline_tiled(int v) { g_spline_tiled = v; }
 int get_spline_tiled() { return g_spline_tiled; }
 
@@ -489,6 +491,377 @@ __global__ void __launch_bounds__(kTfBlock) spline_tile_filter_kernel(const Tile
   }
 }
 
+// ---- the column pass (axis 0) of a float32 image WITHOUT LDS and without barriers --------------------------------------
+// spline_tile_filter_kernel moves a 128 KB tile through LDS in synchronised phases (load, causal warm-up, barrier, causal,
+// barrier, anti-causal warm-up, barrier, ...): one workgroup per CU, the recursion stages bound by LDS writes.  Down the
+// columns nothing has to be exchanged between lanes: lane = column, so a row of the plane is one contiguous 256-byte load
+// (float32 in) / 512-byte store (float64 out) per wave.  Here a wave owns 64 columns x kCsSeg rows and every lane keeps its
+// column's values in REGISTERS: the causal recursion runs over the HP rows in front of the segment from a zero state (or from
+// the exact initial sum at the top of the column), through the segment and HP rows past it; the anti-causal recursion comes
+// back over those HP rows (from zero, or from the exact end value) and through the segment, storing as it goes.  The HP rows
+// on both sides are re-read by the neighbouring segments -- 3.1 loads per sample, of which the L2 / Infinity Cache serve 2.1
+// (the float32 source of a 4096^2 frame is 67 MB) -- in exchange for no LDS traffic, no barrier and 8 independent waves per
+// CU instead of one lock-step workgroup.  Single-pole orders (2, 3), reflect / mirror kinds on columns long enough that
+// z^n underflows (the conditions of the tile kernel); same arithmetic per sample as the tile kernel and the oracle
+// (t = x lam + z t; t = z (t - c)), the same 2^-64 restarts.
+#ifndef DCP_CS_SEG
+#define DCP_CS_SEG 32
+#endif
+constexpr int kCsSeg = DCP_CS_SEG;
+#ifndef DCP_CS_K
+#define DCP_CS_K 1                   // consecutive segments a wave walks: the causal state carries over, only the anti-causal pass restarts
+#endif
+constexpr int kCsK = DCP_CS_K;
+// A wave walks kCsK consecutive segments of kCsSeg rows down its 64 columns: the causal recursion runs on without a restart
+// (its state is exact), only the anti-causal pass of every segment restarts HP rows further down -- from values the causal
+// pass has already produced and that the next segment reuses.  Rows read per output row: (K SEG + 2 HP) / (K SEG) = 1.5 for
+// K = 4 (3.1 for K = 1): the L1-miss stream, which bounds this kernel, is 0.77 of what one segment per wave moves.
+#ifndef DCP_CS_WAVES
+#define DCP_CS_WAVES 2
+#endif
+template <int HP>
+__global__ void __launch_bounds__(256, DCP_CS_WAVES) spline_col_stream_kernel(const TileFilter f) {
+  constexpr int SEG = kCsSeg, K = kCsK, NC = K * SEG + HP;   // causal values of the wave's rows and of the HP rows behind them
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  const int col = blockIdx.x * 64 + lane;
+  const int n = f.n;
+  const int R0 = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * 4 + wave) * (K * SEG));
+  if (R0 >= n) return;
+  const float* __restrict__ src = (const float*)f.in + (int64_t)min(col, f.nlines - 1) * f.in_ls;
+  const int64_t ss = f.in_ss;
+  const double z = f.z[0], lam = f.lam;
+  double* __restrict__ out = f.out + (int64_t)col * f.out_ls;
+  const bool store_lane = col < f.nlines;
+  // the first SEG + HP rows, all in flight while the warm-up runs (rows past the end repeat the last one and are not used)
+  float pre[SEG + HP];
+#pragma unroll
+  for (int j = 0; j < SEG + HP; ++j) pre[j] = src[(int64_t)min(R0 + j, n - 1) * ss];
+  // ---- causal: the state in front of the wave's rows
+  double t = 0.0;
+  int i = max(0, R0 - HP);
+  bool first_exact = false;                                  // t is the exact value of sample 0 (wave-uniform)
+  if (i == 0) {
+    // exact start of the line, z^n == 0 (spline_filter_line() of the oracle with that factor dropped; as the tile kernel)
+    const double x0 = (double)src[0] * lam;
+    double z_i = z, acc = x0;
+    if (f.kind == kSplReflect) {
+      const int m = min(n - 1, kHorizon);
+      for (int k = 1; k <= m; ++k) {
+        acc += z_i * ((double)src[(int64_t)k * ss] * lam);
+        z_i *= z;
+      }
+      t = acc * z / (1.0 - z_i * z_i) + x0;
+    } else {
+      const int m = min(n - 2, kHorizon);
+      for (int k = 1; k <= m; ++k) {
+        acc += z_i * ((double)src[(int64_t)k * ss] * lam);
+        z_i *= z;
+      }
+      t = acc;
+    }
+    first_exact = true;
+    i = 1;
+  }
+  for (; i + 8 <= R0; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(int64_t)(i + j) * ss];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t = (double)v[j] * lam + z * t;
+  }
+  for (; i < R0; ++i) t = (double)src[(int64_t)i * ss] * lam + z * t;
+  const double c_before = t;                                 // causal value of row R0 - 1 (the mirror end formula may need it)
+  double C[NC];                                              // (indices are compile-time constants: registers, live ~SEG + HP at a time)
+  double tc = t;                                             // the causal state
+#pragma unroll
+  for (int j = 0; j < SEG + HP; ++j) {
+    C[j] = 0.0;
+    if (R0 + j < n) {
+      if (!(first_exact && R0 + j == 0)) tc = (double)pre[j] * lam + z * tc;
+      C[j] = tc;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int r0 = R0 + k * SEG;
+    if (r0 < n) {                                            // (wave-uniform)
+      const int r1 = min(n, r0 + SEG), a1 = min(n, r1 + HP);
+      // the next segment's new rows, in flight under this segment's anti-causal pass
+      float nx[SEG];
+      if (k + 1 < K) {
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) nx[j] = src[(int64_t)min(r0 + SEG + HP + j, n - 1) * ss];
+      }
+      // ---- anti-causal: back over the HP rows behind the segment (from zero, or from the exact end value), then through the
+      // segment, storing
+      double ta = 0.0;
+#pragma unroll
+      for (int j = (k + 1) * SEG + HP - 1; j >= k * SEG; --j) {
+        const int row = R0 + j;
+        if (row < a1) {
+          if (a1 == n && row == n - 1) {
+            if (f.kind == kSplReflect) ta = C[j] * (z / (z - 1.0));
+            else ta = (z / (z * z - 1.0)) * (C[j] + z * (j > 0 ? C[j > 0 ? j - 1 : 0] : c_before));
+          } else {
+            ta = z * (ta - C[j]);
+          }
+#if defined(DCP_CS_EXP_NOSTORE)        // timing experiment: the value is computed, the store (practically) never happens
+          if (row < r1 && store_lane && ta == 1.2345e300) out[(int64_t)row * f.out_ss] = ta;
+#elif defined(DCP_CS_EXP_NT)
+          if (row < r1 && store_lane) __builtin_nontemporal_store(ta, &out[(int64_t)row * f.out_ss]);
+#else
+          if (row < r1 && store_lane) out[(int64_t)row * f.out_ss] = ta;
+#endif
+        }
+      }
+      if (k + 1 < K) {
+#pragma unroll
+        for (int j = 0; j < SEG; ++j) {
+          const int jj = (k + 1) * SEG + HP + j;
+          C[jj < NC ? jj : 0] = 0.0;
+          if (R0 + jj < n) {
+            tc = (double)nx[j] * lam + z * tc;
+            C[jj < NC ? jj : 0] = tc;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- the same column pass with the float32 rows of a workgroup staged in LDS ONCE -----------------------------------------
+// spline_col_stream_kernel's four waves read overlapping rows (each wave its segment and HP rows on both sides: 3.1 loads per
+// sample), and what bounds it is the rate at which a CU takes streamed data in (no-store ablation: 38 us for 67 MB of source).
+// Here the workgroup copies the rows its four segments need -- 4 SEG + 2 HP rows of 64 float32 columns, <= 49 KB -- into LDS
+// with 16-byte LDS-DMA loads (one row = 256 contiguous bytes = a quarter of a load), one barrier, and every lane then reads
+// its column out of LDS (lane = column: conflict-free): 1.5 loads per sample from the L2, the rest from LDS.  The recursions
+// run in registers exactly as in the stream kernel; the float64 results go straight to global memory, 512 bytes per wave and
+// row (plain stores: the row pass that follows finds them in the Infinity Cache).
+template <int HP>
+__global__ void __launch_bounds__(256, 3) spline_col_lds_kernel(const TileFilter f, const uint32_t src_bytes) {
+  constexpr int SEG = 32, J = SEG + HP, ROWS = 4 * SEG + 2 * HP;
+  __shared__ __attribute__((aligned(16))) float s_in[ROWS * 64];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  const int col0 = blockIdx.x * 64, col = col0 + lane;
+  const int n = f.n;
+  const int R0 = (int)blockIdx.y * (4 * SEG);                 // first row the workgroup writes
+  const int base = max(0, R0 - HP), top = min(n, R0 + 4 * SEG + HP);   // rows [base, top) are staged
+  // ---- fill: row (base + 4 q + lane / 16), 16-byte chunk (lane % 16), q = wave, wave + 4, ...
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)f.in, 0, (int)src_bytes, 0x00020000);
+    const uint32_t rstep = (uint32_t)f.in_ss * 4u;
+    const uint32_t off0 = (uint32_t)(base + (lane >> 4)) * rstep + (uint32_t)col0 * 4u + (uint32_t)(lane & 15) * 16u;
+    const int ngroups = (top - base + 3) >> 2;
+#pragma unroll
+    for (int q = 0; q < (ROWS + 15) / 16; ++q) {
+      const int g = q * 4 + wave;
+      // (rows past `top` are inside the image or past the descriptor's extent -- zeros --, and the slab has room for whole groups)
+      if (g < ngroups) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(s_in + g * 256), 16, off0 + (uint32_t)g * 4u * rstep, 0, 0, 0);
+    }
+  }
+  const int r0 = __builtin_amdgcn_readfirstlane(R0 + wave * SEG);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (r0 >= n) return;
+  const int r1 = min(n, r0 + SEG), a1 = min(n, r1 + HP);
+  const float* a = s_in + lane - base * 64;                   // a[row * 64]: sample `row` of this lane's column
+  const double z = f.z[0], lam = f.lam;
+  // ---- causal: the state in front of the segment
+  double t = 0.0;
+  int i = max(0, r0 - HP);
+  bool first_exact = false;                                  // t is the exact value of sample 0 (wave-uniform)
+  if (i == 0) {
+    // exact start of the line, z^n == 0 (spline_filter_line() of the oracle with that factor dropped; rows 0 .. 64 are staged:
+    // this is the workgroup at the top of the column)
+    const double x0 = (double)a[0] * lam;
+    double z_i = z, acc = x0;
+    if (f.kind == kSplReflect) {
+      const int m = min(n - 1, kHorizon);
+      for (int k = 1; k <= m; ++k) {
+        acc += z_i * ((double)a[k * 64] * lam);
+        z_i *= z;
+      }
+      t = acc * z / (1.0 - z_i * z_i) + x0;
+    } else {
+      const int m = min(n - 2, kHorizon);
+      for (int k = 1; k <= m; ++k) {
+        acc += z_i * ((double)a[k * 64] * lam);
+        z_i *= z;
+      }
+      t = acc;
+    }
+    first_exact = true;
+    i = 1;
+  }
+  for (; i + 8 <= r0; i += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = a[(i + j) * 64];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t = (double)v[j] * lam + z * t;
+  }
+  for (; i < r0; ++i) t = (double)a[i * 64] * lam + z * t;
+  const double c_before = t;                                 // causal value of row r0 - 1 (the mirror end formula may need it)
+  // ---- causal through the segment and the HP rows behind it, kept in registers
+  double cs[J];
+  const float* as = a + r0 * 64;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    cs[j] = 0.0;
+    if (r0 + j < a1) {
+      if (!(first_exact && r0 + j == 0)) t = (double)as[j * 64] * lam + z * t;
+      cs[j] = t;
+    }
+  }
+  // ---- anti-causal: back over the rows behind the segment (from zero, or from the exact end value), then through the segment
+  double* __restrict__ out = f.out + (int64_t)col * f.out_ls;
+  const bool store_lane = col < f.nlines;
+  t = 0.0;
+#pragma unroll
+  for (int j = J - 1; j >= 0; --j) {
+    const int row = r0 + j;
+    if (row < a1) {
+      if (a1 == n && row == n - 1) {
+        if (f.kind == kSplReflect) t = cs[j] * (z / (z - 1.0));
+        else t = (z / (z * z - 1.0)) * (cs[j] + z * (j > 0 ? cs[j > 0 ? j - 1 : 0] : c_before));
+      } else {
+        t = z * (t - cs[j]);
+      }
+      if (row < r1 && store_lane) out[(int64_t)row * f.out_ss] = t;
+    }
+  }
+}
+
+// ---- the row pass (axis 1) as a cross-lane scan: no LDS, no barrier, every access a contiguous 512 bytes ---------------
+// Along a row the recursion runs ACROSS the lanes of a wave.  c_i = x_i + z c_(i-1) over the 64 samples of a block is an
+// inclusive scan with multiplier z -- six steps v_i += z^d v_(i-d), d = 1, 2, 4, .., 32 (the neighbour's value through the LDS
+// crossbar, ds_bpermute: no memory) -- plus z^(i+1) times the value carried in from the block before; the anti-causal pass is the
+// same scan mirrored.  A wave owns one row and kRsNB consecutive blocks: it starts one block early from a zero carry (64 >= hp
+// samples: the 2^-64 restart of the other kernels; or from the exact initial value at the start of the row), keeps the causal
+// values of its blocks in registers (one double per lane and block), reads one block past its own as the anti-causal warm-up
+// (or takes the exact end value) and comes back storing.  (kRsNB + 2) / kRsNB = 1.25 loads per sample, ~0.8 instructions per
+// sample, 32 768 independent waves for a 4096^2 plane.  The sums associate differently from the sequential recursion
+// (t = x lam + z t), so a coefficient may differ from the tile kernel's / the oracle's in its last bits -- as it does at every
+// restart of those kernels; the float32 result of the interpolation flips with probability ~1e-8 per pixel (tests: <= 4 pixels
+// of a frame against the plain kernels, <= 8 against the oracle, as before).  One pole (orders 2, 3), reflect / mirror kinds
+// on rows long enough that z^n underflows.
+constexpr int kRsNB = 8;
+__device__ __forceinline__ double lane_read(double v, int src_lane) {       // v of lane `src_lane` (any lane pattern; LDS crossbar)
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_uniform(double v, int src_lane) {    // v of lane `src_lane` as a scalar
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane), __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+// v through a DPP lane pattern (VALU, no LDS); lanes the pattern does not reach read 0 (bound_ctrl: no `old` operand to initialise)
+template <int CTRL>
+__device__ __forceinline__ double dpp_read(double v) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(256) spline_row_scan_kernel(const TileFilter f) {
+  constexpr int NB = kRsNB;
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  const int row = (int)blockIdx.y * 4 + wave;
+  const int n = f.n, nbt = (n + 63) >> 6;                      // blocks of the row
+  const int b0 = (int)blockIdx.x * NB;
+  if (row >= f.nlines || b0 >= nbt) return;
+  const int b1 = min(nbt, b0 + NB);                            // the wave writes blocks [b0, b1); b1 < nbt: block b1 is its look-ahead
+  const double* __restrict__ in = (const double*)f.in + (int64_t)row * f.in_ls;
+  double* __restrict__ out = f.out + (int64_t)row * f.out_ls;
+  const double z = f.z[0], lam = f.lam;
+  // blocks b0 - 1 .. b0 + NB, all in flight (samples outside the row read as 0)
+  double xs[NB + 2];
+#pragma unroll
+  for (int q = 0; q < NB + 2; ++q) {
+    const int idx = (b0 - 1 + q) * 64 + lane;
+    xs[q] = (idx >= 0 && idx < n && b0 - 1 + q <= b1) ? in[idx] : 0.0;
+  }
+  // z^1, z^2, z^4, .. z^32 (uniform) and the per-lane powers of the scan
+  double zp[6];
+  zp[0] = z;
+#pragma unroll
+  for (int k = 1; k < 6; ++k) zp[k] = zp[k - 1] * zp[k - 1];
+  const double z64 = zp[5] * zp[5];
+  auto zpow = [&](int e) {                                     // z^e, 0 <= e <= 64
+    double r = (e & 64) ? z64 : 1.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) r = (e >> k) & 1 ? r * zp[k] : r;
+    return r;
+  };
+  // (the two row_bcast steps reach every row; the rows that must not take the value multiply it by 0)
+  const double z_up = zpow(lane + 1), z_l = zpow(lane), z_r16 = (lane & 16) ? zpow((lane & 15) + 1) : 0.0, z_r32 = (lane & 32) ? zpow((lane & 31) + 1) : 0.0;
+  // inclusive scan with multiplier z over the 64 lanes: s_i = sum_(k <= i) z^(i - k) v_k.  Four Kogge-Stone steps inside the rows
+  // of 16 lanes (DPP row_shr), then lane 15 of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3 (DPP row_bcast)
+  auto wscan = [&](double v) {
+    v = __builtin_fma(zp[0], dpp_read<0x111>(v), v);
+    v = __builtin_fma(zp[1], dpp_read<0x112>(v), v);
+    v = __builtin_fma(zp[2], dpp_read<0x114>(v), v);
+    v = __builtin_fma(zp[3], dpp_read<0x118>(v), v);
+    v = __builtin_fma(z_r16, dpp_read<0x142>(v), v);
+    v = __builtin_fma(z_r32, dpp_read<0x143>(v), v);
+    return v;
+  };
+  // ---- causal
+  double c[NB + 2];
+  double carry = 0.0;
+#pragma unroll
+  for (int q = 0; q < NB + 2; ++q) {
+    c[q] = 0.0;
+    const int bq = b0 - 1 + q;
+    if (bq < 0 || bq > b1 || bq >= nbt) continue;              // (wave-uniform)
+    double v = xs[q] * lam;
+    if (bq == 0) {
+      // exact value of sample 0 with z^n dropped: S = sum_k z^k x_k lam over the first samples (z^64 ~ 1e-37: one block holds
+      // everything that can reach a double); mirror: c_0 = S, reflect: c_0 = S z + x_0 lam
+      double s_ = v * z_l;
+      if (f.kind != kSplReflect && lane > n - 2) s_ = 0.0;     // (the mirror sum runs to n - 2)
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) s_ += lane_read(s_, lane ^ d);
+      const double x0 = wave_uniform(v, 0);
+      const double c0 = f.kind == kSplReflect ? s_ * z + x0 : s_;
+      v = lane == 0 ? c0 : v;
+    }
+    v = wscan(v);
+    v = __builtin_fma(z_up, carry, v);
+    carry = wave_uniform(v, 63);
+    c[q] = v;
+  }
+  // ---- anti-causal, on the REVERSED lanes of a block (lane j <-> sample 63 - j: y_i = z (y_(i+1) - c_i) becomes the same forward
+  // scan), storing the wave's own blocks -- a wave's store is still one contiguous 512 bytes
+  carry = 0.0;
+  const double kend_r = z / (z - 1.0), kend_m = z / (z * z - 1.0);
+#pragma unroll
+  for (int q = NB + 1; q >= 1; --q) {
+    const int bq = b0 - 1 + q;
+    if (bq > b1 || bq >= nbt) continue;
+    const int idx = bq * 64 + 63 - lane;
+    const double cr = lane_read(c[q], 63 - lane);
+    double u = idx < n ? -z * cr : 0.0;
+    if (bq == nbt - 1) {
+      // exact value of the last sample (sample L of this block)
+      const int L = (n - 1) & 63;
+      const double cl = wave_uniform(c[q], L);
+      double ye;
+      if (f.kind == kSplReflect) {
+        ye = cl * kend_r;
+      } else {
+        const double cm = L > 0 ? wave_uniform(c[q], L > 0 ? L - 1 : 0) : wave_uniform(c[q - 1], 63);
+        ye = kend_m * (cl + z * cm);
+      }
+      u = lane == 63 - L ? ye : u;
+    }
+    u = wscan(u);
+    u = __builtin_fma(z_up, carry, u);
+    carry = wave_uniform(u, 63);
+    if (bq < b1 && idx < n) out[idx] = u;
+  }
+}
+
 // (rows x cols) -> (cols x rows), 32 x 32 tiles through LDS
 __global__ void __launch_bounds__(kSplBlock) spline_transpose_kernel(const double* in, double* out, int rows, int cols) {
   __shared__ double tile[32][33];
@@ -776,11 +1149,22 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
       DCP_BOUNDS(sy * PB + sx * 8 - org, ORDER * PB + (ORDER + 1) * 8, sizeof(s_box), 7);
       const unsigned char* base = s_box + (sy * PB + sx * 8 - org);
       double t = 0.0;
+      if (a.exact_sum) {                 // scipy's order: t += (c * wy) * wx, tap by tap (wave-uniform branch)
 #pragma unroll
-      for (int j = 0; j <= ORDER; ++j) {
-        const double* row = (const double*)(base + j * PB);
+        for (int j = 0; j <= ORDER; ++j) {
+          const double* row = (const double*)(base + j * PB);
 #pragma unroll
-        for (int q = 0; q <= ORDER; ++q) t += (row[q] * wyv[j]) * wxv[q];
+          for (int q = 0; q <= ORDER; ++q) t += (row[q] * wyv[j]) * wxv[q];
+        }
+      } else {                           // factorised: sum_j wy_j (sum_q c_jq wx_q), fused -- (ORDER + 1)(ORDER + 2) operations instead of 3 (ORDER + 1)^2
+#pragma unroll
+        for (int j = 0; j <= ORDER; ++j) {
+          const double* row = (const double*)(base + j * PB);
+          double r = row[0] * wxv[0];
+#pragma unroll
+          for (int q = 1; q <= ORDER; ++q) r = __builtin_fma(row[q], wxv[q], r);
+          t = j == 0 ? r * wyv[0] : __builtin_fma(r, wyv[j], t);
+        }
       }
       return t;
     };
@@ -888,6 +1272,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     halo += hp[p];
   }
   const int samples = kTfSamples;
+  bool col_stream = false, row_scan = false;
   if (tiled && samples - 2 * halo >= 32) {
     TileFilter f;
     f.kind = a.filter_kind;
@@ -925,7 +1310,26 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ls = 1;
     f.out_ss = a.Wp;
     dim3 grid((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
-    if (direct) {
+    if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {
+      // float32 source, one pole (orders 2 and 3): the register-streaming column pass, no LDS
+      f.in = a.src;
+      f.in_ls = a.src_cstride;
+      f.in_ss = a.src_stride;
+      const dim3 g2((unsigned)((f.nlines + 63) / 64), (unsigned)((f.n + 4 * kCsK * kCsSeg - 1) / (4 * kCsK * kCsSeg)));
+      // (the LDS-staged form needs unit column stride, 16-byte loads inside a 32-bit extent; g_spline_tiled = 3 selects the
+      // unstaged stream kernel for A/B runs)
+      const double ext = ((double)(a.H - 1) * (double)a.src_stride + (double)a.W) * 4.0;
+      if (a.src_cstride == 1 && ext < 4294967000.0 && g_spline_tiled != 3) {
+        const dim3 g3((unsigned)((f.nlines + 63) / 64), (unsigned)((f.n + 127) / 128));
+        if (hp[0] == 26) hipLaunchKernelGGL((spline_col_lds_kernel<26>), g3, dim3(256), 0, stream, f, (uint32_t)ext);
+        else hipLaunchKernelGGL((spline_col_lds_kernel<34>), g3, dim3(256), 0, stream, f, (uint32_t)ext);
+      } else if (hp[0] == 26) {
+        hipLaunchKernelGGL((spline_col_stream_kernel<26>), g2, dim3(256), 0, stream, f);
+      } else {
+        hipLaunchKernelGGL((spline_col_stream_kernel<34>), g2, dim3(256), 0, stream, f);
+      }
+      col_stream = true;
+    } else if (direct) {
       f.in = a.src;
       f.in_ls = a.src_cstride;
       f.in_ss = a.src_stride;
@@ -946,7 +1350,15 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ls = a.Wp;
     f.out_ss = 1;
     grid = dim3((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
-    launch(I1{}, std::false_type{}, SL{}, grid);
+    if (a.npoles == 1 && g_spline_tiled == 4 && f.nlines <= 4 * 65535) {
+      // one pole, option spline_tiled = 4 only: the cross-lane scan along the rows (no LDS) -- measured at 84 us per 4096^2 plane
+      // against the tile kernel's 72 (VALU-bound: ~50 instructions per 64 samples and scan step), kept for A/B runs
+      const int nbt = (f.n + 63) / 64;
+      hipLaunchKernelGGL(spline_row_scan_kernel, dim3((unsigned)((nbt + kRsNB - 1) / kRsNB), (unsigned)((f.nlines + 3) / 4)), dim3(256), 0, stream, f);
+      row_scan = true;
+    } else {
+      launch(I1{}, std::false_type{}, SL{}, grid);
+    }
   } else {
     tiled = false;
   }
@@ -987,7 +1399,9 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
                   (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH;
   {
     char name[160];
-    snprintf(name, sizeof(name), "%s + %s<order=%d>", tiled ? "spline_tile_filter_kernel x 2" : "spline_causal / anticausal / transpose kernels",
+    snprintf(name, sizeof(name), "%s + %s<order=%d>", tiled ? (col_stream ? (row_scan ? "spline_col_stream_kernel + spline_row_scan_kernel" : "spline_col_stream_kernel + spline_tile_filter_kernel")
+                                                                           : (row_scan ? "spline_tile_filter_kernel + spline_row_scan_kernel" : "spline_tile_filter_kernel x 2"))
+                                                                  : "spline_causal / anticausal / transpose kernels",
              wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     set_last_kernel_name(name);
   }

@@ -130,6 +130,16 @@ def _blend_code(blend):
         raise ValueError("unknown blend %r (expected one of %s)" % (name, sorted(F.BLEND_BY_NAME)))
 
 
+SPLINE_SCIPY_SUM = 0x100      # DCP_SPLINE_SCIPY_SUM: OR-ed into the boundary mode of the spline orders
+
+
+def _spline_mode(mode, blend):
+    """Boundary-mode code of an order >= 2 call; blend="scipy" asks for scipy's tap-by-tap summation order (the default sums the
+    taps factorised in the LDS-staged gather: ~1 pixel in 1e8 differs in its last float32 bit)."""
+    code = _MODES.index(mode)
+    return code | SPLINE_SCIPY_SUM if (blend is not None and str(blend).lower() in ("scipy", "exact")) else code
+
+
 def _check_order_mode(order, mode):
     if mode not in _MODES:
         # scipy's own message for an unknown boundary mode
@@ -379,12 +389,12 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_unwarp_image_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
-                                               float(xcenter), float(ycenter), fa, nf, order, _MODES.index(mode),
+                                               float(xcenter), float(ycenter), fa, nf, order, _spline_mode(mode, blend),
                                                img.mem, img.device, img.stream))
         return out
     if order >= 2:
         F.check(F.lib().dcp_unwarp_image_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
-                                                    float(xcenter), float(ycenter), fa, nf, order, _MODES.index(mode),
+                                                    float(xcenter), float(ycenter), fa, nf, order, _spline_mode(mode, blend),
                                                     img.mem, img.device, img.stream))
         return out
     F.check(F.lib().dcp_unwarp_image_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
@@ -775,12 +785,12 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_perspective_image_typed(img.ptr, optr, img.code, height, width, img.strides[0],
-                                                    img.strides[1], ca, order, _MODES.index(mode), img.mem, img.device,
+                                                    img.strides[1], ca, order, _spline_mode(mode, blend), img.mem, img.device,
                                                     img.stream))
         return out
     if order >= 2:
         F.check(F.lib().dcp_perspective_image_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
-                                                         ca, order, _MODES.index(mode), img.mem, img.device, img.stream))
+                                                         ca, order, _spline_mode(mode, blend), img.mem, img.device, img.stream))
         return out
     F.check(F.lib().dcp_perspective_image_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], ca,
                                               order, bcode, img.mem, img.device, img.stream))
@@ -867,12 +877,12 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_unwarp_fused_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
-                                               float(xcenter), float(ycenter), fa, nf, ca, order, _MODES.index(mode),
+                                               float(xcenter), float(ycenter), fa, nf, ca, order, _spline_mode(mode, blend),
                                                img.mem, img.device, img.stream))
         return out
     if order >= 2:
         F.check(F.lib().dcp_unwarp_fused_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
-                                                    float(xcenter), float(ycenter), fa, nf, ca, order, _MODES.index(mode),
+                                                    float(xcenter), float(ycenter), fa, nf, ca, order, _spline_mode(mode, blend),
                                                     img.mem, img.device, img.stream))
         return out
     F.check(F.lib().dcp_unwarp_fused_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1],
@@ -940,12 +950,12 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
     F.require_device()
     if not img.f32:
         F.check(F.lib().dcp_remap_coords_typed(img.ptr, optr, img.code, height, width, img.strides[0], img.strides[1],
-                                               yptr, xptr, cdt, npts, order, _MODES.index(mode), img.mem, img.device,
+                                               yptr, xptr, cdt, npts, order, _spline_mode(mode, blend), img.mem, img.device,
                                                img.stream))
         return out
     if order >= 2:
         F.check(F.lib().dcp_remap_coords_spline_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], yptr,
-                                                    xptr, cdt, npts, order, _MODES.index(mode), img.mem, img.device,
+                                                    xptr, cdt, npts, order, _spline_mode(mode, blend), img.mem, img.device,
                                                     img.stream))
         return out
     F.check(F.lib().dcp_remap_coords_mode_f32(img.ptr, optr, height, width, img.strides[0], img.strides[1], yptr, xptr,

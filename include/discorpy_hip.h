@@ -223,6 +223,12 @@ int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_l
  * and 'grid-constant'):  0 reflect, 1 grid-mirror, 2 constant, 3 grid-constant, 4 nearest, 5 mirror,
  * 6 grid-wrap, 7 wrap.  Results are within one float32 ulp of scipy's.  A float64 coefficient plane
  * of (height + 2 pad) x (width + 2 pad) is kept per device by the library. */
+/* OR-ed into `boundary_mode` of the spline entry points (and of the *_typed ones at orders >= 2): accumulate the (order + 1)^2 taps
+ * of a point in scipy's operation order, t += (c * wy) * wx tap by tap.  Without it the LDS-staged gather of certified maps on
+ * whole frames sums them factorised and fused -- sum_j wy_j (sum_q c_jq wx_q): 20 float64 operations instead of 48 at order 3 --,
+ * which differs from scipy's sum in the last bits of the float64 value, i.e. in the float32 result of ~1 pixel in 1e8 (the
+ * spline orders' contract is "within one float32 ulp of scipy's" either way).  Python: blend="scipy". */
+#define DCP_SPLINE_SCIPY_SUM 0x100
 #define DCP_MODE_REFLECT 0
 #define DCP_MODE_GRID_MIRROR 1
 #define DCP_MODE_CONSTANT 2

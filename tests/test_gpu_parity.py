@@ -318,18 +318,24 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
         for order, mode in [(2, "mirror"), (3, "reflect"), (3, "nearest"), (4, "reflect"), (5, "grid-constant"), (5, "reflect")]:
             a = (img, c["xcenter"] * shape[1] / 4096.0, 500.0, c["list_fact"])
             res = {}
-            for fast in (1, 0):
+            # 1: the default (one-pole orders on float32 frames that need no padding: the register column pass, then the tile kernel
+            # along the rows); 2: the LDS tile kernel on both axes; 0: the plain kernels
+            for fast in (1, 2, 0):
                 F.set_option("spline_tiled", fast)
-                F.set_option("spline_wg", fast)
+                F.set_option("spline_wg", 1 if fast else 0)
                 res[fast] = (pp.unwarp_image_backward(*a, order=order, mode=mode),
                              pp.correct_perspective_image(img, coef, order=order, mode=mode))
-                want_name = ("spline_tile_filter_kernel x 2 + spline_wg_kernel<order=%d>" if fast else
+                one_pole = fast == 1 and order <= 3
+                direct = one_pole and mode not in ("nearest", "grid-constant")        # (those two pad the plane first)
+                pre = "spline_col_stream_kernel + spline_tile_filter_kernel" if direct else "spline_tile_filter_kernel x 2"
+                want_name = (pre + " + spline_wg_kernel<order=%d>" if fast else
                              "spline_causal / anticausal / transpose kernels + spline_remap_kernel<order=%d>") % order
                 assert F.last_kernel() == want_name, F.last_kernel()
             want = (orc.unwarp_image_backward(*a, order=order, mode=mode, poly=orc.POLY_KERNEL),
                     orc.correct_perspective_image(img, coef, order=order, mode=mode))
             for k in (0, 1):
-                assert np.count_nonzero(res[1][k] != res[0][k]) <= 4, (order, mode, k)
+                assert np.count_nonzero(res[1][k] != res[0][k]) <= 4 and np.count_nonzero(res[2][k] != res[0][k]) <= 4, (order, mode, k)
+                assert np.count_nonzero(res[1][k] != res[2][k]) <= 4, (order, mode, k)
                 assert spline_close(res[1][k], want[k]) and np.count_nonzero(res[1][k] != want[k]) <= 8, (order, mode, k)
     finally:
         F.set_option("spline_tiled", 1)
