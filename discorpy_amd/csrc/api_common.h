@@ -24,7 +24,7 @@ const char* last_error();
     }                                                                                                      \
   } while (0)
 
-extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb, g_stack_lds, g_host_duplex, g_host_bands, g_tile_cert, g_wg_box, g_wg_per_cu, g_stack_wg, g_int_exact, g_host_direct;
+extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb, g_stack_lds, g_host_duplex, g_host_bands, g_tile_cert, g_wg_box, g_wg_per_cu, g_stack_wg, g_int_exact, g_host_direct, g_tall_tiles;
 dcp::LaunchOpts current_opts();
 
 // Selects `device` for the calling thread for the lifetime of the object (no-op for device < 0).
@@ -121,7 +121,9 @@ int homography_is_tame(const double* c, int64_t H, int64_t W);
 // level 1: inside any 64 x 16 output tile the map stays within 0.95 px of the bilinear interpolant of the tile's corners;
 // level 2: the same for 128 x 32 tiles (kind: dcp::kRadial or dcp::kPersp; anything else 0) -- lets the staged kernels
 // take a tile's source box from its corner pixels alone, without a per-pixel containment vote
-int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W);
+// *tall_ok (optional): radial maps -- the bound also holds for 64 x 32 tiles and (nearly) all their source boxes fit 80 x 56
+// (remap_wg_color_kernel's tile shape for sheared maps)
+int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W, int* tall_ok = nullptr);
 // yd = yc + B(r) yu increases with yu at every x over the frame (sufficient test): no row of a chunk can then leave the
 // band the reference crops from the chunk's first and last rows
 bool radial_monotone_in_y(const dcp::MapArgs& m, int64_t H, int64_t W);

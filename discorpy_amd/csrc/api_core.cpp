@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -39,6 +39,7 @@ dcp::LaunchOpts current_opts() {
   o.wg_per_cu = g_wg_per_cu.load();
   o.stack_wg = g_stack_wg.load();
   o.int_exact = g_int_exact.load();
+  o.tall_tiles = g_tall_tiles.load();
   return o;
 }
 
@@ -165,8 +166,9 @@ double radial_curvature_bound(const dcp::MapArgs& m, double rmax) {
 // that does not sends its whole workgroup to the direct gather, and with a fifth of the tiles doing so (the 9-term
 // fisheye model of config 5, whose tiles are sheared) the per-wave kernel is the faster one.  The boxes of a 24 x 24
 // lattice of tiles are formed exactly as the kernel forms them (corner hull, one pixel of margin, tap width).
-bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) {
-  const int64_t ntx = (W + 127) / 128, nty = (H + 31) / 32;
+bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W, int tw = 128, int th = 32, double box_cols = kWgBoxCols,
+                         double box_rows = kWgBoxRows) {
+  const int64_t ntx = (W + tw - 1) / tw, nty = (H + th - 1) / th;
   const int sx = (int)std::min<int64_t>(ntx, 24), sy = (int)std::min<int64_t>(nty, 24);
   int bad = 0;
   for (int iy = 0; iy < sy; ++iy)
@@ -175,7 +177,7 @@ bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) 
       double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
       for (int cy = 0; cy < 2; ++cy)
         for (int cx = 0; cx < 2; ++cx) {
-          const double X = (double)std::min<int64_t>(tx * 128 + cx * 127, W - 1), Y = (double)std::min<int64_t>(ty * 32 + cy * 31, H - 1);
+          const double X = (double)std::min<int64_t>(tx * tw + cx * (tw - 1), W - 1), Y = (double)std::min<int64_t>(ty * th + cy * (th - 1), H - 1);
           double xd, yd;
           if (kind == dcp::kRadial) {
             const double xu = X - m.xc, yu = Y - m.yc, r = std::hypot(xu, yu);
@@ -196,7 +198,7 @@ bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) 
           ylo = std::min(ylo, std::floor(yd));
           yhi = std::max(yhi, std::floor(yd));
         }
-      if (xhi - xlo + 4.0 > kWgBoxCols || yhi - ylo + 4.0 > kWgBoxRows) ++bad;
+      if (xhi - xlo + 4.0 > box_cols || yhi - ylo + 4.0 > box_rows) ++bad;
     }
   return bad * 50 <= sx * sy;          // at most 2 % of the sampled tiles
 }
@@ -208,28 +210,33 @@ struct CertEntry {
   int kind = -1, nfact = -1;
   int64_t H = 0, W = 0;
   double xc = 0, yc = 0, fact[dcp::kMaxFact], coef[8];
-  int ok = 0;
+  int ok = 0, tall = 0;
 };
 thread_local CertEntry g_cert_cache[kCertSlots];
 thread_local int g_cert_next = 0, g_cert_last = 0;
 }  // namespace
 
-int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W) {
+int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t W, int* tall_ok) {
+  if (tall_ok) *tall_ok = 0;
   if (H < 1 || W < 1) return 0;
   auto same = [&](const CertEntry& c) {
     return c.kind == kind && c.nfact == m.nfact && c.H == H && c.W == W && c.xc == m.xc && c.yc == m.yc &&
            memcmp(c.fact, m.fact, sizeof(double) * (size_t)(m.nfact > 0 ? m.nfact : 0)) == 0 && memcmp(c.coef, m.coef, sizeof(c.coef)) == 0;
   };
-  if (same(g_cert_cache[g_cert_last])) return g_cert_cache[g_cert_last].ok;      // the common case: the calibration of the previous call
+  if (same(g_cert_cache[g_cert_last])) {      // the common case: the calibration of the previous call
+    if (tall_ok) *tall_ok = g_cert_cache[g_cert_last].tall;
+    return g_cert_cache[g_cert_last].ok;
+  }
   for (int i = 0; i < kCertSlots; ++i)
     if (same(g_cert_cache[i])) {
       g_cert_last = i;
+      if (tall_ok) *tall_ok = g_cert_cache[i].tall;
       return g_cert_cache[i].ok;
     }
   CertEntry& c = g_cert_cache[g_cert_next];
   g_cert_last = g_cert_next;
   g_cert_next = (g_cert_next + 1) % kCertSlots;
-  int ok = 0;
+  int ok = 0, tall = 0;
   if (kind == dcp::kRadial) {
     double rmax = 0.0;
     for (double x : {0.0, (double)(W - 1)})
@@ -237,6 +244,8 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
     const double k2 = radial_curvature_bound(m, rmax * (1.0 + 1e-12) + 1e-9);
     for (int lvl = 0; lvl < 2; ++lvl)
       if ((kSpanX2[lvl] + kSpanY2[lvl]) * k2 <= kTileDevLimit) ok = lvl + 1;
+    // the 64 x 32 tiles of remap_wg_color_kernel's second shape (sheared maps): the same bound for that span, its boxes under 80 x 56
+    tall = (63.0 * 63.0 / 8.0 + 31.0 * 31.0 / 8.0) * k2 <= kTileDevLimit && wg_boxes_mostly_fit(kind, m, H, W, 64, 32, 80.0, 56.0);
   } else if (kind == dcp::kPersp) {
     if (homography_is_tame(m.coef, H, W)) {
       // N / D with N, D affine: d/dx = (N_x D - D_x N) / D^2 and d2/dx2 = -2 D_x (N_x D - D_x N) / D^3.  The numerators
@@ -271,6 +280,8 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
   memcpy(c.fact, m.fact, sizeof(c.fact));
   memcpy(c.coef, m.coef, sizeof(c.coef));
   c.ok = ok;
+  c.tall = tall;
+  if (tall_ok) *tall_ok = tall;
   return ok;
 }
 
@@ -495,6 +506,9 @@ int dcp_set_option(const char* key, int value) {
     if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "host_direct must be 0, 1 or 2");
     g_host_direct = value;            // 0: a host frame's result is always staged on the device and copied back; 1: written straight into a
                                       // registered destination when the runtime cannot overlap an upload with a download; 2: whenever registered
+  } else if (!strcmp(key, "tall_tiles")) {
+    g_tall_tiles = value ? 1 : 0;     // 1: sheared radial maps (level-1 certificate, boxes of 64 x 32 tiles fit 80 x 56) on 64 x 32 workgroup tiles instead of the
+                                      // per-wave-box kernel.  Default 0: measured SLOWER on BASELINE config 5 (128-131 us against 113-116, tools/time_cfg5.py)
   } else if (!strcmp(key, "int_exact")) {
     g_int_exact = value ? 1 : 0;      // 0: integer element types blend in scipy's operation order everywhere (A/B and parity runs)
   } else if (!strcmp(key, "wg_box")) {
@@ -538,6 +552,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else if (!strcmp(key, "int_exact")) *value = g_int_exact;
   else if (!strcmp(key, "host_direct")) *value = g_host_direct;
+  else if (!strcmp(key, "tall_tiles")) *value = g_tall_tiles;
   else if (!strcmp(key, "host_direct_applies")) {        // read-only: measures the runtime once (needs a device)
     int n = 0;
     *value = (hipGetDeviceCount(&n) == hipSuccess && n > 0 && host_direct_applies()) ? 1 : 0;

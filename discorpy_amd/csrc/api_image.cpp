@@ -536,7 +536,11 @@ int dcp_unwarp_image_f32(const float* src, float* dst, int64_t height, int64_t w
     return run_typed(0, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
                      0, mem_kind, device, stream);
   if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
-  map.tile_dev_ok = g_tile_cert.load() ? tile_deviation_certified(dcp::kRadial, map, height, width) : 0;
+  {
+    int tall = 0;
+    map.tile_dev_ok = g_tile_cert.load() ? tile_deviation_certified(dcp::kRadial, map, height, width, &tall) : 0;
+    map.tall_ok = g_tile_cert.load() ? tall : 0;
+  }
   return run_image(dcp::kRadial, src, dst, height, width, src_row_stride, src_col_stride, map, sampler,
                    coord_round_f32 != 0, mem_kind, device, stream);
 }

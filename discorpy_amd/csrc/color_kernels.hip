@@ -34,27 +34,34 @@ namespace dcp {
 #define DCP_COLOR_RPW 8         // rows per wave sub-tile: the workgroup tile is 128 x (2 * DCP_COLOR_RPW)
 #endif
 
-constexpr int kColTW = 128;                      // workgroup tile width (two wave sub-tiles of 64)
+// SHAPE 0: 128 x 16 output tile, the four waves 2 x 2 (each 64 x 8); box <= 144 pixels x 26 rows.
+// SHAPE 1: 64 x 32 output tile, the four waves stacked (each 64 x 8); box <= 80 pixels x 56 rows -- for maps whose tiles are
+//          SHEARED (a fisheye model far from the centre: 128 pixels along x climb ~20 source rows, which overflows the
+//          height of every 128-wide box): half the width under more than twice the height.
 constexpr int kColRPW = DCP_COLOR_RPW;           // rows of a wave sub-tile
-constexpr int kColTH = 2 * kColRPW;              // workgroup tile height
-constexpr int kColBoxPx = 144;                   // widest box in pixels (plus the alignment slack of narrow pixels)
-constexpr int kColBoxH = kColTH + kColTH / 4 + 6;   // tallest box: 26 rows for 16-row tiles, 46 for 32-row tiles
+template <int SHAPE>
+struct TileShape {
+  static constexpr int WX = SHAPE == 0 ? 2 : 1, WY = 4 / WX;             // waves along x / y
+  static constexpr int TW = 64 * WX, TH = kColRPW * WY;                  // workgroup tile
+  static constexpr int BoxPx = SHAPE == 0 ? 144 : 80;                    // widest box in pixels (plus the alignment slack of narrow pixels)
+  static constexpr int BoxH = SHAPE == 0 ? TH + TH / 4 + 6 : 56;         // tallest box in rows
+};
 
 typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2c __attribute__((ext_vector_type(2)));
 
-template <typename T, int NC>
+template <typename T, int NC, int SHAPE = 0>
 struct ColorGeom {
   static constexpr int ES = (int)sizeof(T);
   static constexpr int PS = ES * NC;                                  // bytes per pixel
   // the box's first column is rounded down until its byte offset in the row is a multiple of 4 (the 16-byte copies
   // need dword-aligned addresses): a multiple of `kAlignPx` pixels
   static constexpr int kAlignPx = (PS % 4 == 0) ? 1 : ((PS % 2 == 0) ? 2 : 4);
-  static constexpr int kBoxWPx = kColBoxPx + kAlignPx - 1;
+  static constexpr int kBoxWPx = TileShape<SHAPE>::BoxPx + kAlignPx - 1;
   static constexpr int CH = (kBoxWPx * PS + 15) / 16;                 // 16-byte chunks per slab row
   static constexpr int PB = CH * 16;                                  // slab pitch in bytes
-  static constexpr int NJ = (kColBoxH * CH + 255) / 256;              // loads per wave that cover the slab
+  static constexpr int NJ = (TileShape<SHAPE>::BoxH * CH + 255) / 256;   // loads per wave that cover the slab
   static constexpr int kSlabBytes = NJ * 256 * 16;
 };
 
@@ -129,6 +136,8 @@ __device__ __forceinline__ void store_pixel(const T (&v)[NC], __amdgpu_buffer_rs
     const unsigned long long b = (unsigned long long)__double_as_longlong(v[0]);
     u32x2c p = {(uint32_t)b, (uint32_t)(b >> 32)};
     __builtin_amdgcn_raw_buffer_store_b64(p, dst, voff, soff, DCP_COLOR_STORE_AUX);
+  } else if constexpr (std::is_same<T, float>::value && NC == 1) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), dst, voff, soff, DCP_COLOR_STORE_AUX);
   } else if constexpr (sizeof(T) == 4 && NC == 1) {                      // int32 / uint32
     __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v[0], dst, voff, soff, DCP_COLOR_STORE_AUX);
   } else if constexpr (PS == 4) {                                        // 4 x 8-bit, 2 x 16-bit
@@ -156,9 +165,11 @@ __device__ __forceinline__ void store_pixel(const T (&v)[NC], __amdgpu_buffer_rs
 
 // ImageArgs as for remap_wg_kernel, with src / dst reinterpreted as T*, src_stride = ELEMENTS between source rows, src_col_stride =
 // NC (dense pixels), src_bytes the extent in bytes, W / H in PIXELS; the result is dense (W NC elements per row).
-template <int NF, int SAMPLER, typename T, int NC>
-__global__ void __launch_bounds__(256, (ColorGeom<T, NC>::kSlabBytes <= 53 * 1024 ? 3 : 2)) remap_wg_color_kernel(const ImageArgs img, const MapArgs map) {
-  using G = ColorGeom<T, NC>;
+template <int NF, int SAMPLER, typename T, int NC, int SHAPE = 0>
+__global__ void __launch_bounds__(256, (ColorGeom<T, NC, SHAPE>::kSlabBytes <= 53 * 1024 ? 3 : 2)) remap_wg_color_kernel(const ImageArgs img, const MapArgs map) {
+  using G = ColorGeom<T, NC, SHAPE>;
+  using S = TileShape<SHAPE>;
+  constexpr int kColTW = S::TW, kColTH = S::TH, kColBoxH = S::BoxH;
   constexpr int ES = G::ES, PS = G::PS, CH = G::CH, PB = G::PB, NJ = G::NJ;
   constexpr int RPW = kColRPW;
   __shared__ __attribute__((aligned(16))) unsigned char s_box[G::kSlabBytes];
@@ -169,7 +180,7 @@ __global__ void __launch_bounds__(256, (ColorGeom<T, NC>::kSlabBytes <= 53 * 102
 
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
-  const int wx = wave & 1, wy = wave >> 1;
+  const int wx = S::WX == 2 ? (wave & 1) : 0, wy = S::WX == 2 ? (wave >> 1) : wave;
   // tile order as remap_wg_kernel: XCD blockIdx.x & 7 owns a stripe of tile columns and sweeps it row by row
   int tx, ty;
   if (img.xcd_remap == 2) {
@@ -359,20 +370,21 @@ __global__ void __launch_bounds__(256, (ColorGeom<T, NC>::kSlabBytes <= 53 * 102
 
 DCP_DEFINE_BOUNDS_READER(read_bounds_color)
 
-template <int NF, int SAMPLER, typename T, int NC>
+template <int NF, int SAMPLER, typename T, int NC, int SHAPE = 0>
 static hipError_t launch_color_t(const ImageArgs& img_in, const MapArgs& map, hipStream_t stream) {
+  using S = TileShape<SHAPE>;
   ImageArgs img = img_in;
-  img.tiles_x = (img.W + kColTW - 1) / kColTW;
-  img.tiles_y = (img.rows_out + kColTH - 1) / kColTH;
+  img.tiles_x = (img.W + S::TW - 1) / S::TW;
+  img.tiles_y = (img.rows_out + S::TH - 1) / S::TH;
   // XCD stripes of whole tile columns only when they balance (see launch_wg in unwarp_kernels.hip)
   if (img.xcd_remap != 2 || 8 * ((img.tiles_x + 7) / 8) * 100 > img.tiles_x * 107) img.xcd_remap = 0;
   const dim3 grid(img.xcd_remap == 2 ? 8 * ((img.tiles_x + 7) / 8) : img.tiles_x, img.tiles_y);
   char name[96];
-  snprintf(name, sizeof(name), "remap_wg_color_kernel<NF=%d,%s,%s x %d>", NF, SAMPLER == kNearest ? "nearest" : SAMPLER == kScipy ? "scipy" : "f64lerp",
+  snprintf(name, sizeof(name), "remap_wg_color_kernel<NF=%d,%s,%s x %d%s>", NF, SAMPLER == kNearest ? "nearest" : SAMPLER == kScipy ? "scipy" : "f64lerp",
            std::is_same<T, float>::value ? "float32" : std::is_same<T, double>::value ? "float64" : std::is_same<T, int32_t>::value ? "int32"
-           : std::is_same<T, uint32_t>::value ? "uint32" : sizeof(T) == 2 ? "uint16" : "uint8", NC);
+           : std::is_same<T, uint32_t>::value ? "uint32" : sizeof(T) == 2 ? "uint16" : "uint8", NC, SHAPE == 1 ? ",64x32 tiles" : "");
   set_last_kernel_name(name);
-  hipLaunchKernelGGL((remap_wg_color_kernel<NF, SAMPLER, T, NC>), grid, dim3(256), 0, stream, img, map);
+  hipLaunchKernelGGL((remap_wg_color_kernel<NF, SAMPLER, T, NC, SHAPE>), grid, dim3(256), 0, stream, img, map);
   return hipGetLastError();
 }
 
@@ -385,20 +397,20 @@ static MapArgs pad_to(const MapArgs& m, int n) {
   return p;
 }
 
-template <int SAMPLER, typename T, int NC>
+template <int SAMPLER, typename T, int NC, int SHAPE = 0>
 static hipError_t launch_color_n(const ImageArgs& img, const MapArgs& map, hipStream_t stream) {
-  if (map.nfact <= 5) return launch_color_t<5, SAMPLER, T, NC>(img, pad_to(map, 5), stream);
-  if (map.nfact <= 10) return launch_color_t<10, SAMPLER, T, NC>(img, pad_to(map, 10), stream);
-  return launch_color_t<-1, SAMPLER, T, NC>(img, map, stream);
+  if (map.nfact <= 5) return launch_color_t<5, SAMPLER, T, NC, SHAPE>(img, pad_to(map, 5), stream);
+  if (map.nfact <= 10) return launch_color_t<10, SAMPLER, T, NC, SHAPE>(img, pad_to(map, 10), stream);
+  return launch_color_t<-1, SAMPLER, T, NC, SHAPE>(img, map, stream);
 }
 
-template <typename T, int NC>
+template <typename T, int NC, int SHAPE = 0>
 static hipError_t launch_color_s(const ImageArgs& img, const MapArgs& map, int sampler, hipStream_t stream) {
-  if (sampler == kNearest) return launch_color_n<kNearest, T, NC>(img, map, stream);
+  if (sampler == kNearest) return launch_color_n<kNearest, T, NC, SHAPE>(img, map, stream);
   if constexpr (std::is_same<T, float>::value) {
-    if (sampler == kF64Lerp) return launch_color_n<kF64Lerp, T, NC>(img, map, stream);
+    if (sampler == kF64Lerp) return launch_color_n<kF64Lerp, T, NC, SHAPE>(img, map, stream);
   }
-  return launch_color_n<kScipy, T, NC>(img, map, stream);
+  return launch_color_n<kScipy, T, NC, SHAPE>(img, map, stream);
 }
 
 template <typename T>
@@ -418,9 +430,13 @@ static hipError_t launch_plane(const ImageArgs& img, const MapArgs& map, int sam
 hipError_t launch_color(const ImageArgs& img_in, const MapArgs& map, int channels, int dtype, int sampler, const LaunchOpts& opts, hipStream_t stream,
                         bool* taken) {
   *taken = false;
-  if (map.tile_dev_ok < 2 || !opts.wg_box || !opts.lds_gather || opts.coef_lds || opts.xcd_remap == 1) return hipSuccess;
+  if (!opts.wg_box || !opts.lds_gather || opts.coef_lds || opts.xcd_remap == 1) return hipSuccess;
+  if (!(map.tile_dev_ok >= 2 || (channels == 1 && dtype == kF32 && img_in.tile_rows == 64 && map.tall_ok))) return hipSuccess;
   const bool colour = (channels == 3 || channels == 4) && (dtype == kF32 || dtype == kU8 || dtype == kU16);
-  const bool plane = channels == 1 && (dtype == kF64 || dtype == kI32 || dtype == kU32);
+  // (float32 single planes: only the 64 x 32 tile shape for sheared maps, img.tile_rows = 64 -- launch_plane_tall below; the
+  // 128-wide shapes of float32 belong to remap_wg_kernel)
+  const bool tall = channels == 1 && dtype == kF32 && img_in.tile_rows == 64;
+  const bool plane = channels == 1 && (dtype == kF64 || dtype == kI32 || dtype == kU32 || tall);
   if (!colour && !plane) return hipSuccess;
   if (sampler != kNearest && sampler != kScipy && !(sampler == kF64Lerp && dtype == kF32)) return hipSuccess;
   const int es = elem_size(dtype);
@@ -436,6 +452,7 @@ hipError_t launch_color(const ImageArgs& img_in, const MapArgs& map, int channel
       (int64_t)img.src_stride * es >= (1ll << 31) || img.H >= (1 << 24) || (int64_t)img.W * channels * es >= (1ll << 28))
     return hipSuccess;
   *taken = true;
+  if (tall) return launch_color_s<float, 1, 1>(img, map, sampler, stream);
   switch (dtype) {
     case kF32: return launch_color_c<float>(img, map, channels, sampler, stream);
     case kU8: return launch_color_c<uint8_t>(img, map, channels, sampler, stream);

@@ -44,6 +44,8 @@ struct MapArgs {
   double coef[8];          // perspective c1..c8
   int32_t nfact;
   int32_t fast_div;        // 1: operands of the homography division stay in the normal range over the image
+  int32_t tall_ok;         // host certificate for 64 x 32 tiles under an 80 x 56 box (sheared maps: remap_wg_color_kernel's second tile
+                           // shape): the deviation bound holds for that tile and (nearly) every such tile's box fits
   int32_t tile_dev_ok;     // host certificate -- inside any output tile every source coordinate stays within 0.95 px of
                            // the bilinear interpolant of the tile's corner coordinates: 1 for 64 x 16 tiles, 2 also
                            // for 128 x 32 tiles (radial and perspective maps; api_core.cpp tile_deviation_certified)
@@ -137,6 +139,7 @@ struct LaunchOpts {
   int stack_lds = 1;       // LDS-staged stack kernel: 0 never, 1 when the launch has enough wave tiles, 2 always
   int wg_box = 1;          // 1: remap_wg_kernel (one source box per 128 x 32 workgroup tile) for certified maps
   int wg_per_cu = 0;       // remap_wg_kernel: cap on resident workgroups per CU (0 = none)
+  int tall_tiles = 0;      // (A/B option, off: slower on config 5) sheared radial maps (level-1 certificate, MapArgs::tall_ok): 64 x 32 workgroup tiles (remap_wg_color_kernel) instead of per-wave boxes
   int int_exact = 1;       // integer element types: the exact factorised blend where it is provably exact (0: scipy's operation order everywhere)
   int stack_wg = 1;        // stack_wg_kernel (one box per workgroup, two slabs) for chunks of rows under a certified map: 0 never,
                            // 1 when the launch has enough workgroups (float32 and 8- / 16-bit integers), 2 whenever eligible

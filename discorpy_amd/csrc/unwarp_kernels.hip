@@ -2051,6 +2051,16 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
     return launch_generic<kPersp, true, false>(img, map, sampler, stream);
   }
   if (kind == kRadial) {
+    // a sheared map (the certificate holds, but the boxes of 128 x 32 tiles overflow the slab: a fisheye model far from its
+    // centre) on 64 x 32 workgroup tiles under an 80 x 56 box -- color_kernels.hip, one channel -- instead of per-wave boxes
+    if (pair && round_f32 && !opts.coef_lds && img.lds_gather && img.wg_box && opts.tall_tiles && map.tile_dev_ok == 1 && map.tall_ok &&
+        opts.xcd_remap != 1 && sampler != kF32Lerp) {
+      ImageArgs t = img;
+      t.tile_rows = 64;
+      bool taken = false;
+      const hipError_t e = launch_color(t, map, 1, kF32, sampler, opts, stream, &taken);
+      if (e != hipSuccess || taken) return e;
+    }
     if (pair && round_f32 && !opts.coef_lds) {
       switch (nf) {
         case 1: return launch_fast<kRadial, 1>(img, map, sampler, stream);

@@ -139,3 +139,29 @@ def test_single_plane_frames_of_wide_element_types_on_the_staged_kernel(hip, orc
         assert hip.last_kernel().startswith("remap_wg_color_kernel")
         yd, xd = orc.radial_coords(600, 900, 400.0, 300.0, [1.0, 2e-5], poly=orc.POLY_KERNEL)
         assert np.array_equal(dev.cpu().numpy(), orc.map_coordinates(t.numpy(), yd, xd, 1))
+
+
+def test_sheared_map_on_64x32_workgroup_tiles_is_an_equal_and_slower_alternative(hip, orc):
+    """a second workgroup-tile shape (64 x 32 under an 80 x 56 box) for maps whose 128 x 32 tiles are sheared
+    out of the slab (BASELINE config 5's fisheye model).  Built and measured (tools/time_cfg5.py: 128-131 us against 113-116 for the
+    per-wave-box kernel on the 8192^2 frame), so it stays an option (tall_tiles = 1); what it computes is bit-equal."""
+    from discorpy_amd import configs
+    from discorpy_amd.post import postprocessing as pp
+    c5 = configs.cfg5()
+    s = 8192 / 2048.0
+    H = W = 2048
+    fact = [a * s ** i for i, a in enumerate(c5["list_fact"])]          # the same model on a quarter-size frame
+    xc, yc = c5["xcenter"] / s, c5["ycenter"] / s
+    img = noise(41, (H, W))
+    want = orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+    try:
+        hip.set_option("tall_tiles", 1)
+        got = pp.unwarp_image_backward(img[:1024], xc, yc, fact)          # (a host frame below the banded path's threshold: one launch)
+        assert "64x32 tiles" in hip.last_kernel(), hip.last_kernel()
+        w2 = orc.unwarp_image_backward(np.ascontiguousarray(img[:1024]), xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+        assert np.array_equal(got, w2)
+        hip.set_option("tall_tiles", 0)
+        assert np.array_equal(pp.unwarp_image_backward(img[:1024], xc, yc, fact), w2) and hip.last_kernel().startswith("remap_lds_kernel")
+    finally:
+        hip.set_option("tall_tiles", 0)
+    assert want.shape == (H, W)

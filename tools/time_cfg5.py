@@ -1,30 +1,37 @@
-"""cfg5 (8192^2, 9 terms) per-launch time, settled clocks: python tools/time_cfg5.py [key=value ...]"""
-import os, sys, time
+#!/usr/bin/env python
+"""A/B on one box: BASELINE config 5 (8192^2, 9-term fisheye model) on 64 x 32 workgroup tiles (option tall_tiles = 1:
+remap_wg_color_kernel, one channel, second tile shape) against the per-wave-box kernel (tall_tiles = 0: remap_lds_kernel)."""
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from discorpy_amd import _ffi as F, configs
-L = F.lib(); F.require_device()
-tag = ""
-for kv in sys.argv[1:]:
-    k, v = kv.split("="); F.set_option(k, int(v)); tag += kv + " "
-c = configs.cfg5(); H, W = c["shape"]
-fa, n = F.fact_array(c["list_fact"])
-img = np.random.default_rng(c["seed"]).random((H, W), dtype=np.float32)
-src = [F.DeviceBuffer(img.nbytes).upload(img) for _ in range(4)]
-dst = [F.DeviceBuffer(img.nbytes) for _ in range(4)]
-for order, blend in ((1, 1), (0, 0), (1, 1)):
-    def run(i):
-        F.check(L.dcp_unwarp_image_f32(src[i % 4].ptr, dst[i % 4].ptr, H, W, W, 1, c["xcenter"], c["ycenter"], fa, n, order, 1, blend, 1, -1, None))
-    t0 = time.perf_counter(); i = 0
-    while time.perf_counter() - t0 < 0.3:
-        run(i); i += 1
-        if i % 16 == 0:
-            F.check(L.dcp_stream_synchronize(-1, None))
-    F.check(L.dcp_stream_synchronize(-1, None))
-    F.debug_counters()
-    e0, e1 = F.Event(), F.Event(); e0.record()
-    for r in range(200):
-        run(r)
-    e1.record(); e1.synchronize()
-    us = e0.elapsed_ms(e1) / 200 * 1e3
-    print("%-22s order %d: %7.2f us %.3f of 8 TB/s  %s  fallbacks/launch %s" % (tag, order, us, 8.0 * H * W / us / 1e6 / 8, F.last_kernel(), [v / 200 for v in F.debug_counters()]), flush=True)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+from discorpy_amd import _ffi as F  # noqa: E402
+from discorpy_amd import configs  # noqa: E402
+
+L = F.lib()
+F.require_device()
+dev = -1
+c5 = configs.cfg5()
+H, W = c5["shape"]
+fa, nf = F.fact_array(c5["list_fact"])
+img = np.random.default_rng(c5["seed"]).random((H, W), dtype=np.float32)
+ring = 4
+src = [F.DeviceBuffer(img.nbytes, dev).upload(img) for _ in range(ring)]
+dst = [F.DeviceBuffer(img.nbytes, dev) for _ in range(ring)]
+outs = {}
+for blend, order, name in ((F.BLEND_F64LERP, 1, "f64lerp"), (F.BLEND_SCIPY, 1, "scipy"), (F.BLEND_SCIPY, 0, "nearest")):
+    for tall in (1, 0, 1, 0):
+        F.set_option("tall_tiles", tall)
+
+        def run(i):
+            F.check(L.dcp_unwarp_image_f32(src[i % ring].ptr, dst[i % ring].ptr, H, W, W, 1, c5["xcenter"], c5["ycenter"], fa, nf, order, 1, blend,
+                                           F.MEM_DEVICE, dev, None))
+        t = bench.timed_launches(run, 60, dev, settle_ms=300.0)
+        run(0)
+        outs[tall] = bench.download(dst[0].ptr, (H, W), dev)
+        print("%-8s tall_tiles=%d: %8.2f us  %.3f of 8 TB/s  %s" % (name, tall, t, 8.0 * H * W / (t * 1e-6) / 8e12, F.last_kernel()), flush=True)
+    print("   identical: %s" % bool(np.array_equal(outs[0], outs[1])), flush=True)
+F.set_option("tall_tiles", 1)
