@@ -94,6 +94,7 @@ SIGNATURES = {
     "dcp_unwarp_stack_band": (_int, [_vp, _vp, _int, _int, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp,
                                      _int, _dbl, _i64, _int, _int, _int, _int, _vp]),
     "dcp_map_points_f64": (_int, [_vp, _vp, _i64, _dbl, _dbl, _dp, _int, _int, _int, _vp]),
+    "dcp_map_points_perspective_f64": (_int, [_vp, _vp, _i64, _dp, _int, _int, _vp]),
     "dcp_coordinate_map_f32": (_int, [_vp, _vp, _i64, _i64, _int, _dbl, _dbl, _dp, _int, _dp, _int, _int, _vp]),
     "dcp_debug_counters": (_int, [C.POINTER(C.c_uint64), _int, _int]),
     "dcp_debug_bounds": (_int, [C.POINTER(C.c_uint64), _int, _int]),

@@ -874,6 +874,34 @@ int dcp_map_points_f64(const double* yx_in, double* yx_out, int64_t npts, double
   return DCP_OK;
 }
 
+int dcp_map_points_perspective_f64(const double* yx_in, double* yx_out, int64_t npts, const double* list_coef, int mem_kind, int device,
+                                   void* stream) {
+  int rc;
+  if (npts < 0) return fail(DCP_ERR_INVALID_ARG, "npts < 0");
+  if (npts > 0 && (!yx_in || !yx_out)) return fail(DCP_ERR_INVALID_ARG, "null point pointer");
+  if (!list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  dcp::MapArgs map;
+  if ((rc = fill_map(&map, 0.0, 0.0, nullptr, 0, list_coef)) != DCP_OK) return rc;
+  if (npts == 0) return DCP_OK;
+  DeviceScope scope(device);
+  if (scope.status != hipSuccess) return fail(DCP_ERR_HIP, "cannot select device %d: %s", device, hipGetErrorString(scope.status));
+  hipStream_t st = (hipStream_t)stream;
+  if (mem_kind == DCP_MEM_DEVICE) {
+    DCP_HIP(dcp::launch_map_points_persp(yx_in, yx_out, npts, map, st));
+    return DCP_OK;
+  }
+  if (mem_kind != DCP_MEM_HOST) return fail(DCP_ERR_INVALID_ARG, "unknown mem_kind %d", mem_kind);
+  void *din, *dout;
+  const size_t bytes = (size_t)npts * 16;
+  DCP_HIP(g_staging.get(0, bytes, &din));
+  DCP_HIP(g_staging.get(1, bytes, &dout));
+  DCP_HIP(hipMemcpyAsync(din, yx_in, bytes, hipMemcpyHostToDevice, st));
+  DCP_HIP(dcp::launch_map_points_persp((const double*)din, (double*)dout, npts, map, st));
+  DCP_HIP(hipMemcpyAsync(yx_out, dout, bytes, hipMemcpyDeviceToHost, st));
+  DCP_HIP(hipStreamSynchronize(st));
+  return DCP_OK;
+}
+
 int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t width, int map_kind, double xcenter,
                            double ycenter, const double* list_fact, int nfact, const double* list_coef, int mem_kind,
                            int device, void* stream) {

@@ -199,6 +199,8 @@ hipError_t launch_typed_image(int map_kind, const TypedImageArgs& img, const Map
 hipError_t launch_typed_stack(const TypedStackArgs& st, const MapArgs& map, hipStream_t stream);
 // n points (y, x) -> centre + B(r) (p - centre), float64
 hipError_t launch_map_points(const double* yx_in, double* yx_out, int64_t n, const MapArgs& map, hipStream_t stream);
+// n points (y, x) through the homography map.coef (numpy's operation order), float64
+hipError_t launch_map_points_persp(const double* yx_in, double* yx_out, int64_t n, const MapArgs& map, hipStream_t stream);
 // interleaved (H, W, C) image, radial map, orders 0 / 1; src_cstride = elements between pixels
 hipError_t launch_typed_channels(const TypedImageArgs& img, const MapArgs& map, int channels, hipStream_t stream);
 // color_kernels.hip: the same on remap_wg_kernel's data path (3 / 4 dense channels of float32 / uint8 / uint16, certified radial map);

@@ -216,6 +216,26 @@ __global__ void __launch_bounds__(kTypedBlock) map_points_kernel(const double* _
   yx_out[2 * i + 1] = map.xc + factor * xd;
 }
 
+// The homography applied to a list of points (correct_perspective_line, discorpy/post/postprocessing.py:414-441):
+// xn = (c1 x + c2 y + c3) / (c7 x + c8 y + 1), yn = (c4 x + c5 y + c6) / (c7 x + c8 y + 1) -- numpy's operation order, IEEE
+// divisions (every operation correctly rounded: bit-equal to the reference).
+__global__ void __launch_bounds__(kTypedBlock) map_points_persp_kernel(const double* __restrict__ yx_in, double* __restrict__ yx_out,
+                                                                      int64_t n, const MapArgs map) {
+  const int64_t i = (int64_t)blockIdx.x * kTypedBlock + threadIdx.x;
+  if (i >= n) return;
+  const double y = yx_in[2 * i], x = yx_in[2 * i + 1];
+  const double den = (map.coef[6] * x + map.coef[7] * y) + 1.0;
+  yx_out[2 * i] = ((map.coef[3] * x + map.coef[4] * y) + map.coef[5]) / den;
+  yx_out[2 * i + 1] = ((map.coef[0] * x + map.coef[1] * y) + map.coef[2]) / den;
+}
+
+hipError_t launch_map_points_persp(const double* yx_in, double* yx_out, int64_t n, const MapArgs& map, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(map_points_persp_kernel, dim3((unsigned)((n + kTypedBlock - 1) / kTypedBlock)), dim3(kTypedBlock), 0, stream, yx_in, yx_out, n,
+                     map);
+  return hipGetLastError();
+}
+
 hipError_t launch_map_points(const double* yx_in, double* yx_out, int64_t n, const MapArgs& map, hipStream_t stream) {
   if (n == 0) return hipSuccess;
   hipLaunchKernelGGL(map_points_kernel, dim3((unsigned)((n + kTypedBlock - 1) / kTypedBlock)), dim3(kTypedBlock), 0, stream,

@@ -346,6 +346,43 @@ def unwarp_line_forward(list_lines, xcenter, ycenter, list_fact):
     return res
 
 
+def correct_perspective_line(list_lines, list_coef):
+    """
+    Apply perspective correction to lines (reference ``postprocessing.py:414-441``).
+
+    Parameters
+    ----------
+    list_lines : list of 2D-arrays
+        List of the (y,x)-coordinates of points on each line.
+    list_coef : list of floats
+        Coefficients of the forward-mapping matrix.
+
+    Returns
+    -------
+    list_clines : list of 2D arrays
+        List of the corrected (y,x)-coordinates of points on each line (float64, as the reference builds them).  All points of
+        all lines go through one launch (``dcp_map_points_perspective_f64``); bit-equal to the reference.
+    """
+    if len(list_coef) != 8:
+        raise ValueError("!!! Eight coefficients are required !!!")
+    ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
+    lines = [np.asarray(iline) for iline in list_lines]
+    sizes = [len(line) for line in lines]
+    res = []
+    if sum(sizes) == 0:
+        return [np.asarray([]) for _ in lines]                 # np.asarray(list(zip(yn, xn))) of an empty line
+    pts = np.ascontiguousarray(np.concatenate([line[:, :2].reshape(-1, 2) for line in lines if len(line)]), dtype=np.float64)
+    out = np.empty_like(pts)
+    F.require_device()
+    F.check(F.lib().dcp_map_points_perspective_f64(pts.ctypes.data, out.ctypes.data, pts.shape[0], ca, F.MEM_HOST,
+                                                   int(os.environ.get("DISCORPY_AMD_DEVICE", "-1")), None))
+    pos = 0
+    for n in sizes:
+        res.append(out[pos:pos + n].copy() if n else np.asarray([]))
+        pos += n
+    return res
+
+
 def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="reflect", *, blend=None, out=None):
     """
     Unwarp an image using a backward model (reference ``postprocessing.py:111-148``).

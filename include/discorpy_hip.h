@@ -346,6 +346,12 @@ int dcp_coordinate_map_f32(float* ymap, float* xmap, int64_t height, int64_t wid
 int dcp_map_points_f64(const double* yx_in, double* yx_out, int64_t npts, double xcenter, double ycenter,
                        const double* list_fact, int nfact, int mem_kind, int device, void* stream);
 
+/* discorpy/post/postprocessing.py:414-441 (correct_perspective_line): the homography applied to npts points given as (y, x) pairs of
+ * doubles -- xn = (c1 x + c2 y + c3) / (c7 x + c8 y + 1), yn = (c4 x + c5 y + c6) / (c7 x + c8 y + 1) in numpy's operation order with
+ * IEEE divisions: bit-equal to the reference. */
+int dcp_map_points_perspective_f64(const double* yx_in, double* yx_out, int64_t npts, const double* list_coef, int mem_kind, int device,
+                                   void* stream);
+
 /* Diagnostics of the LDS-staged gather on the current device: out[0] = wave tiles whose source
  * box did not fit the LDS slab, out[1] = wave tiles whose containment vote failed (both fall back
  * to the direct gather).  Synchronises the device. */

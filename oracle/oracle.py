@@ -330,3 +330,15 @@ def unwarp_chunk_slices_backward(mat3D, xcenter, ycenter, list_fact, start_index
         raise ValueError("Selected index is out of the range")
     return unwarp_stack_rows(mat3D, xcenter, ycenter, list_fact, start_index,
                              stop_index - start_index + 1, coord_round_f32=True, poly=poly, blend=blend)
+
+
+def correct_perspective_line(list_lines, list_coef):
+    """The homography applied to lists of (y, x) points, numpy's operation order (reference postprocessing.py:414-441)."""
+    c1, c2, c3, c4, c5, c6, c7, c8 = [float(v) for v in list_coef]
+    out = []
+    for line in list_lines:
+        line = np.asarray(line, dtype=np.float64)
+        x, y = line[:, 1], line[:, 0]
+        den = c7 * x + c8 * y + 1.0
+        out.append(np.column_stack([(c4 * x + c5 * y + c6) / den, (c1 * x + c2 * y + c3) / den]))
+    return out

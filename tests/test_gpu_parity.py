@@ -263,6 +263,26 @@ def test_g13_unwarp_line_forward(hip):
     assert ints[0].dtype.kind == "i"
 
 
+def test_g19_correct_perspective_line(hip, orc):
+    """The homography on point lists (dcp_map_points_perspective_f64; reference postprocessing.py:414-441): numpy's operation order
+    with IEEE divisions, so bit-equal to the reference's own outputs on the reference's own test lines."""
+    g = golden("g19_perspective_lines")
+    lines = [np.array(line) for line in g["lines"]]
+    fwd = pp.correct_perspective_line(lines, list(g["fcoef"]))
+    assert len(fwd) == 4 and all(o.shape == (32, 2) and o.dtype == np.float64 for o in fwd)
+    assert np.array_equal(np.asarray(fwd), g["forward"])
+    assert np.array_equal(np.asarray(pp.correct_perspective_line(fwd, list(g["bcoef"]))), g["back"])
+    assert np.array_equal(np.asarray(orc.correct_perspective_line(lines, g["fcoef"])), g["forward"])
+    with pytest.raises(ValueError, match="Eight coefficients"):
+        pp.correct_perspective_line(lines, [1.0] * 7)
+    assert pp.correct_perspective_line([], list(g["fcoef"])) == []
+    rng = np.random.default_rng(3)
+    big = [rng.uniform(-50, 4000, (n, 2)) for n in (1, 1000, 0, 37)]
+    coef = [0.97, 0.02, 15.0, -0.01, 0.98, 8.0, 1e-5, -2e-5]
+    got, want = pp.correct_perspective_line(big, coef), orc.correct_perspective_line([b for b in big if len(b)], coef)
+    assert got[2].size == 0 and all(np.array_equal(a, b) for a, b in zip([q for q in got if q.size], want))
+
+
 def test_fused_map_at_spline_orders(hip, orc):
     """The one-pass perspective -> radial remap at orders 2..5: equal to sampling the image at the fused coordinate
     planes (which another test holds bit-equal to the reference's numpy planes), float32 and uint16."""

@@ -458,3 +458,10 @@ def test_g12b_complex_is_two_real_interpolations(orc):
     assert want.dtype == np.complex64
     assert np.array_equal(orc.unwarp_image_backward(np.ascontiguousarray(cim.real), *a), want.real)
     assert np.array_equal(orc.unwarp_image_backward(np.ascontiguousarray(cim.imag), *a), want.imag)
+
+
+def test_g19_perspective_lines(orc):
+    g = golden("g19_perspective_lines")
+    lines = [np.array(line) for line in g["lines"]]
+    fwd = orc.correct_perspective_line(lines, g["fcoef"])
+    assert np.array_equal(np.asarray(fwd), g["forward"]) and np.array_equal(np.asarray(orc.correct_perspective_line(fwd, g["bcoef"])), g["back"])

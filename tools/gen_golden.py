@@ -308,6 +308,16 @@ lines13 = [np.column_stack([np.full(12, 40.0 * k) + rng13.uniform(-2, 2, 12), np
 fact13 = np.asarray([1.0, -2.9e-5, 8.9e-8, -1.5e-10, 8.0e-14])
 save("g13_lines_forward", lines=np.asarray(lines13), xcenter=f64(588.69), ycenter=f64(462.09), list_fact=fact13,
      out=np.asarray(post.unwarp_line_forward(lines13, 588.69, 462.09, fact13)))
+# ---- G19: correct_perspective_line (postprocessing.py:414-441) on the reference's own test lines (tests/test_postprocessing.py:
+# 159-176): forward coefficients applied to the lines, backward coefficients applied to the result
+hor19 = [np.asarray([[10.0 + 2 * i / 32, i] for i in range(32)]), np.asarray([[26.0 - 5 * i / 32, i] for i in range(32)])]
+ver19 = [np.asarray([[i, 0.0 + 3 * i / 32] for i in range(32)]), np.asarray([[i, 20.0 - 3 * i / 32] for i in range(32)])]
+src19, tgt19 = proc.generate_source_target_perspective_points(hor19, ver19, equal_dist=False, scale="mean", optimizing=False)
+fcoef19 = proc.calc_perspective_coefficients(src19, tgt19, mapping="forward")
+bcoef19 = proc.calc_perspective_coefficients(src19, tgt19, mapping="backward")
+fwd19 = post.correct_perspective_line(hor19 + ver19, fcoef19)
+save("g19_perspective_lines", lines=np.asarray(hor19 + ver19), fcoef=f64(fcoef19), bcoef=f64(bcoef19), forward=np.asarray(fwd19),
+     back=np.asarray(post.correct_perspective_line(fwd19, bcoef19)))
 # ---- G14: pad=True of util.unwarp_color_image_backward (utility.py:238-263): automatic pad widths from the forward
 # model fitted by proc.transform_coef_backward_and_forward (processing.py:615-674), then the padded unwarp; plus the
 # reference's own pad=True case (tests/test_utility.py:92-101) and the fitted coefficients themselves
