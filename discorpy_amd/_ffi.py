@@ -349,18 +349,53 @@ class DeviceArray:
         self.size = int(np.prod(self.shape, dtype=np.int64))
         self.nbytes = self.size * self.dtype.itemsize
         self._buf = DeviceBuffer(max(self.nbytes, 4), device)
+        self._offset = 0
 
     @property
     def ptr(self):
-        return self._buf.ptr
+        return self._buf.ptr + self._offset
 
     @property
     def __cuda_array_interface__(self):
-        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self._buf.ptr, False), "version": 3,
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 3,
                 "strides": None}
 
     def copy_to_host(self):
-        return self._buf.download(self.shape, self.dtype)
+        import numpy as np
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            check(lib().dcp_memcpy(out.ctypes.data, self.ptr, self.nbytes, COPY_D2H, self._buf.device, None))
+        return out
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, i):
+        """Block `i` along the first axis (an integer index only: a view of the same allocation)."""
+        import operator
+        i = operator.index(i)
+        return self.frame(i + self.shape[0] if i < 0 else i)
+
+    def copy_from_host(self, array):
+        import numpy as np
+        a = np.ascontiguousarray(array, dtype=self.dtype)
+        if a.shape != self.shape:
+            raise ValueError("expected shape %s" % (self.shape,))
+        if a.nbytes:
+            check(lib().dcp_memcpy(self.ptr, a.ctypes.data, a.nbytes, COPY_H2D, self._buf.device, None))
+        return self
+
+    def frame(self, i):
+        """View of block `i` along the first axis (same allocation)."""
+        import numpy as np
+        if not 0 <= i < self.shape[0]:
+            raise IndexError(i)
+        view = DeviceArray.__new__(DeviceArray)
+        view.shape, view.dtype, view._buf = self.shape[1:], self.dtype, self._buf
+        view.size = int(np.prod(view.shape, dtype=np.int64))
+        view.nbytes = view.size * self.dtype.itemsize
+        view._offset = self._offset + i * view.nbytes
+        return view
 
     def reshape(self, shape):
         """A view with another shape (same allocation)."""
@@ -368,4 +403,5 @@ class DeviceArray:
         view = DeviceArray.__new__(DeviceArray)
         view.shape = tuple(int(s) for s in np.empty(self.shape, np.bool_).reshape(shape).shape)
         view.dtype, view.size, view.nbytes, view._buf = self.dtype, self.size, self.nbytes, self._buf
+        view._offset = self._offset
         return view

@@ -205,7 +205,7 @@ bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W, 
 
 // the same calibrations are applied to frame after frame (one per camera / channel / grid-search candidate): keep the
 // answers of the last kCertSlots distinct ones, replaced round-robin
-constexpr int kCertSlots = 64;
+constexpr int kCertSlots = 256;     // (a batch call certifies every frame's calibration: four launches' worth of distinct ones stay cached)
 struct CertEntry {
   int kind = -1, nfact = -1;
   int64_t H = 0, W = 0;

@@ -440,6 +440,18 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
     return out
 
 
+def _reshaped_out(out, shape):
+    """`out` viewed with `shape` -- or a ValueError: reshaping a non-contiguous array (or tensor) gives a COPY, and the result
+    would silently land in it instead of the caller's array."""
+    if isinstance(out, np.ndarray):
+        if not out.flags.c_contiguous:
+            raise ValueError("out must be C-contiguous")
+    elif _is_torch(out):
+        if not out.is_contiguous():
+            raise ValueError("out must be contiguous")
+    return out.reshape(shape)
+
+
 def _per_frame(value, n, what):
     """`value` as n floats: a number is shared by all frames, a sequence must hold one number per frame."""
     if np.ndim(value) == 0:
@@ -508,6 +520,11 @@ def unwarp_images_backward(mats, xcenter, ycenter, list_fact, order=1, mode="ref
             whole = torch.empty((n, height, width), dtype=torch.float32, device=first.keep.device)
             res = [whole[i] for i in range(n)]
             optrs = [whole.data_ptr() + i * height * width * 4 for i in range(n)]
+        elif stacked and outs is None and not first.torch and first.mem == F.MEM_DEVICE:
+            # a 3-D device array that is not a tensor (CuPy, Numba, DeviceArray): one 3-D DeviceArray, as the docstring promises
+            whole = F.DeviceArray((n, height, width), np.float32, first.device)
+            res = [whole.frame(i) for i in range(n)]
+            optrs = [r.ptr for r in res]
         else:
             whole = None
             for i, im in enumerate(imgs):
@@ -551,7 +568,7 @@ def unwarp_slice_backward(mat3D, xcenter, ycenter, list_fact, index, *, blend=No
     if out is not None:
         if tuple(out.shape) != (depth, width):
             raise ValueError("out must have shape (depth, width)")
-        out = out.reshape((depth, 1, width))
+        out = _reshaped_out(out, (depth, 1, width))
     index = index - 0.0                  # (the reference computes index - ycenter: a str or None is a TypeError)
     res = _stack_rows(mat3D, xcenter, ycenter, list_fact, float(index), 1, False, blend, out_float32=True,
                       devices=devices, out=out)
@@ -653,7 +670,7 @@ def unwarp_slice_backward_centres(mat3D, xcenters, ycenters, list_fact, index, *
     if out is not None:
         if tuple(out.shape) != (k, depth, width):
             raise ValueError("out must have shape (centres, depth, width)")
-        out = out.reshape((k, depth, 1, width))
+        out = _reshaped_out(out, (k, depth, 1, width))
     index = index - 0.0
     res = _stack_rows_centres(mat3D, xcenters, ycenters, list_fact, float(index), 1, False, blend, True, out)
     return res.reshape((k, depth, width)) if isinstance(res, F.DeviceArray) else res[:, :, 0, :]
@@ -674,7 +691,15 @@ def unwarp_chunk_slices_backward_centres(mat3D, xcenters, ycenters, list_fact, s
         raise ValueError("Selected index is out of the range")
     nrows = int(stop_index) - int(start_index) + 1
     if nrows < 1:
-        raise ValueError("Selected index is out of the range")
+        # as unwarp_chunk_slices_backward (and the reference's np.arange(start, stop + 1) of nothing): an empty chunk per centre
+        k = len(xcenters)
+        if out is not None:
+            if tuple(out.shape) != (k, depth, 0, width):
+                raise ValueError("out must have shape %s" % ((k, depth, 0, width),))
+            return out
+        if hasattr(mat3D, "new_empty"):
+            return mat3D.new_empty((k, depth, 0, width))
+        return np.empty((k, depth, 0, width), dtype=np.dtype(mat3D.dtype))
     return _stack_rows_centres(mat3D, xcenters, ycenters, list_fact, float(start_index), nrows, True, blend, False, out)
 
 

@@ -193,3 +193,23 @@ def test_front_end_validation_needs_no_gpu():
     assert L.dcp_unwarp_images_f32(None, ptr, 1, 4, 5, 5, 1, one, one, one, 1, 1, 1, F.BLEND_F64LERP, F.MEM_HOST, -1, None) == F.ERR_INVALID_ARG
     assert L.dcp_unwarp_images_f32(ptr, ptr, 1, 4, 5, 5, 1, one, one, one, 40, 1, 1, F.BLEND_F64LERP, F.MEM_HOST, -1, None) == F.ERR_INVALID_ARG
     assert L.dcp_unwarp_images_f32(ptr, ptr, 0, 4, 5, 5, 1, one, one, one, 1, 1, 1, F.BLEND_F64LERP, F.MEM_HOST, -1, None) == F.OK
+
+
+@pytest.mark.gpu
+def test_a_stacked_device_array_that_is_not_a_tensor_comes_back_as_one_3d_array(hip, orc):
+    """unwarp_images_backward promised one 3-D array for a 3-D input and returned a list for DeviceArray / CuPy-style
+    inputs."""
+    from discorpy_amd.post import postprocessing as pp
+    n, H, W = 5, 300, 520
+    stack = noise(91, (n, H, W))
+    dev = hip.DeviceArray((n, H, W), np.float32).copy_from_host(stack)
+    xcs = [250.0 + i for i in range(n)]
+    ycs = [150.0 - i for i in range(n)]
+    fact = [1.0, -2e-5, 3e-8]
+    res = pp.unwarp_images_backward(dev, xcs, ycs, fact)
+    assert isinstance(res, hip.DeviceArray) and res.shape == (n, H, W)
+    assert hip.last_kernel().startswith("remap_wg_batch_kernel"), hip.last_kernel()
+    got = res.copy_to_host()
+    for i in range(n):
+        assert np.array_equal(got[i], orc.unwarp_image_backward(stack[i], xcs[i], ycs[i], fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+        assert np.array_equal(res[i].copy_to_host(), got[i])

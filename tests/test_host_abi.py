@@ -252,3 +252,17 @@ def test_non_native_byte_order_is_normalised():
     im = pp._Image(a, 2)
     assert im.code == F.DTYPE_BY_NAME["uint16"] and im.dtype == np.dtype("uint16") and im.dtype.isnative
     assert np.array_equal(im.keep, a) and im.keep.dtype.isnative
+
+
+def test_out_arrays_that_cannot_be_viewed_are_refused_before_any_work():
+    """out.reshape(...) of a non-contiguous `out` made a copy and the result silently landed there."""
+    vol = np.zeros((4, 8, 6), np.float32)
+    bad = np.zeros((4, 12), np.float32)[:, ::2]                    # (depth, width) but strided
+    with pytest.raises(ValueError, match="C-contiguous"):
+        pp.unwarp_slice_backward(vol, 3.0, 4.0, [1.0], 2, out=bad)
+    bad4 = np.zeros((2, 4, 12), np.float32)[:, :, ::2]
+    with pytest.raises(ValueError, match="C-contiguous"):
+        pp.unwarp_slice_backward_centres(vol, [3.0, 3.5], [4.0, 4.5], [1.0], 2, out=bad4)
+    # an empty chunk per centre, as the single-centre call (and the reference's np.arange of nothing) gives
+    e = pp.unwarp_chunk_slices_backward_centres(vol, [3.0, 3.5], [4.0, 4.5], [1.0], 5, 4)
+    assert e.shape == (2, 4, 0, 6) and e.dtype == np.float32
