@@ -519,7 +519,7 @@ int dcp_set_option(const char* key, int value) {
   } else if (!strcmp(key, "spline_wg")) {
     dcp::set_spline_wg(value ? 1 : 0);
   } else if (!strcmp(key, "spline_tiled")) {
-    dcp::set_spline_tiled(value < 0 ? 0 : (value > 4 ? 4 : value));
+    dcp::set_spline_tiled(value < 0 ? 0 : (value > 5 ? 5 : value));
   } else if (!strcmp(key, "tile_cert")) {
     g_tile_cert = value ? 1 : 0;      // 0: never use the host's tile-deviation certificate (remap_lds_kernel then votes)
   } else if (!strcmp(key, "stack_chunk_kb")) {

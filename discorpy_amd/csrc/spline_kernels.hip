@@ -733,6 +733,137 @@ __global__ void __launch_bounds__(256, 3) spline_col_lds_kernel(const TileFilter
   }
 }
 
+// ---- the row pass (axis 1) with the column pass's recipe: stage once, recurse in registers ---------------------------------
+// Along a row the recursion of a line runs through CONSECUTIVE addresses, so lane = line needs the tile transposed: a workgroup
+// stages 16 rows x 384 float64 samples in LDS at an ODD pitch (385 doubles: the 16 lanes of an LDS pass then hit 32 distinct
+// banks whatever sample they read).  16-byte LDS-DMA cannot write an odd pitch; 4-byte LDS-DMA can: one load = 256 contiguous
+// bytes of a row = 32 samples, twelve per row, 48 per wave.  After ONE barrier thread (row, segment) -- 16 rows x 16 segments of SEG
+// outputs -- runs its causal recursion from HP samples in front of its segment through SEG + HP samples in registers and the
+// anti-causal one back (the restarts and exact end formulas of the other kernels), a second barrier (everybody has read its
+// inputs), the SEG results go into the tile in place, a third barrier, and the core leaves as contiguous 512-byte stores.
+// Three barriers per tile instead of 2 + 4 per pole, a 49 KB tile (three workgroups per CU, not one), no LDS writes inside the
+// recursion.  One pole (orders 2, 3), reflect / mirror kinds, z^n underflowed -- the tile kernel's conditions.
+#ifndef DCP_RL_ROWS
+#define DCP_RL_ROWS 16               // rows of a tile: 16 x 384 samples (32 x 192 moves 1.6 samples per output instead of 1.26)
+#endif
+constexpr int kRlRows = DCP_RL_ROWS, kRlWidth = 6144 / kRlRows, kRlPitch = kRlWidth + 1, kRlSegs = 256 / kRlRows;
+static_assert(kRlRows == 16 || kRlRows == 32, "an LDS pass of 16 lanes must stay inside one segment");
+template <int HP>
+struct RowLds {
+  static constexpr int SEG = (kRlWidth - 2 * HP) / kRlSegs;    // outputs per thread
+  static constexpr int CORE = kRlSegs * SEG;                   // outputs per tile and row
+};
+
+template <int HP>
+__global__ void __launch_bounds__(256, 3) spline_row_lds_kernel(const TileFilter f, const uint32_t in_bytes) {
+  using G = RowLds<HP>;
+  constexpr int SEG = G::SEG, CORE = G::CORE, J = SEG + HP;
+  __shared__ __attribute__((aligned(16))) double s_t[kRlRows * kRlPitch];
+  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+  const int n = f.n;
+  const int l0 = (int)blockIdx.x * kRlRows;                    // first line (row of the plane) of the tile
+  const int g0 = (int)blockIdx.y * CORE;                       // first sample the tile writes
+  const int base = max(0, g0 - HP);                            // first sample staged
+  // ---- fill: rows wave, wave + 4, ...; six 256-byte chunks each (samples past the row's end belong to the next row or lie
+  // past the descriptor's extent -- zeros --, and are never used)
+  {
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)f.in, 0, (int)in_bytes, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < kRlRows / 4; ++q) {
+      const int rr = q * 4 + wave;
+      const uint32_t row_off = (uint32_t)min(l0 + rr, f.nlines - 1) * (uint32_t)f.in_ls * 8u + (uint32_t)base * 8u + (uint32_t)lane * 4u;
+#pragma unroll
+      for (int c = 0; c < kRlWidth / 32; ++c)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(s_t + rr * kRlPitch + c * 32), 4, row_off + (uint32_t)c * 256u, 0, 0, 0);
+    }
+  }
+  const int row_l = (int)threadIdx.x % kRlRows, seg = (int)threadIdx.x / kRlRows;   // 16 consecutive lanes = 16 rows of one segment: conflict-free LDS passes
+  const int s0 = g0 + seg * SEG;                               // this thread's outputs [s0, s1)
+  const double* a = s_t + row_l * kRlPitch - base;             // a[i]: sample i of this thread's row
+  const double z = f.z[0], lam = f.lam;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  double cs[J];
+  const bool interior = g0 - HP >= 0 && g0 + CORE + HP <= n;   // (workgroup-uniform) no line end in reach: every thread does the same
+  if (interior) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < HP; ++i) t = a[s0 - HP + i] * lam + z * t;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      t = a[s0 + j] * lam + z * t;
+      cs[j] = t;
+    }
+    t = 0.0;
+#pragma unroll
+    for (int j = J - 1; j >= 0; --j) {
+      t = z * (t - cs[j]);
+      cs[j] = t;
+    }
+  } else {
+    // a tile at the start or the end of the lines (2 of ~35 tile columns): the same recursions with every bound per thread
+    const int s1 = min(min(g0 + CORE, n), s0 + SEG), a1 = min(n, s1 + HP);
+    double t = 0.0;
+    int i = max(0, s0 - HP);
+    bool first_exact = false;
+    if (i == 0 && s0 < n) {
+      const double x0 = a[0] * lam;
+      double z_i = z, acc = x0;
+      const int m = min(f.kind == kSplReflect ? n - 1 : n - 2, kHorizon);
+      for (int k = 1; k <= m; ++k) {
+        acc += z_i * (a[k] * lam);
+        z_i *= z;
+      }
+      t = f.kind == kSplReflect ? acc * z / (1.0 - z_i * z_i) + x0 : acc;
+      first_exact = true;
+      i = 1;
+    }
+    for (; i < s0; ++i) t = a[i] * lam + z * t;
+    const double c_before = t;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      cs[j] = 0.0;
+      if (s0 + j < a1) {
+        if (!(first_exact && s0 + j == 0)) t = a[s0 + j] * lam + z * t;
+        cs[j] = t;
+      }
+    }
+    t = 0.0;
+#pragma unroll
+    for (int j = J - 1; j >= 0; --j) {
+      const int idx = s0 + j;
+      if (idx < a1) {
+        if (a1 == n && idx == n - 1) {
+          if (f.kind == kSplReflect) t = cs[j] * (z / (z - 1.0));
+          else t = (z / (z * z - 1.0)) * (cs[j] + z * (j > 0 ? cs[j > 0 ? j - 1 : 0] : c_before));
+        } else {
+          t = z * (t - cs[j]);
+        }
+        cs[j] = t;
+      }
+    }
+  }
+  __syncthreads();                                             // every thread has read its inputs: the results may overwrite them
+  {
+    double* w = s_t + row_l * kRlPitch - base + s0;
+#pragma unroll
+    for (int j = 0; j < SEG; ++j)
+      if (s0 + j < n) w[j] = cs[j];
+  }
+  __syncthreads();
+  // ---- the core, 512 contiguous bytes per wave and store
+  const int c_n = min(CORE, n - g0);
+#pragma unroll
+  for (int q = 0; q < kRlRows / 4; ++q) {
+    const int rr = q * 4 + wave;
+    if (l0 + rr >= f.nlines) break;
+    double* o = f.out + (int64_t)(l0 + rr) * f.out_ls + g0;
+    const double* r = s_t + rr * kRlPitch + (g0 - base);
+    for (int idx = lane; idx < c_n; idx += 64) o[idx] = r[idx];
+  }
+}
+
 // ---- the row pass (axis 1) as a cross-lane scan: no LDS, no barrier, every access a contiguous 512 bytes ---------------
 // Along a row the recursion runs ACROSS the lanes of a wave.  c_i = x_i + z c_(i-1) over the 64 samples of a block is an
 // inclusive scan with multiplier z -- six steps v_i += z^d v_(i-d), d = 1, 2, 4, .., 32 (the neighbour's value through the LDS
@@ -886,7 +1017,9 @@ __device__ __forceinline__ double div_c(double x) {
 }
 
 // centred B-spline weights (the expressions of spline_weights() in the oracle); returns the first tap
-template <int ORDER>
+// FAST (the factorised gather only, where the sum is not scipy's to the last bit anyway): the cubic weights as fused polynomials,
+// y^2 (y / 2 - 1) + 2 / 3 and z^3 / 6 -- 15 operations per axis instead of 27; each weight within one float64 ulp of scipy's form.
+template <int ORDER, bool FAST = false>
 __device__ __forceinline__ int spline_weights(double x, double* w) {
   double s;
   if constexpr (ORDER & 1) s = __builtin_floor(x);
@@ -894,7 +1027,12 @@ __device__ __forceinline__ int spline_weights(double x, double* w) {
   const double t = x - s;
   const int start = (int)s - ORDER / 2;
   double y = t, z = 1.0 - t, t2;
-  if constexpr (ORDER == 2) {
+  if constexpr (ORDER == 3 && FAST) {
+    w[1] = __builtin_fma(y * y, __builtin_fma(y, 0.5, -1.0), 2.0 / 3.0);
+    w[2] = __builtin_fma(z * z, __builtin_fma(z, 0.5, -1.0), 2.0 / 3.0);
+    w[0] = (z * z) * (z * (1.0 / 6.0));
+    w[3] = 1.0 - w[0] - w[1] - w[2];
+  } else if constexpr (ORDER == 2) {
     w[1] = 0.75 - t * t;
     y = 0.5 + t;
     w[2] = 0.5 * y * y;
@@ -1042,7 +1180,7 @@ constexpr int kSwNJ = (kSwBoxH * kSwCH + 255) / 256;   // loads per wave that co
 // launcher -- fma(r2, 0, a) = a exactly; -1: any length, coefficients staged in LDS).  Phase 1 is remap_wg_kernel's: a row table
 // per wave and the hoisted evaluation map_coord (dcp_device.h) -- round 2 walked the coefficient vector with one scalar load and
 // one wait per coefficient and pixel row.
-template <int KIND, int ORDER, int NF>
+template <int KIND, int ORDER, int NF, bool EXACT>
 __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, const MapArgs map, void* dst) {
   constexpr int RW = KIND == kRadial ? 2 : 4;
   __shared__ __attribute__((aligned(16))) unsigned char s_box[kSwBoxH * kSwBoxW * 8];
@@ -1144,12 +1282,18 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
     const int org = by0 * PB + bx0 * 8;
     auto value = [&](int k) -> double {
       double wyv[6], wxv[6];
-      const int sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
-      const int sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+      int sy, sx;
+      if constexpr (EXACT) {
+        sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
+        sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+      } else {
+        sy = spline_weights<ORDER, true>((double)yf[k] + padd, wyv);
+        sx = spline_weights<ORDER, true>((double)xf[k] + padd, wxv);
+      }
       DCP_BOUNDS(sy * PB + sx * 8 - org, ORDER * PB + (ORDER + 1) * 8, sizeof(s_box), 7);
       const unsigned char* base = s_box + (sy * PB + sx * 8 - org);
       double t = 0.0;
-      if (a.exact_sum) {                 // scipy's order: t += (c * wy) * wx, tap by tap (wave-uniform branch)
+      if constexpr (EXACT) {             // scipy's order: t += (c * wy) * wx, tap by tap
 #pragma unroll
         for (int j = 0; j <= ORDER; ++j) {
           const double* row = (const double*)(base + j * PB);
@@ -1212,12 +1356,16 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
 template <int KIND, int NF>
 static hipError_t launch_spline_wg_nf(const SplineArgs& a, const MapArgs& map, void* dst, hipStream_t stream) {
   const dim3 grid((unsigned)((a.W + kSwTW - 1) / kSwTW), (unsigned)((a.H + kSwTH - 1) / kSwTH));
+#define DCP_SWG(ORD)                                                                                                        \
+  if (a.exact_sum) hipLaunchKernelGGL((spline_wg_kernel<KIND, ORD, NF, true>), grid, dim3(256), 0, stream, a, map, dst);    \
+  else hipLaunchKernelGGL((spline_wg_kernel<KIND, ORD, NF, false>), grid, dim3(256), 0, stream, a, map, dst)
   switch (a.order) {
-    case 2: hipLaunchKernelGGL((spline_wg_kernel<KIND, 2, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
-    case 3: hipLaunchKernelGGL((spline_wg_kernel<KIND, 3, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
-    case 4: hipLaunchKernelGGL((spline_wg_kernel<KIND, 4, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
-    default: hipLaunchKernelGGL((spline_wg_kernel<KIND, 5, NF>), grid, dim3(256), 0, stream, a, map, dst); break;
+    case 2: DCP_SWG(2); break;
+    case 3: DCP_SWG(3); break;
+    case 4: DCP_SWG(4); break;
+    default: DCP_SWG(5); break;
   }
+#undef DCP_SWG
   return hipGetLastError();
 }
 
@@ -1272,7 +1420,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     halo += hp[p];
   }
   const int samples = kTfSamples;
-  bool col_stream = false, row_scan = false;
+  bool col_stream = false, row_scan = false, row_lds = false;
   if (tiled && samples - 2 * halo >= 32) {
     TileFilter f;
     f.kind = a.filter_kind;
@@ -1350,7 +1498,15 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ls = a.Wp;
     f.out_ss = 1;
     grid = dim3((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
-    if (a.npoles == 1 && g_spline_tiled == 4 && f.nlines <= 4 * 65535) {
+    const double ext1 = (double)a.Hp * (double)a.Wp * 8.0;
+    if (a.npoles == 1 && (g_spline_tiled == 1 || g_spline_tiled == 5) && ext1 < 4294967000.0 && (hp[0] == 26 || hp[0] == 34)) {
+      // one pole: staged once at an odd pitch, recursions in registers (spline_row_lds_kernel)
+      const int core = hp[0] == 34 ? RowLds<34>::CORE : RowLds<26>::CORE;
+      const dim3 g4((unsigned)((f.nlines + kRlRows - 1) / kRlRows), (unsigned)((f.n + core - 1) / core));
+      if (hp[0] == 34) hipLaunchKernelGGL((spline_row_lds_kernel<34>), g4, dim3(256), 0, stream, f, (uint32_t)ext1);
+      else hipLaunchKernelGGL((spline_row_lds_kernel<26>), g4, dim3(256), 0, stream, f, (uint32_t)ext1);
+      row_lds = true;
+    } else if (a.npoles == 1 && g_spline_tiled == 4 && f.nlines <= 4 * 65535) {
       // one pole, option spline_tiled = 4 only: the cross-lane scan along the rows (no LDS) -- measured at 84 us per 4096^2 plane
       // against the tile kernel's 72 (VALU-bound: ~50 instructions per 64 samples and scan step), kept for A/B runs
       const int nbt = (f.n + 63) / 64;
@@ -1399,8 +1555,10 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
                   (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH;
   {
     char name[160];
-    snprintf(name, sizeof(name), "%s + %s<order=%d>", tiled ? (col_stream ? (row_scan ? "spline_col_stream_kernel + spline_row_scan_kernel" : "spline_col_stream_kernel + spline_tile_filter_kernel")
-                                                                           : (row_scan ? "spline_tile_filter_kernel + spline_row_scan_kernel" : "spline_tile_filter_kernel x 2"))
+    snprintf(name, sizeof(name), "%s + %s<order=%d>", tiled ? (col_stream ? (row_scan ? "spline_col_stream_kernel + spline_row_scan_kernel" : row_lds ? "spline_col_stream_kernel + spline_row_lds_kernel"
+                                                                                                                       : "spline_col_stream_kernel + spline_tile_filter_kernel")
+                                                                           : (row_scan ? "spline_tile_filter_kernel + spline_row_scan_kernel" : row_lds ? "spline_tile_filter_kernel + spline_row_lds_kernel"
+                                                                                                                       : "spline_tile_filter_kernel x 2"))
                                                                   : "spline_causal / anticausal / transpose kernels",
              wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     set_last_kernel_name(name);

@@ -338,8 +338,8 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
         for order, mode in [(2, "mirror"), (3, "reflect"), (3, "nearest"), (4, "reflect"), (5, "grid-constant"), (5, "reflect")]:
             a = (img, c["xcenter"] * shape[1] / 4096.0, 500.0, c["list_fact"])
             res = {}
-            # 1: the default (one-pole orders on float32 frames that need no padding: the register column pass, then the tile kernel
-            # along the rows); 2: the LDS tile kernel on both axes; 0: the plain kernels
+            # 1: the default (one-pole orders: the register column pass for float32 frames that need no padding, the register row
+            # pass behind an odd-pitch LDS staging); 2: the LDS tile kernel on both axes; 0: the plain kernels
             for fast in (1, 2, 0):
                 F.set_option("spline_tiled", fast)
                 F.set_option("spline_wg", 1 if fast else 0)
@@ -347,7 +347,8 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
                              pp.correct_perspective_image(img, coef, order=order, mode=mode))
                 one_pole = fast == 1 and order <= 3
                 direct = one_pole and mode not in ("nearest", "grid-constant")        # (those two pad the plane first)
-                pre = "spline_col_stream_kernel + spline_tile_filter_kernel" if direct else "spline_tile_filter_kernel x 2"
+                pre = ("spline_col_stream_kernel + spline_row_lds_kernel" if direct else
+                       "spline_tile_filter_kernel + spline_row_lds_kernel" if one_pole else "spline_tile_filter_kernel x 2")
                 want_name = (pre + " + spline_wg_kernel<order=%d>" if fast else
                              "spline_causal / anticausal / transpose kernels + spline_remap_kernel<order=%d>") % order
                 assert F.last_kernel() == want_name, F.last_kernel()

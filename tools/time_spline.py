@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--orders", default="2,3,5")
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--variants", default="1,2,3,4")
+    ap.add_argument("--variants", default="1,2,3,4")      # 1 default, 2 tile kernel both axes, 3 unstaged column stream, 4 row scan
     a = ap.parse_args()
     L = F.lib()
     F.require_device()
