@@ -1238,7 +1238,16 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
         constexpr int qrow = (256 * j) / kSwCH, rem = (256 * j) % kSwCH;
         const bool wrap = c160 >= kSwCH - rem;
         const uint32_t step_nowrap = (uint32_t)qrow * rstep + (uint32_t)rem * 16u, step_wrap = step_nowrap + rstep - (uint32_t)PB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16, off0 + (wrap ? step_wrap : step_nowrap), 0, 0, 0);
+        // The slab holds kSwBoxH * kSwCH = 3240 chunks, the kSwNJ = 13 loads of the four waves 3328: the LAST load of a box of full
+        // height would write its trailing lanes -- zeros, their rows are past the descriptor's extent -- behind the slab, into the row
+        // tables that follow it in LDS (found in round 4 by the large-frame campaign: tiles with the tallest boxes came out with the
+        // coordinates of some rows zeroed, differently from run to run).  Those lanes are masked; every other load lies inside.
+        if constexpr ((j * 4 + 4) * 64 > kSwBoxH * kSwCH) {
+          if ((j * 4 + wave) * 64 + lane < kSwBoxH * kSwCH)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16, off0 + (wrap ? step_wrap : step_nowrap), 0, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16, off0 + (wrap ? step_wrap : step_nowrap), 0, 0, 0);
+        }
       }
     }
   };

@@ -1511,3 +1511,22 @@ def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
             assert got.dtype == np.dtype(dt) and np.array_equal(got, orc.unwarp_chunk_slices_backward(v, *a, 3, 280, poly=orc.POLY_KERNEL)), dt
     finally:
         hip.set_option("stack_wg", 1)
+
+
+def test_spline_gather_tiles_with_the_tallest_boxes(hip, orc):
+    """Round 4's large-frame campaign (tools/fuzz_parity.py, FUZZ_BIG) found spline_wg_kernel's last LDS-DMA load of a box of
+    full height writing its trailing lanes behind the slab, into the row tables: the tiles with the tallest boxes came out with
+    some rows' coordinates zeroed, differently from run to run (a latent bug of the earlier rounds: their campaigns reached that
+    kernel only with small distortions).  This is the campaign's case: a strong model, orders 3-5, repeated."""
+    h, w = 1571, 1532
+    img = (np.random.default_rng(5).random((h, w)) * 400.0 - 100.0).astype(np.float32)
+    xc, yc, fact = 499.99635858988756, 218.84785084205987, [1.0, 1.9458361635865997e-05, 6.617751424219899e-09, 8.312873297400471e-13]
+    for order in (3, 4, 5):
+        want = orc.unwarp_image_backward(img, xc, yc, fact, order=order, mode="reflect", poly=orc.POLY_KERNEL)
+        for rep in range(3):
+            for blend in (None, "scipy"):
+                got = pp.unwarp_image_backward(img, xc, yc, fact, order=order, mode="reflect", blend=blend)
+                assert "spline_wg_kernel" in hip.last_kernel()
+                bad = np.count_nonzero(np.abs(got.astype(np.float64) - want) > 1e-4)
+                assert bad == 0, (order, rep, blend, bad)
+                assert np.count_nonzero(got != want) <= (0 if blend == "scipy" and order == 3 else 16), (order, rep, blend)

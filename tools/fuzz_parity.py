@@ -128,6 +128,9 @@ def to_host(a):
 def one_case(rng, k):
     kind = ["radial"] * 5 + ["persp", "fused", "stack", "coords", "spline", "color", "batch", "centres"]
     kind = kind[int(rng.integers(0, len(kind)))]
+    if os.environ.get("FUZZ_ONLY"):             # FUZZ_ONLY=spline,color: only these case kinds (the other draws are still consumed)
+        only = os.environ["FUZZ_ONLY"].split(",")
+        kind = only[int(rng.integers(0, len(only)))]
     h, w = rand_shape(rng)
     dt = DTYPES[int(rng.integers(0, len(DTYPES)))]
     order = int(rng.integers(0, 2))
@@ -136,7 +139,7 @@ def one_case(rng, k):
     if rng.integers(0, 5) == 0:
         xc, yc = float(round(xc)), float(round(yc))
     fact = rand_fact(rng, h, w)
-    staged = rng.integers(0, 3) == 0
+    staged = rng.integers(0, 3) == 0 and not os.environ.get("FUZZ_ONLY")
     if staged:
         # aimed at the staged kernels: a frame of several tiles, a certified calibration, an element type they take
         kind = ("radial", "radial", "batch", "stack", "color", "persp")[int(rng.integers(0, 6))]
@@ -151,6 +154,8 @@ def one_case(rng, k):
         F.set_option("stack_wg", 2)
     okw = dict(poly=orc.POLY_KERNEL)
     tag = "case %d %s%s %dx%d %s order %d blend %s xc=%r yc=%r fact=%r" % (k, "staged " if staged else "", kind, h, w, dt, order, blend, xc, yc, fact)
+    if os.environ.get("FUZZ_TRACE"):          # one line per case BEFORE it runs: what was running when a device fault ended the process
+        print(tag, flush=True)
     f32 = dt == "float32"
     kw = dict(blend=blend) if f32 else {}
     if f32:
@@ -273,7 +278,7 @@ def one_case(rng, k):
             got = pp.remap_coordinates(img, ys, xs, order=order, **kw)
         same(got, orc.remap_coords(img, ys, xs, order=order, **ok2), order, tag)
     elif kind == "spline":
-        if os.environ.get("FUZZ_BIG") and rng.integers(0, 2):
+        if (os.environ.get("FUZZ_BIG") and rng.integers(0, 2)) or (not os.environ.get("FUZZ_BIG") and rng.integers(0, 8) == 0):
             # frames large enough for the one-pass tile prefilter (lines of >= ~900 samples) and many gather tiles
             h, w = int(rng.integers(900, 1700)), int(rng.integers(900, 1700))
         else:
@@ -286,6 +291,8 @@ def one_case(rng, k):
         xc, yc = float(rng.uniform(0, w)), float(rng.uniform(0, h))
         fact = [1.0] + [float(rng.uniform(-0.05, 0.05)) / float(np.hypot(h, w)) ** i for i in range(1, int(rng.integers(1, 5)))]
         tag = "case %d spline %dx%d %s order %d mode %s xc=%r yc=%r fact=%r" % (k, h, w, dt, so, mode, xc, yc, fact)
+        if os.environ.get("FUZZ_TRACE"):
+            print(tag, flush=True)
         same(pp.unwarp_image_backward(img, xc, yc, fact, order=so, mode=mode),
              orc.unwarp_image_backward(img, xc, yc, fact, order=so, mode=mode, poly=orc.POLY_KERNEL), so, tag)
     else:
