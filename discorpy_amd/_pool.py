@@ -70,21 +70,35 @@ class _Block:
     staging it on the device and copying it back (csrc/api_image.cpp: run_host_direct).  The registration costs ~0.8 ms per 64 MiB
     once per block and is undone before the memory goes away.  DISCORPY_AMD_PIN_OUTPUTS=0 switches it off."""
 
-    __slots__ = ("arr", "registered")
+    __slots__ = ("arr", "registered", "_map", "_span")
 
     def __init__(self, nbytes):
-        self.arr = np.empty(nbytes, np.uint8)
         self.registered = False
+        self._map = None
+        self._span = 0
         if _may_pin(nbytes):
+            # A block that gets REGISTERED lives in an anonymous mapping of its own, whole pages, and the whole pages are what is
+            # registered: a malloc'ed block (glibc serves up to 32 MiB from the brk heap once large arrays have been freed) shares
+            # its first and last page with neighbouring heap objects, and when one of those neighbours is the pageable source or
+            # destination of another copy the runtime pins and unpins that shared page on the fly under the registration --
+            # round 4's large-frame campaign ended in "Memory access fault by GPU" on a heap address about once per 10 000 cases.
             try:
+                import mmap
                 from . import _ffi as F
-                self.arr[::4096] = 0                      # fault the pages in before they are pinned
+                page = mmap.PAGESIZE
+                self._span = (nbytes + page - 1) // page * page
+                self._map = mmap.mmap(-1, self._span)
+                self.arr = np.frombuffer(self._map, dtype=np.uint8, count=nbytes)
+                self.arr[::page] = 0                      # fault the pages in before they are pinned
                 dev = int(os.environ.get("DISCORPY_AMD_DEVICE", "-1"))
-                self.registered = F.lib().dcp_host_register(self.arr.ctypes.data, nbytes, dev) == 0
+                self.registered = F.lib().dcp_host_register(self.arr.ctypes.data, self._span, dev) == 0
             except Exception:      # noqa: BLE001 -- a plain block
                 self.registered = False
             if not self.registered:
                 _unpin(nbytes)
+                self._map = None
+        if not self.registered:
+            self.arr = np.empty(nbytes, np.uint8)
 
     @property
     def nbytes(self):

@@ -386,7 +386,9 @@ int dcp_memcpy(void* dst, const void* src, size_t bytes, int kind, int device, v
 /* Host memory the GPU can address (hipHostRegister): a DCP_MEM_HOST frame call whose `dst` lies in registered memory -- these, or
  * anything from hipHostMalloc -- has its result written straight into it by the kernels, band by band while the source is still
  * uploading (no device copy of the result, no download; option "host_direct" = 0 switches that off).  Registration costs ~0.8 ms
- * per 64 MiB: for buffers that are reused.  Unregister before the memory is freed. */
+ * per 64 MiB: for buffers that are reused.  Unregister before the memory is freed.  Register WHOLE PAGES that nothing else lives in
+ * (an mmap'ed or page-aligned allocation): a malloc'ed block shares its edge pages with other heap objects, and a pageable copy of
+ * one of those is pinned and unpinned by the runtime under the registration (GPU memory access faults, round 4). */
 int dcp_host_register(void* ptr, size_t bytes, int device);
 int dcp_host_unregister(void* ptr);
 int dcp_stream_create(void** stream, int device);   /* a non-blocking stream for DCP_MEM_DEVICE calls */
