@@ -507,7 +507,7 @@ int dcp_set_option(const char* key, int value) {
     g_host_direct = value;            // 0: a host frame's result is always staged on the device and copied back; 1: written straight into a
                                       // registered destination when the runtime cannot overlap an upload with a download; 2: whenever registered
   } else if (!strcmp(key, "tall_tiles")) {
-    g_tall_tiles = value ? 1 : 0;     // 1: sheared radial maps (level-1 certificate, boxes of 64 x 32 tiles fit 80 x 56) on 64 x 32 workgroup tiles instead of the
+    g_tall_tiles = value < 0 ? 0 : (value > 2 ? 2 : value);     // 1: sheared radial maps (level-1 certificate, boxes of 64 x 32 tiles fit 80 x 56) on 64 x 32 workgroup tiles instead of the
                                       // per-wave-box kernel.  Default 0: measured SLOWER on BASELINE config 5 (128-131 us against 113-116, tools/time_cfg5.py)
   } else if (!strcmp(key, "int_exact")) {
     g_int_exact = value ? 1 : 0;      // 0: integer element types blend in scipy's operation order everywhere (A/B and parity runs)

@@ -432,11 +432,13 @@ hipError_t launch_color(const ImageArgs& img_in, const MapArgs& map, int channel
   *taken = false;
   if (!opts.wg_box || !opts.lds_gather || opts.coef_lds || opts.xcd_remap == 1) return hipSuccess;
   if (!(map.tile_dev_ok >= 2 || (channels == 1 && dtype == kF32 && img_in.tile_rows == 64 && map.tall_ok))) return hipSuccess;
+  if (channels == 1 && dtype == kF32 && img_in.tile_rows == 128 && map.tile_dev_ok < 2) return hipSuccess;
   const bool colour = (channels == 3 || channels == 4) && (dtype == kF32 || dtype == kU8 || dtype == kU16);
   // (float32 single planes: only the 64 x 32 tile shape for sheared maps, img.tile_rows = 64 -- launch_plane_tall below; the
   // 128-wide shapes of float32 belong to remap_wg_kernel)
   const bool tall = channels == 1 && dtype == kF32 && img_in.tile_rows == 64;
-  const bool plane = channels == 1 && (dtype == kF64 || dtype == kI32 || dtype == kU32 || tall);
+  const bool flat = channels == 1 && dtype == kF32 && img_in.tile_rows == 128;      // (A/B only: option tall_tiles = 2)
+  const bool plane = channels == 1 && (dtype == kF64 || dtype == kI32 || dtype == kU32 || tall || flat);
   if (!colour && !plane) return hipSuccess;
   if (sampler != kNearest && sampler != kScipy && !(sampler == kF64Lerp && dtype == kF32)) return hipSuccess;
   const int es = elem_size(dtype);
@@ -453,6 +455,7 @@ hipError_t launch_color(const ImageArgs& img_in, const MapArgs& map, int channel
     return hipSuccess;
   *taken = true;
   if (tall) return launch_color_s<float, 1, 1>(img, map, sampler, stream);
+  if (flat) return launch_color_s<float, 1, 0>(img, map, sampler, stream);
   switch (dtype) {
     case kF32: return launch_color_c<float>(img, map, channels, sampler, stream);
     case kU8: return launch_color_c<uint8_t>(img, map, channels, sampler, stream);

@@ -2061,6 +2061,14 @@ hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& ma
       const hipError_t e = launch_color(t, map, 1, kF32, sampler, opts, stream, &taken);
       if (e != hipSuccess || taken) return e;
     }
+    if (pair && round_f32 && !opts.coef_lds && img.lds_gather && img.wg_box && opts.tall_tiles == 2 && map.tile_dev_ok >= 2 && opts.xcd_remap != 1 &&
+        sampler != kF32Lerp) {        // A/B: the generic interleaved-pixel kernel with one channel on 128 x 16 tiles in remap_wg_kernel's place
+      ImageArgs t = img;
+      t.tile_rows = 128;
+      bool taken = false;
+      const hipError_t e = launch_color(t, map, 1, kF32, sampler, opts, stream, &taken);
+      if (e != hipSuccess || taken) return e;
+    }
     if (pair && round_f32 && !opts.coef_lds) {
       switch (nf) {
         case 1: return launch_fast<kRadial, 1>(img, map, sampler, stream);
