@@ -65,6 +65,7 @@ struct StackArgs {
                            // a row coordinate outside it is reflected inside it, as scipy does with the cropped band.  rbh = 0:
                            // the host has shown that no coordinate can leave the band (or the call is not a chunk): no check
   int32_t int_exact;       // as ImageArgs::int_exact (stack_wg_kernel on integer element types)
+  int32_t xcd_order = 0;   // stack_wg_kernel: tiles dealt to the XCDs in contiguous runs (LaunchOpts::xcd_remap != 0)
 };
 
 struct CoordArgs {

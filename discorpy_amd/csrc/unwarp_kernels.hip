@@ -1537,10 +1537,29 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
   const int wx = wave & 1, wy = wave >> 1;
-  const int rblk = blockIdx.y * kWgTH;
+  // ---- which (tile column, tile row, depth chunk) this workgroup owns.  The dispatcher deals workgroups to the eight XCDs round robin
+  // by their linear id (see logical_tile): in grid order the tiles left and right of this one stream THEIR boxes -- which share the
+  // lines at this box's edges and, above and below, whole rows -- through other L2s.  xcd_order: XCD k takes the k-th eighth of the
+  // (x fastest, then rows, then depth chunks) enumeration, so that the ~100 workgroups an XCD holds at a time are neighbouring tiles
+  // of one depth chunk and walk its projections together
+  int tile_x = (int)blockIdx.x, tile_y = (int)blockIdx.y, tile_z = (int)blockIdx.z;
+  if (st.xcd_order) {
+    const uint32_t gx = gridDim.x, gxy = gx * gridDim.y, n = gxy * gridDim.z;
+    const uint32_t b = blockIdx.x + gx * blockIdx.y + gxy * blockIdx.z;
+    const uint32_t xcd = b & 7u;
+    uint32_t lin = xcd * (n >> 3) + min(xcd, n & 7u) + (b >> 3);
+    tile_z = (int)(lin / gxy);
+    lin -= (uint32_t)tile_z * gxy;
+    tile_y = (int)(lin / gx);
+    tile_x = (int)(lin - (uint32_t)tile_y * gx);
+  }
+  tile_x = __builtin_amdgcn_readfirstlane(tile_x);
+  tile_y = __builtin_amdgcn_readfirstlane(tile_y);
+  tile_z = __builtin_amdgcn_readfirstlane(tile_z);
+  const int rblk = tile_y * kWgTH;
   const int r0 = __builtin_amdgcn_readfirstlane(rblk + wy * kLdsTH);   // first requested row of this wave's sub-tile
-  const int x = blockIdx.x * kWgTW + wx * kLdsTW + lane;
-  const int d0 = blockIdx.z * st.d_chunk, d1 = min(st.D, d0 + st.d_chunk);
+  const int x = tile_x * kWgTW + wx * kLdsTW + lane;
+  const int d0 = tile_z * st.d_chunk, d1 = min(st.D, d0 + st.d_chunk);
   const float wmaxf = (float)(st.W - 1), hmaxf = (float)(st.H - 1);
   const T* const volT = (const T*)st.vol;
   T* const outT = (T*)st.out;
@@ -1548,7 +1567,7 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
   // ---- the tile's four corner pixels (lanes 0..3, every wave for itself) -> box
   int cx0, cx1, cy0, cy1;
   {
-    const double X = (double)min(blockIdx.x * kWgTW + (lane & 1) * (kWgTW - 1), st.W - 1);
+    const double X = (double)min(tile_x * kWgTW + (lane & 1) * (kWgTW - 1), st.W - 1);
     const double Y = st.row_start + (double)min(rblk + ((lane >> 1) & 1) * (kWgTH - 1), st.nrows - 1);
     const double xu = X - map.xc, yu = Y - map.yc;
     const double r2 = xu * xu + yu * yu;
@@ -2256,6 +2275,17 @@ static int wg_stack_chunk(const StackArgs& st, int d_chunk, bool force = false) 
   return dc;
 }
 
+// stack_wg_kernel's tile order.  Measured (tools/ab_stack_order.py, tools/pmc_stack_order.sh; cfg4 shards of 64 / 256 / 1024
+// projections): XCD runs cut the L2's fetches from 1.50 to 1.07 x the algorithmic reads (float32) and from 1.95 to 0.99 x
+// (uint16), but the kernel is not bound by them: uint16 shards run 2-5 % faster in every process tried, float32 shards
+// anywhere between 11 % faster and 9 % slower from process to process (the same spread the grid order has by itself).
+// Integer element types take the runs; float32 keeps the grid order unless option xcd_remap = 1 asks for them.
+static int wg_stack_xcd_order(const StackArgs& st, const LaunchOpts& opts, int es) {
+  const int64_t n = (int64_t)((st.W + kWgTW - 1) / kWgTW) * ((st.nrows + kWgTH - 1) / kWgTH) * ((st.D + st.d_chunk - 1) / st.d_chunk);
+  if (opts.xcd_remap == 0 || n >= (int64_t(1) << 31)) return 0;      // (the kernel enumerates the grid in 32 bits)
+  return es < 4 || opts.xcd_remap == 1 ? 1 : 0;
+}
+
 static bool wg_stack_eligible(const StackArgs& st, const MapArgs& map, const LaunchOpts& opts, int es) {
   return map.tile_dev_ok >= 2 && opts.wg_box && opts.lds_gather && opts.stack_lds && !opts.coef_lds && st.nrows >= 8 && st.W >= 2 && st.H >= 2 &&
          st.row_stride < (1 << 22) && st.H < (1 << 24) && (((uintptr_t)st.vol) & 3u) == 0 && (((int64_t)st.row_stride * es) & 3) == 0 &&
@@ -2297,6 +2327,7 @@ hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int
   st.d_chunk = wg_stack_chunk(st, opts.d_chunk, opts.stack_wg >= 2);
   if (st.d_chunk == 0) return hipSuccess;
   st.int_exact = opts.int_exact;
+  st.xcd_order = wg_stack_xcd_order(st, opts, elem_size(dtype));
   *taken = true;
   switch (dtype) {
     case kU8: return launch_stack_wg_n<uint8_t>(st, map, kScipy, stream);
@@ -2316,6 +2347,7 @@ hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler,
     const int dc = wg_stack_chunk(st, st.d_chunk, opts.stack_wg >= 2);
     if (dc > 0) {
       st.d_chunk = dc;
+      st.xcd_order = wg_stack_xcd_order(st, opts, 4);
       return launch_stack_wg_n<float>(st, map, sampler, stream);
     }
   }

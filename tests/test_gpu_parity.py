@@ -1513,6 +1513,35 @@ def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
         hip.set_option("stack_wg", 1)
 
 
+def test_stack_wg_kernel_xcd_runs_tile_order(hip, orc):
+    """Round 4: stack_wg_kernel deals its (tile column, tile row, depth chunk) triples to the eight XCDs in contiguous runs (the
+    default for integer stacks, option xcd_remap = 1 for float32 ones).  A permutation of the workgroups only: every voxel equal
+    to the grid order's and to the oracle, on grids whose workgroup count does and does not divide by eight, with ragged tiles
+    and a ragged last depth chunk."""
+    torch = pytest.importorskip("torch")
+    a = (250.3, 140.8, [1.0, 3.0e-5, -4.0e-8, 1e-11, -2e-14])
+    hip.set_option("stack_wg", 2)
+    try:
+        for (D, H, W, r0, r1) in ((21, 300, 517, 7, 291), (9, 200, 640, 0, 199), (5, 97, 130, 3, 60)):
+            vol = noise(700 + D, (D, H, W))
+            want = orc.unwarp_chunk_slices_backward(vol, *a, r0, r1, **kernel_oracle(orc, "f64lerp"))
+            for order in (1, 0, 2):
+                hip.set_option("xcd_remap", order)
+                got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *a, r0, r1).cpu().numpy()
+                assert hip.last_kernel() == "stack_wg_kernel<NF=5,f64lerp>", hip.last_kernel()
+                assert np.array_equal(got, want), (D, H, W, order)
+            v = typed_image("uint16", (D, H, W + (4 - W % 4) % 4), 710 + D)
+            want = orc.unwarp_chunk_slices_backward(v, *a, r0, r1, poly=orc.POLY_KERNEL)
+            for order in (2, 0):
+                hip.set_option("xcd_remap", order)
+                got = pp.unwarp_chunk_slices_backward(torch.from_numpy(v).cuda(), *a, r0, r1).cpu().numpy()
+                assert hip.last_kernel().startswith("stack_wg_kernel<NF=5,scipy,16-bit"), hip.last_kernel()
+                assert np.array_equal(got, want), (D, H, W, order)
+    finally:
+        hip.set_option("xcd_remap", 2)
+        hip.set_option("stack_wg", 1)
+
+
 def test_spline_gather_tiles_with_the_tallest_boxes(hip, orc):
     """Round 4's large-frame campaign (tools/fuzz_parity.py, FUZZ_BIG) found spline_wg_kernel's last LDS-DMA load of a box of
     full height writing its trailing lanes behind the slab, into the row tables: the tiles with the tallest boxes came out with
