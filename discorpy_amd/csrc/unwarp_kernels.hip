@@ -1539,19 +1539,29 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
   const int wx = wave & 1, wy = wave >> 1;
   // ---- which (tile column, tile row, depth chunk) this workgroup owns.  The dispatcher deals workgroups to the eight XCDs round robin
   // by their linear id (see logical_tile): in grid order the tiles left and right of this one stream THEIR boxes -- which share the
-  // lines at this box's edges and, above and below, whole rows -- through other L2s.  xcd_order: XCD k takes the k-th eighth of the
+  // lines at this box's edges and, above and below, whole rows -- through other L2s.  xcd_order 1: XCD k takes the k-th eighth of the
   // (x fastest, then rows, then depth chunks) enumeration, so that the ~100 workgroups an XCD holds at a time are neighbouring tiles
-  // of one depth chunk and walk its projections together
+  // of one depth chunk and walk its projections together; 2: whole tile rows (wg_stack_xcd_order has the measurements)
   int tile_x = (int)blockIdx.x, tile_y = (int)blockIdx.y, tile_z = (int)blockIdx.z;
   if (st.xcd_order) {
     const uint32_t gx = gridDim.x, gxy = gx * gridDim.y, n = gxy * gridDim.z;
     const uint32_t b = blockIdx.x + gx * blockIdx.y + gxy * blockIdx.z;
     const uint32_t xcd = b & 7u;
-    uint32_t lin = xcd * (n >> 3) + min(xcd, n & 7u) + (b >> 3);
-    tile_z = (int)(lin / gxy);
-    lin -= (uint32_t)tile_z * gxy;
-    tile_y = (int)(lin / gx);
-    tile_x = (int)(lin - (uint32_t)tile_y * gx);
+    if (st.xcd_order == 2) {
+      // XCD k takes the tile rows k, k + 8, ... of every depth chunk (gridDim.y is the number of tile rows rounded up to a multiple of
+      // eight: the workgroups of the rows that do not exist leave).  Left and right neighbours share an L2, the eight XCDs stay
+      // inside one band of rows of one depth chunk as in grid order
+      const uint32_t l = b - gxy * blockIdx.z, j = l >> 3, q = j / gx;
+      tile_y = (int)(q * 8u + xcd);
+      tile_x = (int)(j - q * gx);
+      if (tile_y * kWgTH >= st.nrows) return;
+    } else {
+      uint32_t lin = xcd * (n >> 3) + min(xcd, n & 7u) + (b >> 3);
+      tile_z = (int)(lin / gxy);
+      lin -= (uint32_t)tile_z * gxy;
+      tile_y = (int)(lin / gx);
+      tile_x = (int)(lin - (uint32_t)tile_y * gx);
+    }
   }
   tile_x = __builtin_amdgcn_readfirstlane(tile_x);
   tile_y = __builtin_amdgcn_readfirstlane(tile_y);
@@ -2275,15 +2285,20 @@ static int wg_stack_chunk(const StackArgs& st, int d_chunk, bool force = false) 
   return dc;
 }
 
-// stack_wg_kernel's tile order.  Measured (tools/ab_stack_order.py, tools/pmc_stack_order.sh; cfg4 shards of 64 / 256 / 1024
-// projections): XCD runs cut the L2's fetches from 1.50 to 1.07 x the algorithmic reads (float32) and from 1.95 to 0.99 x
-// (uint16), but the kernel is not bound by them: uint16 shards run 2-5 % faster in every process tried, float32 shards
-// anywhere between 11 % faster and 9 % slower from process to process (the same spread the grid order has by itself).
-// Integer element types take the runs; float32 keeps the grid order unless option xcd_remap = 1 asks for them.
+// stack_wg_kernel's tile order: 0 grid order, 1 XCD runs, 2 XCD tile rows (see the kernel).  Measured (tools/ab_stack_order.py,
+// tools/pmc_stack_order.sh; cfg4 shards of 64 / 256 / 1024 projections, 2560^2): the L2s fetch 1.50 x the algorithmic reads of a
+// float32 shard in grid order, 1.10 x by tile rows (what is left is the four rows two vertical neighbours share), 1.07 x by runs;
+// uint16: 1.95 / 1.09 / 0.99.  The kernel is not bound by those fetches, so time moves little: float32 by rows 0-1 % faster than grid
+// order in every process tried, by runs anywhere between 11 % faster and 9 % slower from process to process (eight XCDs streaming
+// eight distant regions); uint16 by runs 3-5 % faster, by rows 2-4 %.  So: float32 by tile rows -- the same speed for a fifth less
+// HBM traffic, which the exchange of a sharded stack runs beside -- unless the padding to eight rows costs more than 7 % (then grid
+// order); integer element types by runs.  Option xcd_remap: 0 grid order, 1 runs for every type.
 static int wg_stack_xcd_order(const StackArgs& st, const LaunchOpts& opts, int es) {
-  const int64_t n = (int64_t)((st.W + kWgTW - 1) / kWgTW) * ((st.nrows + kWgTH - 1) / kWgTH) * ((st.D + st.d_chunk - 1) / st.d_chunk);
+  const int64_t ty = (st.nrows + kWgTH - 1) / kWgTH, ty8 = 8 * ((ty + 7) / 8);
+  const int64_t n = (int64_t)((st.W + kWgTW - 1) / kWgTW) * ty8 * ((st.D + st.d_chunk - 1) / st.d_chunk);
   if (opts.xcd_remap == 0 || n >= (int64_t(1) << 31)) return 0;      // (the kernel enumerates the grid in 32 bits)
-  return es < 4 || opts.xcd_remap == 1 ? 1 : 0;
+  if (es < 4 || opts.xcd_remap == 1) return 1;
+  return ty8 * 100 <= ty * 107 && ty8 <= 65535 ? 2 : 0;
 }
 
 static bool wg_stack_eligible(const StackArgs& st, const MapArgs& map, const LaunchOpts& opts, int es) {
@@ -2294,7 +2309,8 @@ static bool wg_stack_eligible(const StackArgs& st, const MapArgs& map, const Lau
 
 template <int NF, typename T>
 static hipError_t launch_stack_wg_t(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
-  const dim3 grid((unsigned)((st.W + kWgTW - 1) / kWgTW), (unsigned)((st.nrows + kWgTH - 1) / kWgTH), (unsigned)((st.D + st.d_chunk - 1) / st.d_chunk));
+  dim3 grid((unsigned)((st.W + kWgTW - 1) / kWgTW), (unsigned)((st.nrows + kWgTH - 1) / kWgTH), (unsigned)((st.D + st.d_chunk - 1) / st.d_chunk));
+  if (st.xcd_order == 2) grid.y = 8 * ((grid.y + 7) / 8);            // see the kernel's tile order
   if constexpr (std::is_same<T, float>::value) {
     note_kernel("stack_wg_kernel", -1, NF, sampler);
     switch (sampler) {

@@ -1515,14 +1515,16 @@ def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
 
 def test_stack_wg_kernel_xcd_runs_tile_order(hip, orc):
     """Round 4: stack_wg_kernel deals its (tile column, tile row, depth chunk) triples to the eight XCDs in contiguous runs (the
-    default for integer stacks, option xcd_remap = 1 for float32 ones).  A permutation of the workgroups only: every voxel equal
+    default for integer stacks, option xcd_remap = 1 for float32 ones) or by whole tile rows (the default for float32 stacks whose
+    tile rows pad to a multiple of eight cheaply).  A permutation of the workgroups only: every voxel equal
     to the grid order's and to the oracle, on grids whose workgroup count does and does not divide by eight, with ragged tiles
     and a ragged last depth chunk."""
     torch = pytest.importorskip("torch")
     a = (250.3, 140.8, [1.0, 3.0e-5, -4.0e-8, 1e-11, -2e-14])
     hip.set_option("stack_wg", 2)
     try:
-        for (D, H, W, r0, r1) in ((21, 300, 517, 7, 291), (9, 200, 640, 0, 199), (5, 97, 130, 3, 60)):
+        # (the last two: 15 and 16 tile rows -- float32 stacks then go by tile rows, the first with a vacant sixteenth row)
+        for (D, H, W, r0, r1) in ((21, 300, 517, 7, 291), (9, 200, 640, 0, 199), (5, 97, 130, 3, 60), (6, 520, 300, 5, 474), (5, 530, 200, 0, 511)):
             vol = noise(700 + D, (D, H, W))
             want = orc.unwarp_chunk_slices_backward(vol, *a, r0, r1, **kernel_oracle(orc, "f64lerp"))
             for order in (1, 0, 2):
