@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0}, g_store_wait{1};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -40,6 +40,7 @@ dcp::LaunchOpts current_opts() {
   o.stack_wg = g_stack_wg.load();
   o.int_exact = g_int_exact.load();
   o.tall_tiles = g_tall_tiles.load();
+  o.store_wait = g_store_wait.load();
   return o;
 }
 
@@ -506,6 +507,8 @@ int dcp_set_option(const char* key, int value) {
     if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "host_direct must be 0, 1 or 2");
     g_host_direct = value;            // 0: a host frame's result is always staged on the device and copied back; 1: written straight into a
                                       // registered destination when the runtime cannot overlap an upload with a download; 2: whenever registered
+  } else if (!strcmp(key, "store_wait")) {
+    g_store_wait = value ? 1 : 0;     // 0: stack_wg_kernel waits for its own stores at every projection (rounds 2-3), A/B
   } else if (!strcmp(key, "tall_tiles")) {
     g_tall_tiles = value < 0 ? 0 : (value > 2 ? 2 : value);     // 1: sheared radial maps (level-1 certificate, boxes of 64 x 32 tiles fit 80 x 56) on 64 x 32 workgroup tiles instead of the
                                       // per-wave-box kernel.  Default 0: measured SLOWER on BASELINE config 5 (128-131 us against 113-116, tools/time_cfg5.py)
@@ -553,6 +556,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "int_exact")) *value = g_int_exact;
   else if (!strcmp(key, "host_direct")) *value = g_host_direct;
   else if (!strcmp(key, "tall_tiles")) *value = g_tall_tiles;
+  else if (!strcmp(key, "store_wait")) *value = g_store_wait;
   else if (!strcmp(key, "host_direct_applies")) {        // read-only: measures the runtime once (needs a device)
     int n = 0;
     *value = (hipGetDeviceCount(&n) == hipSuccess && n > 0 && host_direct_applies()) ? 1 : 0;

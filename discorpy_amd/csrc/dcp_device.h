@@ -45,6 +45,26 @@ __device__ __forceinline__ void check_lds_tap(uint32_t first, uint32_t span, uin
   }
 #endif
 
+// ------------------------------------------------------------------ LDS-DMA the compiler does not know about
+// hipcc tracks a `buffer_load ... lds` it issued as a pending write to ALL of LDS and puts `s_waitcnt vmcnt(0)` in front of the next LDS
+// read of the wave, whichever slab that read is from (SIInsertWaitcnts needs alias scopes to tell slabs apart; a slab picked by a
+// run-time index has none): a kernel that streams the NEXT box into one slab while it blends out of the other was made to wait for the
+// stream before every blend.  These two hide the load in an asm statement (M0 -- the LDS address of lane 0's 16 bytes -- saved and
+// restored around it); the caller owns the wait (`s_waitcnt vmcnt(n)` + barrier before the slab is read).
+typedef int dcp_rsrc_words __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ dcp_rsrc_words raw_rsrc_words(const void* base, uint32_t bytes) {       // as make_buffer_rsrc(base, 0, bytes, 0x00020000)
+  const uint64_t a = (uint64_t)(uintptr_t)base;
+  dcp_rsrc_words r = {(int)(uint32_t)a, (int)((uint32_t)(a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  return r;
+}
+__device__ __forceinline__ void lds_dma16_untracked(dcp_rsrc_words rs, uint32_t lds_addr, uint32_t voffset) {
+  uint32_t m0_saved;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(m0_saved)
+               : "s"(lds_addr), "v"(voffset), "s"(rs)
+               : "memory");
+}
+
 // ------------------------------------------------------------------ fp64 helpers
 
 constexpr double kTinyR2 = 1e-300;   // keeps rsq finite at the centre pixel; absorbed everywhere else

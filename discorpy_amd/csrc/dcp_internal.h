@@ -65,6 +65,7 @@ struct StackArgs {
                            // a row coordinate outside it is reflected inside it, as scipy does with the cropped band.  rbh = 0:
                            // the host has shown that no coordinate can leave the band (or the call is not a chunk): no check
   int32_t int_exact;       // as ImageArgs::int_exact (stack_wg_kernel on integer element types)
+  int32_t store_wait = 0;  // stack_wg_kernel: LaunchOpts::store_wait
   int32_t xcd_order = 0;   // stack_wg_kernel: tiles dealt to the XCDs in contiguous runs (LaunchOpts::xcd_remap != 0)
 };
 
@@ -140,6 +141,7 @@ struct LaunchOpts {
   int stack_lds = 1;       // LDS-staged stack kernel: 0 never, 1 when the launch has enough wave tiles, 2 always
   int wg_box = 1;          // 1: remap_wg_kernel (one source box per 128 x 32 workgroup tile) for certified maps
   int wg_per_cu = 0;       // remap_wg_kernel: cap on resident workgroups per CU (0 = none)
+  int store_wait = 1;      // stack_wg_kernel: 1 waits for the fill only (the stores of the previous projection stay in flight), 0 for everything
   int tall_tiles = 0;      // (A/B option, off: slower on config 5) sheared radial maps (level-1 certificate, MapArgs::tall_ok): 64 x 32 workgroup tiles (remap_wg_color_kernel) instead of per-wave boxes
   int int_exact = 1;       // integer element types: the exact factorised blend where it is provably exact (0: scipy's operation order everywhere)
   int stack_wg = 1;        // stack_wg_kernel (one box per workgroup, two slabs) for chunks of rows under a certified map: 0 never,

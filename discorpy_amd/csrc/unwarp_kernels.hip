@@ -711,6 +711,9 @@ constexpr int kWgBoxW = 144, kWgBoxH = 42;        // largest box: 36 chunks of 1
 constexpr int kWgSlabRows = 42;                   // 24 192 B: six workgroups per CU
 static_assert(kLdsTW == 64 && kLdsTH == 16, "remap_wg_kernel assumes 64 x 16 wave tiles");
 
+#ifndef DCP_WG_UNTRACKED_DMA
+#define DCP_WG_UNTRACKED_DMA 1   // 0: remap_wg_kernel's fill through the compiler's LDS-DMA builtin (rounds 2-3; A/B)
+#endif
 #ifndef DCP_WG_FILL_START
 #define DCP_WG_FILL_START 0   // phase 1 row in front of which the first load of the fill is issued
 #endif
@@ -845,7 +848,9 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
   // which replaces the per-lane row test of every load (7 -> 3 vector instructions per load)
   const unsigned long long rows_end = (unsigned long long)(by1 + 1) * rstep;
   const uint32_t fill_extent = rows_end < (unsigned long long)img.src_bytes ? (uint32_t)rows_end : img.src_bytes;
-  const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img.src, 0, (int)fill_extent, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img.src, 0, (int)fill_extent, 0x00020000);
+  [[maybe_unused]] const dcp_rsrc_words src_words = raw_rsrc_words(img.src, fill_extent);
+  [[maybe_unused]] const uint32_t box0 = (uint32_t)(uintptr_t)(lds_ptr)&s_box[0];
   const int fc = wave * 64 + lane;
   const int crow0 = fc / CH;                                            // (constant divisor: a multiply and a shift)
   const int c160 = fc - crow0 * CH;
@@ -864,8 +869,14 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
         const bool wrap = c160 >= CH - rem;
         // (the two alternatives are scalars: one compare, one select, one add per load)
         const uint32_t step_nowrap = (uint32_t)qrow * rstep + (uint32_t)rem * 16u, step_wrap = step_nowrap + rstep - (uint32_t)PB;
+#if DCP_WG_UNTRACKED_DMA
+        // (hidden from the compiler, which otherwise puts `s_waitcnt vmcnt(0)` in front of a row-table read in the middle of phase 1
+        // on the interior-tile path: see lds_dma16_untracked.  The wait for the fill is the explicit one in front of the barrier below)
+        lds_dma16_untracked(src_words, box0 + (uint32_t)((j * 4 + wave) * 1024), off0 + (wrap ? step_wrap : step_nowrap));
+#else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)(s_box + (j * 4 + wave) * 1024), 16, off0 + (wrap ? step_wrap : step_nowrap), 0, 0,
                                                  DCP_FILL_AUX);
+#endif
       }
     }
   };
@@ -1517,6 +1528,9 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 // copy runs under the arithmetic inside the workgroup) and blend their 1024 pixels each out of the other.  One barrier
 // per projection.  T as in remap_wg_kernel: float (any blend) or an 8- / 16-bit integer type (scipy's blend and integer
 // store) -- tomography detectors deliver uint16.  float32 coordinates only (unwarp_chunk_slices_backward).
+#ifndef DCP_STACK_UNTRACKED_DMA
+#define DCP_STACK_UNTRACKED_DMA 1   // 0: the fill through the compiler's LDS-DMA builtin (rounds 2-3; A/B) -- see lds_dma16_untracked
+#endif
 #ifndef DCP_STACK_INT_WAVES
 #define DCP_STACK_INT_WAVES 4   // waves per SIMD the integer instantiations are allocated for (128 VGPRs; at 5 = 96 VGPRs the projection loop spills: 575 us against 435 per uint16 shard)
 #endif
@@ -1655,17 +1669,25 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
   const int c160 = fc - crow0 * CH;
   const uint32_t off0 = ((uint32_t)by0 * (uint32_t)st.row_stride + (uint32_t)bx0) * (uint32_t)ES + (uint32_t)crow0 * rstep + (uint32_t)c160 * 16u;
   const int nchunk = bh * CH;
+  // lds_dma16_untracked: seen by the compiler, the stream of projection d + 1 is waited for before the blend of projection d.  Integer
+  // stacks (bound by that chain's latency) gain 3-9 % without the wait; float32 stacks (at the rate the box copies memory at) lose 1 %:
+  // they keep the builtin
+  constexpr bool kUntrackedFill = DCP_STACK_UNTRACKED_DMA && !kIsF32;
+  [[maybe_unused]] const uint32_t slab0 = (uint32_t)(uintptr_t)(lds_ptr)&s_box[0][0];
   auto fill = [&](const T* proj, int slab) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)proj, 0, (int)st.proj_bytes, 0x00020000);
+    [[maybe_unused]] const dcp_rsrc_words rs = raw_rsrc_words(proj, st.proj_bytes);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rs_seen = __builtin_amdgcn_make_buffer_rsrc((void*)proj, 0, (int)st.proj_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       if ((j * 4 + wave) * 64 < nchunk) {
         const int qrow = (256 * j) / CH, rem = (256 * j) % CH;
         const bool wrap = c160 >= CH - rem;
         const int crow = crow0 + qrow + (wrap ? 1 : 0);
-        if (crow < bh)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(s_box[slab] + (j * 4 + wave) * 1024), 16,
-                                                   off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u, 0, 0, 0);
+        const uint32_t voff = off0 + (wrap ? rstep - (uint32_t)PB : 0u) + (uint32_t)qrow * rstep + (uint32_t)rem * 16u;
+        if (crow < bh) {
+          if constexpr (kUntrackedFill) lds_dma16_untracked(rs, slab0 + (uint32_t)(slab * (kWgSlabRows * PB) + (j * 4 + wave) * 1024), voff);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_seen, (lds_ptr)(s_box[slab] + (j * 4 + wave) * 1024), 16, voff, 0, 0, 0);
+        }
       }
     }
   };
@@ -1710,11 +1732,19 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
     }
   };
 
+  static_assert(kLdsTH == 16, "the partial wait below counts the stores of one projection");
+  const bool lazy_wait = kUntrackedFill && st.store_wait && rows == kLdsTH && __builtin_amdgcn_readfirstlane((int)(__ballot(active) != 0ull));
   if (fits) {
     fill(proj, 0);
     for (int d = d0; d < d1; ++d) {
       const int cur = (d - d0) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of projection d (and its earlier stores)
+      // this wave's share of projection d.  Vector memory operations of a wave complete in issue order (one counter for loads and stores
+      // on gfx9-class hardware), and what the wave issued AFTER that share are the stores of projection d - 1: exactly kLdsTH of them
+      // when the wave has all its rows and a lane inside the image -- then "at most kLdsTH outstanding" means the fill has landed and
+      // the stores stay in flight under the barrier, the next fill and the blend (waiting for them too cost a write round trip per
+      // projection).  Fewer stores than that (ragged waves): wait for everything
+      if (lazy_wait && d > d0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // (d0: no stores behind the first fill yet)
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                      // everyone's share has landed; everyone is done with the other slab
       if (d + 1 < d1) fill(proj + st.proj_stride, cur ^ 1); // projection d + 1 streams in under the blend of d
       if (active) {
@@ -2344,6 +2374,7 @@ hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int
   if (st.d_chunk == 0) return hipSuccess;
   st.int_exact = opts.int_exact;
   st.xcd_order = wg_stack_xcd_order(st, opts, elem_size(dtype));
+  st.store_wait = opts.store_wait;
   *taken = true;
   switch (dtype) {
     case kU8: return launch_stack_wg_n<uint8_t>(st, map, kScipy, stream);
@@ -2364,6 +2395,7 @@ hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler,
     if (dc > 0) {
       st.d_chunk = dc;
       st.xcd_order = wg_stack_xcd_order(st, opts, 4);
+      st.store_wait = opts.store_wait;
       return launch_stack_wg_n<float>(st, map, sampler, stream);
     }
   }

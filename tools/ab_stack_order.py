@@ -35,16 +35,17 @@ for name, dt, scale in (("float32", np.float32, 1.0), ("uint16", np.uint16, 6000
         else:
             F.check(L.dcp_unwarp_stack_rows_typed(vol.ptr, out.ptr, F.DTYPE_BY_NAME[name], 0, D, Hs, Ws, Hs * Ws, Ws, c4["xcenter"], c4["ycenter"],
                                                   f4, n4, 0.0, Hs, 1, F.MEM_DEVICE, dev, None))
+    opt = os.environ.get("AB_OPTION", "xcd_remap")       # AB_OPTION=store_wait AB_MODES=1,0: another option of the stack kernel
     modes = [int(m) for m in os.environ.get("AB_MODES", "2,1,0").split(",")]       # (one mode, few launches: the counter passes)
     outs, ts = {m: None for m in (0, 1, 2)}, {m: ([] if m in modes else [1e9]) for m in (0, 1, 2)}
     for rep in range(int(os.environ.get("AB_REPS", "3"))):
         for mode in modes:
-            F.set_option("xcd_remap", mode)
+            F.set_option(opt, mode)
             ts[mode].append(bench.timed_launches(shard, int(os.environ.get("AB_LAUNCHES", "12")), dev, settle_ms=float(os.environ.get("AB_SETTLE_MS", "100"))))
             g = np.empty((2, Hs, Ws), dt)
             F.check(L.dcp_memcpy(g.ctypes.data, out.ptr + (D - 3) * Hs * Ws * es, g.nbytes, F.COPY_D2H, dev, None))
             outs[mode] = g
-    F.set_option("xcd_remap", 2)
+    F.set_option(opt, int(os.environ.get("AB_DEFAULT", "2")))
     alg = 2.0 * D * Hs * Ws * es
     got = [o for o in outs.values() if o is not None]
     print("%-7s shard (%d, %d, %d): default %s us (%.3f of 8 TB/s)   XCD runs %s us (%.3f)   grid order %s us (%.3f)   identical %s   (%s)" % (
