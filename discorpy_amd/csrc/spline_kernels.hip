@@ -1429,7 +1429,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     halo += hp[p];
   }
   const int samples = kTfSamples;
-  bool col_stream = false, row_scan = false, row_lds = false;
+  bool col_stream = false, col_lds = false, row_scan = false, row_lds = false;
   if (tiled && samples - 2 * halo >= 32) {
     TileFilter f;
     f.kind = a.filter_kind;
@@ -1480,6 +1480,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
         const dim3 g3((unsigned)((f.nlines + 63) / 64), (unsigned)((f.n + 127) / 128));
         if (hp[0] == 26) hipLaunchKernelGGL((spline_col_lds_kernel<26>), g3, dim3(256), 0, stream, f, (uint32_t)ext);
         else hipLaunchKernelGGL((spline_col_lds_kernel<34>), g3, dim3(256), 0, stream, f, (uint32_t)ext);
+        col_lds = true;
       } else if (hp[0] == 26) {
         hipLaunchKernelGGL((spline_col_stream_kernel<26>), g2, dim3(256), 0, stream, f);
       } else {
@@ -1564,12 +1565,11 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
                   (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH;
   {
     char name[160];
-    snprintf(name, sizeof(name), "%s + %s<order=%d>", tiled ? (col_stream ? (row_scan ? "spline_col_stream_kernel + spline_row_scan_kernel" : row_lds ? "spline_col_stream_kernel + spline_row_lds_kernel"
-                                                                                                                       : "spline_col_stream_kernel + spline_tile_filter_kernel")
-                                                                           : (row_scan ? "spline_tile_filter_kernel + spline_row_scan_kernel" : row_lds ? "spline_tile_filter_kernel + spline_row_lds_kernel"
-                                                                                                                       : "spline_tile_filter_kernel x 2"))
-                                                                  : "spline_causal / anticausal / transpose kernels",
-             wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
+    const char* colk = col_lds ? "spline_col_lds_kernel" : col_stream ? "spline_col_stream_kernel" : "spline_tile_filter_kernel";
+    const char* rowk = row_scan ? "spline_row_scan_kernel" : row_lds ? "spline_row_lds_kernel" : "spline_tile_filter_kernel";
+    if (!tiled) snprintf(name, sizeof(name), "spline_causal / anticausal / transpose kernels + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
+    else if (!col_stream && !row_scan && !row_lds) snprintf(name, sizeof(name), "spline_tile_filter_kernel x 2 + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
+    else snprintf(name, sizeof(name), "%s + %s + %s<order=%d>", colk, rowk, wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     set_last_kernel_name(name);
   }
   if (wg) {

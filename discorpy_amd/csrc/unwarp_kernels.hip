@@ -50,6 +50,9 @@ constexpr int kBlock = 256;
 #define DCP_PIPE_DEPTH 2
 #endif
 constexpr int kPipeDepth = DCP_PIPE_DEPTH;
+#ifndef DCP_LDS_UNTRACKED_DMA
+#define DCP_LDS_UNTRACKED_DMA 1  // 0: remap_lds_kernel's fill through the compiler's LDS-DMA builtin (rounds 1-3; A/B)
+#endif
 #ifndef DCP_FILL_AUX
 #define DCP_FILL_AUX 0   // cache-policy bits of remap_wg_kernel's LDS-DMA fill (2 = nt)
 #endif
@@ -487,15 +490,30 @@ __global__ void __launch_bounds__(64 * kLdsBW, (KIND == kFused && NF < 0) ? 3 : 
     const int lrow = (int)(__umul24((uint32_t)lane, 13u) >> 8);        // lane / 20 for lane < 64
     const int lcol = lane - lrow * 20;
     const uint32_t voff = (uint32_t)lrow * rstep + (uint32_t)lcol * 16u;   // full 32-bit product: a row stride may exceed 2^24 bytes
+    [[maybe_unused]] const dcp_rsrc_words src_words = raw_rsrc_words(img.src, img.src_bytes);
+    [[maybe_unused]] const uint32_t box_lds = (uint32_t)(uintptr_t)(lds_ptr)box;
     if (lane < 60) {
+      // the whole offset goes through the VGPR so that the descriptor's bounds check sees it: the slab pitch can reach past the last
+      // image column / the end of the source buffer, where the load must return zeros instead of touching memory.
+      // Radial and perspective maps: hidden from the compiler, which otherwise waits for the fill in front of the first row-table
+      // read of phase 1b on the unclipped path -- see lds_dma16_untracked; the wave's own wait is the explicit one below (cfg5
+      // 115.3 -> 113.5 us).  The fused map, whose instantiation has no such wait, is 3 % slower that way: it keeps the builtin
+      auto three_rows = [&](int r) {
+        if (r + lrow < bh) {
+          if constexpr (DCP_LDS_UNTRACKED_DMA && KIND != kFused)
+            lds_dma16_untracked(src_words, box_lds + (uint32_t)(r * kBoxW * 4), voff + (org + (uint32_t)r * rstep));
+          else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(box + r * kBoxW), 16, voff + (org + (uint32_t)r * rstep), 0, 0, 0);
+        }
+      };
+      if constexpr (DCP_LDS_UNTRACKED_DMA && KIND != kFused) {
+        for (int r = 0; r < bh; r += 6) {       // (two loads per turn, by hand: `#pragma unroll` does not unroll around the asm)
+          three_rows(r);
+          three_rows(r + 3);
+        }
+      } else {
 #pragma unroll 2
-      for (int r = 0; r < bh; r += 3) {
-        // the whole offset goes through the VGPR so that the descriptor's bounds check sees it:
-        // the slab pitch can reach past the last image column / the end of the source buffer,
-        // where the load must return zeros instead of touching memory
-        if (r + lrow < bh)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_ptr)(box + r * kBoxW), 16,
-                                                   voff + (org + (uint32_t)r * rstep), 0, 0, 0);
+        for (int r = 0; r < bh; r += 3) three_rows(r);
       }
     }
   }

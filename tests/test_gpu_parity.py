@@ -347,7 +347,7 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
                              pp.correct_perspective_image(img, coef, order=order, mode=mode))
                 one_pole = fast == 1 and order <= 3
                 direct = one_pole and mode not in ("nearest", "grid-constant")        # (those two pad the plane first)
-                pre = ("spline_col_stream_kernel + spline_row_lds_kernel" if direct else
+                pre = ("spline_col_lds_kernel + spline_row_lds_kernel" if direct else
                        "spline_tile_filter_kernel + spline_row_lds_kernel" if one_pole else "spline_tile_filter_kernel x 2")
                 want_name = (pre + " + spline_wg_kernel<order=%d>" if fast else
                              "spline_causal / anticausal / transpose kernels + spline_remap_kernel<order=%d>") % order
@@ -1542,6 +1542,36 @@ def test_stack_wg_kernel_xcd_runs_tile_order(hip, orc):
     finally:
         hip.set_option("xcd_remap", 2)
         hip.set_option("stack_wg", 1)
+
+
+def test_stack_wg_integer_streams_under_the_blend(hip, orc):
+    """Round 4: the integer stack kernel issues the LDS-DMA of projection d + 1 from an asm statement the compiler does not track, blends
+    projection d meanwhile, and at the top of the next projection waits with `s_waitcnt vmcnt(16)` -- for the fill only, the sixteen
+    stores of the blend stay in flight (vector memory operations of a wave complete in issue order).  A wait that let a blend start
+    before its slab had landed would show as voxels that differ from the oracle or from run to run: a shard of many workgroups and
+    projections, every voxel against the oracle once and 40 more launches against that result; ragged waves (rows not a multiple of 16,
+    width not a multiple of 64) take the full wait and are part of it."""
+    torch = pytest.importorskip("torch")
+    dot05 = [1.00227490554, -2.99523692178e-05, 8.99519088e-08, -1.57066461911e-10, 8.08880211618e-14]      # BASELINE cfg1, 1280 wide
+    # (frames of the calibration's own aspect ratio: beyond it the model is not monotone and the call takes the checked kernels)
+    for dt, (D, H, W), (r0, r1) in (("uint16", (37, 560, 900), (0, 559)), ("uint8", (20, 400, 644), (9, 390))):
+        sc = 1280.0 / W
+        a = (588.692801577 / sc, 462.092631791 / sc, [c * sc ** i for i, c in enumerate(dot05)])
+        v = typed_image(dt, (D, H, W), 900 + D)
+        dev = torch.from_numpy(v).cuda()
+        hip.set_option("stack_wg", 2)                         # also for launches this small
+        try:
+            first = pp.unwarp_chunk_slices_backward(dev, *a, r0, r1).cpu().numpy()
+            assert hip.last_kernel().startswith("stack_wg_kernel<NF=5,scipy,"), hip.last_kernel()
+            assert np.array_equal(first, orc.unwarp_chunk_slices_backward(v, *a, r0, r1, poly=orc.POLY_KERNEL)), dt
+            for rep in range(40):
+                again = pp.unwarp_chunk_slices_backward(dev, *a, r0, r1)
+                assert torch.equal(again, torch.from_numpy(first).cuda()), (dt, rep)
+            hip.set_option("store_wait", 0)
+            assert np.array_equal(pp.unwarp_chunk_slices_backward(dev, *a, r0, r1).cpu().numpy(), first), dt
+        finally:
+            hip.set_option("store_wait", 1)
+            hip.set_option("stack_wg", 1)
 
 
 def test_spline_gather_tiles_with_the_tallest_boxes(hip, orc):

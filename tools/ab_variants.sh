@@ -11,7 +11,10 @@ for lib in $ROOT/discorpy_amd/lib/variants/lib_*.so; do
 import csv, glob, sys
 name = sys.argv[1]
 for f in glob.glob("/tmp/abv_%s/**/out_kernel_stats.csv" % name, recursive=True):
+    import os
     rows = [r for r in csv.DictReader(open(f)) if "rocclr" not in r["Name"]]
-    print(name, " | ".join("%s %.1f us" % (r["Name"].split("(")[0].replace("void dcp::", "")[:44], float(r["AverageNs"]) / 1e3) for r in rows[:4]))
+    want = [w for w in os.environ.get("AB_KERNELS", "").split(",") if w]        # AB_KERNELS=remap_lds_kernel<0, 9,stack_wg: only these
+    rows = [r for r in rows if any(w in r["Name"] for w in want)] if want else rows[:4]
+    print(name, " | ".join("%s %.1f us" % (r["Name"].split("(")[0].replace("void dcp::", "")[:44], float(r["AverageNs"]) / 1e3) for r in rows))
 PY
 done
