@@ -77,7 +77,11 @@ int dcp_release_scratch(void);
  * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box), "host_direct" (0: never write a host frame's result straight into registered
  * host memory), "int_exact" (0: 8- / 16-bit integer
  * data blend in scipy's operation order everywhere instead of the factorised form where that form is provably exact), "box_table"
- * (0: the waves of a multi-frame launch evaluate their tiles' corner pixels themselves instead of reading them from a table kernel's output).  Returns
+ * (0: the waves of a multi-frame launch evaluate their tiles' corner pixels themselves instead of reading them from a table kernel's output),
+ * "tall_tiles" (A/B: 1 sheared radial maps on 64 x 32 workgroup tiles, 2 radial float32 frames on the interleaved-pixel kernel; default 0),
+ * "store_wait" (0: the integer stack kernel waits for its own stores at every projection, as rounds 2-3 did; default 1: for the fill
+ * only).  "xcd_remap" also orders the stack kernel's tiles: 0 grid order, 1 contiguous runs per XCD for every element type, 2 (default)
+ * tile rows per XCD for float32 stacks and runs for integer ones.  "host_direct_applies" can only be read.  Returns
  * DCP_ERR_INVALID_ARG for an unknown key. */
 int dcp_set_option(const char* key, int value);
 int dcp_get_option(const char* key, int* value);
