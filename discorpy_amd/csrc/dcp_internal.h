@@ -66,6 +66,7 @@ struct StackArgs {
                            // the host has shown that no coordinate can leave the band (or the call is not a chunk): no check
   int32_t int_exact;       // as ImageArgs::int_exact (stack_wg_kernel on integer element types)
   int32_t store_wait = 0;  // stack_wg_kernel: LaunchOpts::store_wait
+  int32_t wg_per_cu = 0;   // stack_wg_kernel: LaunchOpts::wg_per_cu (1..3: workgroups per CU capped through unused dynamic LDS; A/B)
   int32_t xcd_order = 0;   // stack_wg_kernel: tiles dealt to the XCDs in contiguous runs (LaunchOpts::xcd_remap != 0)
 };
 

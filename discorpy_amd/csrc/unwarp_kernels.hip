@@ -1549,6 +1549,9 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 #ifndef DCP_STACK_UNTRACKED_DMA
 #define DCP_STACK_UNTRACKED_DMA 1   // 0: the fill through the compiler's LDS-DMA builtin (rounds 2-3; A/B) -- see lds_dma16_untracked
 #endif
+#ifndef DCP_STACK_UNTRACKED_F32
+#define DCP_STACK_UNTRACKED_F32 0   // 1: float32 stacks too (A/B: 1.5 % slower)
+#endif
 #ifndef DCP_STACK_INT_WAVES
 #define DCP_STACK_INT_WAVES 4   // waves per SIMD the integer instantiations are allocated for (128 VGPRs; at 5 = 96 VGPRs the projection loop spills: 575 us against 435 per uint16 shard)
 #endif
@@ -1690,7 +1693,7 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
   // lds_dma16_untracked: seen by the compiler, the stream of projection d + 1 is waited for before the blend of projection d.  Integer
   // stacks (bound by that chain's latency) gain 3-9 % without the wait; float32 stacks (at the rate the box copies memory at) lose 1 %:
   // they keep the builtin
-  constexpr bool kUntrackedFill = DCP_STACK_UNTRACKED_DMA && !kIsF32;
+  constexpr bool kUntrackedFill = DCP_STACK_UNTRACKED_DMA && (!kIsF32 || DCP_STACK_UNTRACKED_F32);
   [[maybe_unused]] const uint32_t slab0 = (uint32_t)(uintptr_t)(lds_ptr)&s_box[0][0];
   auto fill = [&](const T* proj, int slab) {
     [[maybe_unused]] const dcp_rsrc_words rs = raw_rsrc_words(proj, st.proj_bytes);
@@ -2359,16 +2362,19 @@ template <int NF, typename T>
 static hipError_t launch_stack_wg_t(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
   dim3 grid((unsigned)((st.W + kWgTW - 1) / kWgTW), (unsigned)((st.nrows + kWgTH - 1) / kWgTH), (unsigned)((st.D + st.d_chunk - 1) / st.d_chunk));
   if (st.xcd_order == 2) grid.y = 8 * ((grid.y + 7) / 8);            // see the kernel's tile order
+  // (A/B) workgroups per CU capped through unused dynamic LDS
+  unsigned pad = 0;
+  if (st.wg_per_cu >= 1 && st.wg_per_cu <= 3) pad = (unsigned)(160 * 1024 / st.wg_per_cu - 56 * 1024) & ~255u;
   if constexpr (std::is_same<T, float>::value) {
     note_kernel("stack_wg_kernel", -1, NF, sampler);
     switch (sampler) {
-      case kScipy: hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, float>), grid, dim3(256), 0, stream, st, map); break;
-      case kF64Lerp: hipLaunchKernelGGL((stack_wg_kernel<NF, kF64Lerp, float>), grid, dim3(256), 0, stream, st, map); break;
-      default: hipLaunchKernelGGL((stack_wg_kernel<NF, kF32Lerp, float>), grid, dim3(256), 0, stream, st, map); break;
+      case kScipy: hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, float>), grid, dim3(256), pad, stream, st, map); break;
+      case kF64Lerp: hipLaunchKernelGGL((stack_wg_kernel<NF, kF64Lerp, float>), grid, dim3(256), pad, stream, st, map); break;
+      default: hipLaunchKernelGGL((stack_wg_kernel<NF, kF32Lerp, float>), grid, dim3(256), pad, stream, st, map); break;
     }
   } else {
     note_kernel("stack_wg_kernel", -1, NF, kScipy, sizeof(T) == 2 ? ",16-bit" : ",8-bit");
-    hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, T>), grid, dim3(256), 0, stream, st, map);
+    hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, T>), grid, dim3(256), pad, stream, st, map);
   }
   return hipGetLastError();
 }
@@ -2393,6 +2399,7 @@ hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int
   st.int_exact = opts.int_exact;
   st.xcd_order = wg_stack_xcd_order(st, opts, elem_size(dtype));
   st.store_wait = opts.store_wait;
+  st.wg_per_cu = opts.wg_per_cu;
   *taken = true;
   switch (dtype) {
     case kU8: return launch_stack_wg_n<uint8_t>(st, map, kScipy, stream);
@@ -2409,11 +2416,15 @@ hipError_t launch_stack(const StackArgs& st_in, const MapArgs& map, int sampler,
   if (st.D == 0 || st.nrows == 0) return hipSuccess;
   // chunks of rows under a certified map: one box per workgroup, two slabs (stack_wg_kernel)
   if (round_f32 && opts.stack_wg && wg_stack_eligible(st, map, opts, 4)) {
-    const int dc = wg_stack_chunk(st, st.d_chunk, opts.stack_wg >= 2);
+    // (float32: half the generic depth chunk -- 8 projections per workgroup at the default.  Measured on cfg4 shards of 64 and 256
+    // projections, five processes: 1-4 % faster than 16 in every one, 4 as fast as 8, 32 and 64 slower by 2 and 4 %; the integer
+    // instantiations, whose fill streams in under the blend, are fastest at 16)
+    const int dc = wg_stack_chunk(st, (st.d_chunk + 1) / 2, opts.stack_wg >= 2);
     if (dc > 0) {
       st.d_chunk = dc;
       st.xcd_order = wg_stack_xcd_order(st, opts, 4);
       st.store_wait = opts.store_wait;
+      st.wg_per_cu = opts.wg_per_cu;
       return launch_stack_wg_n<float>(st, map, sampler, stream);
     }
   }

@@ -37,7 +37,7 @@ for name, dt, scale in (("float32", np.float32, 1.0), ("uint16", np.uint16, 6000
                                                   f4, n4, 0.0, Hs, 1, F.MEM_DEVICE, dev, None))
     opt = os.environ.get("AB_OPTION", "xcd_remap")       # AB_OPTION=store_wait AB_MODES=1,0: another option of the stack kernel
     modes = [int(m) for m in os.environ.get("AB_MODES", "2,1,0").split(",")]       # (one mode, few launches: the counter passes)
-    outs, ts = {m: None for m in (0, 1, 2)}, {m: ([] if m in modes else [1e9]) for m in (0, 1, 2)}
+    outs, ts = {m: None for m in modes}, {m: [] for m in modes}
     for rep in range(int(os.environ.get("AB_REPS", "3"))):
         for mode in modes:
             F.set_option(opt, mode)
@@ -47,9 +47,9 @@ for name, dt, scale in (("float32", np.float32, 1.0), ("uint16", np.uint16, 6000
             outs[mode] = g
     F.set_option(opt, int(os.environ.get("AB_DEFAULT", "2")))
     alg = 2.0 * D * Hs * Ws * es
-    got = [o for o in outs.values() if o is not None]
-    print("%-7s shard (%d, %d, %d): default %s us (%.3f of 8 TB/s)   XCD runs %s us (%.3f)   grid order %s us (%.3f)   identical %s   (%s)" % (
-        name, D, Hs, Ws, ["%.1f" % t for t in ts[2]], alg / (min(ts[2]) * 1e-6) / 8e12, ["%.1f" % t for t in ts[1]], alg / (min(ts[1]) * 1e-6) / 8e12,
-        ["%.1f" % t for t in ts[0]], alg / (min(ts[0]) * 1e-6) / 8e12, all(np.array_equal(got[0], o) for o in got[1:]), F.last_kernel()), flush=True)
+    got = list(outs.values())
+    print("%-7s shard (%d, %d, %d), option %s: %s   identical %s   (%s)" % (
+        name, D, Hs, Ws, opt, "   ".join("%d: %s us (%.3f of 8 TB/s)" % (m, ["%.1f" % t for t in ts[m]], alg / (min(ts[m]) * 1e-6) / 8e12) for m in modes),
+        all(np.array_equal(got[0], o) for o in got[1:]), F.last_kernel()), flush=True)
     vol.free()
     out.free()
