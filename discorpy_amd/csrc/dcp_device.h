@@ -574,19 +574,30 @@ __device__ __forceinline__ double load_any(const void* p, int dtype, size_t i) {
     default: return (double)((const int32_t*)p)[i];
   }
 }
+#ifndef DCP_ANY_NT_STORE
+#define DCP_ANY_NT_STORE 1   // store_any: nt stores -- every caller writes a final result that no kernel of the call reads again (0: plain, A/B)
+#endif
+template <typename E>
+__device__ __forceinline__ void store_final(E* p, E v) {
+#if DCP_ANY_NT_STORE
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 __device__ __forceinline__ void store_any(void* p, int dtype, size_t i, double t) {
   switch (dtype) {
-    case kF32: ((float*)p)[i] = to_elem<float>(t); break;
-    case kF64: ((double*)p)[i] = t; break;
-    case kU8: ((uint8_t*)p)[i] = to_elem<uint8_t>(t); break;
-    case kI8: ((int8_t*)p)[i] = to_elem<int8_t>(t); break;
-    case kU16: ((uint16_t*)p)[i] = to_elem<uint16_t>(t); break;
-    case kI16: ((int16_t*)p)[i] = to_elem<int16_t>(t); break;
-    case kU32: ((uint32_t*)p)[i] = to_elem<uint32_t>(t); break;
-    case kI64: ((int64_t*)p)[i] = to_elem<int64_t>(t); break;
-    case kU64: ((uint64_t*)p)[i] = to_elem<uint64_t>(t); break;
-    case kBool: ((Bool8*)p)[i] = to_elem<Bool8>(t); break;
-    default: ((int32_t*)p)[i] = to_elem<int32_t>(t); break;
+    case kF32: store_final((float*)p + i, to_elem<float>(t)); break;
+    case kF64: store_final((double*)p + i, t); break;
+    case kU8: store_final((uint8_t*)p + i, to_elem<uint8_t>(t)); break;
+    case kI8: store_final((int8_t*)p + i, to_elem<int8_t>(t)); break;
+    case kU16: store_final((uint16_t*)p + i, to_elem<uint16_t>(t)); break;
+    case kI16: store_final((int16_t*)p + i, to_elem<int16_t>(t)); break;
+    case kU32: store_final((uint32_t*)p + i, to_elem<uint32_t>(t)); break;
+    case kI64: store_final((int64_t*)p + i, to_elem<int64_t>(t)); break;
+    case kU64: store_final((uint64_t*)p + i, to_elem<uint64_t>(t)); break;
+    case kBool: store_final((uint8_t*)p + i, to_elem<Bool8>(t).v); break;
+    default: store_final((int32_t*)p + i, to_elem<int32_t>(t)); break;
   }
 }
 

@@ -20,6 +20,10 @@
 #include <cstdio>
 #include <type_traits>
 
+#ifndef DCP_SPLINE_OUT_AUX
+#define DCP_SPLINE_OUT_AUX 2   // cache-policy bits of spline_wg_kernel's result store: 2 = nt (0: plain, A/B)
+#endif
+
 namespace dcp {
 
 constexpr int kSplBlock = 256;
@@ -1328,7 +1332,7 @@ __global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, c
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
         if (k >= rows) continue;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)value(k)), drs, xoff, (uint32_t)k * row_bytes, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)value(k)), drs, xoff, (uint32_t)k * row_bytes, DCP_SPLINE_OUT_AUX);
       }
     } else {
 #pragma unroll

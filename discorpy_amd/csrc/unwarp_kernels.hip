@@ -56,6 +56,9 @@ constexpr int kPipeDepth = DCP_PIPE_DEPTH;
 #ifndef DCP_FILL_AUX
 #define DCP_FILL_AUX 0   // cache-policy bits of remap_wg_kernel's LDS-DMA fill (2 = nt)
 #endif
+#ifndef DCP_ROWS_NT_STORE
+#define DCP_ROWS_NT_STORE 1   // stack_rows_body: nt stores (0: plain, rounds 1-3 -- the 121-centre grid 104 -> 87 us, one sinogram 4.0 -> 3.7)
+#endif
 #ifndef DCP_STORE_AUX
 #define DCP_STORE_AUX 2  // cache-policy bits of the output store: 2 = nt (streamed once, never re-read here)
 #endif
@@ -1360,7 +1363,11 @@ __device__ __forceinline__ void stack_rows_body(const StackArgs& st, const MapAr
         __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)st.proj_bytes, 0x00020000);
     ft.a = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0);
     ft.b = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, row_bytes, 0);
+#if DCP_ROWS_NT_STORE
+    __builtin_nontemporal_store(finish<SAMPLER, true, CT>(ft), out);     // (written once, never re-read here)
+#else
     *out = finish<SAMPLER, true, CT>(ft);
+#endif
     base += st.proj_stride;
     out += out_step;
   }
