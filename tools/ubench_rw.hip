@@ -56,6 +56,26 @@ __global__ void __launch_bounds__(256) tile_store_k(float* __restrict__ out, int
   }
 }
 
+// the same bytes as rows of LONG segments: a lane owns 4 adjacent pixels of 4 rows, a wave 256 pixels x 4 rows, the four waves of a
+// workgroup WX side by side and 4 / WX on top of each other: segments of 1 KB x WX
+template <int WX>
+__global__ void __launch_bounds__(256) wide_store_k(float* __restrict__ out, int H, int W, int D, int dc) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int x0 = blockIdx.x * (256 * WX) + (wave % WX) * 256 + lane * 4;
+  const int y0 = blockIdx.y * (16 / WX) + (wave / WX) * 4;
+  const int d0 = blockIdx.z * dc;
+  typedef float vec __attribute__((ext_vector_type(4)));
+  if (x0 >= W) return;
+  for (int d = d0; d < d0 + dc && d < D; ++d) {
+    float* o = out + ((size_t)d * H + y0) * W + x0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      vec v = {(float)d, (float)r, 1.f, 2.f};
+      __builtin_nontemporal_store(v, (vec*)(o + (size_t)r * W));
+    }
+  }
+}
+
 template <typename F>
 static double time_us(F launch, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -102,6 +122,9 @@ int main() {
     us = time_us([&] { hipLaunchKernelGGL((tile_store_k<1>), dim3(W / 128, H / 32, D), dim3(256), 0, 0, vol, H, W, D, 1); }, 5); REPORT("stack tiles, ONE projection per workgroup", vb, us);
     us = time_us([&] { hipLaunchKernelGGL((tile_store_k<1>), dim3(W / 128, H / 32, D / 2), dim3(256), 0, 0, vol, H, W, D, 2); }, 5); REPORT("stack tiles, two projections per workgroup", vb, us);
     us = time_us([&] { hipLaunchKernelGGL((tile_store_k<1>), dim3(W / 128, H / 32, D / 40), dim3(256), 0, 0, vol, H, W, D, 40); }, 5); REPORT("stack tiles, 40 projections per workgroup", vb, us);
+    us = time_us([&] { hipLaunchKernelGGL((wide_store_k<1>), dim3(W / 256, H / 16, D / dc), dim3(256), 0, 0, vol, H, W, D, dc); }, 5); REPORT("tiles  256 x 16, 1 KB row segments", vb, us);
+    us = time_us([&] { hipLaunchKernelGGL((wide_store_k<2>), dim3(W / 512, H / 8, D / dc), dim3(256), 0, 0, vol, H, W, D, dc); }, 5); REPORT("tiles  512 x  8, 2 KB row segments", vb, us);
+    us = time_us([&] { hipLaunchKernelGGL((wide_store_k<4>), dim3((W + 1023) / 1024, H / 4, D / dc), dim3(256), 0, 0, vol, H, W, D, dc); }, 5); REPORT("tiles 1024 x  4, 4 KB row segments", vb, us);
     CK(hipFree(vol));
   }
   us = time_us([&] { CK(hipMemcpyAsync(b, a, bytes, hipMemcpyDeviceToDevice, 0)); }, 5); REPORT("hipMemcpyAsync device to device", 2 * bytes, us);
