@@ -41,7 +41,8 @@ def test_version_and_device_count_do_not_need_a_gpu():
 
 def test_options_round_trip():
     for key, val in [("tile_rows", 8), ("pipe_depth", 4), ("xcd_remap", 1), ("xcd_remap", 2), ("coef_lds", 1), ("d_chunk", 32),
-                     ("lds_gather", 1), ("stack_lds", 2), ("stack_chunk_kb", 512), ("host_duplex", 0), ("int_exact", 0), ("host_direct", 2), ("box_table", 0)]:
+                     ("lds_gather", 1), ("stack_lds", 2), ("stack_chunk_kb", 512), ("host_duplex", 0), ("int_exact", 0), ("host_direct", 2), ("box_table", 0),
+                     ("store_wait", 0), ("tall_tiles", 1), ("wg_per_cu", 2), ("stack_wg", 2), ("spline_tiled", 3)]:
         old = F.get_option(key)
         F.set_option(key, val)
         assert F.get_option(key) == val
