@@ -1563,7 +1563,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 #define DCP_STACK_INT_WAVES 4   // waves per SIMD the integer instantiations are allocated for (128 VGPRs; at 5 = 96 VGPRs the projection loop spills: 575 us against 435 per uint16 shard)
 #endif
 template <int NF, int SAMPLER, typename T = float>
-__global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_STACK_INT_WAVES)) stack_wg_kernel(const StackArgs st, const MapArgs map) {
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES)) stack_wg_kernel(const StackArgs st, const MapArgs map) {
   constexpr bool kIsF32 = std::is_same<T, float>::value;
   constexpr int ES = (int)sizeof(T);
   constexpr int CH = ES == 4 ? 36 : (ES == 2 ? 20 : 10);
@@ -1650,7 +1650,8 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
   const bool fits = bw <= kBoxWEl && bh <= kWgBoxH;          // workgroup-uniform
   if (!fits && lane == 0 && wave == 0) atomicAdd(&g_lds_stats[0], 1ull);
   // integer elements: the tile's coordinates are all >= its box origin; at >= 32 the factorised blend is exact (exact_lerp_pairs)
-  const bool exact = !kIsF32 && SAMPLER != kNearest && fits && st.int_exact && bx0 >= (int)kExactLerpMinCoord && by0 >= (int)kExactLerpMinCoord;
+  // (32-bit integers: the products of the factorised blend do not fit a float64 exactly -- scipy's order, as for float32)
+  const bool exact = !kIsF32 && ES < 4 && SAMPLER != kNearest && fits && st.int_exact && bx0 >= (int)kExactLerpMinCoord && by0 >= (int)kExactLerpMinCoord;
 
   // ---- coordinates of this wave's 16 rows, once for all projections: slab address (or byte offset inside a projection
   // when the box does not fit) and fractions
@@ -1754,7 +1755,8 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
       acc += ((double)t_hi[1] * wy1_) * wx1_;
       const T v = to_elem<T>(acc);
       if (k < rows) {
-        if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+        if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+        else if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
         else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
       }
     }
@@ -1781,7 +1783,7 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
         // (the pointers advance below, in uniform control flow: advanced inside this per-lane branch they -- and the store descriptor built
         // from them -- become per-lane values and every store a waterfall loop)
         [[maybe_unused]] bool done = false;
-        if constexpr (!kIsF32) {
+        if constexpr (!kIsF32 && ES < 4) {
           if (exact) {
             // every coordinate of the tile >= 32: the factorised blend is exact (exact_lerp_pairs) and scipy's w1 = 1 - (1 - f) IS the fraction
 #pragma unroll
@@ -1803,8 +1805,8 @@ __global__ void __launch_bounds__(256, (std::is_same<T, float>::value ? 3 : DCP_
 #pragma unroll
         for (int k = 0; k < kLdsTH; ++k) {
           DCP_BOUNDS(addr[k], PB + 2 * ES, kWgSlabRows * PB, 5);
-          if constexpr (kIsF32) {
-            const float* t = (const float*)(boxb + addr[k]);
+          if constexpr (ES == 4) {                          // float32, int32, uint32: the taps are aligned elements
+            const T* t = (const T*)(boxb + addr[k]);
             blend_store(t, t + kBoxWEl, dst, k);
           } else {
             // tap pairs as the two aligned dwords around them, shifted down (see remap_wg_kernel)
@@ -2380,7 +2382,7 @@ static hipError_t launch_stack_wg_t(const StackArgs& st, const MapArgs& map, int
       default: hipLaunchKernelGGL((stack_wg_kernel<NF, kF32Lerp, float>), grid, dim3(256), pad, stream, st, map); break;
     }
   } else {
-    note_kernel("stack_wg_kernel", -1, NF, kScipy, sizeof(T) == 2 ? ",16-bit" : ",8-bit");
+    note_kernel("stack_wg_kernel", -1, NF, kScipy, sizeof(T) == 4 ? ",32-bit" : sizeof(T) == 2 ? ",16-bit" : ",8-bit");
     hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, T>), grid, dim3(256), pad, stream, st, map);
   }
   return hipGetLastError();
@@ -2393,12 +2395,12 @@ static hipError_t launch_stack_wg_n(const StackArgs& st, const MapArgs& map, int
   return launch_stack_wg_t<-1, T>(st, map, sampler, stream);
 }
 
-// 8- / 16-bit integer stacks, float32 coordinates, result of the input's type (unwarp_chunk_slices_backward): st.vol / out
+// 8- / 16- / 32-bit integer stacks, float32 coordinates, result of the input's type (unwarp_chunk_slices_backward): st.vol / out
 // reinterpreted, strides in elements, proj_bytes the extent of a projection in bytes.  *taken = false: use launch_typed_stack.
 hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int dtype, const LaunchOpts& opts, hipStream_t stream,
                                  bool* taken) {
   *taken = false;
-  if (dtype != kU8 && dtype != kI8 && dtype != kU16 && dtype != kI16) return hipSuccess;
+  if (dtype != kU8 && dtype != kI8 && dtype != kU16 && dtype != kI16 && dtype != kU32 && dtype != kI32) return hipSuccess;
   if (st_in.D == 0 || st_in.nrows == 0 || !wg_stack_eligible(st_in, map, opts, elem_size(dtype))) return hipSuccess;
   StackArgs st = st_in;
   st.d_chunk = wg_stack_chunk(st, opts.d_chunk, opts.stack_wg >= 2);
@@ -2412,7 +2414,9 @@ hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int
     case kU8: return launch_stack_wg_n<uint8_t>(st, map, kScipy, stream);
     case kI8: return launch_stack_wg_n<int8_t>(st, map, kScipy, stream);
     case kU16: return launch_stack_wg_n<uint16_t>(st, map, kScipy, stream);
-    default: return launch_stack_wg_n<int16_t>(st, map, kScipy, stream);
+    case kI16: return launch_stack_wg_n<int16_t>(st, map, kScipy, stream);
+    case kU32: return launch_stack_wg_n<uint32_t>(st, map, kScipy, stream);
+    default: return launch_stack_wg_n<int32_t>(st, map, kScipy, stream);
   }
 }
 

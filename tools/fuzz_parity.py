@@ -5,7 +5,7 @@ kernels' evaluation order -- bit for bit for orders 0/1, within one ulp on a few
 
 --bounds: the run must be on the bounds-checking build (make -C discorpy_amd/csrc bounds; DCP_LIB_PATH=discorpy_amd/lib/
 libdiscorpy_hip_bounds.so) and ends by asserting that no LDS tap of any staged kernel left its slab (dcp_debug_bounds).
-A third of the cases are drawn so that they REACH the staged kernels (certified calibrations, float32 / 8- / 16-bit data, frames of
+A third of the cases are drawn so that they REACH the staged kernels (certified calibrations, float32 / 8- / 16- / 32-bit integer data, frames of
 at least a few tiles): remap_wg_kernel, remap_wg_batch_kernel, stack_wg_kernel, remap_wg_color_kernel.
 
 Shapes from 1 x 1 to ~1500 x 1500, centres inside and far outside the image, polynomial lengths 0..12 from mild to
@@ -144,7 +144,7 @@ def one_case(rng, k):
         # aimed at the staged kernels: a frame of several tiles, a certified calibration, an element type they take
         kind = ("radial", "radial", "batch", "stack", "color", "persp")[int(rng.integers(0, 6))]
         h, w = int(rng.integers(40, 900)), int(rng.integers(130, 1400))
-        dt = ("float32", "float32", "float32", "uint8", "uint16", "int16")[int(rng.integers(0, 6))]
+        dt = ("float32", "float32", "float32", "uint8", "uint16", "int16", "int32", "uint32")[int(rng.integers(0, 8))]
         xc, yc = float(rng.uniform(0.1, 0.9) * w), float(rng.uniform(0.1, 0.9) * h)
         fact = certified_fact(rng, h, w, xc, yc)
         if blend == "f32" and kind == "color":
