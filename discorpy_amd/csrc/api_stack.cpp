@@ -65,7 +65,7 @@ hipError_t launch_stack_any(const StackCall& c, bool fast, const void* base, voi
     return dcp::launch_stack(st, c.map, c.sampler, c.round_f32 != 0, opts, hs);
   }
   if (c.round_f32 && !c.out_f32 && opts.stack_wg && c.rbh == 0) {
-    // 8- / 16-bit integer stacks under a certified map: the workgroup-box kernel (uint16 cfg4 shard 0.42 of the 8 TB/s peak
+    // 8- / 16- / 32-bit integer stacks under a certified map: the workgroup-box kernel (uint16 cfg4 shard 0.42 of the 8 TB/s peak
     // against 0.30 for the generic kernel; its launcher declines small launches and ineligible layouts)
     const int64_t esz = dcp::elem_size(c.dtype);
     const double ext = (double)((rows_end - 1) * row_stride + c.width) * (double)esz;

@@ -1551,7 +1551,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 // address and fractions ONCE; then for every projection of the depth chunk the four waves copy the box of THAT
 // projection into one of two slabs (LDS-DMA, the loads of projection d + 1 issued before projection d is blended, so the
 // copy runs under the arithmetic inside the workgroup) and blend their 1024 pixels each out of the other.  One barrier
-// per projection.  T as in remap_wg_kernel: float (any blend) or an 8- / 16-bit integer type (scipy's blend and integer
+// per projection.  T as in remap_wg_kernel: float (any blend) or an 8- / 16- / 32-bit integer type (scipy's blend and integer
 // store) -- tomography detectors deliver uint16.  float32 coordinates only (unwarp_chunk_slices_backward).
 #ifndef DCP_STACK_UNTRACKED_DMA
 #define DCP_STACK_UNTRACKED_DMA 1   // 0: the fill through the compiler's LDS-DMA builtin (rounds 2-3; A/B) -- see lds_dma16_untracked
