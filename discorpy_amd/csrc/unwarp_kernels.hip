@@ -1559,6 +1559,9 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 #ifndef DCP_STACK_UNTRACKED_F32
 #define DCP_STACK_UNTRACKED_F32 0   // 1: float32 stacks too (A/B: 1.5 % slower)
 #endif
+#ifndef DCP_STACK_UNTRACKED_I32
+#define DCP_STACK_UNTRACKED_I32 1   // 0: int32 / uint32 stacks through the builtin as float32 ones (A/B)
+#endif
 #ifndef DCP_STACK_INT_WAVES
 #define DCP_STACK_INT_WAVES 4   // waves per SIMD the integer instantiations are allocated for (128 VGPRs; at 5 = 96 VGPRs the projection loop spills: 575 us against 435 per uint16 shard)
 #endif
@@ -1701,7 +1704,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES
   // lds_dma16_untracked: seen by the compiler, the stream of projection d + 1 is waited for before the blend of projection d.  Integer
   // stacks (bound by that chain's latency) gain 3-9 % without the wait; float32 stacks (at the rate the box copies memory at) lose 1 %:
   // they keep the builtin
-  constexpr bool kUntrackedFill = DCP_STACK_UNTRACKED_DMA && (!kIsF32 || DCP_STACK_UNTRACKED_F32);
+  constexpr bool kUntrackedFill = DCP_STACK_UNTRACKED_DMA && ((!kIsF32 && (ES < 4 || DCP_STACK_UNTRACKED_I32)) || DCP_STACK_UNTRACKED_F32);
   [[maybe_unused]] const uint32_t slab0 = (uint32_t)(uintptr_t)(lds_ptr)&s_box[0][0];
   auto fill = [&](const T* proj, int slab) {
     [[maybe_unused]] const dcp_rsrc_words rs = raw_rsrc_words(proj, st.proj_bytes);
