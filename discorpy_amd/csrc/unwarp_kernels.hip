@@ -1551,7 +1551,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 // address and fractions ONCE; then for every projection of the depth chunk the four waves copy the box of THAT
 // projection into one of two slabs (LDS-DMA, the loads of projection d + 1 issued before projection d is blended, so the
 // copy runs under the arithmetic inside the workgroup) and blend their 1024 pixels each out of the other.  One barrier
-// per projection.  T as in remap_wg_kernel: float (any blend) or an 8- / 16- / 32-bit integer type (scipy's blend and integer
+// per projection.  T as in remap_wg_kernel: float (any blend), an 8- / 16- / 32-bit integer type or double (scipy's blend and its
 // store) -- tomography detectors deliver uint16.  float32 coordinates only (unwarp_chunk_slices_backward).
 #ifndef DCP_STACK_UNTRACKED_DMA
 #define DCP_STACK_UNTRACKED_DMA 1   // 0: the fill through the compiler's LDS-DMA builtin (rounds 2-3; A/B) -- see lds_dma16_untracked
@@ -1566,15 +1566,19 @@ __global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(c
 #define DCP_STACK_INT_WAVES 4   // waves per SIMD the integer instantiations are allocated for (128 VGPRs; at 5 = 96 VGPRs the projection loop spills: 575 us against 435 per uint16 shard)
 #endif
 template <int NF, int SAMPLER, typename T = float>
-__global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES)) stack_wg_kernel(const StackArgs st, const MapArgs map) {
+__global__ void __launch_bounds__(256, (sizeof(T) >= 4 ? 3 : DCP_STACK_INT_WAVES)) stack_wg_kernel(const StackArgs st, const MapArgs map) {
   constexpr bool kIsF32 = std::is_same<T, float>::value;
   constexpr int ES = (int)sizeof(T);
-  constexpr int CH = ES == 4 ? 36 : (ES == 2 ? 20 : 10);
+  constexpr int CH = ES == 8 ? 72 : ES == 4 ? 36 : (ES == 2 ? 20 : 10);
   constexpr int PB = CH * 16;
   constexpr int kBoxWEl = PB / ES;
   constexpr int NJ = (kWgBoxH * CH + 255) / 256;
-  static_assert(kIsF32 || SAMPLER == kScipy, "integer element types blend in scipy's exact order");
-  __shared__ __attribute__((aligned(16))) unsigned char s_box[2][kWgSlabRows * PB];
+  // float64: ONE slab of 48 KB (two would leave a CU a single workgroup) -- fill, wait, blend, the other two workgroups of the CU
+  // covering the wait
+  constexpr int NSLAB = ES == 8 ? 1 : 2;
+  constexpr int kAlignEl = ES >= 4 ? 1 : 4 / ES;               // the box's first column: a dword-aligned byte offset
+  static_assert(kIsF32 || SAMPLER == kScipy, "integer and float64 element types blend in scipy's exact order");
+  __shared__ __attribute__((aligned(16))) unsigned char s_box[NSLAB][kWgSlabRows * PB];
   __shared__ double s_row[4][kLdsTH][2];
   __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
   using FetchT = Fetch<SAMPLER, true, float>;
@@ -1645,7 +1649,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES
     cy0 = min(min(ya, yb), min(yc_, yd_));
     cy1 = max(max(ya, yb), max(yc_, yd_));
   }
-  const int bx0 = max(min(cx0 - 1, st.W - 2), 0) & ~(4 / ES - 1);
+  const int bx0 = max(min(cx0 - 1, st.W - 2), 0) & ~(kAlignEl - 1);
   const int bx1 = min(cx1 + 2, st.W - 1);
   const int by0 = max(min(cy0 - 1, st.H - 2), 0);
   const int by1 = min(cy1 + 2, st.H - 1);
@@ -1704,7 +1708,8 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES
   // lds_dma16_untracked: seen by the compiler, the stream of projection d + 1 is waited for before the blend of projection d.  Integer
   // stacks (bound by that chain's latency) gain 3-9 % without the wait; float32 stacks (at the rate the box copies memory at) lose 1 %:
   // they keep the builtin
-  constexpr bool kUntrackedFill = DCP_STACK_UNTRACKED_DMA && ((!kIsF32 && (ES < 4 || DCP_STACK_UNTRACKED_I32)) || DCP_STACK_UNTRACKED_F32);
+  // (one slab -- float64: the wait behind the fill is for everything, the builtin says so to the compiler)
+  constexpr bool kUntrackedFill = DCP_STACK_UNTRACKED_DMA && NSLAB == 2 && ((!kIsF32 && (ES < 4 || DCP_STACK_UNTRACKED_I32)) || DCP_STACK_UNTRACKED_F32);
   [[maybe_unused]] const uint32_t slab0 = (uint32_t)(uintptr_t)(lds_ptr)&s_box[0][0];
   auto fill = [&](const T* proj, int slab) {
     [[maybe_unused]] const dcp_rsrc_words rs = raw_rsrc_words(proj, st.proj_bytes);
@@ -1758,7 +1763,12 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES
       acc += ((double)t_hi[1] * wy1_) * wx1_;
       const T v = to_elem<T>(acc);
       if (k < rows) {
-        if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+        if constexpr (ES == 8) {
+          typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+          const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
+          const u32x2_t pk = {(uint32_t)b, (uint32_t)(b >> 32)};
+          __builtin_amdgcn_raw_buffer_store_b64(pk, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+        } else if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32((uint32_t)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
         else if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
         else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
       }
@@ -1768,9 +1778,13 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES
   static_assert(kLdsTH == 16, "the partial wait below counts the stores of one projection");
   const bool lazy_wait = kUntrackedFill && st.store_wait && rows == kLdsTH && __builtin_amdgcn_readfirstlane((int)(__ballot(active) != 0ull));
   if (fits) {
-    fill(proj, 0);
+    if constexpr (NSLAB == 2) fill(proj, 0);
     for (int d = d0; d < d1; ++d) {
-      const int cur = (d - d0) & 1;
+      const int cur = NSLAB == 2 ? ((d - d0) & 1) : 0;
+      if constexpr (NSLAB == 1) {
+        __syncthreads();                                    // everyone is done with the slab's previous projection
+        fill(proj, 0);
+      }
       // this wave's share of projection d.  Vector memory operations of a wave complete in issue order (one counter for loads and stores
       // on gfx9-class hardware), and what the wave issued AFTER that share are the stores of projection d - 1: exactly kLdsTH of them
       // when the wave has all its rows and a lane inside the image -- then "at most kLdsTH outstanding" means the fill has landed and
@@ -1779,7 +1793,9 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES
       if (lazy_wait && d > d0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // (d0: no stores behind the first fill yet)
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                      // everyone's share has landed; everyone is done with the other slab
-      if (d + 1 < d1) fill(proj + st.proj_stride, cur ^ 1); // projection d + 1 streams in under the blend of d
+      if constexpr (NSLAB == 2) {
+        if (d + 1 < d1) fill(proj + st.proj_stride, cur ^ 1); // projection d + 1 streams in under the blend of d
+      }
       if (active) {
         const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((uint32_t)rows * out_row), 0x00020000);
         const char* boxb = (const char*)s_box[cur];
@@ -1808,7 +1824,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : DCP_STACK_INT_WAVES
 #pragma unroll
         for (int k = 0; k < kLdsTH; ++k) {
           DCP_BOUNDS(addr[k], PB + 2 * ES, kWgSlabRows * PB, 5);
-          if constexpr (ES == 4) {                          // float32, int32, uint32: the taps are aligned elements
+          if constexpr (ES >= 4) {                          // float32, int32, uint32, float64: the taps are aligned elements
             const T* t = (const T*)(boxb + addr[k]);
             blend_store(t, t + kBoxWEl, dst, k);
           } else {
@@ -2385,7 +2401,7 @@ static hipError_t launch_stack_wg_t(const StackArgs& st, const MapArgs& map, int
       default: hipLaunchKernelGGL((stack_wg_kernel<NF, kF32Lerp, float>), grid, dim3(256), pad, stream, st, map); break;
     }
   } else {
-    note_kernel("stack_wg_kernel", -1, NF, kScipy, sizeof(T) == 4 ? ",32-bit" : sizeof(T) == 2 ? ",16-bit" : ",8-bit");
+    note_kernel("stack_wg_kernel", -1, NF, kScipy, sizeof(T) == 8 ? ",float64" : sizeof(T) == 4 ? ",32-bit" : sizeof(T) == 2 ? ",16-bit" : ",8-bit");
     hipLaunchKernelGGL((stack_wg_kernel<NF, kScipy, T>), grid, dim3(256), pad, stream, st, map);
   }
   return hipGetLastError();
@@ -2403,12 +2419,12 @@ static hipError_t launch_stack_wg_n(const StackArgs& st, const MapArgs& map, int
 hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int dtype, const LaunchOpts& opts, hipStream_t stream,
                                  bool* taken) {
   *taken = false;
-  if (dtype != kU8 && dtype != kI8 && dtype != kU16 && dtype != kI16 && dtype != kU32 && dtype != kI32) return hipSuccess;
+  if (dtype != kU8 && dtype != kI8 && dtype != kU16 && dtype != kI16 && dtype != kU32 && dtype != kI32 && dtype != kF64) return hipSuccess;
   if (st_in.D == 0 || st_in.nrows == 0 || !wg_stack_eligible(st_in, map, opts, elem_size(dtype))) return hipSuccess;
   StackArgs st = st_in;
   // (32-bit integers move float32's bytes: half the depth chunk as there -- tools/ab_int32_stack.py: 8 projections per workgroup 0-2 %
   // faster than 16 in every process, 32 slower by 2-3 %; untracked against tracked fill: equal to 1 % better)
-  st.d_chunk = wg_stack_chunk(st, elem_size(dtype) == 4 ? (opts.d_chunk + 1) / 2 : opts.d_chunk, opts.stack_wg >= 2);
+  st.d_chunk = wg_stack_chunk(st, elem_size(dtype) >= 4 ? (opts.d_chunk + 1) / 2 : opts.d_chunk, opts.stack_wg >= 2);
   if (st.d_chunk == 0) return hipSuccess;
   st.int_exact = opts.int_exact;
   st.xcd_order = wg_stack_xcd_order(st, opts, elem_size(dtype));
@@ -2421,6 +2437,7 @@ hipError_t launch_stack_wg_typed(const StackArgs& st_in, const MapArgs& map, int
     case kU16: return launch_stack_wg_n<uint16_t>(st, map, kScipy, stream);
     case kI16: return launch_stack_wg_n<int16_t>(st, map, kScipy, stream);
     case kU32: return launch_stack_wg_n<uint32_t>(st, map, kScipy, stream);
+    case kF64: return launch_stack_wg_n<double>(st, map, kScipy, stream);
     default: return launch_stack_wg_n<int32_t>(st, map, kScipy, stream);
   }
 }

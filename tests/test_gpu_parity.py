@@ -1479,7 +1479,7 @@ def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
 
 def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
     """stack_wg_kernel beyond the benched geometry: ragged tiles and depth chunks, rows not starting at 0, every blend, a
-    9-term model (coefficients from LDS), strided projections, and the 8- / 16- / 32-bit integer instantiations (stack_wg = 2: also for
+    9-term model (coefficients from LDS), strided projections, and the 8- / 16- / 32-bit integer and float64 instantiations (stack_wg = 2: also for
     launches this small)."""
     torch = pytest.importorskip("torch")
     D, H, W = 21, 300, 517
@@ -1504,10 +1504,10 @@ def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
         view = big[:, 4:4 + H, 8:8 + W]                      # row stride W + 11 = 528 (4-byte aligned rows), offset base
         got = pp.unwarp_chunk_slices_backward(view, *a, 30, 200).cpu().numpy()
         assert np.array_equal(got, orc.unwarp_chunk_slices_backward(np.ascontiguousarray(view.cpu().numpy()), *a, 30, 200, **kernel_oracle(orc, "f64lerp")))
-        for dt in ("uint16", "int16", "uint8", "int8", "int32", "uint32"):
+        for dt in ("uint16", "int16", "uint8", "int8", "int32", "uint32", "float64"):
             v = typed_image(dt, (D, H, W + 3), 600 + len(dt))        # W + 3 = 520: rows are 4-byte aligned for every type
             got = pp.unwarp_chunk_slices_backward(torch.from_numpy(v).cuda(), *a, 3, 280).cpu().numpy()
-            bits = {1: "8-bit", 2: "16-bit", 4: "32-bit"}[np.dtype(dt).itemsize]
+            bits = {1: "8-bit", 2: "16-bit", 4: "32-bit", 8: "float64"}[np.dtype(dt).itemsize]
             assert hip.last_kernel().startswith("stack_wg_kernel<NF=4,scipy," + bits), (dt, hip.last_kernel())
             assert got.dtype == np.dtype(dt) and np.array_equal(got, orc.unwarp_chunk_slices_backward(v, *a, 3, 280, poly=orc.POLY_KERNEL)), dt
     finally:

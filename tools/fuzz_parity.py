@@ -144,7 +144,7 @@ def one_case(rng, k):
         # aimed at the staged kernels: a frame of several tiles, a certified calibration, an element type they take
         kind = ("radial", "radial", "batch", "stack", "color", "persp")[int(rng.integers(0, 6))]
         h, w = int(rng.integers(40, 900)), int(rng.integers(130, 1400))
-        dt = ("float32", "float32", "float32", "uint8", "uint16", "int16", "int32", "uint32")[int(rng.integers(0, 8))]
+        dt = ("float32", "float32", "float32", "uint8", "uint16", "int16", "int32", "uint32", "float64")[int(rng.integers(0, 9))]
         xc, yc = float(rng.uniform(0.1, 0.9) * w), float(rng.uniform(0.1, 0.9) * h)
         fact = certified_fact(rng, h, w, xc, yc)
         if blend == "f32" and kind == "color":

@@ -25,7 +25,7 @@ def best(fn, n=5):
     return min(ts) * 1e6
 
 
-for dt in (torch.float32, torch.uint16, torch.int32, torch.uint32):
+for dt in (torch.float32, torch.uint16, torch.int32, torch.uint32, torch.float64):
     if dt == torch.uint32:
         vol = torch.from_numpy(np.random.default_rng(1).integers(0, 2**32 - 1, size=(D, H, W), dtype=np.uint32)).cuda()
     else:
