@@ -3,7 +3,7 @@ against the generic one-thread-per-voxel typed_stack_kernel (stack_wg = 0).  cfg
 
     python tools/time_typed_stack.py [depth]
 """
-import sys, time
+import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, ".")
@@ -15,9 +15,13 @@ c4 = configs.cfg4(D)
 H = W = 2560
 
 
+QUICK = bool(os.environ.get("TTS_QUICK"))           # one timed launch per case (counter passes: tools/pmc_typed_stack.sh)
+
+
 def best(fn, n=5):
     fn(); torch.cuda.synchronize(); ts = []
-    for _ in range(3):
+    n = 1 if QUICK else n
+    for _ in range(1 if QUICK else 3):
         t = time.perf_counter()
         for _ in range(n):
             fn()
