@@ -757,32 +757,35 @@ def free_device_bytes(dev):
     return None
 
 
-def stack_uint16_shard(a, dev):
-    """One 8-GPU shard of config 4 as uint16 projections (64 of them, every row): dcp_unwarp_stack_rows_typed."""
+def stack_typed_shard(a, dev, dtype="uint16"):
+    """One 8-GPU shard of config 4 as projections of another element type (64 of them, every row): dcp_unwarp_stack_rows_typed.
+    uint16 is what tomography detectors deliver; int32 and float64 are the other types on stack_wg_kernel."""
     L = F.lib()
     orc = oracle_module(a.cpu_threads)
     cfg = configs.cfg4(64)
     D, H, W = cfg["shape"]
     fa, nf = F.fact_array(cfg["list_fact"])
-    chunk = (np.random.default_rng(cfg["seed"] + 5).random((4, H, W), dtype=np.float32) * 60000.0).astype(np.uint16)
-    vol = F.DeviceBuffer(D * H * W * 2, dev)
-    out = F.DeviceBuffer(D * H * W * 2, dev)
+    dt = np.dtype(dtype)
+    es = dt.itemsize
+    chunk = (np.random.default_rng(cfg["seed"] + 5).random((4, H, W), dtype=np.float32) * 60000.0).astype(dt)
+    vol = F.DeviceBuffer(D * H * W * es, dev)
+    out = F.DeviceBuffer(D * H * W * es, dev)
     for d in range(0, D, 4):
-        F.check(L.dcp_memcpy(vol.ptr + d * H * W * 2, chunk.ctypes.data, chunk.nbytes, F.COPY_H2D, dev, None))
-    code = F.DTYPE_BY_NAME["uint16"]
+        F.check(L.dcp_memcpy(vol.ptr + d * H * W * es, chunk.ctypes.data, chunk.nbytes, F.COPY_H2D, dev, None))
+    code = F.DTYPE_BY_NAME[dt.name]
 
     def run(_i):
         F.check(L.dcp_unwarp_stack_rows_typed(vol.ptr, out.ptr, code, 0, D, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"], fa, nf, 0.0, H, 1,
                                               F.MEM_DEVICE, dev, None))
     us = timed_launches(run, 12, dev, settle_ms=60.0)
     k = F.last_kernel()
-    got = np.empty((1, H, W), np.uint16)
-    F.check(L.dcp_memcpy(got.ctypes.data, out.ptr + 3 * H * W * 2, got.nbytes, F.COPY_D2H, dev, None))
+    got = np.empty((1, H, W), dt)
+    F.check(L.dcp_memcpy(got.ctypes.data, out.ptr + 3 * H * W * es, got.nbytes, F.COPY_D2H, dev, None))
     want = orc.unwarp_chunk_slices_backward(chunk[3:4], cfg["xcenter"], cfg["ycenter"], cfg["list_fact"], 0, H - 1, poly=orc.POLY_KERNEL)
     ok = np.array_equal(got, want)
     vol.free()
     out.free()
-    return entry(us, D * H * W, 4, k, ok, shape=[D, H, W], note="uint16 projections, every row: 4 algorithmic bytes per voxel")
+    return entry(us, D * H * W, 2 * es, k, ok, shape=[D, H, W], note="%s projections, every row: %d algorithmic bytes per voxel" % (dt.name, 2 * es))
 
 
 def stack_one_gpu_cases(a, dev):
@@ -1339,7 +1342,8 @@ def main(argv=None):
     if others is not None and "error" not in others:
         for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("color_4096x3", lambda: color_frame(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev)),
                          ("cfg4_grid_search_121_centres", lambda: grid_search_centres(a, dev)),
-                         ("cfg4_uint16_shard64", lambda: stack_uint16_shard(a, dev))):
+                         ("cfg4_uint16_shard64", lambda: stack_typed_shard(a, dev, "uint16")),
+                         ("cfg4_int32_shard64", lambda: stack_typed_shard(a, dev, "int32")), ("cfg4_float64_shard64", lambda: stack_typed_shard(a, dev, "float64"))):
             try:
                 others[name] = fn()
             except Exception as e:      # noqa: BLE001

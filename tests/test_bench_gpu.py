@@ -32,10 +32,11 @@ def test_bench_line_carries_every_config_verified(hip):
     oc = j["other_configs"]
     for key in ("cfg2_scipy_exact_blend", "cfg2_order0_nearest", "cfg3_fused", "cfg3_perspective_only",
                 "cfg3_two_pass_reference_semantics", "cfg5_frame8192_radial9", "cfg4_one_sinogram", "cfg4_grid_search_121_centres", "cfg4_stack_one_gpu", "cfg2_uint16_frame",
-                "cfg4_uint16_shard64", "color_4096x3"):
+                "cfg4_uint16_shard64", "cfg4_int32_shard64", "cfg4_float64_shard64", "color_4096x3"):
         assert key in oc and oc[key].get("verified_vs_oracle") is True, (key, oc.get(key))
         assert oc[key]["launch_us"] > 0 and oc[key]["kernel"]
     assert "stack_wg_kernel" in oc["cfg4_stack_one_gpu"]["kernel"]          # the workgroup-box stack kernel, auto-selected
+    assert oc["cfg4_int32_shard64"]["kernel"].startswith("stack_wg_kernel<NF=5,scipy,32-bit") and oc["cfg4_float64_shard64"]["kernel"].startswith("stack_wg_kernel<NF=5,scipy,float64")
     assert oc["color_4096x3"]["kernel"].startswith("remap_wg_color_kernel<NF=5,f64lerp,float32 x 3>") and oc["color_4096x3"]["algorithmic_bytes_per_pixel"] == 24
     ss = j["stack_scaling"]
     assert ss["compute_plus_allgather"] is None and ss["verified_vs_oracle"] is True and ss["compute_only"]["ms_per_step"] > 0
