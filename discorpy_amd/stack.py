@@ -32,6 +32,15 @@ def _hip_rows(local_vol, xcenter, ycenter, list_fact, row_start, nrows, coord_ro
                           bool(coord_round_f32), blend)
 
 
+def _wire(t):
+    """The tensor as the collective sees it.  RCCL / NCCL and gloo have no 16-bit integer element type, and torch's uint16 / uint32 /
+    uint64 are not c10d element types either -- tomography detectors deliver uint16 -- so those stacks travel as the bytes they are
+    (a uint8 view of the contiguous block: the last axis times the element size; the bits are the payload)."""
+    import torch
+    native = (torch.uint8, torch.int8, torch.int32, torch.int64, torch.float16, torch.bfloat16, torch.float32, torch.float64)
+    return t if t.dtype in native else t.view(torch.uint8)
+
+
 def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_start, nrows, *,
                          coord_round_f32=True, gather=True, group=None, blend=None, compute=None, pipeline=1):
     """
@@ -80,8 +89,8 @@ def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_star
             loc = loc.contiguous()
             if out is None:
                 out = torch.empty((depth, nrows, loc.shape[2]), dtype=loc.dtype, device=loc.device)
-            pieces = [out[r * dl + s0:r * dl + s1] for r in range(world)]      # contiguous views: depth is the outer axis
-            pending.append((dist.all_gather(pieces, loc, group=group, async_op=True), loc))
+            pieces = [_wire(out[r * dl + s0:r * dl + s1]) for r in range(world)]      # contiguous views: depth is the outer axis
+            pending.append((dist.all_gather(pieces, _wire(loc), group=group, async_op=True), loc))
         for work, _keep in pending:
             work.wait()
         return out
@@ -93,14 +102,14 @@ def unwarp_stack_sharded(local_vol, depth, xcenter, ycenter, list_fact, row_star
     width = local.shape[2]
     if len(set(counts)) == 1:
         out = torch.empty((depth, nrows, width), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        dist.all_gather_into_tensor(_wire(out), _wire(local.contiguous()), group=group)
         return out
     # ragged shards: pad to the largest, gather, trim
     m = max(counts)
     pad = torch.zeros((m, nrows, width), dtype=local.dtype, device=local.device)
     pad[:local.shape[0]] = local
     buf = torch.empty((world * m, nrows, width), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(buf, pad, group=group)
+    dist.all_gather_into_tensor(_wire(buf), _wire(pad), group=group)
     return torch.cat([buf[r * m:r * m + counts[r]] for r in range(world)], dim=0)
 
 

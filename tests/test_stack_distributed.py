@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, noise
+from conftest import ROOT, noise, typed_image
 
 from discorpy_amd import stack
 
@@ -60,8 +60,19 @@ def _worker(rank, world, port, depth, result_dir):
         piped9 = stack.unwarp_stack_sharded(local, depth, *args, 10, 6, coord_round_f32=True, compute=cpu_rows, pipeline=9)
         # the sharding without a collective: every rank holds the stack and owns output rows of every projection
         rows, (r0, r1) = stack.unwarp_stack_row_sharded(torch.from_numpy(vol), *args, 3, 29, coord_round_f32=True, compute=cpu_rows)
+        # a uint16 stack (what detectors deliver): torch's uint16 is not an element type of the collectives -- it travels as int16 views
+        vol16 = typed_image("uint16", (depth, 40, 56), 78)
+        local16 = torch.from_numpy(vol16[d0:d1].copy())
+
+        def cpu_rows16(lv, xc, yc, fact, row_start, nrows, round32, blend):
+            return torch.from_numpy(orc.unwarp_chunk_slices_backward(lv.numpy(), xc, yc, fact, int(row_start), int(row_start) + nrows - 1, poly=orc.POLY_KERNEL))
+
+        full16 = stack.unwarp_stack_sharded(local16, depth, *args, 10, 6, coord_round_f32=True, compute=cpu_rows16)
+        piped16 = stack.unwarp_stack_sharded(local16, depth, *args, 10, 6, coord_round_f32=True, compute=cpu_rows16, pipeline=2)
+        assert full16.dtype == torch.uint16 and piped16.dtype == torch.uint16
         np.savez(os.path.join(result_dir, "rank%d.npz" % rank), full=full.numpy(), part=part.numpy(), sl=sl.numpy(),
-                 piped=piped.numpy(), piped9=piped9.numpy(), d0=d0, d1=d1, rows=np.asarray(rows), r0=r0, r1=r1)
+                 piped=piped.numpy(), piped9=piped9.numpy(), d0=d0, d1=d1, rows=np.asarray(rows), r0=r0, r1=r1,
+                 full16=full16.numpy(), piped16=piped16.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -78,6 +89,7 @@ def test_two_rank_gloo_all_gather_reassembles_the_stack(tmp_path, orc, depth):
     want_sl = orc.unwarp_stack_rows(vol, *args, 21, 1, coord_round_f32=False, poly=orc.POLY_KERNEL,
                                     blend=orc.BLEND_F64LERP)
     want_rows = orc.unwarp_stack_rows(vol, *args, 3, 29, coord_round_f32=True, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+    want16 = orc.unwarp_chunk_slices_backward(typed_image("uint16", (depth, 40, 56), 78), *args, 10, 15, poly=orc.POLY_KERNEL)
     covered = []
     for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
@@ -91,3 +103,4 @@ def test_two_rank_gloo_all_gather_reassembles_the_stack(tmp_path, orc, depth):
         assert np.array_equal(z["part"], want[int(z["d0"]):int(z["d1"])])
         assert np.array_equal(z["sl"], want_sl)
         assert np.array_equal(z["piped"], want) and np.array_equal(z["piped9"], want)
+        assert z["full16"].dtype == np.uint16 and np.array_equal(z["full16"], want16) and np.array_equal(z["piped16"], want16)
