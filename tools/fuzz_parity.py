@@ -140,9 +140,12 @@ def one_case(rng, k):
         xc, yc = float(round(xc)), float(round(yc))
     fact = rand_fact(rng, h, w)
     staged = rng.integers(0, 3) == 0 and not os.environ.get("FUZZ_ONLY")
+    if os.environ.get("FUZZ_STAGED_KIND"):       # FUZZ_STAGED_KIND=stack: every case a staged case of that kind (a campaign aimed at one kernel family)
+        staged = True
     if staged:
         # aimed at the staged kernels: a frame of several tiles, a certified calibration, an element type they take
         kind = ("radial", "radial", "batch", "stack", "color", "persp")[int(rng.integers(0, 6))]
+        kind = os.environ.get("FUZZ_STAGED_KIND", kind)
         h, w = int(rng.integers(40, 900)), int(rng.integers(130, 1400))
         dt = ("float32", "float32", "float32", "uint8", "uint16", "int16", "int32", "uint32", "float64")[int(rng.integers(0, 9))]
         xc, yc = float(rng.uniform(0.1, 0.9) * w), float(rng.uniform(0.1, 0.9) * h)
