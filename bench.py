@@ -3,9 +3,13 @@
 
 Headline at every N: BASELINE config 2 -- 4096x4096 float32 frames, 5-term backward polynomial
 (coef_dot_05 rescaled), bilinear -- device-resident, ONE launch of dcp_unwarp_image_f32 per frame.  One "step"
-is one pass of the hot path over a batch of `--batch` DISTINCT frames (default 24: 3.2 GB of input+output per
-GPU, so the 256 MiB Infinity Cache cannot hold the working set).  With N > 1 every rank unwarps its own batch
-(independent frames, no data-path collective): weak scaling.
+is `cycles` passes of the hot path over a ring of `--batch` DISTINCT frames (default 24: 3.2 GB of input+output
+per GPU, so the 256 MiB Infinity Cache cannot hold the working set); `cycles` is chosen from one probe pass so that
+the K timed steps last at least --min-timed-ms (300 ms) whatever K is, and the line says how many frames a step was
+(config.frames_per_step_per_gpu).  `value` is computed from the HIP events on the launch stream around the K steps,
+`value_wall` / `ms_per_step` from the host clock between the barrier + synchronize pairs, and the host's share is
+spelled out (host_enqueue_us_per_launch, sync_ms).  With N > 1 every rank unwarps its own ring (independent frames,
+no data-path collective): weak scaling.
 
 After the timed region the same run also measures, outside it and reported beside the headline:
   other_configs   (N = 1) config 2 with scipy's exact blend and at order 0, config 3 fused / two-pass /
@@ -49,7 +53,13 @@ def parse(argv=None):
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="back-to-back launches for this long before the warm-up steps: the core clock needs ~100 ms under "
                          "load to reach its sustained level (tools/time_ramp.py); 0 disables")
-    ap.add_argument("--batch", type=int, default=24, help="distinct frames per step (ring size)")
+    ap.add_argument("--batch", type=int, default=24, help="distinct frames in the ring (3.2 GB at 24: the Infinity Cache cannot hold it)")
+    ap.add_argument("--cycles", type=int, default=0,
+                    help="passes over the ring per step; 0 = chosen from one probe pass so that the K timed steps last at least "
+                         "--min-timed-ms whatever K is (a step is then cycles x batch frames, reported as frames_per_step_per_gpu)")
+    ap.add_argument("--min-timed-ms", type=float, default=300.0,
+                    help="lower bound of the timed region used to choose --cycles 0: a 14 ms region (20 steps x 24 frames) lost 25 %% "
+                         "to 4.7 ms of one-off host latency on the driver's box in round 4")
     ap.add_argument("--blend", default="f64lerp", choices=sorted(BLEND_NAMES))
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -278,6 +288,18 @@ def entry(us, pixels, bytes_per_pixel, kernel, verified, **more):
          "verified_vs_oracle": bool(verified)}
     d.update(more)
     return d
+
+
+class RingFrame:
+    """One frame of the ring: a view (pointer + length) into the ring's single allocation."""
+
+    def __init__(self, ring, offset):
+        self.ptr, self.nbytes, self.device = ring.ptr + offset, ring.nbytes - offset, ring.device
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        F.check(F.lib().dcp_memcpy(self.ptr, a.ctypes.data, a.nbytes, F.COPY_H2D, self.device, None))
+        return self
 
 
 def download(buf_ptr, shape, dev, offset=0):
@@ -1201,15 +1223,19 @@ def main(argv=None):
     fa, nf = F.fact_array(cfg["list_fact"])
 
     # device-resident batch: `batch` distinct input frames + as many output frames
+    # (ONE allocation per side, the frames at a constant pitch: the ring is a (batch, H, W) array -- what a caller holding a
+    # stack of frames of one camera has, and what the batch entry point recognises as such)
+    frame_bytes = H * W * 4
+    ring_src, ring_dst = F.DeviceBuffer(frame_bytes * a.batch, dev), F.DeviceBuffer(frame_bytes * a.batch, dev)
     srcs, dsts, img0 = [], [], None
     for i in range(a.batch):
         img = rng.random((H, W), dtype=np.float32)
         if i == 0:
             img0 = img
-        srcs.append(F.DeviceBuffer(img.nbytes, dev).upload(img))
-        dsts.append(F.DeviceBuffer(img.nbytes, dev))
+        srcs.append(RingFrame(ring_src, i * frame_bytes).upload(img))
+        dsts.append(RingFrame(ring_dst, i * frame_bytes))
 
-    def step():
+    def ring_pass():
         for s, d in zip(srcs, dsts):
             rc = L.dcp_unwarp_image_f32(s.ptr, d.ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"], fa, nf,
                                         a.order, 1, blend, F.MEM_DEVICE, dev, None)
@@ -1225,8 +1251,40 @@ def main(argv=None):
     if a.settle_ms > 0:            # let the clocks reach their sustained level before anything is counted
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:
-            step()
+            ring_pass()
             sync()
+    # how many passes over the ring make one step: the K timed steps must last long enough that a few milliseconds of one-off host
+    # latency (first launch after an idle queue, the wake-up of the final synchronize) cannot move the number -- VERDICT r4 item 1
+    cycles, probe_ms = a.cycles, None
+    if cycles <= 0:
+        p0, p1 = F.Event(dev), F.Event(dev)
+        p0.record()
+        ring_pass()
+        ring_pass()
+        p1.record()
+        p1.synchronize()
+        probe_ms = p0.elapsed_ms(p1) / 2.0
+        cycles = max(1, int(np.ceil(a.min_timed_ms / (a.steps * max(probe_ms, 1e-3)))))
+        if dist is not None:            # every rank must run the same number of launches
+            import torch
+            tc = torch.tensor([cycles], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+            cycles = int(tc[0])
+
+    def step():
+        for _ in range(cycles):
+            ring_pass()
+
+    # the host's own cost of one launch, on a queue that never fills: 64 calls behind a synchronize (outside the timed region)
+    sync()
+    pairs, n_host = list(zip(srcs, dsts)), 64
+    th0 = time.perf_counter()
+    for i in range(n_host):
+        s, d = pairs[i % len(pairs)]
+        L.dcp_unwarp_image_f32(s.ptr, d.ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"], fa, nf, a.order, 1, blend, F.MEM_DEVICE, dev, None)
+    host_call_us = (time.perf_counter() - th0) * 1e6 / n_host
+    sync()
+
     for _ in range(a.warmup):
         step()
     sync()
@@ -1239,12 +1297,15 @@ def main(argv=None):
     for _ in range(a.steps):
         step()
     e1.record()
+    t_enq = time.perf_counter()            # every launch of the K steps is in the queue (the call blocks while the queue is full)
     sync()
+    t_sync = time.perf_counter()
     if dist is not None:
         dist.barrier()
     sync()
     wall = time.perf_counter() - t0
-    dev_ms = e0.elapsed_ms(e1)            # HIP events on the launch stream: device time of the K steps
+    enqueue_ms, sync_ms = (t_enq - t0) * 1e3, (t_sync - t_enq) * 1e3
+    dev_ms = e0.elapsed_ms(e1)            # HIP events on the launch stream: device time of the K steps, gaps between launches included
     headline_kernel = F.last_kernel()
     if dist is not None:
         import torch
@@ -1292,32 +1353,35 @@ def main(argv=None):
         except Exception as e:      # noqa: BLE001 -- context only
             dist_launch = {"error": repr(e)}
 
-    box = clocks_under_load(step, sync) if (rank == 0 and n_gpus == 1 and not a.no_extras) else None
+    box = clocks_under_load(ring_pass, sync) if (rank == 0 and n_gpus == 1 and not a.no_extras) else None
 
     batched = None
     if rank == 0 and n_gpus == 1 and a.order == 1 and not a.no_extras:
-        # context, not the metric: the frames of a step share one calibration, so the whole batch can also go
-        # through ONE launch of the stack entry point (depth = batch, all rows) -- bit-identical output, the
-        # coordinates evaluated once per pixel position instead of once per frame
+        # context, not the metric: the frames of the ring share one calibration and lie in one (batch, H, W) array, so the PUBLIC batch
+        # entry point (dcp_unwarp_images_f32: one pointer, centre and coefficient vector per frame) recognises them as the projections
+        # of a stack and runs stack_wg_kernel -- bit-identical output, the coordinates evaluated once per pixel position instead of
+        # once per frame.  The headline frames were written by per-frame launches: keep one to compare with.
         try:
-            nbytes = H * W * 4
-            vsrc, vdst = F.DeviceBuffer(nbytes * a.batch, dev), F.DeviceBuffer(nbytes * a.batch, dev)
-            for i, sbuf in enumerate(srcs):
-                F.check(L.dcp_memcpy(vsrc.ptr + i * nbytes, sbuf.ptr, nbytes, F.COPY_D2D, dev, None))
+            import ctypes as C
+            n = a.batch
+            ref = download(dsts[n - 1].ptr, (H, W), dev)
+            dsts[n - 1].upload(np.zeros((H, W), np.float32))          # so that the comparison below cannot pass on stale pixels
+            sp = (C.c_void_p * n)(*[b.ptr for b in srcs])
+            dp = (C.c_void_p * n)(*[b.ptr for b in dsts])
+            xa, ya = (C.c_double * n)(*([cfg["xcenter"]] * n)), (C.c_double * n)(*([cfg["ycenter"]] * n))
+            table = np.ascontiguousarray([cfg["list_fact"]] * n, dtype=np.float64)
+            tp = table.ctypes.data_as(C.POINTER(C.c_double))
 
-            def stack_step(_i):
-                F.check(L.dcp_unwarp_stack_rows_f32(vsrc.ptr, vdst.ptr, a.batch, H, W, H * W, W, cfg["xcenter"], cfg["ycenter"],
-                                                    fa, nf, 0.0, H, 1, blend, F.MEM_DEVICE, dev, None))
-            per_frame_us = timed_launches(stack_step, max(4, a.steps // 4), dev) / a.batch
+            def batch_step(_i):
+                F.check(L.dcp_unwarp_images_f32(sp, dp, n, H, W, W, 1, xa, ya, tp, nf, a.order, 1, blend, F.MEM_DEVICE, dev, None))
+            per_frame_us = timed_launches(batch_step, max(4, min(a.steps, 40) // 4), dev) / n
             kb = F.last_kernel()
-            chk = download(vdst.ptr, (H, W), dev, offset=(a.batch - 1) * nbytes)
-            ref = download(dsts[a.batch - 1].ptr, (H, W), dev)
-            batched = {"what": "the %d frames of a step in one dcp_unwarp_stack_rows_f32 launch (same calibration)" % a.batch,
+            chk = download(dsts[n - 1].ptr, (H, W), dev)
+            batched = {"what": "the %d frames of the ring in ONE dcp_unwarp_images_f32 call (one calibration, frames of one array: "
+                               "routed to the stack kernel)" % n,
                        "Mpixels_per_s": round(H * W / per_frame_us, 1), "us_per_frame": round(per_frame_us, 3),
                        "frac_of_hbm_peak": round(configs.BYTES_PER_PIXEL * H * W / (per_frame_us * 1e-6) / 1e9 / configs.HBM_PEAK_GBPS, 4),
                        "kernel": kb, "identical_to_per_frame_launches": bool(np.array_equal(chk, ref))}
-            vsrc.free()
-            vdst.free()
         except Exception as e:      # noqa: BLE001 -- context only, never fails the bench
             batched = {"error": repr(e)}
 
@@ -1337,8 +1401,8 @@ def main(argv=None):
             others = other_configs(a, dev, srcs, dsts, img0)
         except Exception as e:      # noqa: BLE001 -- context only
             others = {"error": repr(e)}
-    for b in srcs + dsts:           # the ring is no longer needed: make room for the 8192^2 frames and the stack
-        b.free()
+    ring_src.free()                 # the ring is no longer needed: make room for the 8192^2 frames and the stack
+    ring_dst.free()
     if others is not None and "error" not in others:
         for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("color_4096x3", lambda: color_frame(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev)),
                          ("cfg4_grid_search_121_centres", lambda: grid_search_centres(a, dev)),
@@ -1380,10 +1444,11 @@ def main(argv=None):
                 dist.barrier()
 
     if rank == 0:
-        launches = a.steps * a.batch
+        launches = a.steps * cycles * a.batch
         pix_per_launch = H * W
         total_pix = launches * pix_per_launch * n_gpus
-        value = total_pix / wall / 1e6
+        value_wall = total_pix / wall / 1e6
+        value = total_pix / (dev_ms * 1e-3) / 1e6
         launch_us = dev_ms * 1e3 / launches
         achieved = configs.BYTES_PER_PIXEL * pix_per_launch / (launch_us * 1e-6) / 1e9
         traffic, traffic_source, traffic_stale = None, None, None
@@ -1405,8 +1470,21 @@ def main(argv=None):
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(wall * 1e3 / a.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            # value: from the HIP events on the launch stream around the K steps (max over ranks; the gaps between launches are
+            # inside); value_wall / ms_per_step: host clock between the two barrier + synchronize pairs (max over ranks)
+            "value_basis": "device events around the K timed steps; value_wall is the same work over the host's wall clock",
+            "value_wall": round(value_wall, 1), "ms_per_step_device": round(dev_ms / a.steps, 4),
+            "timed_region_ms": round(wall * 1e3, 3), "launches_timed_per_gpu": launches,
+            # rank 0's host side of the timed region: the launch loop (it blocks while the queue is full, so this tends to the
+            # device time on long regions), the final synchronize, and one launch call on a queue that never fills
+            "host_enqueue_us_per_launch": round(enqueue_ms * 1e3 / launches, 3), "sync_ms": round(sync_ms, 3),
+            "host_call_us_per_launch_idle_queue": round(host_call_us, 3),
+            "launch_us": round(launch_us, 3),
+            "launch_us_median": None if not isinstance(dist_launch, dict) else dist_launch.get("median_us"),
+            "launch_us_p90": None if not isinstance(dist_launch, dict) else dist_launch.get("p90_us"),
             "data": "synthetic (numpy default_rng uniform [0,1) float32 frames, device-resident)",
-            "config": {"workload": cfg["name"], "frames_per_step_per_gpu": a.batch, "height": H, "width": W,
+            "config": {"workload": cfg["name"], "frames_per_step_per_gpu": cycles * a.batch, "distinct_frames_in_ring": a.batch,
+                       "ring_passes_per_step": cycles, "ring_pass_probe_ms": None if probe_ms is None else round(probe_ms, 4), "height": H, "width": W,
                        "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True, "pixel_dtype": "f32",
                        "arithmetic": "coordinates and blend in float64 (as numpy / scipy compute them), pixels float32; the f64lerp "
                                      "blend is a factorisation within one float32 ulp of scipy's operation order (other_configs."

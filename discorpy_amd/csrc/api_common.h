@@ -133,6 +133,11 @@ void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start
 void host_row_band_rect(const dcp::MapArgs& m, int64_t H, double x_lo, double x_hi, double y_lo, double y_hi, int64_t* b0,
                         int64_t* b1);
 
+// api_stack.cpp: frames of one calibration at a constant pitch as the projections of a stack (see there)
+int frames_as_stack(const float* src0, float* dst0, int nframes, int64_t height, int64_t width, int64_t pitch, int64_t row_stride,
+                    double xcenter, double ycenter, const double* list_fact, int nfact, int blend_mode, int device, void* stream,
+                    bool* taken);
+
 // api_spline.cpp: frees the coefficient planes of every device (waits for the devices first)
 int release_spline_workspace();
 

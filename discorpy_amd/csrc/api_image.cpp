@@ -573,6 +573,23 @@ int dcp_unwarp_images_f32(const float* const* srcs, float* const* dsts, int nfra
     return one_by_one(0);
   for (int i = 0; i < nframes; ++i)
     if ((rc = check_image(srcs[i], dsts[i], height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  // Frames of ONE calibration, evenly spaced, results dense -- a (n, height, width) array, which is what the reference's callers
+  // loop over (the channels of demo_06.py:111-113, the frames of demo_07.py:25,60): the projections of a stack, every row wanted.
+  if (order == 1 && src_col_stride == 1) {
+    bool same = true;
+    const ptrdiff_t pitch = srcs[1] - srcs[0];
+    const int64_t extent = (height - 1) * src_row_stride + width;
+    for (int i = 1; i < nframes && same; ++i)
+      same = xcenters[i] == xcenters[0] && ycenters[i] == ycenters[0] && srcs[i] - srcs[i - 1] == pitch &&
+             dsts[i] - dsts[i - 1] == (ptrdiff_t)(height * width) &&
+             (nfact == 0 || memcmp(list_facts + (size_t)i * (size_t)nfact, list_facts, (size_t)nfact * sizeof(double)) == 0);
+    if (same && (int64_t)pitch >= extent) {
+      bool taken = false;
+      rc = frames_as_stack(srcs[0], dsts[0], nframes, height, width, (int64_t)pitch, src_row_stride, xcenters[0], ycenters[0],
+                           list_facts, nfact, blend_mode, device, stream, &taken);
+      if (rc != DCP_OK || taken) return rc;
+    }
+  }
   // every frame's calibration must hold the level-2 tile certificate (one box per 128 x 32 workgroup tile)
   std::vector<dcp::BatchFrame> fr((size_t)nframes);
   bool all_certified = g_tile_cert.load() != 0;

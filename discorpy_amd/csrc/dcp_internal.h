@@ -173,6 +173,7 @@ hipError_t launch_stack_wg_typed(const StackArgs& st, const MapArgs& map, int dt
 hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler, hipStream_t stream);
 hipError_t launch_coord_map(MapKind kind, const ImageArgs& img, const MapArgs& map, float* ymap, float* xmap,
                             hipStream_t stream);
+bool stack_wg_would_take(const StackArgs& st, const MapArgs& map, const LaunchOpts& opts);
 hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream);
 

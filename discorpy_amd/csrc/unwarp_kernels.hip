@@ -2386,6 +2386,14 @@ static bool wg_stack_eligible(const StackArgs& st, const MapArgs& map, const Lau
          (((int64_t)st.proj_stride * es) & 3) == 0;
 }
 
+// would launch_stack() hand this float32 call (float32 coordinates) to stack_wg_kernel?  (dcp_unwarp_images_f32 routes frames of one
+// calibration here only when it does: the generic stack kernels are slower than remap_wg_batch_kernel)
+bool stack_wg_would_take(const StackArgs& st, const MapArgs& map, const LaunchOpts& opts) {
+  if (st.D == 0 || st.nrows == 0 || !opts.stack_wg || !wg_stack_eligible(st, map, opts, 4)) return false;
+  const int dc = opts.d_chunk < 1 ? 1 : opts.d_chunk;
+  return wg_stack_chunk(st, (dc + 1) / 2, opts.stack_wg >= 2) > 0;
+}
+
 template <int NF, typename T>
 static hipError_t launch_stack_wg_t(const StackArgs& st, const MapArgs& map, int sampler, hipStream_t stream) {
   dim3 grid((unsigned)((st.W + kWgTW - 1) / kWgTW), (unsigned)((st.nrows + kWgTH - 1) / kWgTH), (unsigned)((st.D + st.d_chunk - 1) / st.d_chunk));

@@ -213,3 +213,69 @@ def test_a_stacked_device_array_that_is_not_a_tensor_comes_back_as_one_3d_array(
     for i in range(n):
         assert np.array_equal(got[i], orc.unwarp_image_backward(stack[i], xcs[i], ycs[i], fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
         assert np.array_equal(res[i].copy_to_host(), got[i])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("blend", ["f64lerp", "scipy"])
+def test_frames_of_one_calibration_in_one_array_take_the_stack_kernel(hip, orc, blend):
+    """the reference's callers loop ONE calibration over the channels / frames of an array
+    (demo_06.py:111-113, demo_07.py:25,60).  dcp_unwarp_images_f32 sees equal calibrations + a constant pitch + dense results and
+    runs the frames as the projections of a stack (stack_wg_kernel: a tile's coordinates once for all frames) -- bit-identical
+    to one call per frame.  A gap between the frames (pitch > frame) is fine; scattered results are not (the batch kernel)."""
+    L = hip.lib()
+    H, W, n = 1100, 1400, 5
+    c2 = configs.cfg2()
+    s = 4096.0 / W
+    xc, yc = c2["xcenter"] / s, c2["ycenter"] / s
+    fact = [v * s ** k for k, v in enumerate(c2["list_fact"])]
+    frames = np.stack([noise(300 + i, (H, W)) for i in range(n)])
+    gap = 4096                                   # elements between the end of one frame and the start of the next
+    pitch = H * W + gap
+    host = np.zeros(n * pitch, np.float32)
+    for i in range(n):
+        host[i * pitch:i * pitch + H * W] = frames[i].ravel()
+    src = hip.DeviceBuffer(host.nbytes).upload(host)
+    dst = hip.DeviceBuffer(frames.nbytes)
+    fa = (C.c_double * (n * len(fact)))(*(fact * n))
+    xa, ya = (C.c_double * n)(*([xc] * n)), (C.c_double * n)(*([yc] * n))
+    sp = (C.c_void_p * n)(*[src.ptr + 4 * i * pitch for i in range(n)])
+    dp = (C.c_void_p * n)(*[dst.ptr + 4 * i * H * W for i in range(n)])
+    code = hip.BLEND_BY_NAME[blend]
+    hip.check(L.dcp_unwarp_images_f32(sp, dp, n, H, W, W, 1, xa, ya, fa, len(fact), 1, 1, code, hip.MEM_DEVICE, -1, None))
+    assert hip.last_kernel().startswith("stack_wg_kernel<NF=5," + blend), hip.last_kernel()
+    got = dst.download((n, H, W), np.float32)
+    for i in range(n):
+        want = orc.unwarp_image_backward(frames[i], xc, yc, fact, poly=orc.POLY_KERNEL, blend=getattr(orc, ORC_BLEND[blend]))
+        assert np.array_equal(got[i], want)
+        assert np.array_equal(got[i], pp.unwarp_image_backward(frames[i], xc, yc, fact, blend=blend))
+    # results NOT dense (frame 1 and 2 swapped): the frame-per-blockIdx.z kernel, the same pixels
+    dp2 = (C.c_void_p * n)(*[dst.ptr + 4 * i * H * W for i in (0, 2, 1, 3, 4)])
+    hip.check(L.dcp_unwarp_images_f32(sp, dp2, n, H, W, W, 1, xa, ya, fa, len(fact), 1, 1, code, hip.MEM_DEVICE, -1, None))
+    assert hip.last_kernel().startswith("remap_wg_batch_kernel"), hip.last_kernel()
+    got2 = dst.download((n, H, W), np.float32)
+    assert all(np.array_equal(got2[j], got[i]) for i, j in enumerate((0, 2, 1, 3, 4)))
+    # one centre differs in the last bit: not one calibration any more
+    xb = (C.c_double * n)(*([xc] * (n - 1) + [np.nextafter(xc, 1e9)]))
+    hip.check(L.dcp_unwarp_images_f32(sp, dp, n, H, W, W, 1, xb, ya, fa, len(fact), 1, 1, code, hip.MEM_DEVICE, -1, None))
+    assert hip.last_kernel().startswith("remap_wg_batch_kernel"), hip.last_kernel()
+    src.free()
+    dst.free()
+
+
+@pytest.mark.gpu
+def test_unwarp_images_backward_on_a_3d_array_of_one_calibration(hip, orc):
+    """The Python entry on a (n, H, W) device array with ONE centre / coefficient vector: the stack kernel, one 3-D result."""
+    torch = pytest.importorskip("torch")
+    H, W, n = 900, 1300, 3
+    c2 = configs.cfg2()
+    s = 4096.0 / W
+    xc, yc = c2["xcenter"] / s, c2["ycenter"] / s
+    fact = [v * s ** k for k, v in enumerate(c2["list_fact"])]
+    frames = np.stack([noise(400 + i, (H, W)) for i in range(n)])
+    t = torch.from_numpy(frames).cuda()
+    out = pp.unwarp_images_backward(t, xc, yc, fact)
+    assert hip.last_kernel().startswith("stack_wg_kernel<NF=5,f64lerp"), hip.last_kernel()
+    assert tuple(out.shape) == (n, H, W)
+    got = out.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], orc.unwarp_image_backward(frames[i], xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
