@@ -223,7 +223,7 @@ def test_frames_of_one_calibration_in_one_array_take_the_stack_kernel(hip, orc, 
     runs the frames as the projections of a stack (stack_wg_kernel: a tile's coordinates once for all frames) -- bit-identical
     to one call per frame.  A gap between the frames (pitch > frame) is fine; scattered results are not (the batch kernel)."""
     L = hip.lib()
-    H, W, n = 1100, 1400, 5
+    H, W, n = 2048, 2304, 5              # (enough tiles for the stack kernel: its launcher declines launches of < 1024 workgroups)
     c2 = configs.cfg2()
     s = 4096.0 / W
     xc, yc = c2["xcenter"] / s, c2["ycenter"] / s
@@ -266,7 +266,7 @@ def test_frames_of_one_calibration_in_one_array_take_the_stack_kernel(hip, orc, 
 def test_unwarp_images_backward_on_a_3d_array_of_one_calibration(hip, orc):
     """The Python entry on a (n, H, W) device array with ONE centre / coefficient vector: the stack kernel, one 3-D result."""
     torch = pytest.importorskip("torch")
-    H, W, n = 900, 1300, 3
+    H, W, n = 2048, 2200, 3
     c2 = configs.cfg2()
     s = 4096.0 / W
     xc, yc = c2["xcenter"] / s, c2["ycenter"] / s
