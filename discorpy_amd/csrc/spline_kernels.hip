@@ -1185,7 +1185,7 @@ constexpr int kSwNJ = (kSwBoxH * kSwCH + 255) / 256;   // loads per wave that co
 // per wave and the hoisted evaluation map_coord (dcp_device.h) -- round 2 walked the coefficient vector with one scalar load and
 // one wait per coefficient and pixel row.
 template <int KIND, int ORDER, int NF, bool EXACT>
-__global__ void __launch_bounds__(256, 3) spline_wg_kernel(const SplineArgs a, const MapArgs map, void* dst) {
+__global__ void __launch_bounds__(256, ORDER >= 5 ? 2 : 3) spline_wg_kernel(const SplineArgs a, const MapArgs map, void* dst) {
   constexpr int RW = KIND == kRadial ? 2 : 4;
   __shared__ __attribute__((aligned(16))) unsigned char s_box[kSwBoxH * kSwBoxW * 8];
   __shared__ double s_row[4][16][RW];                                // one row table per wave: no barrier before it is read

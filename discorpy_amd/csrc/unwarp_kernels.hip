@@ -358,7 +358,7 @@ constexpr int kLdsBW = DCP_LDS_BLOCK_WAVES;
 // VOTE = true: no certificate (fused map, strongly curved models): zero margin, every pixel verified.
 // (the fused map with runtime-length coefficients needs > 96 VGPRs: three waves per SIMD is what it gets, and what it declares)
 template <int KIND, int NF, int SAMPLER, bool VOTE>
-__global__ void __launch_bounds__(64 * kLdsBW, (KIND == kFused && NF < 0) ? 3 : DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
+__global__ void __launch_bounds__(64 * kLdsBW, NF < 0 ? 3 : DCP_LDS_WAVES) remap_lds_kernel(const ImageArgs img, const MapArgs map) {
   constexpr int kMargin = VOTE ? DCP_LDS_MARGIN : 1;
   // 4 x 7680 B slabs + row table + coefficients <= 32 KB: five workgroups (20 waves) per CU
   __shared__ float s_box[kLdsBW][kBoxH * kBoxW];
@@ -1144,8 +1144,11 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
   }
 }
 
+// (runtime-length coefficient vectors -- NF < 0 -- walk the vector in LDS and need more registers than six waves per SIMD leave: at six
+// they spilled 116-148 bytes into scratch, and every reload of a spill is a VMEM wait that also waits for the untracked fill;
+// tools/isa_hazards.py keeps the shipped instantiations free of scratch)
 template <int KIND, int NF, int SAMPLER, typename T = float>
-__global__ void __launch_bounds__(256, DCP_WG_WAVES) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
+__global__ void __launch_bounds__(256, (NF < 0 ? 4 : (NF == 1 ? 5 : DCP_WG_WAVES))) remap_wg_kernel(const ImageArgs img, const MapArgs map) {
   remap_wg_body<KIND, NF, SAMPLER, T>(img, map);
 }
 
@@ -1404,7 +1407,7 @@ __global__ void __launch_bounds__(kBlock) stack_centres_kernel(const StackArgs s
 // does not fit the slab, or whose containment vote fails, gathers directly as stack_rows_kernel does.
 // float32 coordinates only (unwarp_chunk_slices_backward); the slice path keeps stack_rows_kernel.
 template <int NF, int SAMPLER>
-__global__ void __launch_bounds__(64 * kLdsBW, DCP_LDS_WAVES) stack_lds_kernel(const StackArgs st, const MapArgs map) {
+__global__ void __launch_bounds__(64 * kLdsBW, (NF < 0 || SAMPLER == kScipy) ? 3 : DCP_LDS_WAVES) stack_lds_kernel(const StackArgs st, const MapArgs map) {
   __shared__ float s_box[kLdsBW][kBoxH * kBoxW];
   __shared__ double s_row[kLdsBW * kLdsTH][2];
   __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
