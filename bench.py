@@ -840,6 +840,96 @@ def stack_one_gpu_cases(a, dev):
 
 # ----------------------------------------------------------------------------------------- exchange without torch (C ABI only)
 
+def rccl_comm_report(comm, world):
+    """What the communicator of the C-ABI exchange says about ITSELF (dcp_rccl_comm_info: ncclCommCount / ncclCommUserRank /
+    ncclCommCuDevice / ncclGetVersion, the librccl file the symbols were bound from, the shard depths of the last agreement)."""
+    import ctypes as C
+    L = F.lib()
+    info = (C.c_int64 * 10)()
+    depths = (C.c_int64 * max(world, 1))()
+    path = C.create_string_buffer(1024)
+    F.check(L.dcp_rccl_comm_info(comm, info, 10, depths, world, path, 1024))
+    lib = path.value.decode(errors="replace")
+    v = int(info[3])
+    return {"nccl_comm_count": int(info[0]), "nccl_comm_user_rank": int(info[1]), "nccl_comm_device": int(info[2]),
+            "nccl_version_code": v, "nccl_version": ("%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100)) if v >= 10000 else str(v),
+            "world_given": int(info[4]), "rank_given": int(info[5]), "hip_device": int(info[6]), "shard_agreement_in_force": bool(info[7]),
+            "exchanges": int(info[8]), "agreements": int(info[9]), "shard_depths": [int(d) for d in depths[:world]], "librccl": lib,
+            # tests/c/libfake_rccl.so (DCP_RCCL_PATH on the one-GPU test boxes) reports version 1: never mistaken for RCCL
+            "rccl_is_stand_in": bool(v < 10000 or "fake_rccl" in lib)}
+
+
+def rccl_debug_env(env, tag):
+    """NCCL_DEBUG=INFO into a side file per process under gpurun_out/rccl_debug/ (unless the caller already set NCCL_DEBUG): the
+    topology, algorithm and protocol lines of the first multi-GPU run, kept beside the numbers."""
+    if "NCCL_DEBUG" in env and env.get("DCP_BENCH_NCCL_DEBUG_IS_OURS") != "1":
+        return None
+    d = os.path.join(ROOT, "gpurun_out", "rccl_debug")
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        return None
+    env["NCCL_DEBUG"] = "INFO"
+    env["DCP_BENCH_NCCL_DEBUG_IS_OURS"] = "1"
+    env.setdefault("NCCL_DEBUG_SUBSYS", "INIT,ENV,TUNING")
+    env["NCCL_DEBUG_FILE"] = os.path.join(d, tag + ".%h.%p.log")
+    return d
+
+
+def rccl_debug_digest(d, tag, limit=16):
+    """A few distinct lines of the side files written under rccl_debug_env (ranks, transport, algorithm / protocol choices)."""
+    import glob
+    import re
+    if not d:
+        return None
+    files = sorted(glob.glob(os.path.join(d, tag + ".*.log")))
+    keep, seen = [], set()
+    pat = re.compile(r"nranks|nRanks|Algo|Proto|via P2P|via SHM|via NET|Connected all|Using network|RCCL version|NCCL version|comm 0x", re.I)
+    for f in files:
+        try:
+            for ln in open(f, errors="replace"):
+                if "NCCL" in ln and pat.search(ln):
+                    key = re.sub(r"0x[0-9a-f]+|\d+", "#", ln.split("NCCL", 1)[1])[:80]
+                    if key not in seen and len(keep) < limit:
+                        seen.add(key)
+                        keep.append(ln.strip()[:220])
+        except OSError:
+            pass
+    return {"dir": os.path.relpath(d, ROOT), "files": len(files), "sample_lines": keep}
+
+
+def torch_rccl_report(dist, backend, world, rank, dev_index, dbg_dir):
+    """COLLECTIVE (every rank calls it).  What the torch.distributed job that carried stack_scaling's all-gather consisted of, from
+    the collectives themselves: an all-reduce of ones counts the ranks that took part, an object all-gather lists their devices."""
+    import torch
+    t = torch.ones(1, dtype=torch.float32, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, {"rank": rank, "device": dev_index, "pid": os.getpid()})
+    ver, lib = None, None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:      # noqa: BLE001
+            ver = None
+    try:
+        for ln in open("/proc/self/maps"):
+            if "librccl" in ln or "libnccl" in ln:
+                lib = ln.split()[-1]
+                break
+    except OSError:
+        pass
+    rep = {"backend": backend, "ranks_in_all_reduce": int(round(float(t.item()))), "torch_world_size": dist.get_world_size(), "n_gpus": world,
+           "nccl_version": ver, "librccl": lib, "ranks": ranks,
+           # DCP_BENCH_BACKEND=gloo (ranks sharing the one GPU of a test box): not an RCCL number, and the line says so
+           "rccl_is_stand_in": backend != "nccl"}
+    if rank == 0:
+        rep["debug_log"] = rccl_debug_digest(dbg_dir, "torch")
+    if rep["ranks_in_all_reduce"] != world or len({r["rank"] for r in ranks if r}) != world:
+        rep["error"] = "the collective saw %d ranks, the launcher started %d" % (rep["ranks_in_all_reduce"], world)
+    return rep
+
+
 def native_rccl_child(a):
     """One rank of config 4 with the exchange done by dcp_unwarp_stack_rows_rccl_f32 (dlopen'ed librccl: ncclAllGather in place on
     the kernel's stream; pipelined: grouped ncclBroadcasts of depth sub-blocks on a side stream) -- no torch in this process.
@@ -893,14 +983,20 @@ def native_rccl_child(a):
     for name, pipeline in (("allgather", 1), ("allgather_pipelined", 4)):
         for r, d in ((rank, 0), ((rank + 1) % world, dl - 1)):      # the projections check() reads must come from THIS variant
             F.check(L.dcp_memcpy(full.ptr + (r * dl + d) * nrows * W * 4, zeros.ctypes.data, zeros.nbytes, F.COPY_H2D, dev, None))
-        run(pipeline)                                   # warm-up; its collective also lines the ranks up
+        F.check(L.dcp_rccl_comm_fixed_shards(comm, 0))
+        run(pipeline)                                   # warm-up; its shard agreement (a collective + a host wait) also lines the ranks up
         F.check(L.dcp_stream_synchronize(dev, None))
+        # the timed calls repeat the agreed shapes on every rank: say so, and they are stream-ordered end to end (no agreement, no host
+        # wait between two exchanges -- ADVICE r4: with it, back-to-back calls were synchronous)
+        F.check(L.dcp_rccl_comm_fixed_shards(comm, 1))
         t0 = time.perf_counter()
         for _ in range(a.steps):
             run(pipeline)
         F.check(L.dcp_stream_synchronize(dev, None))
         res[name + "_ms"] = (time.perf_counter() - t0) * 1e3 / a.steps
         res[name + "_verified"] = check()
+    res["rccl"] = rccl_comm_report(comm, world)
+    res["bytes_received"] = int((D - dl) * nrows * W * 4)
     F.check(L.dcp_rccl_comm_destroy(comm))
     vol.free()
     full.free()
@@ -966,6 +1062,7 @@ def native_exchange_variants(a, world, depth, steps=3, timeout=None):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dbg_dir = rccl_debug_env(env, "native")
 
     def last_json(text):
         lines = [ln for ln in (text or "").strip().split("\n") if ln.startswith("{")]
@@ -987,9 +1084,22 @@ def native_exchange_variants(a, world, depth, steps=3, timeout=None):
                     p_.kill()
                     p_.communicate()
                     errs.append("timeout after %d s" % timeout)
+        seen = sorted({r["rccl"]["nccl_comm_count"] for r in res}) if res and all("rccl" in r for r in res) else None
         if errs or len(res) != world:
             out["native_rccl"] = {"error": errs[:2]}
+        elif seen != [world]:
+            # the entry fails, not the bench: the communicators did not span the ranks the launcher started
+            out["native_rccl"] = {"error": "ncclCommCount reports %r ranks, %d processes were launched" % (seen, world),
+                                  "per_rank": [r.get("rccl") for r in res]}
         else:
+            r0 = sorted(res, key=lambda r: r["rank"])
+            out["native_rccl_comm"] = {
+                "ranks_seen_by_rccl": seen[0], "n_gpus": world, "nccl_version": r0[0]["rccl"]["nccl_version"], "librccl": r0[0]["rccl"]["librccl"],
+                "rccl_is_stand_in": any(r["rccl"]["rccl_is_stand_in"] for r in r0),
+                "user_ranks": [r["rccl"]["nccl_comm_user_rank"] for r in r0], "devices": [r["rccl"]["nccl_comm_device"] for r in r0],
+                "shard_depths": r0[0]["rccl"]["shard_depths"], "bytes_received_per_rank": [r["bytes_received"] for r in r0],
+                "exchanges_per_rank": [r["rccl"]["exchanges"] for r in r0], "agreements_per_rank": [r["rccl"]["agreements"] for r in r0],
+                "debug_log": rccl_debug_digest(dbg_dir, "native")}
             for name in ("allgather", "allgather_pipelined"):
                 ms = max(r[name + "_ms"] for r in res)
                 out["native_rccl_" + name] = {"ms_per_step": round(ms, 4), "Mpixels_per_s": round(vox / ms / 1e3, 1),
@@ -1199,6 +1309,7 @@ def main(argv=None):
             e2e = end_to_end_numpy()
         except Exception as e:      # noqa: BLE001 -- context only
             e2e = {"error": repr(e)}
+    torch_dbg_dir = rccl_debug_env(os.environ, "torch") if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not a.no_extras else None
     world, rank, dev_index, dist, backend = init_dist()
     n_gpus = world
     if a.gpus != world and rank == 0:
@@ -1248,11 +1359,27 @@ def main(argv=None):
             import torch
             torch.cuda.synchronize()
 
-    if a.settle_ms > 0:            # let the clocks reach their sustained level before anything is counted
+    # let the clocks reach their sustained level before anything is counted: ring passes for at least --settle-ms, then on until three
+    # consecutive passes agree to 1.5 % (device time per pass; at most 8 x --settle-ms) -- a cold box ramps for longer than a warm one,
+    # and two consecutive runs of the driver's command differed by 3.6 % with the fixed 250 ms
+    settle = {"ms": 0.0, "passes": 0, "last_pass_ms": []}
+    if a.settle_ms > 0:
         t_settle = time.perf_counter()
-        while (time.perf_counter() - t_settle) * 1e3 < a.settle_ms:
+        s0, s1 = F.Event(dev), F.Event(dev)
+        recent = []
+        while True:
+            s0.record()
             ring_pass()
-            sync()
+            s1.record()
+            s1.synchronize()
+            recent = (recent + [s0.elapsed_ms(s1)])[-3:]
+            settle["passes"] += 1
+            el = (time.perf_counter() - t_settle) * 1e3
+            if el >= a.settle_ms and len(recent) == 3 and max(recent) <= 1.015 * min(recent):
+                break
+            if el >= 8.0 * a.settle_ms:
+                break
+        settle["ms"], settle["last_pass_ms"] = round(el, 1), [round(v, 4) for v in recent]
     # how many passes over the ring make one step: the K timed steps must last long enough that a few milliseconds of one-off host
     # latency (first launch after an idle queue, the wake-up of the final synchronize) cannot move the number -- VERDICT r4 item 1
     cycles, probe_ms = a.cycles, None
@@ -1429,6 +1556,13 @@ def main(argv=None):
                                                      shape=[D_, 2560, W_], note="every row of every projection in one launch")
         except Exception as e:      # noqa: BLE001
             scaling = {"error": repr(e)}
+        if world > 1 and isinstance(scaling, dict) and "error" not in scaling:
+            try:
+                scaling["rccl"] = torch_rccl_report(dist, backend, world, rank, dev_index, torch_dbg_dir)
+                if "error" in scaling["rccl"]:          # the entry fails, not the bench
+                    scaling["compute_plus_allgather"] = {"error": scaling["rccl"]["error"]}
+            except Exception as e:      # noqa: BLE001
+                scaling["rccl"] = {"error": repr(e)}
         # the exchange without torch (native RCCL through the C ABI; peer copies): child processes of rank 0, the other ranks wait
         # (on a one-GPU test box -- DCP_BENCH_DEVICE set -- only when DCP_RCCL_PATH names the tests' stand-in for librccl: RCCL
         # itself refuses two ranks on one device)
@@ -1488,7 +1622,7 @@ def main(argv=None):
                        "nfact": nf, "order": a.order, "blend": a.blend, "coord_round_f32": True, "pixel_dtype": "f32",
                        "arithmetic": "coordinates and blend in float64 (as numpy / scipy compute them), pixels float32; the f64lerp "
                                      "blend is a factorisation within one float32 ulp of scipy's operation order (other_configs."
-                                     "cfg2_scipy_exact_blend is the bit-equal mode)", "clock_settle_ms": a.settle_ms,
+                                     "cfg2_scipy_exact_blend is the bit-equal mode)", "clock_settle_ms": a.settle_ms, "clock_settle": settle,
                        "parallelism": "independent frames per GPU (no collective)" if n_gpus > 1 else "1 GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": configs.HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": round(achieved / configs.HBM_PEAK_GBPS, 4), "traffic": traffic,

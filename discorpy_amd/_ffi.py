@@ -68,6 +68,8 @@ SIGNATURES = {
     "dcp_rccl_unique_id": (_int, [_vp, _sz]),
     "dcp_rccl_comm_create": (_int, [C.POINTER(_vp), _int, _int, _vp, _int]),
     "dcp_rccl_comm_destroy": (_int, [_vp]),
+    "dcp_rccl_comm_fixed_shards": (_int, [_vp, _int]),
+    "dcp_rccl_comm_info": (_int, [_vp, C.POINTER(_i64), _int, C.POINTER(_i64), _int, C.c_char_p, _sz]),
     "dcp_unwarp_stack_rows_rccl_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _dbl, _i64, _int, _int, _vp,
                                               _int, _vp]),
     "dcp_unwarp_image_spline_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, _dbl, _dp, _int, _int, _int, _int,

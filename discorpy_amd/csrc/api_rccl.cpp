@@ -31,6 +31,8 @@ typedef int (*fn_all_gather)(const void*, void*, size_t, int, rcclComm, hipStrea
 typedef int (*fn_broadcast)(const void*, void*, size_t, int, int, rcclComm, hipStream_t);
 typedef int (*fn_group)(void);
 typedef const char* (*fn_error_string)(int);
+typedef int (*fn_comm_query)(const rcclComm, int*);
+typedef int (*fn_get_version)(int*);
 constexpr int kRcclFloat = 7;      // ncclFloat32 (rccl.h)
 constexpr int kRcclInt64 = 4;      // ncclInt64
 
@@ -44,6 +46,8 @@ struct Rccl {
   fn_broadcast broadcast = nullptr;
   fn_group group_start = nullptr, group_end = nullptr;
   fn_error_string error_string = nullptr;
+  fn_comm_query comm_count = nullptr, comm_user_rank = nullptr, comm_device = nullptr;      // optional: what the communicator itself says
+  fn_get_version get_version = nullptr;
 };
 
 Rccl& rccl() {
@@ -81,6 +85,14 @@ Rccl& rccl() {
     r.group_start = (fn_group)dlsym(r.handle, "ncclGroupStart");
     r.group_end = (fn_group)dlsym(r.handle, "ncclGroupEnd");
     r.error_string = (fn_error_string)dlsym(r.handle, "ncclGetErrorString");
+    r.comm_count = (fn_comm_query)dlsym(r.handle, "ncclCommCount");
+    r.comm_user_rank = (fn_comm_query)dlsym(r.handle, "ncclCommUserRank");
+    r.comm_device = (fn_comm_query)dlsym(r.handle, "ncclCommCuDevice");
+    r.get_version = (fn_get_version)dlsym(r.handle, "ncclGetVersion");
+    {                                  // the file that was really mapped (dlopen may have resolved a bare name through the search path)
+      Dl_info where;
+      if (r.get_unique_id && dladdr((void*)r.get_unique_id, &where) && where.dli_fname) r.path = where.dli_fname;
+    }
     if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.broadcast || !r.group_start || !r.group_end) {
       r.why = "librccl.so lacks an expected symbol";
       dlclose(r.handle);
@@ -113,6 +125,9 @@ struct Comm {
   hipEvent_t computed = nullptr, gathered = nullptr;
   int64_t* meta_dev = nullptr;     // world x kMetaWords
   int64_t* meta_host = nullptr;    // pinned, world x kMetaWords
+  bool agreed = false;             // meta_host holds the table of a completed agreement
+  bool fixed = false;              // dcp_rccl_comm_fixed_shards: the caller vouches that every rank repeats the agreed shapes
+  int64_t exchanges = 0, agreements = 0;
 };
 
 void release(Comm* c) {
@@ -130,16 +145,33 @@ void release(Comm* c) {
 // caller's stream is not waited for), then a wait for that stream only.  Collective: every rank of the world makes this call.
 int agree_on_shards(Comm* c, int64_t depth_local, int64_t nrows, int64_t width, int pipeline, bool local_error) {
   int64_t* mine = c->meta_host + (size_t)c->rank * kMetaWords;
+  if (c->fixed && c->agreed) {
+    // The caller has promised (on EVERY rank) that the shapes of the last agreement repeat: no collective, no host wait -- the call is
+    // then stream-ordered end to end, and back-to-back calls overlap.  A rank that breaks the promise is told so; its peers cannot be.
+    if (local_error || mine[0] != depth_local || mine[1] != nrows || mine[2] != width || mine[3] != pipeline)
+      return fail(DCP_ERR_INVALID_ARG, "dcp_rccl_comm_fixed_shards is set but this call's depth_local / nrows / width / pipeline differ from the "
+                                       "agreed ones (%lld, %lld, %lld, %lld): clear it first", (long long)mine[0], (long long)mine[1],
+                  (long long)mine[2], (long long)mine[3]);
+    return DCP_OK;
+  }
+  c->agreed = false;
   mine[0] = depth_local;
   mine[1] = nrows;
   mine[2] = width;
   mine[3] = pipeline;
   mine[4] = local_error ? 1 : 0;
-  if (c->world == 1) return DCP_OK;
+  ++c->agreements;
+  if (c->world == 1) {
+    c->agreed = !local_error;
+    return DCP_OK;
+  }
+  // (the side stream may still carry the previous call's pipelined exchange, and RCCL serialises the operations of one communicator:
+  // this wait is therefore also a wait for the previous exchange -- see the header; dcp_rccl_comm_fixed_shards avoids it)
   DCP_HIP(hipMemcpyAsync(c->meta_dev + (size_t)c->rank * kMetaWords, mine, kMetaWords * sizeof(int64_t), hipMemcpyHostToDevice, c->side));
   DCP_RCCL(rccl().all_gather(c->meta_dev + (size_t)c->rank * kMetaWords, c->meta_dev, kMetaWords, kRcclInt64, c->comm, c->side));
   DCP_HIP(hipMemcpyAsync(c->meta_host, c->meta_dev, (size_t)c->world * kMetaWords * sizeof(int64_t), hipMemcpyDeviceToHost, c->side));
   DCP_HIP(hipStreamSynchronize(c->side));
+  c->agreed = true;
   return DCP_OK;
 }
 
@@ -210,6 +242,31 @@ int dcp_rccl_comm_destroy(void* comm) {
   return DCP_OK;
 }
 
+int dcp_rccl_comm_fixed_shards(void* comm, int on) {
+  if (!comm) return fail(DCP_ERR_INVALID_ARG, "null communicator (dcp_rccl_comm_create)");
+  ((Comm*)comm)->fixed = on != 0;
+  return DCP_OK;
+}
+
+int dcp_rccl_comm_info(void* comm, int64_t* info, int ninfo, int64_t* shard_depths, int nshards, char* librccl_path, size_t path_bytes) {
+  if (!comm) return fail(DCP_ERR_INVALID_ARG, "null communicator (dcp_rccl_comm_create)");
+  int rc;
+  if ((rc = need_rccl()) != DCP_OK) return rc;
+  Comm* c = (Comm*)comm;
+  Rccl& r = rccl();
+  int count = -1, user_rank = -1, dev = -1, version = -1;
+  if (r.comm_count) DCP_RCCL(r.comm_count(c->comm, &count));
+  if (r.comm_user_rank) DCP_RCCL(r.comm_user_rank(c->comm, &user_rank));
+  if (r.comm_device) DCP_RCCL(r.comm_device(c->comm, &dev));
+  if (r.get_version) DCP_RCCL(r.get_version(&version));
+  const int64_t v[10] = {count, user_rank, dev, version, c->world, c->rank, c->device, c->agreed ? 1 : 0, c->exchanges, c->agreements};
+  for (int i = 0; i < ninfo && i < 10; ++i)
+    if (info) info[i] = v[i];
+  for (int i = 0; shard_depths && i < nshards; ++i) shard_depths[i] = (c->agreed && i < c->world) ? c->meta_host[(size_t)i * kMetaWords] : -1;
+  if (librccl_path && path_bytes) snprintf(librccl_path, path_bytes, "%s", r.path.c_str());
+  return DCP_OK;
+}
+
 int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_local, int64_t height, int64_t width, int64_t proj_stride,
                                    int64_t row_stride, double xcenter, double ycenter, const double* list_fact, int nfact, double row_start,
                                    int64_t nrows, int coord_round_f32, int blend_mode, void* comm, int pipeline, void* stream) {
@@ -230,12 +287,15 @@ int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_l
     return fail(DCP_ERR_INVALID_ARG, "null volume / result pointer");
   }
   for (int r = 0; r < c->world; ++r)
-    if (c->meta_host[(size_t)r * kMetaWords + 4] != 0)
+    if (c->meta_host[(size_t)r * kMetaWords + 4] != 0) {
+      c->agreed = false;
       return fail(DCP_ERR_INVALID_ARG, "rank %d was called with unusable arguments (its own error says which); nothing was exchanged", r);
+    }
   int64_t total = 0, deepest = 0, first_of_mine = 0;
   bool even = true;
   for (int r = 0; r < c->world; ++r) {
     const int64_t* m = c->meta_host + (size_t)r * kMetaWords;
+    if (m[1] != nrows || m[2] != width || m[3] != pipeline || m[0] < 0) c->agreed = false;
     if (m[1] != nrows || m[2] != width || m[3] != pipeline)
       return fail(DCP_ERR_INVALID_ARG, "rank %d was called with nrows %lld, width %lld, pipeline %lld; rank %d with %lld, %lld, %d: the ranks must agree",
                   r, (long long)m[1], (long long)m[2], (long long)m[3], c->rank, (long long)nrows, (long long)width, pipeline);
@@ -246,6 +306,7 @@ int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_l
     total += m[0];
   }
   if (total == 0 || nrows == 0) return DCP_OK;                       // nothing to compute anywhere: every rank returns here
+  ++c->exchanges;
   const size_t block = (size_t)nrows * (size_t)width;                // floats per projection of the result
   // depth is the outer axis of the result and the shards are laid down in rank order: rank r's block starts at the sum of the
   // shards before it and is contiguous

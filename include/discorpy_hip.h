@@ -210,11 +210,26 @@ int dcp_unwarp_stack_rows_peer_f32(const float* const* vol, float* const* out, i
  *       sub-block s (grouped ncclBroadcasts on the side stream) overlaps the kernel of sub-block s + 1.  Stream-ordered: returns
  *       without waiting for the result, `stream` is complete when the whole (depth, nrows, width) result is.  After a HIP / RCCL
  *       failure on one rank the others may be blocked in their collectives: destroy the communicator (the caller's stream is
- *       re-joined to the side stream on every path, so nothing is left running behind the caller's back). */
+ *       re-joined to the side stream on every path, so nothing is left running behind the caller's back).
+ *       The agreement is a HOST wait on the side stream, and RCCL serialises the operations of one communicator: a call therefore also
+ *       waits for the previous call's exchange (back-to-back calls do not overlap) -- unless
+ *   dcp_rccl_comm_fixed_shards(comm, 1)
+ *       has been set, by which the caller vouches ON EVERY RANK that the following calls repeat the depth_local / nrows / width /
+ *       pipeline of the last agreed call: the agreement is skipped (no collective, no host wait) and the call is stream-ordered end to
+ *       end.  A rank that then passes other shapes gets DCP_ERR_INVALID_ARG; its peers are not told (destroy the communicator).
+ *   dcp_rccl_comm_info
+ *       what the communicator ITSELF reports, so that a multi-GPU run can prove what RCCL saw rather than what the launcher claimed:
+ *       info[0] ncclCommCount, [1] ncclCommUserRank, [2] ncclCommCuDevice, [3] ncclGetVersion (-1 each where the loaded library lacks
+ *       the query), [4] / [5] the world size / rank given to dcp_rccl_comm_create, [6] the HIP device, [7] 1 if a shard agreement is
+ *       in force, [8] exchanges done, [9] agreements done (up to `ninfo` values are written); shard_depths[r] = depth_local of rank r
+ *       as agreed in the last exchange (-1 without one; up to `nshards`); librccl_path = the file the ncclXxx symbols were bound
+ *       from (DCP_RCCL_PATH, the librccl.so next to the loaded HIP runtime, or the search path).  Not a collective. */
 int dcp_rccl_available(void);
 int dcp_rccl_unique_id(void* id, size_t bytes);
 int dcp_rccl_comm_create(void** comm, int world_size, int rank, const void* id, int device);
 int dcp_rccl_comm_destroy(void* comm);
+int dcp_rccl_comm_fixed_shards(void* comm, int on);
+int dcp_rccl_comm_info(void* comm, int64_t* info, int ninfo, int64_t* shard_depths, int nshards, char* librccl_path, size_t path_bytes);
 int dcp_unwarp_stack_rows_rccl_f32(const float* vol, float* out, int64_t depth_local, int64_t height, int64_t width, int64_t proj_stride,
                                    int64_t row_stride, double xcenter, double ycenter, const double* list_fact, int nfact, double row_start,
                                    int64_t nrows, int coord_round_f32, int blend_mode, void* comm, int pipeline, void* stream);

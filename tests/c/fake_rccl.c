@@ -235,6 +235,30 @@ int ncclCommDestroy(void* comm) {
   return kSuccess;
 }
 
+/* what a communicator says about itself (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), and a version no RCCL ever had */
+int ncclCommCount(const void* comm, int* count) {
+  if (!comm || !count) return kInvalidArgument;
+  *count = ((const Comm*)comm)->world;
+  return kSuccess;
+}
+
+int ncclCommUserRank(const void* comm, int* rank) {
+  if (!comm || !rank) return kInvalidArgument;
+  *rank = ((const Comm*)comm)->rank;
+  return kSuccess;
+}
+
+int ncclCommCuDevice(const void* comm, int* device) {
+  if (!comm || !device) return kInvalidArgument;
+  return hipGetDevice(device) == hipSuccess ? kSuccess : kUnhandledCuda;
+}
+
+int ncclGetVersion(int* version) {
+  if (!version) return kInvalidArgument;
+  *version = 1;          /* "fake_rccl": real versions are >= 20000 */
+  return kSuccess;
+}
+
 int ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, int datatype, void* comm, hipStream_t stream) {
   const size_t es = dtype_bytes(datatype);
   if (!comm || !es || (sendcount && (!sendbuff || !recvbuff))) return kInvalidArgument;

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--rows", default="100,64", help="row_start,nrows")
     ap.add_argument("--seed", type=int, default=77)
     ap.add_argument("--own-stream", action="store_true")
+    ap.add_argument("--fixed-repeats", type=int, default=0,
+                    help="after the exchanges: dcp_rccl_comm_fixed_shards(1), then the last exchange this many times back to back "
+                         "(no synchronisation in between), result rank<r>_fixed.npy; then every rank breaks the promise the same way")
     ap.add_argument("--disagree", default=None, choices=[None, "nrows", "null", "pipeline"],
                     help="the LAST rank passes a different nrows / a null volume / another pipeline: every rank must get an error")
     a = ap.parse_args()
@@ -80,6 +83,27 @@ def main():
         F.check(L.dcp_stream_synchronize(0, stream))
         if rc == 0 and D:
             np.save(os.path.join(a.outdir, "rank%d_p%d.npy" % (a.rank, p)), dout.download((D, nrows, W), np.float32))
+    def info_of():
+        info, depths, path = (C.c_int64 * 10)(), (C.c_int64 * a.world)(), C.create_string_buffer(1024)
+        F.check(L.dcp_rccl_comm_info(comm, info, 10, depths, a.world, path, 1024))
+        return {"info": [int(v) for v in info], "shard_depths": [int(v) for v in depths], "librccl": path.value.decode()}
+    report["comm"] = info_of()
+    if a.fixed_repeats > 0 and a.disagree is None:
+        p = int(a.pipelines.split(",")[-1])
+        F.check(L.dcp_rccl_comm_fixed_shards(comm, 1))
+        dout.upload(np.full((max(D, 1), nrows, W), np.nan, np.float32)[:D] if D else np.zeros(1, np.float32))
+        F.check(L.dcp_stream_synchronize(0, None))
+        for _ in range(a.fixed_repeats):
+            F.check(L.dcp_unwarp_stack_rows_rccl_f32(dvol.ptr, dout.ptr, dl, H, W, H * W, W, xc, yc, fa, nf, row0, nrows, 1, F.BLEND_F64LERP, comm,
+                                                     p, stream))
+        F.check(L.dcp_stream_synchronize(0, stream))
+        if D:
+            np.save(os.path.join(a.outdir, "rank%d_fixed.npy" % a.rank), dout.download((D, nrows, W), np.float32))
+        report["comm_after_fixed"] = info_of()
+        # every rank passes one row fewer: each is refused locally, nobody enters a collective
+        report["rc_broken_promise"] = int(L.dcp_unwarp_stack_rows_rccl_f32(dvol.ptr, dout.ptr, dl, H, W, H * W, W, xc, yc, fa, nf, row0, nrows - 1, 1,
+                                                                           F.BLEND_F64LERP, comm, p, stream))
+        report["err_broken_promise"] = F.last_error()
     F.check(L.dcp_rccl_comm_destroy(comm))
     json.dump(report, open(os.path.join(a.outdir, "rank%d.json" % a.rank), "w"))
 

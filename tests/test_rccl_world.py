@@ -3,7 +3,7 @@ postprocessing.py:226-228, 310-312 carry no state, so depth shards and one excha
 
 RCCL refuses two ranks on one device, so the ranks of these tests load tests/c/libfake_rccl.so through the DCP_RCCL_PATH hook
 (api_rccl.cpp): the eight nccl* symbols the library binds, between processes that share the GPU, payload through a host bounce
-buffer on the stream each call was given.  What is covered: everything of dcp_unwarp_stack_rows_rccl_f32 ABOVE the collective
+buffer on the stream each call was given (plus the four queries dcp_rccl_comm_info makes).  What is covered: everything of dcp_unwarp_stack_rows_rccl_f32 ABOVE the collective
 calls -- the shard agreement, block offsets (even and ragged shards, empty shards), the in-place all-gather's send / receive
 pointers, the grouped per-sub-block broadcasts, the side-stream event chain, the error agreement.  What is NOT covered: RCCL
 itself, its asynchrony and xGMI (the stand-in blocks the host per call)."""
@@ -34,7 +34,7 @@ def test_the_stand_in_exports_exactly_what_the_library_binds():
     src = open(os.path.join(ROOT, "discorpy_amd", "csrc", "api_rccl.cpp")).read()
     import re
     bound = set(re.findall(r'dlsym\(r\.handle, "(\w+)"\)', src))
-    assert len(bound) == 8
+    assert len(bound) == 12          # eight the exchange needs + ncclCommCount / UserRank / CuDevice / GetVersion (dcp_rccl_comm_info)
     out = subprocess.run(["nm", "-D", "--defined-only", FAKE], capture_output=True, text=True, check=True).stdout
     exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
     assert bound <= exported and exported - bound <= {"fake_rccl_stat"}
@@ -117,3 +117,22 @@ def test_ranks_that_disagree_all_get_an_error_and_none_hangs(hip, tmp_path, what
         assert "null volume" in reports[2]["err"][0] and "rank 2 was called with unusable arguments" in reports[0]["err"][0]
     else:
         assert "the ranks must agree" in reports[0]["err"][0]
+
+
+@pytest.mark.gpu
+def test_the_communicator_reports_itself_and_fixed_shards_skip_the_agreement(hip, orc, tmp_path):
+    """VERDICT r4 item 7 / ADVICE r4: dcp_rccl_comm_info -- ranks, rank, version and the bound librccl from the library itself, the
+    agreed shard depths -- and dcp_rccl_comm_fixed_shards: repeated exchanges without the 40-byte agreement (a collective and a
+    host wait per call), the same result; a broken promise is refused locally."""
+    counts, pipelines = [5, 2, 3], [1, 2]
+    reports = run_world(tmp_path, counts, pipelines, extra=["--fixed-repeats", "3"])
+    want = expected(orc, counts)
+    for r, rep in enumerate(reports):
+        c = rep["comm"]
+        assert c["info"][0] == 3 and c["info"][1] == r and c["info"][3] == 1 and c["info"][4] == 3 and c["info"][5] == r
+        assert c["librccl"].endswith("libfake_rccl.so") and c["shard_depths"] == counts
+        assert c["info"][7] == 1 and c["info"][8] == 2 and c["info"][9] == 2
+        after = rep["comm_after_fixed"]["info"]
+        assert after[8] == 5 and after[9] == 2                                   # three more exchanges, no further agreement
+        assert np.array_equal(np.load(tmp_path / ("rank%d_fixed.npy" % r)), want)
+        assert rep["rc_broken_promise"] == -1 and "dcp_rccl_comm_fixed_shards" in rep["err_broken_promise"]
