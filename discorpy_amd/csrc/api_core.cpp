@@ -24,7 +24,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0}, g_store_wait{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0}, g_store_wait{1}, g_fused_wg{1};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -180,16 +180,37 @@ bool wg_boxes_mostly_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W, 
         for (int cx = 0; cx < 2; ++cx) {
           const double X = (double)std::min<int64_t>(tx * tw + cx * (tw - 1), W - 1), Y = (double)std::min<int64_t>(ty * th + cy * (th - 1), H - 1);
           double xd, yd;
-          if (kind == dcp::kRadial) {
-            const double xu = X - m.xc, yu = Y - m.yc, r = std::hypot(xu, yu);
+          auto radial = [&](double px, double py) {
+            const double xu = px - m.xc, yu = py - m.yc, r = std::hypot(xu, yu);
             double b = 0.0;
             for (int i = m.nfact - 1; i >= 0; --i) b = b * r + m.fact[i];
             xd = m.xc + b * xu;
             yd = m.yc + b * yu;
+          };
+          auto persp = [&](double px, double py) {
+            const double den = (m.coef[6] * px + m.coef[7] * py) + 1.0;
+            xd = ((m.coef[0] * px + m.coef[1] * py) + m.coef[2]) / den;
+            yd = ((m.coef[3] * px + m.coef[4] * py) + m.coef[5]) / den;
+          };
+          if (kind == dcp::kRadial) {
+            radial(X, Y);
+          } else if (kind == dcp::kPersp) {
+            persp(X, Y);
           } else {
-            const double den = (m.coef[6] * X + m.coef[7] * Y) + 1.0;
-            xd = ((m.coef[0] * X + m.coef[1] * Y) + m.coef[2]) / den;
-            yd = ((m.coef[3] * X + m.coef[4] * Y) + m.coef[5]) / den;
+            // fused, as wg_corner_tap forms the box: the radial map at the corners of the bounding box of the tile's four (clipped)
+            // perspective positions
+            const double x0 = (double)(tx * tw), x1 = (double)std::min<int64_t>(tx * tw + tw - 1, W - 1);
+            const double y0 = (double)(ty * th), y1 = (double)std::min<int64_t>(ty * th + th - 1, H - 1);
+            double qx0 = 1e300, qx1 = -1e300, qy0 = 1e300, qy1 = -1e300;
+            for (double px : {x0, x1})
+              for (double py : {y0, y1}) {
+                persp(px, py);
+                if (!(xd == xd) || !(yd == yd)) return false;
+                xd = std::min(std::max(xd, 0.0), (double)(W - 1));
+                yd = std::min(std::max(yd, 0.0), (double)(H - 1));
+                qx0 = std::min(qx0, xd), qx1 = std::max(qx1, xd), qy0 = std::min(qy0, yd), qy1 = std::max(qy1, yd);
+              }
+            radial(cx ? qx1 : qx0, cy ? qy1 : qy0);
           }
           xd = std::min(std::max(xd, 0.0), (double)(W - 1));
           yd = std::min(std::max(yd, 0.0), (double)(H - 1));
@@ -271,7 +292,35 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
       }
     }
   }
-  if (ok == 2 && !wg_boxes_mostly_fit(kind, m, H, W)) ok = 1;
+  else if (kind == dcp::kFused) {
+    // R o f32clip o P.  The tile's perspective positions lie in the bounding box Q of its corners' positions (P is projective with a
+    // denominator of one sign: convex image; clip and rounding are monotone), |Q| <= (127 |dxp/dx| + 31 |dxp/dy|, 127 |dyp/dx| +
+    // 31 |dyp/dy|) with the derivative bounds of the perspective branch; the radial map deviates from the bilinear interpolant of
+    // its values at Q's corners by at most (qw^2 + qh^2) / 8 * sup(4 |B'| + r |B''|) over the radii of the frame (the positions are
+    // clipped into it).  Level 2 only: an uncertified fused map keeps the per-wave kernel with its per-pixel vote.
+    if (homography_is_tame(m.coef, H, W)) {
+      double dmin = 1e300, gx[4] = {0, 0, 0, 0};
+      for (double x : {0.0, (double)(W - 1)})
+        for (double y : {0.0, (double)(H - 1)}) {
+          const double d = (m.coef[6] * x + m.coef[7] * y) + 1.0;
+          const double nx = (m.coef[0] * x + m.coef[1] * y) + m.coef[2], ny = (m.coef[3] * x + m.coef[4] * y) + m.coef[5];
+          dmin = std::min(dmin, std::fabs(d));
+          gx[0] = std::max(gx[0], std::fabs(m.coef[0] * d - m.coef[6] * nx));
+          gx[1] = std::max(gx[1], std::fabs(m.coef[1] * d - m.coef[7] * nx));
+          gx[2] = std::max(gx[2], std::fabs(m.coef[3] * d - m.coef[6] * ny));
+          gx[3] = std::max(gx[3], std::fabs(m.coef[4] * d - m.coef[7] * ny));
+        }
+      const double d2 = dmin * dmin;
+      const double qw = (127.0 * gx[0] + 31.0 * gx[1]) / d2 + 1e-3, qh = (127.0 * gx[2] + 31.0 * gx[3]) / d2 + 1e-3;
+      double rmax = 0.0;
+      for (double x : {0.0, (double)(W - 1)})
+        for (double y : {0.0, (double)(H - 1)}) rmax = std::max(rmax, std::hypot(x - m.xc, y - m.yc));
+      const double k2 = radial_curvature_bound(m, rmax * (1.0 + 1e-12) + 1e-9);
+      const double dev = (qw * qw + qh * qh) / 8.0 * k2;
+      if (std::isfinite(dev) && dev <= kTileDevLimit && g_fused_wg.load()) ok = 2;
+    }
+  }
+  if (ok == 2 && !wg_boxes_mostly_fit(kind, m, H, W)) ok = kind == dcp::kFused ? 0 : 1;
   c.kind = kind;
   c.nfact = m.nfact;
   c.H = H;
@@ -509,6 +558,9 @@ int dcp_set_option(const char* key, int value) {
                                       // registered destination when the runtime cannot overlap an upload with a download; 2: whenever registered
   } else if (!strcmp(key, "store_wait")) {
     g_store_wait = value ? 1 : 0;     // 0: stack_wg_kernel waits for its own stores at every projection (rounds 2-3), A/B
+  } else if (!strcmp(key, "fused_wg")) {
+    g_fused_wg = value ? 1 : 0;       // 0: the fused perspective o radial map always on the per-wave kernel with the per-pixel vote (rounds 1-4), A/B
+    for (auto& e : g_cert_cache) e.kind = -1;      // the calling thread's cached certificates were made under the old setting
   } else if (!strcmp(key, "tall_tiles")) {
     g_tall_tiles = value < 0 ? 0 : (value > 2 ? 2 : value);     // 1: sheared radial maps (level-1 certificate, boxes of 64 x 32 tiles fit 80 x 56) on 64 x 32 workgroup tiles instead of the
                                       // per-wave-box kernel.  Default 0: measured SLOWER on BASELINE config 5 (128-131 us against 113-116, tools/time_cfg5.py)
@@ -556,6 +608,7 @@ int dcp_get_option(const char* key, int* value) {
   else if (!strcmp(key, "int_exact")) *value = g_int_exact;
   else if (!strcmp(key, "host_direct")) *value = g_host_direct;
   else if (!strcmp(key, "tall_tiles")) *value = g_tall_tiles;
+  else if (!strcmp(key, "fused_wg")) *value = g_fused_wg;
   else if (!strcmp(key, "store_wait")) *value = g_store_wait;
   else if (!strcmp(key, "host_direct_applies")) {        // read-only: measures the runtime once (needs a device)
     int n = 0;

@@ -647,6 +647,7 @@ int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t w
     return run_typed(2, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
                      0, mem_kind, device, stream);
   if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
+  map.tile_dev_ok = g_tile_cert.load() ? tile_deviation_certified(dcp::kFused, map, height, width) : 0;
   return run_image(dcp::kFused, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
                    mem_kind, device, stream);
 }

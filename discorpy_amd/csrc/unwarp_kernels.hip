@@ -752,7 +752,27 @@ __device__ __forceinline__ void wg_corner_tap(const ImageArgs& img, const MapArg
   const double X = (double)min(tx * kWgTW + (corner & 1) * (kWgTW - 1), img.W - 1);
   const double Y = (double)(img.y_origin + min(yblk + ((corner >> 1) & 1) * (kWgTH - 1), img.rows_out - 1));
   double xd, yd;
-  corner_coord<KIND, NF>(map, X, Y, &xd, &yd);
+  if constexpr (KIND == kFused) {
+    // Lanes 0..3 together (corner = lane).  The homography maps the tile onto a convex quadrilateral (denominator of one sign: the
+    // host's certificate), so the float32-rounded, clipped perspective positions of ALL its pixels -- rounding and clipping are
+    // monotone -- lie in the bounding box Q of the four corners' positions.  The radial map is then taken at the corners of Q: its
+    // deviation from the bilinear interpolant of those four values over Q is what the certificate bounds, so their hull grown by
+    // one pixel holds every tap of the tile -- also of a tile that the inner clip cuts through, where the composed map has a kink.
+    double px, py;
+    corner_coord<kPersp, NF>(map, X, Y, &px, &py);
+    const float pxf = round_clip_f32(px, wmaxf), pyf = round_clip_f32(py, hmaxf);
+    float qx[4], qy[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      qx[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pxf), i));
+      qy[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pyf), i));
+    }
+    const float qx0 = fminf(fminf(qx[0], qx[1]), fminf(qx[2], qx[3])), qx1 = fmaxf(fmaxf(qx[0], qx[1]), fmaxf(qx[2], qx[3]));
+    const float qy0 = fminf(fminf(qy[0], qy[1]), fminf(qy[2], qy[3])), qy1 = fmaxf(fmaxf(qy[0], qy[1]), fmaxf(qy[2], qy[3]));
+    corner_coord<kRadial, NF>(map, (double)((corner & 1) ? qx1 : qx0), (double)((corner & 2) ? qy1 : qy0), &xd, &yd);
+  } else {
+    corner_coord<KIND, NF>(map, X, Y, &xd, &yd);
+  }
   *cxi = (int)round_clip_f32(xd, wmaxf);
   *cyi = (int)round_clip_f32(yd, hmaxf);
 }
@@ -2090,6 +2110,11 @@ hipError_t launch_wg_typed(MapKind kind, const ImageArgs& img_in, const MapArgs&
 template <int KIND, int NF, int SAMPLER>
 static hipError_t launch_lds_vote(const ImageArgs& img, const MapArgs& map, hipStream_t stream) {
   if constexpr (KIND == kFused) {
+    // (round 5) a tame homography in front of a radial model of certified curvature: one box per 128 x 32 workgroup tile from the
+    // corners of the tile's perspective bounding box (wg_corner_tap) -- no per-pixel vote.  Anything else votes.
+    if constexpr (NF >= 0) {
+      if (map.tile_dev_ok >= 2 && img.wg_box && img.xcd_remap != 1) return launch_wg<KIND, NF, SAMPLER>(img, map, stream);
+    }
     return launch_lds<KIND, NF, SAMPLER, true>(img, map, stream);
   } else {
     // certificate levels: 2 = holds for 128 x 32 tiles (workgroup-shared box), 1 = for 64 x 16 tiles only

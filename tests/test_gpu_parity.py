@@ -1411,9 +1411,18 @@ def test_cfg3_device_resident_calls_equal_the_oracle(hip, orc):
     L = hip.lib()
     fused = _device_call(hip, lambda s, d: L.dcp_unwarp_fused_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, ca, 1,
                                                                    hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None), img)
-    assert hip.last_kernel().startswith("remap_lds_kernel<Fused,NF=5,f64lerp")
-    assert np.array_equal(fused, orc.unwarp_fused(img, c["xcenter"], c["ycenter"], c["list_fact"], c["list_coef"],
-                                                  **kernel_oracle(orc, "f64lerp")))
+    # (round 5) a tame homography in front of a radial model of certified curvature: the workgroup-box kernel, no per-pixel vote --
+    # also where the inner clip cuts through a tile (config 3's homography maps the frame's right and bottom edges outside it)
+    assert hip.last_kernel() == "remap_wg_kernel<Fused,NF=5,f64lerp>", hip.last_kernel()
+    want_fused = orc.unwarp_fused(img, c["xcenter"], c["ycenter"], c["list_fact"], c["list_coef"], **kernel_oracle(orc, "f64lerp"))
+    assert np.array_equal(fused, want_fused)
+    hip.set_option("fused_wg", 0)               # rounds 1-4: one box per wave tile, every pixel voting on it -- the same pixels
+    try:
+        voted = _device_call(hip, lambda s, d: L.dcp_unwarp_fused_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, ca, 1,
+                                                                       hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None), img)
+        assert hip.last_kernel().startswith("remap_lds_kernel<Fused,NF=5,f64lerp") and np.array_equal(voted, want_fused)
+    finally:
+        hip.set_option("fused_wg", 1)
     persp = _device_call(hip, lambda s, d: L.dcp_perspective_image_f32(s, d, H, W, W, 1, ca, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None), img)
     assert hip.last_kernel() == "remap_wg_kernel<Persp,NF=-1,f64lerp>"
     assert np.array_equal(persp, orc.correct_perspective_image(img, c["list_coef"], blend=orc.BLEND_F64LERP))

@@ -228,7 +228,7 @@ def test_example_04_call_sequence_on_hdf_datasets(hip, orc, h5, tmp_path, dtype)
                                                                                     blend=orc.BLEND_F64LERP if dtype == "<f4" else orc.BLEND_SCIPY))
     # the whole corrected stack, streamed into a new file in passes of 64 rows
     dst = losa.open_hdf_stream(str(tmp_path / "out" / "corrected.hdf"), (D, H, W), key_path="entry/data", data_type=native.dtype.name,
-                               options={"entry/meta": {"entry/xcenter": xcenter, "entry/ycenter": ycenter}})
+                               options={"entry/xcenter": xcenter, "entry/ycenter": ycenter})
     src.reads.clear()
     passes = correct_stack(src, dst, xcenter, ycenter, list_fact, rows_per_pass=64, blend="scipy")
     assert passes == 4 and max(k[1].stop - k[1].start for k in src.reads) < 100                 # never a whole projection

@@ -58,11 +58,11 @@ def rand_image(rng, shape, dt):
     return rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=np.int64).astype(dt)
 
 
-def certified_fact(rng, h, w, xc, yc):
+def certified_fact(rng, h, w, xc, yc, lengths=None):
     """A calibration that holds the level-2 tile certificate (what the staged kernels need): mild coefficients, checked on the host."""
     R = float(np.hypot(h, w))
     for _ in range(20):
-        n = int(rng.integers(1, 8))
+        n = int(rng.integers(1, 8)) if lengths is None else int(lengths[int(rng.integers(0, len(lengths)))])
         f = [1.0 + float(rng.uniform(-0.03, 0.03))] + [float(rng.uniform(-0.04, 0.04)) / R ** i for i in range(1, n)]
         fa, nf = F.fact_array(f)
         if F.lib().dcp_debug_tile_certificate(0, h, w, xc, yc, fa, nf, None) >= 2:
@@ -144,12 +144,13 @@ def one_case(rng, k):
         staged = True
     if staged:
         # aimed at the staged kernels: a frame of several tiles, a certified calibration, an element type they take
-        kind = ("radial", "radial", "batch", "stack", "color", "persp")[int(rng.integers(0, 6))]
+        kind = ("radial", "radial", "batch", "stack", "color", "persp", "fused")[int(rng.integers(0, 7))]
         kind = os.environ.get("FUZZ_STAGED_KIND", kind)
         h, w = int(rng.integers(40, 900)), int(rng.integers(130, 1400))
         dt = ("float32", "float32", "float32", "uint8", "uint16", "int16", "int32", "uint32", "float64")[int(rng.integers(0, 9))]
         xc, yc = float(rng.uniform(0.1, 0.9) * w), float(rng.uniform(0.1, 0.9) * h)
-        fact = certified_fact(rng, h, w, xc, yc)
+        # (the fused map takes the workgroup-box kernel with 4 or 5 coefficients in the kernel arguments)
+        fact = certified_fact(rng, h, w, xc, yc, (4, 5) if kind == "fused" else None)
         if blend == "f32" and kind == "color":
             blend = "f64lerp"
         for key in ("wg_box", "tile_cert"):
@@ -225,6 +226,10 @@ def one_case(rng, k):
     elif kind == "fused":
         img = rand_image(rng, (h, w), dt)
         coef = rand_coef(rng, h, w)
+        if staged:      # a mild (tame) homography whose image of the frame crosses the frame's edges: the inner clip cuts through tiles
+            s_, p_ = (0.02, 1e-5) if rng.integers(0, 2) else (0.08, 6e-5)
+            coef = [1.0 + rng.uniform(-s_, s_), rng.uniform(-s_, s_), rng.uniform(-0.1, 0.1) * w, rng.uniform(-s_, s_), 1.0 + rng.uniform(-s_, s_),
+                    rng.uniform(-0.1, 0.1) * h, rng.uniform(-p_, p_), rng.uniform(-p_, p_)]
         got = pp.unwarp_perspective_fused(img, xc, yc, fact, coef, order=order, **kw)
         if f32:
             want = orc.unwarp_fused(img, xc, yc, fact, coef, order=order, **okw)
@@ -338,7 +343,11 @@ def main():
 
     def recording_check(rc):
         plain_check(rc)
-        launched.add(F.last_kernel().split("<")[0].split(" ")[0] or "(spline / point kernels)")
+        name = F.last_kernel()
+        base = name.split("<")[0].split(" ")[0]
+        if "<Fused" in name or "<Persp" in name:           # the map kind beside the kernel: which kernels the fused / perspective maps reach
+            base += name.split(",")[0][len(base):] + ">"
+        launched.add(base or "(spline / point kernels)")
     F.check = recording_check
     for k in range(cases):
         F.set_option("stack_lds", (1, 2, 0)[k % 3])       # stack cases: automatic choice / forced staged kernel / direct
