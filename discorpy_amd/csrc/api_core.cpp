@@ -519,8 +519,21 @@ int dcp_device_count(void) {
 
 const char* dcp_last_error(void) { return dcpapi::last_error(); }
 
-int dcp_set_option(const char* key, int value) {
-  if (!key) return fail(DCP_ERR_INVALID_ARG, "null option key");
+// The seven documented options are spelt as they are; every other knob is a switch of the measurement lab (A/B runs, parity campaigns,
+// tests that force a kernel) and answers only to its name with an "x_" prefix -- undocumented in the header, free to change.
+static const char* const kStableOptions[] = {"stack_chunk_kb", "host_duplex", "host_bands", "host_direct", "host_direct_applies", "tile_cert",
+                                             "lds_gather"};
+static const char* option_name(const char* key) {
+  bool stable = false;
+  const bool lab = !strncmp(key, "x_", 2);
+  const char* name = lab ? key + 2 : key;
+  for (const char* k : kStableOptions) stable = stable || !strcmp(name, k);
+  return lab == stable ? "" : name;          // a stable key with the prefix, or a lab key without it: unknown
+}
+
+int dcp_set_option(const char* key_in, int value) {
+  if (!key_in) return fail(DCP_ERR_INVALID_ARG, "null option key");
+  const char* key = option_name(key_in);
   if (!strcmp(key, "tile_rows")) {
     if (value < 1 || value > dcp::kMaxTileRows) return fail(DCP_ERR_INVALID_ARG, "tile_rows must be in [1, %d]", dcp::kMaxTileRows);
     g_tile_rows = value;
@@ -581,13 +594,14 @@ int dcp_set_option(const char* key, int value) {
     if (value < 1) return fail(DCP_ERR_INVALID_ARG, "stack_chunk_kb must be >= 1");
     g_stack_chunk_kb = value;
   } else {
-    return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
+    return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key_in);
   }
   return DCP_OK;
 }
 
-int dcp_get_option(const char* key, int* value) {
-  if (!key || !value) return fail(DCP_ERR_INVALID_ARG, "null argument");
+int dcp_get_option(const char* key_in, int* value) {
+  if (!key_in || !value) return fail(DCP_ERR_INVALID_ARG, "null argument");
+  const char* key = option_name(key_in);
   if (!strcmp(key, "tile_rows")) *value = g_tile_rows;
   else if (!strcmp(key, "xcd_remap")) *value = g_xcd_remap;
   else if (!strcmp(key, "coef_lds")) *value = g_coef_lds;
@@ -614,7 +628,7 @@ int dcp_get_option(const char* key, int* value) {
     int n = 0;
     *value = (hipGetDeviceCount(&n) == hipSuccess && n > 0 && host_direct_applies()) ? 1 : 0;
   }
-  else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key);
+  else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key_in);
   return DCP_OK;
 }
 

@@ -17,6 +17,7 @@
 // straight from global memory.
 #include "dcp_internal.h"
 #include "dcp_device.h"
+#include "dcp_lab.h"
 #include <cstdio>
 #include <type_traits>
 
@@ -251,27 +252,7 @@ struct TileFilter {
 constexpr int kTfBlock = 1024;       // 16 waves move the tile (16 rows of loads in flight each); wave 0 runs the recursions
 constexpr int kTfWaves = kTfBlock / 64;
 
-#ifdef DCP_EXPERIMENT_TF_TRACE      // timing experiment: phase timestamps of every tile (thread 0), read by tools/trace_tf.py
-__device__ unsigned long long g_tf_trace[2][4096][8];
-extern "C" int dcp_experiment_read_tf_trace(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tf_trace), sizeof(g_tf_trace));
-}
-#define TF_TRACE(slot)                                                                       \
-  do {                                                                                       \
-    if (threadIdx.x == 0 && tile < 4096) g_tf_trace[AXIS][tile][slot] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-__device__ unsigned long long g_tf_trace_r[2][4096][8];       // the stages of the recursion as wave 8 sees them
-extern "C" int dcp_experiment_read_tf_trace_r(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tf_trace_r), sizeof(g_tf_trace_r));
-}
-#define TF_TRACE_R(slot)                                                                     \
-  do {                                                                                       \
-    if (threadIdx.x == 512 && tile < 4096) g_tf_trace_r[AXIS][tile][slot] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define TF_TRACE(slot) do { } while (0)
-#define TF_TRACE_R(slot) do { } while (0)
-#endif
+DCP_LAB_DEFINITIONS_SPLINE
 
 // Workgroup barrier that orders LDS traffic only (__syncthreads() also drains the wave's global memory operations; the tile
 // lives in LDS and the prefetched values in registers the compiler tracks itself, so the barriers here need lgkmcnt only and
@@ -609,13 +590,7 @@ __global__ void __launch_bounds__(256, DCP_CS_WAVES) spline_col_stream_kernel(co
           } else {
             ta = z * (ta - C[j]);
           }
-#if defined(DCP_CS_EXP_NOSTORE)        // timing experiment: the value is computed, the store (practically) never happens
-          if (row < r1 && store_lane && ta == 1.2345e300) out[(int64_t)row * f.out_ss] = ta;
-#elif defined(DCP_CS_EXP_NT)
-          if (row < r1 && store_lane) __builtin_nontemporal_store(ta, &out[(int64_t)row * f.out_ss]);
-#else
           if (row < r1 && store_lane) out[(int64_t)row * f.out_ss] = ta;
-#endif
         }
       }
       if (k + 1 < K) {

@@ -37,6 +37,7 @@
 // the arithmetic is the same sequence of IEEE operations as oracle/unwarp_oracle.c.
 #include "dcp_internal.h"
 #include "dcp_device.h"
+#include "dcp_lab.h"
 #include <type_traits>
 #include <cstdio>
 #include <cstring>
@@ -316,19 +317,6 @@ __global__ void __launch_bounds__(kBlock) remap_tile_kernel(const ImageArgs img,
 // [1] containment vote failed.  Read through dcp_debug_counters().
 __device__ unsigned long long g_lds_stats[2];
 
-#ifdef DCP_EXPERIMENT_TRACE   // timing experiment: per-wave phase timestamps (tools/trace_k1.py)
-__device__ unsigned long long g_trace[65536 * 12];
-#define DCP_TRACE(slot)                                                                                         \
-  do {                                                                                                          \
-    if (trace_on) {                                                                                             \
-      const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                               \
-      if (lane == 0) g_trace[trace_id * 12 + (slot)] = t_;                                                      \
-    }                                                                                                           \
-  } while (0)
-#else
-#define DCP_TRACE(slot) do { } while (0)
-#endif
-
 #ifndef DCP_LDS_TH
 #define DCP_LDS_TH 16
 #endif
@@ -370,19 +358,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, NF < 0 ? 3 : DCP_LDS_WAVES) remap
   // is treated as divergent and wrapped in a waterfall loop
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
-#ifdef DCP_EXPERIMENT_TRACE
-  const unsigned trace_id = ((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * kLdsBW + (unsigned)wave;
-  const bool trace_on = trace_id < 65536u;
-  DCP_TRACE(0);
-  if (trace_on && lane == 0) {
-    unsigned hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_trace[trace_id * 12 + 7] = ((unsigned long long)xcc << 32) | hwid;
-    g_trace[trace_id * 12 + 8] = __builtin_readcyclecounter() * 0 + __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  DCP_TRACE_WAVE_BEGIN(((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * kLdsBW + (unsigned)wave);
   int tx, ty;
   if (img.xcd_remap == 2) {
     // stripe order without divisions: a 2-D grid whose x extent is 8 * (widest stripe); the
@@ -463,27 +439,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, NF < 0 ? 3 : DCP_LDS_WAVES) remap
   // All rows are in flight at once and complete underneath phase 1b.  (The slab is filled to its
   // full 80-float pitch: up to 12 columns more than the box needs, from cache lines the
   // neighbouring tile fetches anyway.)
-#if defined(DCP_EXPERIMENT_VGPR_FILL)        // timing experiment: the same box through VGPRs (buffer loads, then ds_write_b128)
-  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 fillv[8];
-  const int lrow = (int)(__umul24((uint32_t)lane, 13u) >> 8);
-  const int lcol = lane - lrow * 20;
-  {
-    const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
-    const uint32_t rstep = (uint32_t)img.src_stride * 4u;
-    const uint32_t voff = (uint32_t)lrow * rstep + (uint32_t)lcol * 16u;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const bool pred = fits && lane < 60 && 3 * j + lrow < bh;
-      fillv[j] = __builtin_amdgcn_raw_buffer_load_b128(src.rsrc, pred ? voff + (org + (uint32_t)(3 * j) * rstep) : 0xfffffff0u, 0, 0);
-    }
-  }
-#elif defined(DCP_EXPERIMENT_NO_FILL)
-  if (false) {
-#else
   if (fits) {
-#endif
-#if !defined(DCP_EXPERIMENT_VGPR_FILL)
     // 16 bytes per lane: 20 lanes cover one slab row (pitch 80 floats), so one instruction fills
     // three consecutive box rows (lanes 0-59) and the LDS image stays lane-linear as LDS-DMA needs
     const uint32_t org = ((uint32_t)by0 * (uint32_t)img.src_stride + (uint32_t)bx0) * 4u;
@@ -520,7 +476,6 @@ __global__ void __launch_bounds__(64 * kLdsBW, NF < 0 ? 3 : DCP_LDS_WAVES) remap
       }
     }
   }
-#endif
 
   DCP_TRACE(3);
   // ---- phase 1b: the other rows, and this lane's extremes for the containment vote.
@@ -575,15 +530,8 @@ __global__ void __launch_bounds__(64 * kLdsBW, NF < 0 ? 3 : DCP_LDS_WAVES) remap
   }
   if (!staged && lane == 0) atomicAdd(&g_lds_stats[fits ? 1 : 0], 1ull);
   DCP_TRACE(4);
-#if defined(DCP_EXPERIMENT_VGPR_FILL)
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-    if (fits && lane < 60 && 3 * j + lrow < bh) *(u32x4*)(box + (3 * j + lrow) * kBoxW + lcol * 4) = fillv[j];
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#elif !defined(DCP_EXPERIMENT_NO_FILL_WAIT)      // timing experiment only (results are then garbage)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#endif
 
   DCP_TRACE(5);
   // one descriptor for the rows of the tile that exist; the row offset goes through the scalar
@@ -644,11 +592,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, NF < 0 ? 3 : DCP_LDS_WAVES) remap
           f.b.y = __float_as_uint(t[kBoxW + 1]);
           v = finish<SAMPLER, true, float, !decltype(inner)::value>(f);
         }
-#if defined(DCP_EXPERIMENT_NO_STORE)     // timing experiment only: the value is computed, the store (practically) never happens
-        if (__float_as_uint(v) == 0x7fc12345u)
-#else
         if (decltype(full)::value || k < rows)
-#endif
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out,
                                                 DCP_STORE_AUX);
       }
@@ -657,9 +601,7 @@ __global__ void __launch_bounds__(64 * kLdsBW, NF < 0 ? 3 : DCP_LDS_WAVES) remap
     else if (rows == kLdsTH) tile_rows_loop(std::true_type{}, std::false_type{});
     else tile_rows_loop(std::false_type{}, std::false_type{});
     DCP_TRACE(6);
-#ifdef DCP_EXPERIMENT_TRACE
-    if (trace_on && lane == 0) g_trace[trace_id * 12 + 9] = __builtin_amdgcn_s_memrealtime();
-#endif
+    DCP_TRACE_WAVE_END();
   } else {
     // ---- box too large for the slab, or a tap outside the predicted box: direct global gather
 #pragma unroll
@@ -808,18 +750,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
   const int wx = wave & 1, wy = wave >> 1;
-#ifdef DCP_EXPERIMENT_TRACE
-  const unsigned trace_id = (((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4u + (unsigned)wave;
-  const bool trace_on = trace_id < 65536u;
-  DCP_TRACE(0);
-  if (trace_on && lane == 0) {
-    unsigned hwid, xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    g_trace[trace_id * 12 + 7] = ((unsigned long long)xcc << 32) | hwid;
-    g_trace[trace_id * 12 + 8] = __builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  DCP_TRACE_WAVE_BEGIN((((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4u + (unsigned)wave);
   // tile order: XCD blockIdx.x & 7 owns a vertical stripe of tile columns and sweeps it row by row (see remap_lds_kernel)
   int tx, ty;
   if (img.xcd_remap == 2) {
@@ -899,11 +830,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
   const int nchunk = bh * CH;
   auto issue_fill = [&](auto jc) {
     constexpr int j = decltype(jc)::value;
-#if defined(DCP_EXPERIMENT_NO_FILL)       // timing experiment only (results are then garbage)
-    if constexpr (false) {
-#else
     if constexpr (j < NJ) {
-#endif
       if (fits && (j * 4 + wave) * 64 < nchunk) {             // wave-uniform: does any chunk of this load lie inside the box?
         // 256 j chunks further on: (256 j) / CH whole rows, and the column wraps into the next row at most once
         constexpr int qrow = (256 * j) / CH, rem = (256 * j) % CH;
@@ -1053,11 +980,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
             f.b.y = __float_as_uint(t[kBoxWEl + 1]);
             v = finish<SAMPLER, true, float, !decltype(inner)::value>(f);
           }
-#if defined(DCP_EXPERIMENT_NO_STORE)
-          if (__float_as_uint(v) == 0x7fc12345u)
-#else
           if (decltype(full)::value || k < rows)
-#endif
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
         } else {
           T v;
@@ -1095,11 +1018,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
               v = to_elem<T>(acc);
             }
           }
-#if defined(DCP_EXPERIMENT_NO_STORE)     // timing experiment only: the value is computed, the store (practically) never happens
-          if ((uint32_t)v + 0x10000u == img.src_bytes) {         // (cannot be proven false: the blend stays)
-#else
           if (decltype(full)::value || k < rows) {
-#endif
             if constexpr (ES == 2)
               __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * row_bytes_out, DCP_STORE_AUX);
             else
@@ -1120,9 +1039,7 @@ __device__ __forceinline__ void remap_wg_body(const ImageArgs& img, const MapArg
       else tile_rows_loop(std::false_type{}, std::false_type{}, std::false_type{});
     }
     DCP_TRACE(6);
-#ifdef DCP_EXPERIMENT_TRACE
-    if (trace_on && lane == 0) g_trace[trace_id * 12 + 9] = __builtin_amdgcn_s_memrealtime();
-#endif
+    DCP_TRACE_WAVE_END();
   } else {
     // ---- box too large for the slab: direct global gather
 #pragma unroll
@@ -2351,11 +2268,7 @@ hipError_t launch_stack_centres(const StackArgs& st_in, const MapArgs& map, cons
                    : launch_centres_t<-1, false>(st, map, xcs, ycs, ncentres, sampler, stream);
 }
 
-#ifdef DCP_EXPERIMENT_TRACE
-extern "C" int dcp_experiment_read_trace(unsigned long long* out, int nwaves) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 12 * (size_t)nwaves);
-}
-#endif
+DCP_LAB_HOST_DEFINITIONS_UNWARP
 
 DCP_DEFINE_BOUNDS_READER(read_bounds_unwarp)
 

@@ -64,25 +64,20 @@ const char* dcp_last_error(void);
  * spline path -- is released; the next call allocates again.  For long-running services. */
 int dcp_release_scratch(void);
 
-/* Tuning knobs (process-wide): "tile_rows" (1..64, rows walked by one workgroup), "xcd_remap"
- * (0..2), "coef_lds" (0/1: force LDS-staged polynomial coefficients), "d_chunk" (projections per
- * thread in the stack kernel), "pipe_depth" (1/2/4), "lds_gather" (0/1), "stack_chunk_kb" (KiB of one
- * projection chunk when a host stack is streamed through the GPU), "stack_lds" (LDS-staged stack kernel:
- * 0 never, 1 when the launch has enough wave tiles, 2 always), "host_duplex" (host frames of the radial map
- * go through the GPU in bands of rows, uploads and downloads at the same time: 0 never, 1 when a one-off probe
- * finds that the HIP runtime overlaps the two directions, 2 always), "host_bands" (number of those bands, default 6),
- * "tile_cert" (0: never use the host's tile-deviation certificate), "wg_box" (0: one source box per wave tile),
- * "wg_per_cu", "stack_wg" (0 never / 1 when the launch is large enough / 2 whenever eligible: the workgroup-box stack
- * kernel), "spline_tiled" (0: chunked spline prefilter passes + transposes instead of the one-pass LDS tiles),
- * "spline_wg" (0: spline taps gathered from global memory instead of an LDS-staged box), "host_direct" (0: never write a host frame's result straight into registered
- * host memory), "int_exact" (0: 8- / 16-bit integer
- * data blend in scipy's operation order everywhere instead of the factorised form where that form is provably exact), "box_table"
- * (0: the waves of a multi-frame launch evaluate their tiles' corner pixels themselves instead of reading them from a table kernel's output),
- * "tall_tiles" (A/B: 1 sheared radial maps on 64 x 32 workgroup tiles, 2 radial float32 frames on the interleaved-pixel kernel; default 0),
- * "store_wait" (0: the integer stack kernel waits for its own stores at every projection, as rounds 2-3 did; default 1: for the fill
- * only).  "xcd_remap" also orders the stack kernel's tiles: 0 grid order, 1 contiguous runs per XCD for every element type, 2 (default)
- * tile rows per XCD for float32 stacks and runs for integer ones.  "host_direct_applies" can only be read.  Returns
- * DCP_ERR_INVALID_ARG for an unknown key. */
+/* Options (process-wide).  The documented ones:
+ *   "stack_chunk_kb"  KiB of one projection chunk when a HOST stack is streamed through the GPU (device scratch = 4 chunks; default 24576)
+ *   "host_duplex"     host frames of the radial map through the GPU in bands of rows, uploads and downloads at the same time:
+ *                     0 never, 1 (default) when a one-off probe finds that the HIP runtime overlaps the two directions, 2 always
+ *   "host_bands"      number of those bands (default 6)
+ *   "host_direct"     0: never write a host frame's result straight into registered host memory; 1 (default): when the runtime
+ *                     cannot overlap an upload with a download; 2: whenever the destination is registered
+ *   "host_direct_applies"   read-only: 1 if "host_direct" = 1 takes effect on this runtime (measured once; needs a device)
+ *   "tile_cert"       0: never trust the host's tile-deviation certificate -- every staged kernel then verifies every pixel's taps
+ *                     against its source box (default 1)
+ *   "lds_gather"      0: no LDS-staged kernels at all: every tap a global load (default 1)
+ * Every other switch of the library (which kernel takes a call, tile orders, chunk sizes: what the A/B runs under tools/ and the
+ * parity campaigns flip) answers only to its name prefixed with "x_"; those are not part of this interface and may change
+ * (list: csrc/api_core.cpp, dcp_set_option).  Returns DCP_ERR_INVALID_ARG for an unknown key. */
 int dcp_set_option(const char* key, int value);
 int dcp_get_option(const char* key, int* value);
 

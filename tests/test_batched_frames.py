@@ -68,12 +68,12 @@ def test_batch_of_distinct_calibrations_equals_the_oracle_per_frame(hip, orc, bl
         assert np.array_equal(got, want)
         assert np.array_equal(got, pp.unwarp_image_backward(f, xc, yc, fact, blend=blend))     # == one call per image
     # (seven frames: the tile hulls came from box_table_kernel's table; the same batch with every wave evaluating its corners)
-    old = hip.get_option("box_table")
-    hip.set_option("box_table", 0)
+    old = hip.get_option("x_box_table")
+    hip.set_option("x_box_table", 0)
     try:
         outs0, _ = _device_batch(hip, frames, cals, 1, hip.BLEND_BY_NAME[blend])
     finally:
-        hip.set_option("box_table", old)
+        hip.set_option("x_box_table", old)
     assert all(np.array_equal(a, b) for a, b in zip(outs, outs0))
 
 

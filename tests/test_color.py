@@ -155,13 +155,13 @@ def test_sheared_map_on_64x32_workgroup_tiles_is_an_equal_and_slower_alternative
     img = noise(41, (H, W))
     want = orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
     try:
-        hip.set_option("tall_tiles", 1)
+        hip.set_option("x_tall_tiles", 1)
         got = pp.unwarp_image_backward(img[:1024], xc, yc, fact)          # (a host frame below the banded path's threshold: one launch)
         assert "64x32 tiles" in hip.last_kernel(), hip.last_kernel()
         w2 = orc.unwarp_image_backward(np.ascontiguousarray(img[:1024]), xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
         assert np.array_equal(got, w2)
-        hip.set_option("tall_tiles", 0)
+        hip.set_option("x_tall_tiles", 0)
         assert np.array_equal(pp.unwarp_image_backward(img[:1024], xc, yc, fact), w2) and hip.last_kernel().startswith("remap_lds_kernel")
     finally:
-        hip.set_option("tall_tiles", 0)
+        hip.set_option("x_tall_tiles", 0)
     assert want.shape == (H, W)

@@ -341,8 +341,8 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
             # 1: the default (one-pole orders: the register column pass for float32 frames that need no padding, the register row
             # pass behind an odd-pitch LDS staging); 2: the LDS tile kernel on both axes; 0: the plain kernels
             for fast in (1, 2, 0):
-                F.set_option("spline_tiled", fast)
-                F.set_option("spline_wg", 1 if fast else 0)
+                F.set_option("x_spline_tiled", fast)
+                F.set_option("x_spline_wg", 1 if fast else 0)
                 res[fast] = (pp.unwarp_image_backward(*a, order=order, mode=mode),
                              pp.correct_perspective_image(img, coef, order=order, mode=mode))
                 one_pole = fast == 1 and order <= 3
@@ -359,8 +359,8 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
                 assert np.count_nonzero(res[1][k] != res[2][k]) <= 4, (order, mode, k)
                 assert spline_close(res[1][k], want[k]) and np.count_nonzero(res[1][k] != want[k]) <= 8, (order, mode, k)
     finally:
-        F.set_option("spline_tiled", 1)
-        F.set_option("spline_wg", 1)
+        F.set_option("x_spline_tiled", 1)
+        F.set_option("x_spline_wg", 1)
 
 
 # --------------------------------------------------------------------------- (b) oracle, seeded inputs
@@ -389,11 +389,11 @@ def test_every_polynomial_length(hip, orc, nfact):
     fact = fact[:nfact]
     want = orc.unwarp_image_backward(img, 70.3, 44.9, fact, **kernel_oracle(orc, "scipy"))
     assert np.array_equal(pp.unwarp_image_backward(img, 70.3, 44.9, fact, blend="scipy"), want)
-    hip.set_option("coef_lds", 1)
+    hip.set_option("x_coef_lds", 1)
     try:
         assert np.array_equal(pp.unwarp_image_backward(img, 70.3, 44.9, fact, blend="scipy"), want)
     finally:
-        hip.set_option("coef_lds", 0)
+        hip.set_option("x_coef_lds", 0)
     with pytest.raises(ValueError):
         pp.unwarp_image_backward(img, 1, 1, [1.0] * 33)
 
@@ -410,7 +410,7 @@ def test_tuning_knobs_do_not_change_results(hip, orc):
     img = noise(4, (200, 1700))          # 27 tile columns: uneven XCD stripes
     a = (img, 833.3, 80.8, list(configs.COEF_DOT_05))
     want = orc.unwarp_image_backward(*a, **kernel_oracle(orc, "f64lerp"))
-    keys = {"tile_rows": [1, 3, 8, 16, 64], "pipe_depth": [1, 2, 4], "xcd_remap": [0, 1, 2], "lds_gather": [0, 1]}
+    keys = {"x_tile_rows": [1, 3, 8, 16, 64], "x_pipe_depth": [1, 2, 4], "x_xcd_remap": [0, 1, 2], "lds_gather": [0, 1]}
     for key, vals in keys.items():
         old = hip.get_option(key)
         try:
@@ -510,7 +510,7 @@ def test_stack_rows_match_oracle(hip, orc):
         for blend in ("scipy", "f64lerp", "f32"):
             want = orc.unwarp_chunk_slices_backward(vol, *a, s0, s1, **kernel_oracle(orc, blend))
             assert np.array_equal(pp.unwarp_chunk_slices_backward(vol, *a, s0, s1, blend=blend), want)
-    for key, vals in {"d_chunk": [1, 3, 64]}.items():
+    for key, vals in {"x_d_chunk": [1, 3, 64]}.items():
         old = hip.get_option(key)
         try:
             for v in vals:
@@ -531,10 +531,10 @@ def test_lds_staged_stack_kernel_and_its_fallbacks(hip, orc):
     ragged tiles, every polynomial path, all blends, a strong model whose boxes do not fit (direct-gather fallback),
     odd depth chunks, padded projections."""
     torch = pytest.importorskip("torch")
-    old = hip.get_option("stack_lds"), hip.get_option("d_chunk")
+    old = hip.get_option("x_stack_lds"), hip.get_option("x_d_chunk")
     try:
         for force in (2, 0):
-            hip.set_option("stack_lds", force)
+            hip.set_option("x_stack_lds", force)
             for (d, h, w, r0, r1), fact in [((5, 100, 140, 20, 60), [1.0, 2e-3]), ((3, 77, 263, 0, 76), list(configs.COEF_DOT_05)),
                                             ((4, 90, 130, 10, 17), [1.0, 1e-3, 1e-6, 1e-9, 1e-12, 1e-15]),
                                             ((2, 200, 300, 50, 150), [0.4, 8e-3]), ((7, 64, 65, 3, 40), [1.0, -2e-3, 3e-5])]:
@@ -543,7 +543,7 @@ def test_lds_staged_stack_kernel_and_its_fallbacks(hip, orc):
                 for blend in ("scipy", "f64lerp", "f32"):
                     want = orc.unwarp_chunk_slices_backward(vol, *a, r0, r1, **kernel_oracle(orc, blend))
                     for dc in (1, 3, 16):
-                        hip.set_option("d_chunk", dc)
+                        hip.set_option("x_d_chunk", dc)
                         got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *a, r0, r1, blend=blend)
                         assert np.array_equal(got.cpu().numpy(), want), (force, d, h, w, blend, dc)
                 big = np.zeros((d, h + 4, w + 9), np.float32)
@@ -552,14 +552,14 @@ def test_lds_staged_stack_kernel_and_its_fallbacks(hip, orc):
                 assert np.array_equal(pp.unwarp_chunk_slices_backward(view, *a, r0, r1).cpu().numpy(),
                                       orc.unwarp_chunk_slices_backward(vol, *a, r0, r1, **kernel_oracle(orc, "f64lerp")))
         hip.debug_counters()
-        hip.set_option("stack_lds", 2)
+        hip.set_option("x_stack_lds", 2)
         vol = noise(9, (2, 200, 300))
         pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), 150.0, 100.0, [0.4, 8e-3], 50, 150)
         nofit, vote = hip.debug_counters()
         assert nofit + vote > 0                      # that model really exercised the fallback
     finally:
-        hip.set_option("stack_lds", old[0])
-        hip.set_option("d_chunk", old[1])
+        hip.set_option("x_stack_lds", old[0])
+        hip.set_option("x_d_chunk", old[1])
 
 
 def test_host_stack_sharded_over_devices_of_one_process(hip, orc):
@@ -853,7 +853,7 @@ def test_non_finite_pixels_next_to_a_clipped_edge_scipy_blend(hip, orc):
         a = (img, 0.75 * w, 0.7 * h, [1.08, 2.0e-4])            # magnifying model: a band of pixels clips to the right / bottom edge
         want = orc.unwarp_image_backward(*a, poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY)
         assert np.isfinite(want[:, -1]).sum() > h // 4              # (clipped pixels stay finite in scipy's arithmetic)
-        for opts in ({}, {"wg_box": 0}, {"lds_gather": 0}):
+        for opts in ({}, {"x_wg_box": 0}, {"lds_gather": 0}):
             try:
                 for k, v in opts.items():
                     hip.set_option(k, v)
@@ -1336,11 +1336,11 @@ def test_cfg5_nine_term_8192_frame(hip, orc):
     a = (img, c["xcenter"], c["ycenter"], c["list_fact"])
     out = pp.unwarp_image_backward(*a)
     assert np.array_equal(out, orc.unwarp_image_backward(*a, **kernel_oracle(orc, "f64lerp")))
-    hip.set_option("coef_lds", 1)                               # LDS-staged coefficients: same bits
+    hip.set_option("x_coef_lds", 1)                               # LDS-staged coefficients: same bits
     try:
         assert np.array_equal(pp.unwarp_image_backward(*a), out)
     finally:
-        hip.set_option("coef_lds", 0)
+        hip.set_option("x_coef_lds", 0)
 
 
 def test_cfg4_stack_sample(hip, orc):
@@ -1391,7 +1391,7 @@ def test_cfg2_device_resident_call_is_the_benched_kernel_and_equals_the_oracle(h
     finally:
         hip.set_option("host_duplex", old)
     # the two other staged kernels on the same frame: one box per wave tile with the certificate, and with the per-pixel vote
-    for opt, name in (("wg_box", "remap_lds_kernel<Radial,NF=5,%s,certified>" % blend), ("tile_cert", "remap_lds_kernel<Radial,NF=-1,%s,vote>" % blend)):
+    for opt, name in (("x_wg_box", "remap_lds_kernel<Radial,NF=5,%s,certified>" % blend), ("tile_cert", "remap_lds_kernel<Radial,NF=-1,%s,vote>" % blend)):
         hip.set_option(opt, 0)
         try:
             got = _device_call(hip, lambda s, d: L.dcp_unwarp_image_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, 1, 1, b,
@@ -1416,13 +1416,13 @@ def test_cfg3_device_resident_calls_equal_the_oracle(hip, orc):
     assert hip.last_kernel() == "remap_wg_kernel<Fused,NF=5,f64lerp>", hip.last_kernel()
     want_fused = orc.unwarp_fused(img, c["xcenter"], c["ycenter"], c["list_fact"], c["list_coef"], **kernel_oracle(orc, "f64lerp"))
     assert np.array_equal(fused, want_fused)
-    hip.set_option("fused_wg", 0)               # rounds 1-4: one box per wave tile, every pixel voting on it -- the same pixels
+    hip.set_option("x_fused_wg", 0)               # rounds 1-4: one box per wave tile, every pixel voting on it -- the same pixels
     try:
         voted = _device_call(hip, lambda s, d: L.dcp_unwarp_fused_f32(s, d, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, ca, 1,
                                                                        hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None), img)
         assert hip.last_kernel().startswith("remap_lds_kernel<Fused,NF=5,f64lerp") and np.array_equal(voted, want_fused)
     finally:
-        hip.set_option("fused_wg", 1)
+        hip.set_option("x_fused_wg", 1)
     persp = _device_call(hip, lambda s, d: L.dcp_perspective_image_f32(s, d, H, W, W, 1, ca, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None), img)
     assert hip.last_kernel() == "remap_wg_kernel<Persp,NF=-1,f64lerp>"
     assert np.array_equal(persp, orc.correct_perspective_image(img, c["list_coef"], blend=orc.BLEND_F64LERP))
@@ -1470,7 +1470,7 @@ def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
     want = orc.unwarp_stack_rows(vol, c["xcenter"], c["ycenter"], c["list_fact"], 0, H, coord_round_f32=True,
                                  **kernel_oracle(orc, "f64lerp"))
     for stack_wg, name in ((1, "stack_wg_kernel<NF=5,f64lerp>"), (0, "stack_lds_kernel<NF=5,f64lerp>")):
-        hip.set_option("stack_wg", stack_wg)
+        hip.set_option("x_stack_wg", stack_wg)
         try:
             hip.debug_counters()
             hip.check(L.dcp_memcpy(dst.ptr, src.ptr, 4096, hip.COPY_D2D, -1, None))        # (scribble: the result must be rewritten)
@@ -1481,7 +1481,7 @@ def test_cfg4_shard_all_rows_takes_the_staged_stack_kernel(hip, orc):
             assert nofit == 0 and vote <= 64             # staged throughout (a handful of tiles may fail the zero-margin vote of the per-wave kernel)
             assert np.array_equal(dst.download((D, H, W), np.float32), want), name
         finally:
-            hip.set_option("stack_wg", 1)
+            hip.set_option("x_stack_wg", 1)
     src.free()
     dst.free()
 
@@ -1494,7 +1494,7 @@ def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
     D, H, W = 21, 300, 517
     vol = noise(501, (D, H, W))
     a = (250.3, 140.8, [1.0, 3.0e-5, -4.0e-8])
-    hip.set_option("stack_wg", 2)                         # also for launches this small
+    hip.set_option("x_stack_wg", 2)                         # also for launches this small
     try:
         for blend in ("f64lerp", "scipy", "f32"):
             got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *a, 7, 291, blend=blend).cpu().numpy()
@@ -1520,7 +1520,7 @@ def test_stack_wg_kernel_shapes_blends_and_integer_types(hip, orc):
             assert hip.last_kernel().startswith("stack_wg_kernel<NF=4,scipy," + bits), (dt, hip.last_kernel())
             assert got.dtype == np.dtype(dt) and np.array_equal(got, orc.unwarp_chunk_slices_backward(v, *a, 3, 280, poly=orc.POLY_KERNEL)), dt
     finally:
-        hip.set_option("stack_wg", 1)
+        hip.set_option("x_stack_wg", 1)
 
 
 def test_stack_wg_kernel_xcd_runs_tile_order(hip, orc):
@@ -1531,27 +1531,27 @@ def test_stack_wg_kernel_xcd_runs_tile_order(hip, orc):
     and a ragged last depth chunk."""
     torch = pytest.importorskip("torch")
     a = (250.3, 140.8, [1.0, 3.0e-5, -4.0e-8, 1e-11, -2e-14])
-    hip.set_option("stack_wg", 2)
+    hip.set_option("x_stack_wg", 2)
     try:
         # (the last two: 15 and 16 tile rows -- float32 stacks then go by tile rows, the first with a vacant sixteenth row)
         for (D, H, W, r0, r1) in ((21, 300, 517, 7, 291), (9, 200, 640, 0, 199), (5, 97, 130, 3, 60), (6, 520, 300, 5, 474), (5, 530, 200, 0, 511)):
             vol = noise(700 + D, (D, H, W))
             want = orc.unwarp_chunk_slices_backward(vol, *a, r0, r1, **kernel_oracle(orc, "f64lerp"))
             for order in (1, 0, 2):
-                hip.set_option("xcd_remap", order)
+                hip.set_option("x_xcd_remap", order)
                 got = pp.unwarp_chunk_slices_backward(torch.from_numpy(vol).cuda(), *a, r0, r1).cpu().numpy()
                 assert hip.last_kernel() == "stack_wg_kernel<NF=5,f64lerp>", hip.last_kernel()
                 assert np.array_equal(got, want), (D, H, W, order)
             v = typed_image("uint16", (D, H, W + (4 - W % 4) % 4), 710 + D)
             want = orc.unwarp_chunk_slices_backward(v, *a, r0, r1, poly=orc.POLY_KERNEL)
             for order in (2, 0):
-                hip.set_option("xcd_remap", order)
+                hip.set_option("x_xcd_remap", order)
                 got = pp.unwarp_chunk_slices_backward(torch.from_numpy(v).cuda(), *a, r0, r1).cpu().numpy()
                 assert hip.last_kernel().startswith("stack_wg_kernel<NF=5,scipy,16-bit"), hip.last_kernel()
                 assert np.array_equal(got, want), (D, H, W, order)
     finally:
-        hip.set_option("xcd_remap", 2)
-        hip.set_option("stack_wg", 1)
+        hip.set_option("x_xcd_remap", 2)
+        hip.set_option("x_stack_wg", 1)
 
 
 def test_stack_wg_integer_streams_under_the_blend(hip, orc):
@@ -1569,7 +1569,7 @@ def test_stack_wg_integer_streams_under_the_blend(hip, orc):
         a = (588.692801577 / sc, 462.092631791 / sc, [c * sc ** i for i, c in enumerate(dot05)])
         v = typed_image(dt, (D, H, W), 900 + D)
         dev = torch.from_numpy(v).cuda()
-        hip.set_option("stack_wg", 2)                         # also for launches this small
+        hip.set_option("x_stack_wg", 2)                         # also for launches this small
         try:
             first = pp.unwarp_chunk_slices_backward(dev, *a, r0, r1).cpu().numpy()
             assert hip.last_kernel().startswith("stack_wg_kernel<NF=5,scipy,"), hip.last_kernel()
@@ -1577,11 +1577,11 @@ def test_stack_wg_integer_streams_under_the_blend(hip, orc):
             for rep in range(40):
                 again = pp.unwarp_chunk_slices_backward(dev, *a, r0, r1)
                 assert torch.equal(again, torch.from_numpy(first).cuda()), (dt, rep)
-            hip.set_option("store_wait", 0)
+            hip.set_option("x_store_wait", 0)
             assert np.array_equal(pp.unwarp_chunk_slices_backward(dev, *a, r0, r1).cpu().numpy(), first), dt
         finally:
-            hip.set_option("store_wait", 1)
-            hip.set_option("stack_wg", 1)
+            hip.set_option("x_store_wait", 1)
+            hip.set_option("x_stack_wg", 1)
 
 
 def test_spline_gather_tiles_with_the_tallest_boxes(hip, orc):

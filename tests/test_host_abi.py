@@ -40,19 +40,32 @@ def test_version_and_device_count_do_not_need_a_gpu():
 
 
 def test_options_round_trip():
-    for key, val in [("tile_rows", 8), ("pipe_depth", 4), ("xcd_remap", 1), ("xcd_remap", 2), ("coef_lds", 1), ("d_chunk", 32),
-                     ("lds_gather", 1), ("stack_lds", 2), ("stack_chunk_kb", 512), ("host_duplex", 0), ("int_exact", 0), ("host_direct", 2), ("box_table", 0),
-                     ("store_wait", 0), ("tall_tiles", 1), ("wg_per_cu", 2), ("stack_wg", 2), ("spline_tiled", 3)]:
+    # the documented options by their names, the lab's switches by theirs with the "x_" prefix -- and neither the other way round
+    for key, val in [("x_tile_rows", 8), ("x_pipe_depth", 4), ("x_xcd_remap", 1), ("x_xcd_remap", 2), ("x_coef_lds", 1), ("x_d_chunk", 32),
+                     ("lds_gather", 1), ("x_stack_lds", 2), ("stack_chunk_kb", 512), ("host_duplex", 0), ("x_int_exact", 0), ("host_direct", 2),
+                     ("x_box_table", 0), ("x_store_wait", 0), ("x_tall_tiles", 1), ("x_wg_per_cu", 2), ("x_stack_wg", 2), ("x_spline_tiled", 3),
+                     ("x_fused_wg", 0), ("host_bands", 4), ("tile_cert", 0)]:
         old = F.get_option(key)
         F.set_option(key, val)
         assert F.get_option(key) == val
         F.set_option(key, old)
     with pytest.raises(ValueError, match="unknown option"):
         F.set_option("no_such_knob", 1)
+    for key in ("tile_rows", "wg_box", "x_host_duplex", "x_tile_cert", "x_", ""):
+        with pytest.raises(ValueError, match="unknown option"):
+            F.set_option(key, 1)
+        with pytest.raises(ValueError, match="unknown option"):
+            F.get_option(key)
+    # the header documents the stable options and nothing else of them
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "discorpy_hip.h")).read()
+    doc = hdr[hdr.index("/* Options (process-wide)"):hdr.index("int dcp_set_option")]
+    import re as _re
+    assert sorted(set(_re.findall(r'^ \*   "([a-z_]+)"', doc, _re.M))) == sorted(
+        ["stack_chunk_kb", "host_duplex", "host_bands", "host_direct", "host_direct_applies", "tile_cert", "lds_gather"])
     with pytest.raises(ValueError):
-        F.set_option("tile_rows", 1000)
+        F.set_option("x_tile_rows", 1000)
     with pytest.raises(ValueError):
-        F.set_option("pipe_depth", 3)
+        F.set_option("x_pipe_depth", 3)
 
 
 def test_abi_rejects_bad_arguments_before_any_gpu_work():

@@ -23,13 +23,13 @@ def test_integer_frames_and_stacks_exact_blend_equals_scipy_order(hip, orc, dt):
     vol = typed_image(dt, (6, H, W), 32)
     got = {}
     for mode in (1, 0):
-        F.set_option("int_exact", mode)
+        F.set_option("x_int_exact", mode)
         try:
             got[mode] = (pp.unwarp_image_backward(img, xc, yc, fact), pp.correct_perspective_image(img, coef),
                          pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, 0, H - 1))
             kernel = F.last_kernel()
         finally:
-            F.set_option("int_exact", 1)
+            F.set_option("x_int_exact", 1)
     assert "stack_wg_kernel" in kernel or "stack" in kernel
     for a, b in zip(got[0], got[1]):
         assert a.dtype == np.dtype(dt) and np.array_equal(a, b)
@@ -51,12 +51,12 @@ def test_short_coefficient_vectors_run_the_four_term_kernels_zero_padded(hip, or
     assert F.last_kernel().startswith("remap_wg_kernel<Radial,NF=4,"), F.last_kernel()
     assert np.array_equal(got, orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL))
     vol = typed_image("uint16", (5, H, W), 78)
-    F.set_option("stack_wg", 2)
+    F.set_option("x_stack_wg", 2)
     try:
         got = pp.unwarp_chunk_slices_backward(vol, xc, yc, fact, 0, H - 1)
         assert "NF=4" in F.last_kernel(), F.last_kernel()
     finally:
-        F.set_option("stack_wg", 1)
+        F.set_option("x_stack_wg", 1)
     assert np.array_equal(got, orc.unwarp_chunk_slices_backward(vol, xc, yc, fact, 0, H - 1, poly=orc.POLY_KERNEL))
     volf = np.random.default_rng(5).random((4, H, W), dtype=np.float32)
     cents = [(xc + 3.5 * i, yc - 2.25 * i) for i in range(3)]

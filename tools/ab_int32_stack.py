@@ -9,7 +9,7 @@ from discorpy_amd.post import postprocessing as pp
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 c4 = configs.cfg4(D)
 H = W = 2560
-DEFAULTS = {"d_chunk": 16, "xcd_remap": 2, "store_wait": 1}
+DEFAULTS = {"x_d_chunk": 16, "x_xcd_remap": 2, "x_store_wait": 1}
 
 
 def best(fn, n=6):
@@ -27,7 +27,7 @@ for dt in (torch.int32, torch.float32):
     out = torch.empty((D, H, W), dtype=dt, device="cuda")
     call = lambda: pp.unwarp_chunk_slices_backward(vol, c4["xcenter"], c4["ycenter"], c4["list_fact"], 0, H - 1, out=out)
     for rnd in range(2):
-        for key, values in (("d_chunk", (16, 8, 32)), ("xcd_remap", (2, 1, 0)), ("store_wait", (1, 0))):
+        for key, values in (("x_d_chunk", (16, 8, 32)), ("x_xcd_remap", (2, 1, 0)), ("x_store_wait", (1, 0))):
             for v in values:
                 F.set_option(key, v)
                 us = best(call)

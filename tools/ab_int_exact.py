@@ -30,11 +30,11 @@ for name, dt, scale in (("uint16", np.uint16, 60000.0), ("uint8", np.uint8, 255.
     outs, ts = {}, {0: [], 1: []}
     for rep in range(3):
         for mode in (1, 0):
-            F.set_option("int_exact", mode)
+            F.set_option("x_int_exact", mode)
             ts[mode].append(bench.timed_launches(run, 400, dev, settle_ms=200.0))
             run(0)
             outs[mode] = dst[0].download((H, W), dt)
-    F.set_option("int_exact", 1)
+    F.set_option("x_int_exact", 1)
     print("%-7s frame 4096^2: exact %s us   scipy-order %s us   identical %s   (%s)" % (
         name, ["%.2f" % t for t in ts[1]], ["%.2f" % t for t in ts[0]], bool(np.array_equal(outs[0], outs[1])), F.last_kernel()), flush=True)
     for b in src + dst:
@@ -56,11 +56,11 @@ def shard(_i):
 outs, ts = {}, {0: [], 1: []}
 for rep in range(3):
     for mode in (1, 0):
-        F.set_option("int_exact", mode)
+        F.set_option("x_int_exact", mode)
         ts[mode].append(bench.timed_launches(shard, 12, dev, settle_ms=100.0))
         g = np.empty((2, Hs, Ws), np.uint16)
         F.check(L.dcp_memcpy(g.ctypes.data, out.ptr + 5 * Hs * Ws * 2, g.nbytes, F.COPY_D2H, dev, None))
         outs[mode] = g
-F.set_option("int_exact", 1)
+F.set_option("x_int_exact", 1)
 print("uint16 shard (64, 2560, 2560): exact %s us   scipy-order %s us   identical %s   (%s)" % (
     ["%.1f" % t for t in ts[1]], ["%.1f" % t for t in ts[0]], bool(np.array_equal(outs[0], outs[1])), F.last_kernel()), flush=True)

@@ -35,7 +35,7 @@ for name, dt, scale in (("float32", np.float32, 1.0), ("uint16", np.uint16, 6000
         else:
             F.check(L.dcp_unwarp_stack_rows_typed(vol.ptr, out.ptr, F.DTYPE_BY_NAME[name], 0, D, Hs, Ws, Hs * Ws, Ws, c4["xcenter"], c4["ycenter"],
                                                   f4, n4, 0.0, Hs, 1, F.MEM_DEVICE, dev, None))
-    opt = os.environ.get("AB_OPTION", "xcd_remap")       # AB_OPTION=store_wait AB_MODES=1,0: another option of the stack kernel
+    opt = os.environ.get("AB_OPTION", "x_xcd_remap")       # AB_OPTION=x_store_wait AB_MODES=1,0: another option of the stack kernel
     modes = [int(m) for m in os.environ.get("AB_MODES", "2,1,0").split(",")]       # (one mode, few launches: the counter passes)
     outs, ts = {m: None for m in modes}, {m: [] for m in modes}
     for rep in range(int(os.environ.get("AB_REPS", "3"))):

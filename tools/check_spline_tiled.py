@@ -15,7 +15,7 @@ for shape in ((1024, 4096), (2000, 1500)):
         want = orc.unwarp_image_backward(*a, order=order, mode=mode, poly=orc.POLY_KERNEL)
         res = {}
         for t in (1, 0):
-            F.set_option("spline_tiled", t); F.set_option("spline_wg", t)
+            F.set_option("x_spline_tiled", t); F.set_option("x_spline_wg", t)
             res[t] = pp.unwarp_image_backward(*a, order=order, mode=mode)
         d1, d0 = np.count_nonzero(res[1] != want), np.count_nonzero(res[0] != want)
         ok = d1 <= 8 and np.max(np.abs(res[1].astype(np.float64) - want)) < 1e-5
@@ -28,7 +28,7 @@ src = F.DeviceBuffer(img.nbytes).upload(img); dst = F.DeviceBuffer(img.nbytes)
 fa, n = F.fact_array(c["list_fact"])
 for order in (3, 2, 5):
     for t in (0, 1):
-        F.set_option("spline_tiled", t); F.set_option("spline_wg", t)
+        F.set_option("x_spline_tiled", t); F.set_option("x_spline_wg", t)
         def run():
             F.check(L.dcp_unwarp_image_spline_f32(src.ptr, dst.ptr, H, W, W, 1, c["xcenter"], c["ycenter"], fa, n, order, 0, 1, -1, None))
         run(); F.check(L.dcp_stream_synchronize(-1, None))

@@ -153,9 +153,9 @@ def one_case(rng, k):
         fact = certified_fact(rng, h, w, xc, yc, (4, 5) if kind == "fused" else None)
         if blend == "f32" and kind == "color":
             blend = "f64lerp"
-        for key in ("wg_box", "tile_cert"):
+        for key in ("x_wg_box", "tile_cert"):
             F.set_option(key, 1)
-        F.set_option("stack_wg", 2)
+        F.set_option("x_stack_wg", 2)
     okw = dict(poly=orc.POLY_KERNEL)
     tag = "case %d %s%s %dx%d %s order %d blend %s xc=%r yc=%r fact=%r" % (k, "staged " if staged else "", kind, h, w, dt, order, blend, xc, yc, fact)
     if os.environ.get("FUZZ_TRACE"):          # one line per case BEFORE it runs: what was running when a device fault ended the process
@@ -350,9 +350,9 @@ def main():
         launched.add(base or "(spline / point kernels)")
     F.check = recording_check
     for k in range(cases):
-        F.set_option("stack_lds", (1, 2, 0)[k % 3])       # stack cases: automatic choice / forced staged kernel / direct
-        F.set_option("stack_wg", (2, 1, 2, 0)[k % 4])     # workgroup-box stack kernel: whenever eligible / automatic / off
-        F.set_option("wg_box", 0 if k % 5 == 4 else 1)    # one box per workgroup, or per wave tile
+        F.set_option("x_stack_lds", (1, 2, 0)[k % 3])       # stack cases: automatic choice / forced staged kernel / direct
+        F.set_option("x_stack_wg", (2, 1, 2, 0)[k % 4])     # workgroup-box stack kernel: whenever eligible / automatic / off
+        F.set_option("x_wg_box", 0 if k % 5 == 4 else 1)    # one box per workgroup, or per wave tile
         F.set_option("tile_cert", 0 if k % 7 == 6 else 1) # the host certificate, or the per-pixel vote
         launched.clear()
         kind = one_case(rng, k)
@@ -361,7 +361,7 @@ def main():
             kernels[name] = kernels.get(name, 0) + 1
     nofit, vote = F.debug_counters()
     bounds = F.debug_bounds()
-    for key in ("stack_lds", "stack_wg", "wg_box", "tile_cert"):
+    for key in ("x_stack_lds", "x_stack_wg", "x_wg_box", "tile_cert"):
         F.set_option(key, 1)
     print("fuzz_parity: %d cases (seed %d) all equal in %.1f s: %s; cases in which each kernel ran: %s; LDS-kernel fallbacks exercised: "
           "%d tiles did not fit, %d tiles failed the vote" % (cases, seed, time.time() - t0, dict(sorted(counts.items())),

@@ -51,11 +51,11 @@ del src, dst
 c = configs.cfg5(); H, W, src, dst = frames(c, 4)
 fa, n = F.fact_array(c["list_fact"])
 for coef_lds in (0, 1):
-    F.set_option("coef_lds", coef_lds)
+    F.set_option("x_coef_lds", coef_lds)
     for name, order, blend in [("f64lerp", 1, 1), ("nearest", 0, 0)]:
         us = timed(lambda r: F.check(L.dcp_unwarp_image_f32(src[r % 4].ptr, dst[r % 4].ptr, H, W, W, 1, c["xcenter"], c["ycenter"], fa, n, order, 1, blend, 1, -1, None)), 30)
         report("cfg5 radial 8192^2 9-term %s coef_%s" % (name, "LDS" if coef_lds else "SGPR"), us, H * W, 8)
-F.set_option("coef_lds", 0)
+F.set_option("x_coef_lds", 0)
 del src, dst
 
 # ---- cfg4: stack kernel on a depth-64 sample of the 2560^2 stack (device-generated data would be the same speed)
@@ -69,7 +69,7 @@ for nrows, row0, r32, label in [(1, 1277.0, 0, "unwarp_slice_backward (1 row, f6
                                 (H, 0.0, 1, "all 2560 rows (full corrected stack)")]:
     out = F.DeviceBuffer(D * nrows * W * 4)
     for dch in (8, 16, 64):
-        F.set_option("d_chunk", dch)
+        F.set_option("x_d_chunk", dch)
         us = timed(lambda r: F.check(L.dcp_unwarp_stack_rows_f32(vol.ptr, out.ptr, D, H, W, H * W, W, c["xcenter"], c["ycenter"], fa, n, row0, nrows, r32, 1, 1, -1, None)), 10 if nrows > 64 else 50)
         report("cfg4 stack D=%d %s d_chunk=%d" % (D, label, dch), us, D * nrows * W, 12 if nrows == 1 else 8)
     del out

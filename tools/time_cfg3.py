@@ -26,7 +26,7 @@ dst = [F.DeviceBuffer(H * W * 4, dev) for _ in range(ring)]
 outs = {}
 for blend, order, name in ((F.BLEND_F64LERP, 1, "f64lerp"), (F.BLEND_SCIPY, 1, "scipy"), (F.BLEND_SCIPY, 0, "nearest")):
     for wg in (1, 0, 1, 0, 1, 0):
-        F.set_option("fused_wg", wg)
+        F.set_option("x_fused_wg", wg)
 
         def run(i):
             F.check(L.dcp_unwarp_fused_f32(src[i % ring].ptr, dst[i % ring].ptr, H, W, W, 1, c3["xcenter"], c3["ycenter"], fa, nf, ca, order, blend,
@@ -36,6 +36,6 @@ for blend, order, name in ((F.BLEND_F64LERP, 1, "f64lerp"), (F.BLEND_SCIPY, 1, "
         outs[wg] = bench.download(dst[0].ptr, (H, W), dev)
         print("%-8s fused_wg=%d: %8.2f us  %.3f of 8 TB/s  %s" % (name, wg, t, 8.0 * H * W / (t * 1e-6) / 8e12, F.last_kernel()), flush=True)
     print("   identical: %s" % bool(np.array_equal(outs[0], outs[1])), flush=True)
-F.set_option("fused_wg", 1)
+F.set_option("x_fused_wg", 1)
 cnt = F.debug_counters() if hasattr(F, "debug_counters") else None
 print("counters (tiles whose box did not fit, ...):", cnt)

@@ -24,7 +24,7 @@ dst = [F.DeviceBuffer(img.nbytes, dev) for _ in range(ring)]
 outs = {}
 for blend, order, name in ((F.BLEND_F64LERP, 1, "f64lerp"), (F.BLEND_SCIPY, 1, "scipy"), (F.BLEND_SCIPY, 0, "nearest")):
     for tall in (1, 0, 1, 0):
-        F.set_option("tall_tiles", tall)
+        F.set_option("x_tall_tiles", tall)
 
         def run(i):
             F.check(L.dcp_unwarp_image_f32(src[i % ring].ptr, dst[i % ring].ptr, H, W, W, 1, c5["xcenter"], c5["ycenter"], fa, nf, order, 1, blend,
@@ -34,4 +34,4 @@ for blend, order, name in ((F.BLEND_F64LERP, 1, "f64lerp"), (F.BLEND_SCIPY, 1, "
         outs[tall] = bench.download(dst[0].ptr, (H, W), dev)
         print("%-8s tall_tiles=%d: %8.2f us  %.3f of 8 TB/s  %s" % (name, tall, t, 8.0 * H * W / (t * 1e-6) / 8e12, F.last_kernel()), flush=True)
     print("   identical: %s" % bool(np.array_equal(outs[0], outs[1])), flush=True)
-F.set_option("tall_tiles", 1)
+F.set_option("x_tall_tiles", 1)

@@ -56,9 +56,9 @@ def main():
                     F.check(L.dcp_unwarp_image_typed(srcs[i % ring].ptr, dsts[i % ring].ptr, code, H, W, W, 1, xc, yc, fa, nf, order, 0, F.MEM_DEVICE, dev, None))
                 t = bench.timed_launches(run, a.reps, dev, settle_ms=300.0)
                 k = F.last_kernel()
-                F.set_option("wg_box", 0)
+                F.set_option("x_wg_box", 0)
                 tg = bench.timed_launches(run, max(4, a.reps // 4), dev, settle_ms=100.0)
-                F.set_option("wg_box", 1)
+                F.set_option("x_wg_box", 1)
                 print("%-6s %-8s %8.2f us  %.3f of 8 TB/s (%d B/px)  %s   | one thread per pixel: %.2f us" % (
                     case, name, t, 2 * nbytes / (t * 1e-6) / 8e12, 2 * es, k, tg), flush=True)
                 continue
@@ -70,9 +70,9 @@ def main():
             k = F.last_kernel()
             line = "%-6s %-8s %8.2f us  %.3f of 8 TB/s (%d B/px)  %s" % (case, name, t, 2 * nbytes / (t * 1e-6) / 8e12, 2 * nc * es, k)
             if not a.no_generic:
-                F.set_option("wg_box", 0)
+                F.set_option("x_wg_box", 0)
                 tg = bench.timed_launches(run, max(4, a.reps // 4), dev, settle_ms=100.0)
-                F.set_option("wg_box", 1)
+                F.set_option("x_wg_box", 1)
                 line += "   | one thread per pixel: %.2f us" % tg
             print(line, flush=True)
         if tname == "f32":

@@ -24,7 +24,7 @@ dst = [F.DeviceBuffer(H * W * 4, dev) for _ in range(ring)]
 for blend, order, name in ((F.BLEND_F64LERP, 1, "f64lerp"), (F.BLEND_SCIPY, 1, "scipy"), (F.BLEND_SCIPY, 0, "nearest")):
     outs = {}
     for opt in (0, 2, 0, 2):
-        F.set_option("tall_tiles", opt)
+        F.set_option("x_tall_tiles", opt)
 
         def run(i):
             F.check(L.dcp_unwarp_image_f32(src[i % ring].ptr, dst[i % ring].ptr, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, order, 1, blend, F.MEM_DEVICE, dev, None))
@@ -33,4 +33,4 @@ for blend, order, name in ((F.BLEND_F64LERP, 1, "f64lerp"), (F.BLEND_SCIPY, 1, "
         outs[opt] = bench.download(dst[0].ptr, (H, W), dev)
         print("%-8s %8.2f us  %.3f  %s" % (name, t, 8.0 * H * W / (t * 1e-6) / 8e12, F.last_kernel()), flush=True)
     print("   identical:", bool(np.array_equal(outs[0], outs[2])), flush=True)
-F.set_option("tall_tiles", 0)
+F.set_option("x_tall_tiles", 0)

@@ -39,12 +39,12 @@ def main():
                                                   F.MEM_DEVICE, dev, None))
         outs = {}
         for v in [int(x) for x in a.variants.split(",")]:
-            F.set_option("spline_tiled", v)
+            F.set_option("x_spline_tiled", v)
             t = bench.timed_launches(run, a.reps, dev, settle_ms=300.0)
             run(0)
             outs[v] = bench.download(dsts[0].ptr, (H, W), dev)
             print("order %d spline_tiled=%d: %8.2f us  %s" % (order, v, t, F.last_kernel()), flush=True)
-        F.set_option("spline_tiled", 1)
+        F.set_option("x_spline_tiled", 1)
         ks = sorted(outs)
         for v in ks[1:]:
             d = outs[ks[0]] != outs[v]

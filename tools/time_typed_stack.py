@@ -37,12 +37,12 @@ for dt in (torch.float32, torch.uint16, torch.int32, torch.uint32, torch.float64
     out = torch.empty((D, H, W), dtype=dt, device="cuda")
     res = {}
     for wg in (1, 0):
-        F.set_option("stack_wg", wg)
+        F.set_option("x_stack_wg", wg)
         us = best(lambda: pp.unwarp_chunk_slices_backward(vol, c4["xcenter"], c4["ycenter"], c4["list_fact"], 0, H - 1, out=out))
         res[wg] = (us, F.last_kernel(), out.clone() if wg else None)
         nb = out.numel() * out.element_size() * 2
         print("%-8s D=%d all rows stack_wg=%d: %9.1f us  %5.3f of 8 TB/s   %s" % (str(dt).replace("torch.", ""), D, wg, us, nb / us / 1e6 / 8.0, F.last_kernel()), flush=True)
     same = torch.equal(res[1][2].view(torch.uint8), out.view(torch.uint8))
     print("         staged == generic: %s" % same, flush=True)
-    F.set_option("stack_wg", 1)
+    F.set_option("x_stack_wg", 1)
     del vol, out, res

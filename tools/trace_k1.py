@@ -1,4 +1,4 @@
-"""Per-wave phase timeline of one cfg2 launch of remap_lds_kernel (variant built with -DDCP_EXPERIMENT_TRACE):
+"""Per-wave phase timeline of one cfg2 launch of remap_lds_kernel (the lab build: `make -C discorpy_amd/csrc lab`, DCP_LIB_PATH=discorpy_amd/lib/libdiscorpy_hip_lab.so):
 DCP_LIB_PATH=discorpy_amd/lib/libdcp_var_trace.so python tools/trace_k1.py [blend order]"""
 import ctypes as C
 import os

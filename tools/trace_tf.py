@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase timeline of spline_tile_filter_kernel (library built with -DDCP_EXPERIMENT_TF_TRACE, selected through DCP_LIB_PATH):
+"""Phase timeline of spline_tile_filter_kernel (the lab build: `make -C discorpy_amd/csrc lab`, DCP_LIB_PATH=discorpy_amd/lib/libdiscorpy_hip_lab.so):
 per tile, cycles between the phase boundaries [commit+barrier | issue next loads | recursion | store issue | last barrier]."""
 import ctypes as C
 import os
