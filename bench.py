@@ -258,7 +258,76 @@ def e2e_child():
     res["cfg4_unwarp_slice_backward_depth32"] = {"ms": round(ms, 3), "Mpixels_per_s": round(D * W / ms / 1e3, 2)}
     ms = med(lambda: pp.unwarp_chunk_slices_backward(vol, c4["xcenter"], c4["ycenter"], c4["list_fact"], 1248, 1311), 6)
     res["cfg4_unwarp_chunk_slices_64rows_depth32"] = {"ms": round(ms, 3), "Mpixels_per_s": round(D * 64 * W / ms / 1e3, 1)}
+    try:
+        res["pcie"] = pcie_floor(img.nbytes)
+        fl = res["pcie"].get("both_directions_concurrent_ms")
+        if fl:
+            res["cfg2_unwarp_image_backward_4096"]["pcie_floor_ms"] = fl
+            res["cfg2_unwarp_image_backward_4096"]["of_pcie_floor"] = round(res["cfg2_unwarp_image_backward_4096"]["ms"] / fl, 3)
+    except Exception as e:      # noqa: BLE001 -- context only
+        res["pcie"] = {"error": repr(e)}
     print(json.dumps(res), flush=True)
+
+
+def pcie_floor(nbytes, reps=7):
+    """What the PCIe link of THIS box and THIS HIP runtime gives a frame's worth of data: `nbytes` up, `nbytes` down, from / into
+    registered (pinned, page-aligned) host memory through the C ABI's copy helper -- each direction alone, one after the other, and
+    both at once from two host threads on two streams.  `both_directions_concurrent_ms` is the floor of a NumPy -> NumPy call that
+    moves its frame with runtime copies; where a runtime does not overlap the two (the one bundled with PyTorch-ROCm), it equals
+    the serial figure and the drop-in's direct-write path is what beats it."""
+    import ctypes as C
+    import mmap
+    import threading
+    L = F.lib()
+    dev = -1
+    bufs = [mmap.mmap(-1, nbytes) for _ in range(2)]          # page-aligned, nothing else in their pages
+    ptrs = [C.addressof(C.c_char.from_buffer(b)) for b in bufs]
+    for b in bufs:
+        b.write(b"\1" * nbytes)
+    for p_ in ptrs:
+        F.check(L.dcp_host_register(p_, nbytes, dev))
+    d_up, d_down = F.DeviceBuffer(nbytes, dev), F.DeviceBuffer(nbytes, dev)
+    s_up, s_down = C.c_void_p(), C.c_void_p()
+    F.check(L.dcp_stream_create(C.byref(s_up), dev))
+    F.check(L.dcp_stream_create(C.byref(s_down), dev))
+
+    def up():
+        F.check(L.dcp_memcpy(d_up.ptr, ptrs[0], nbytes, F.COPY_H2D, dev, s_up))
+
+    def down():
+        F.check(L.dcp_memcpy(ptrs[1], d_down.ptr, nbytes, F.COPY_D2H, dev, s_down))
+
+    def both():
+        th = threading.Thread(target=down)
+        th.start()
+        up()
+        th.join()
+
+    def serial():
+        up()
+        down()
+
+    def best(fn):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return round(min(ts) * 1e3, 3)
+    try:
+        out = {"bytes_each_way": int(nbytes), "h2d_ms": best(up), "d2h_ms": best(down), "both_directions_serial_ms": best(serial),
+               "both_directions_concurrent_ms": best(both)}
+        out["runtime_overlaps_directions"] = bool(out["both_directions_concurrent_ms"] < 0.85 * out["both_directions_serial_ms"])
+        out["h2d_GBps"], out["d2h_GBps"] = round(nbytes / out["h2d_ms"] / 1e6, 1), round(nbytes / out["d2h_ms"] / 1e6, 1)
+    finally:
+        for p_ in ptrs:
+            L.dcp_host_unregister(p_)
+        L.dcp_stream_destroy(s_up)
+        L.dcp_stream_destroy(s_down)
+        d_up.free()
+        d_down.free()
+    return out
 
 
 def end_to_end_numpy():

@@ -50,6 +50,12 @@ def test_bench_line_carries_every_config_verified(hip):
     # the drop-in caller's number: NumPy in -> NumPy out, PCIe-inclusive
     e2e = j["end_to_end_numpy"]
     assert e2e["default_runtime"]["cfg2_unwarp_image_backward_4096"]["ms"] > 0 and e2e["default_runtime"]["cfg4_unwarp_slice_backward_depth32"]["ms"] > 0
+    # ... next to what the link and the runtime of this box give a frame each way at once
+    for rt in ("default_runtime", "system_rocm_runtime"):
+        pc = e2e[rt]["pcie"]
+        assert pc["bytes_each_way"] == 4096 * 4096 * 4 and 0 < pc["h2d_ms"] and 0 < pc["d2h_ms"], pc
+        assert 0 < pc["both_directions_concurrent_ms"] <= 1.1 * pc["both_directions_serial_ms"], pc
+        assert e2e[rt]["cfg2_unwarp_image_backward_4096"]["pcie_floor_ms"] == pc["both_directions_concurrent_ms"]
 
 
 def test_the_drivers_command_is_self_consistent_and_repeatable(hip):
