@@ -162,6 +162,14 @@ class HostPool:
                 self.hits += 1
             else:
                 self.misses += 1
+        if block is not None and not block.registered and nbytes >= _PIN_MIN_BYTES:
+            # a block that was created plain -- the pinned budget was used up, or the direct-write path did not apply at the time
+            # (host_direct set later) -- gets another chance when it is handed out again: a registered twin replaces it (a plain
+            # block cannot be registered in place: it shares its edge pages with the heap).  ADVICE r4
+            if _pinned_bytes + nbytes <= _pin_cap() and os.environ.get("DISCORPY_AMD_PIN_OUTPUTS", "1") != "0":
+                twin = _Block(nbytes)
+                if twin.registered:
+                    block = twin
         if block is None:
             block = _Block(nbytes)
         return np.asarray(_Lease(self, block, shape, dtype))

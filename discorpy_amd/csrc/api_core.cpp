@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace dcpapi {
@@ -626,7 +627,17 @@ int dcp_get_option(const char* key_in, int* value) {
   else if (!strcmp(key, "store_wait")) *value = g_store_wait;
   else if (!strcmp(key, "host_direct_applies")) {        // read-only: measures the runtime once (needs a device)
     int n = 0;
-    *value = (hipGetDeviceCount(&n) == hipSuccess && n > 0 && host_direct_applies()) ? 1 : 0;
+    // (the one-off probe moves 32 MiB each way: on the device host frames will go to -- DISCORPY_AMD_DEVICE, as the Python front end
+    // reads it -- rather than on whatever device happens to be current)
+    int dev = -1;
+    if (const char* e = getenv("DISCORPY_AMD_DEVICE")) dev = atoi(e);
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      *value = 0;
+    } else {
+      DeviceScope scope(dev >= 0 && dev < n ? dev : -1);
+      *value = host_direct_applies() ? 1 : 0;
+    }
   }
   else return fail(DCP_ERR_INVALID_ARG, "unknown option '%s'", key_in);
   return DCP_OK;

@@ -1674,6 +1674,9 @@ __global__ void __launch_bounds__(256, (sizeof(T) >= 4 ? 3 : DCP_STACK_INT_WAVES
   const T* proj = volT + (size_t)d0 * (size_t)st.proj_stride;
   T* out = outT + ((size_t)d0 * (size_t)st.nrows + (size_t)min(r0, st.nrows - 1)) * (size_t)st.W;
   const size_t out_step = (size_t)st.nrows * (size_t)st.W;
+  // (bounds-checking build: the vector-memory instructions this lane's wave has issued since its share of the last fill -- the lazy
+  // wait below is right only if there were at least kLdsTH of them)
+  DCP_VM_COUNTER(vm_since_fill);
   auto blend_store = [&](const T* t_lo, const T* t_hi, const __amdgpu_buffer_rsrc_t& dst, int k) {
     // t_lo / t_hi: the tap pairs of the two rows (LDS or global); a_: the byte address (for the aligned-dword extraction)
     if constexpr (kIsF32) {
@@ -1690,7 +1693,10 @@ __global__ void __launch_bounds__(256, (sizeof(T) >= 4 ? 3 : DCP_STACK_INT_WAVES
         f.b.y = __float_as_uint(t_hi[1]);
       }
       const float v = finish<SAMPLER, true, float>(f);
-      if (k < rows) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+      if (k < rows) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
+        DCP_VM_ISSUED(vm_since_fill);
+      }
     } else {
       // scipy NI_GeometricTransform: w0 = 1 - f, w1 = 1 - w0 (not f itself where 1 - f rounds); ((v * wy) * wx) summed left to right
       // (the empty asm keeps the conversions and the weights inside the projection loop: hoisted, they are 128 registers again)
@@ -1703,6 +1709,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) >= 4 ? 3 : DCP_STACK_INT_WAVES
       acc += ((double)t_hi[1] * wy1_) * wx1_;
       const T v = to_elem<T>(acc);
       if (k < rows) {
+        DCP_VM_ISSUED(vm_since_fill);
         if constexpr (ES == 8) {
           typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
           const unsigned long long b = (unsigned long long)__double_as_longlong((double)v);
@@ -1730,11 +1737,16 @@ __global__ void __launch_bounds__(256, (sizeof(T) >= 4 ? 3 : DCP_STACK_INT_WAVES
       // when the wave has all its rows and a lane inside the image -- then "at most kLdsTH outstanding" means the fill has landed and
       // the stores stay in flight under the barrier, the next fill and the blend (waiting for them too cost a write round trip per
       // projection).  Fewer stores than that (ragged waves): wait for everything
-      if (lazy_wait && d > d0) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // (d0: no stores behind the first fill yet)
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lazy_wait && d > d0) {
+        DCP_VM_CHECK(active, vm_since_fill, kLdsTH);                                     // (checking build only)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // (d0: no stores behind the first fill yet)
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __syncthreads();                                      // everyone's share has landed; everyone is done with the other slab
       if constexpr (NSLAB == 2) {
         if (d + 1 < d1) fill(proj + st.proj_stride, cur ^ 1); // projection d + 1 streams in under the blend of d
+        DCP_VM_RESET(vm_since_fill);
       }
       if (active) {
         const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (int)((uint32_t)rows * out_row), 0x00020000);
@@ -1753,6 +1765,7 @@ __global__ void __launch_bounds__(256, (sizeof(T) >= 4 ? 3 : DCP_STACK_INT_WAVES
               asm volatile("" : "+v"(fy_), "+v"(fx_));            // (see blend_store)
               const T v = to_elem_in_range<T>(exact_lerp_taps<T>(t, t + kBoxWEl, (double)fx_, (double)fy_));
               if (k < rows) {
+                DCP_VM_ISSUED(vm_since_fill);
                 if constexpr (ES == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
                 else __builtin_amdgcn_raw_buffer_store_b8((unsigned char)v, dst, xoff, (uint32_t)k * out_row, DCP_STORE_AUX);
               }

@@ -185,7 +185,8 @@ def unwarp_color_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode=
         dense = (lambda t: t.contiguous()) if is_torch else np.ascontiguousarray
         return parts[2](unwarp_color_image_backward(dense(parts[0]), xcenter, ycenter, list_fact, order, mode, blend=blend),
                         unwarp_color_image_backward(dense(parts[1]), xcenter, ycenter, list_fact, order, mode, blend=blend))
-    if order <= 1 and blend in (None, "scipy", "exact", "f64lerp", "f64") and 1 <= mat_pad.shape[2] <= 64:
+    # (`blend` names are case-insensitive everywhere, here too: "SciPy" must not fall to the plane-by-plane path -- ADVICE r4)
+    if order <= 1 and (blend is None or str(blend).lower() in ("scipy", "exact", "f64lerp", "f64")) and 1 <= mat_pad.shape[2] <= 64:
         return _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order, blend)
     # channels as dense planes through the batched entry point (the reference's loop over mat_pad[:, :, i], utility.py:320-341):
     # device-resident float32 planes at order 0 / 1 share ONE launch, the other cases go plane by plane inside it

@@ -708,8 +708,19 @@ static inline uint64_t x86_double_to_u64(double t)
 static inline void store_typed(void *dst, int dtype, int64_t i, double t)
 {
     switch (dtype) {
-    case ORC_DT_I64: ((int64_t *)dst)[i] = x86_cvttsd2si(round_signed(t, -9223372036854775808.0, 9223372036854775808.0)); break;
-    case ORC_DT_U64: ((uint64_t *)dst)[i] = x86_double_to_u64(round_unsigned(t, 18446744073709551616.0)); break;
+    case ORC_DT_I64: {
+        /* (round 5, golden G12b at order 3) a value STRICTLY above 2^63 takes scipy's clamp branch, `_t = NPY_MAX_INT64; (npy_int64)_t`,
+         * whose out-of-range conversion the reference's compiler folded at build time -- to INT64_MAX, saturating --, while a value
+         * of exactly 2^63 is not clamped and goes through the run-time cvttsd2si: INT64_MIN.  Likewise 2^64 / UINT64_MAX below. */
+        const double r_ = round_signed(t, -9223372036854775808.0, 1.0e300);
+        ((int64_t *)dst)[i] = r_ > 9223372036854775808.0 ? INT64_MAX : x86_cvttsd2si(r_);
+        break;
+    }
+    case ORC_DT_U64: {
+        const double r_ = round_unsigned(t, 1.0e300);
+        ((uint64_t *)dst)[i] = r_ > 18446744073709551616.0 ? UINT64_MAX : x86_double_to_u64(r_);
+        break;
+    }
     case ORC_DT_BOOL: ((uint8_t *)dst)[i] = (uint8_t)(t >= 0.0 && t < 256.0 ? t : 0.0); break;   /* CASE_INTERP_OUT(NPY_BOOL): a C cast, truncation */
     case ORC_DT_F32: ((float *)dst)[i] = (float)t; break;
     case ORC_DT_F64: ((double *)dst)[i] = t; break;
