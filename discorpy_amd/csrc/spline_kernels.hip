@@ -1484,12 +1484,23 @@ __global__ void __launch_bounds__(256, 2) spline_wg_rowfused_kernel(const Spline
       double cs[J];
       if (interior_x) {
         if (live) {
+          // every sample of the thread's reach into registers FIRST (the compiler otherwise sinks each LDS read next to its use and
+          // waits for it alone: 39 exposed LDS latencies per pass), scaled by lam on the way; the causal values overwrite them
+          double w[HP];
+#pragma unroll
+          for (int i = 0; i < HP; ++i) w[i] = line[s0 - HP + i];
+#pragma unroll
+          for (int j = 0; j < J; ++j) cs[j] = line[s0 + j];
+#pragma unroll
+          for (int i = 0; i < HP; i += 6)
+            asm volatile("" : "+v"(w[i]), "+v"(w[i + 1 < HP ? i + 1 : i]), "+v"(w[i + 2 < HP ? i + 2 : i]), "+v"(w[i + 3 < HP ? i + 3 : i]),
+                              "+v"(w[i + 4 < HP ? i + 4 : i]), "+v"(w[i + 5 < HP ? i + 5 : i]));
           double t = 0.0;
 #pragma unroll
-          for (int i = 0; i < HP; ++i) t = line[s0 - HP + i] * lam + z * t;
+          for (int i = 0; i < HP; ++i) t = w[i] * lam + z * t;
 #pragma unroll
           for (int j = 0; j < J; ++j) {
-            t = line[s0 + j] * lam + z * t;
+            t = cs[j] * lam + z * t;
             cs[j] = t;
           }
           t = 0.0;
@@ -1555,65 +1566,80 @@ __global__ void __launch_bounds__(256, 2) spline_wg_rowfused_kernel(const Spline
   if (rows == 0 || x >= a.W) return;
   // ---- phase 2: the taps out of the slab
   const double padd = (double)a.pad;
-  auto value = [&](int k) -> double {
-    double wyv[6], wxv[6];
-    int sy, sx;
-    if constexpr (EXACT) {
-      sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
-      sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+  if (inside) {
+    // no tap folds: base address + constant offsets, sixteen rows unrolled (spline_wg_kernel's code on the wider slab)
+    const int org = by0 * PD + so;
+    auto value = [&](int k) -> double {
+      double wyv[6], wxv[6];
+      int sy, sx;
+      if constexpr (EXACT) {
+        sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
+        sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
+      } else {
+        sy = spline_weights<ORDER, true>((double)yf[k] + padd, wyv);
+        sx = spline_weights<ORDER, true>((double)xf[k] + padd, wxv);
+      }
+      DCP_BOUNDS((sy * PD + sx - org) * 8, (ORDER * PD + ORDER + 1) * 8, sizeof(s_box), 10);
+      const double* base = s_box + (sy * PD + sx - org);
+      double t = 0.0;
+      if constexpr (EXACT) {
+#pragma unroll
+        for (int j = 0; j <= ORDER; ++j) {
+          const double* row = base + j * PD;
+#pragma unroll
+          for (int q = 0; q <= ORDER; ++q) t += (row[q] * wyv[j]) * wxv[q];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j <= ORDER; ++j) {
+          const double* row = base + j * PD;
+          double r = row[0] * wxv[0];
+#pragma unroll
+          for (int q = 1; q <= ORDER; ++q) r = __builtin_fma(row[q], wxv[q], r);
+          t = j == 0 ? r * wyv[0] : __builtin_fma(r, wyv[j], t);
+        }
+      }
+      return t;
+    };
+    if (a.dst_dtype == kF32 && (uint64_t)a.H * (uint64_t)a.W * 4u < (1ull << 32)) {
+      const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((uint32_t)a.H * (uint32_t)a.W * 4u), 0x00020000);
+      const uint32_t xoff = ((uint32_t)y0 * (uint32_t)a.W + (uint32_t)x) * 4u, row_bytes = (uint32_t)a.W * 4u;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k >= rows) continue;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)value(k)), drs, xoff, (uint32_t)k * row_bytes, DCP_SPLINE_OUT_AUX);
+      }
     } else {
-      sy = spline_weights<ORDER, true>((double)yf[k] + padd, wyv);
-      sx = spline_weights<ORDER, true>((double)xf[k] + padd, wxv);
-    }
-    int ry[ORDER + 1], rx[ORDER + 1];
-    if (inside) {
 #pragma unroll
-      for (int q = 0; q <= ORDER; ++q) {
-        ry[q] = sy + q - by0;
-        rx[q] = sx + q - so;
+      for (int k = 0; k < 16; ++k) {
+        if (k >= rows) continue;
+        store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, value(k));
       }
-    } else {                     // a tile at the plane's edge: its taps fold as the boundary mode says, into rows / columns of the slab
-#pragma unroll
-      for (int q = 0; q <= ORDER; ++q) {
-        ry[q] = spline_fold(sy + q, a.Hp, a.mode) - by0;
-        rx[q] = spline_fold(sx + q, a.Wp, a.mode) - so;
-      }
-    }
-    DCP_BOUNDS((ry[0] * PD + rx[0]) * 8, 8, sizeof(s_box), 10);
-    DCP_BOUNDS((ry[ORDER] * PD + rx[ORDER]) * 8, 8, sizeof(s_box), 11);
-    double t = 0.0;
-    if constexpr (EXACT) {
-#pragma unroll
-      for (int j = 0; j <= ORDER; ++j) {
-        const double* row = s_box + ry[j] * PD;
-#pragma unroll
-        for (int q = 0; q <= ORDER; ++q) t += (row[rx[q]] * wyv[j]) * wxv[q];
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j <= ORDER; ++j) {
-        const double* row = s_box + ry[j] * PD;
-        double r = row[rx[0]] * wxv[0];
-#pragma unroll
-        for (int q = 1; q <= ORDER; ++q) r = __builtin_fma(row[rx[q]], wxv[q], r);
-        t = j == 0 ? r * wyv[0] : __builtin_fma(r, wyv[j], t);
-      }
-    }
-    return t;
-  };
-  if (a.dst_dtype == kF32 && (uint64_t)a.H * (uint64_t)a.W * 4u < (1ull << 32)) {
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((uint32_t)a.H * (uint32_t)a.W * 4u), 0x00020000);
-    const uint32_t xoff = ((uint32_t)y0 * (uint32_t)a.W + (uint32_t)x) * 4u, row_bytes = (uint32_t)a.W * 4u;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (k >= rows) continue;
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)value(k)), drs, xoff, (uint32_t)k * row_bytes, DCP_SPLINE_OUT_AUX);
     }
   } else {
+    // a tile at the plane's edge: its taps fold as the boundary mode says, into rows / columns of the slab.  One ROLLED loop over the
+    // rows (sixteen unrolled copies of the folding gather were most of a 340 KB kernel that lived on instruction-cache misses)
+#pragma unroll 1
+    for (int k = 0; k < rows; ++k) {
+      double xd, yd;            // (evaluated again -- the same values -- rather than indexing the register arrays with a loop variable)
+      map_coord<KIND, NF, RW>(map, s_row[wave], s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
+      double wyv[6], wxv[6];
+      const int sy = spline_weights<ORDER>((double)round_clip_f32(yd, hmaxf) + padd, wyv);
+      const int sx = spline_weights<ORDER>((double)round_clip_f32(xd, wmaxf) + padd, wxv);
+      int ry[ORDER + 1], rx[ORDER + 1];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (k >= rows) continue;
-      store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, value(k));
+      for (int q = 0; q <= ORDER; ++q) {
+        ry[q] = (spline_fold(sy + q, a.Hp, a.mode) - by0) * PD;
+        rx[q] = spline_fold(sx + q, a.Wp, a.mode) - so;
+        DCP_BOUNDS((ry[q] + rx[q]) * 8, 8, sizeof(s_box), 11);
+      }
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j <= ORDER; ++j) {
+#pragma unroll
+        for (int q = 0; q <= ORDER; ++q) t += (s_box[ry[j] + rx[q]] * wyv[j]) * wxv[q];
+      }
+      store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, t);
     }
   }
 }
