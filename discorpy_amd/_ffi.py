@@ -207,12 +207,11 @@ def get_option(key):
     return v.value
 
 
-def debug_counters(reset=True, n=2):
-    """(tiles whose box did not fit, tiles whose containment vote failed[, tiles of the row-fused spline gather whose box did not
-    fit: must stay 0]) since the last reset."""
-    out = (C.c_uint64 * 3)()
-    check(lib().dcp_debug_counters(out, int(n), int(reset)))
-    return tuple(int(out[i]) for i in range(int(n)))
+def debug_counters(reset=True):
+    """(tiles whose box did not fit, tiles whose containment vote failed) since the last reset."""
+    out = (C.c_uint64 * 2)()
+    check(lib().dcp_debug_counters(out, 2, int(reset)))
+    return int(out[0]), int(out[1])
 
 
 def debug_bounds(reset=True):

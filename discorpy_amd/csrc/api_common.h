@@ -127,8 +127,6 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
 // yd = yc + B(r) yu increases with yu at every x over the frame (sufficient test): no row of a chunk can then leave the
 // band the reference crops from the chunk's first and last rows
 bool radial_monotone_in_y(const dcp::MapArgs& m, int64_t H, int64_t W);
-// rigorous: every 128 x 32 tile's box of spline taps (corner hull + 4 + order) fits box_cols x box_rows (api_core.cpp)
-bool wg_boxes_all_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W, int order, double box_cols, double box_rows);
 // that band, [*b0, *b1), with the reference's own arithmetic (postprocessing.py:289-301)
 void reference_chunk_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_first, double row_last, int64_t* b0, int64_t* b1);
 void host_row_band(const dcp::MapArgs& m, int64_t H, int64_t W, double row_start, int64_t nrows, int64_t* b0, int64_t* b1);

@@ -336,66 +336,6 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
   return ok;
 }
 
-// Rigorous: does EVERY 128 x 32 output tile's box of spline taps fit box_cols x box_rows (spline_wg_rowfused_kernel has no filtered
-// plane to fall back to)?  The box is the hull of the tile's four corner coordinates (rounded, clipped: both 1-Lipschitz up to a
-// float32 ulp) widened by `extra` = 4 + order columns / rows.  Hull width <= 127 Lxx + 31 Lxy, height <= 31 Lyy + 127 Lyx with
-// first-derivative bounds over the frame: radial xd = xc + B(r) xu: |d xd / d x| = |B + B' xu^2 / r| <= |B| + |B'| r, |d xd / d y| =
-// |B' xu yu / r| <= |B'| r (x and y alike), suprema on 2048 midpoints plus a Lipschitz term; homography: the derivative numerators
-// are affine, extreme at the frame's corners, over the smallest |D|^2.
-bool wg_boxes_all_fit(int kind, const dcp::MapArgs& m, int64_t H, int64_t W, int order, double box_cols, double box_rows) {
-  double lxx, lxy, lyx, lyy;
-  if (kind == dcp::kRadial) {
-    const int n = m.nfact;
-    double rmax = 0.0;
-    for (double x : {0.0, (double)(W - 1)})
-      for (double y : {0.0, (double)(H - 1)}) rmax = std::max(rmax, std::hypot(x - m.xc, y - m.yc));
-    rmax = rmax * (1.0 + 1e-12) + 1e-9;
-    if (!std::isfinite(rmax) || n < 0) return false;
-    // Lipschitz constants of B and of r B' on [0, rmax] (triangle inequality on the coefficients)
-    double lb = 0.0, lrb = 0.0, rp = 1.0;
-    for (int i = 1; i < n; ++i) {
-      lb += (double)i * std::fabs(m.fact[i]) * rp;
-      lrb += (double)i * (double)i * std::fabs(m.fact[i]) * rp;
-      rp *= rmax;
-    }
-    constexpr int kNodes = 2048;
-    const double h = rmax / kNodes;
-    double sb = 0.0, srb = 0.0;
-    for (int k = 0; k < kNodes; ++k) {
-      const double r = (k + 0.5) * h;
-      double b = 0.0, b1 = 0.0;
-      for (int i = n - 1; i >= 0; --i) b = b * r + m.fact[i];
-      for (int i = n - 1; i >= 1; --i) b1 = b1 * r + (double)i * m.fact[i];
-      sb = std::max(sb, std::fabs(b));
-      srb = std::max(srb, std::fabs(b1) * r);
-    }
-    sb += 0.5 * h * lb;
-    srb += 0.5 * h * lrb;
-    lxx = lyy = sb + srb;
-    lxy = lyx = srb;
-  } else if (kind == dcp::kPersp) {
-    if (!homography_is_tame(m.coef, H, W)) return false;
-    double dmin = 1e300, gx[4] = {0, 0, 0, 0};
-    for (double x : {0.0, (double)(W - 1)})
-      for (double y : {0.0, (double)(H - 1)}) {
-        const double d = (m.coef[6] * x + m.coef[7] * y) + 1.0;
-        const double nx = (m.coef[0] * x + m.coef[1] * y) + m.coef[2], ny = (m.coef[3] * x + m.coef[4] * y) + m.coef[5];
-        dmin = std::min(dmin, std::fabs(d));
-        gx[0] = std::max(gx[0], std::fabs(m.coef[0] * d - m.coef[6] * nx));
-        gx[1] = std::max(gx[1], std::fabs(m.coef[1] * d - m.coef[7] * nx));
-        gx[2] = std::max(gx[2], std::fabs(m.coef[3] * d - m.coef[6] * ny));
-        gx[3] = std::max(gx[3], std::fabs(m.coef[4] * d - m.coef[7] * ny));
-      }
-    const double d2 = dmin * dmin;
-    lxx = gx[0] / d2, lxy = gx[1] / d2, lyx = gx[2] / d2, lyy = gx[3] / d2;
-  } else {
-    return false;
-  }
-  const double extra = 4.0 + (double)order + 2.0;          // margins and tap width of the box + one for the rounding, one for the floor
-  const double bw = 127.0 * lxx + 31.0 * lxy + extra, bh = 31.0 * lyy + 127.0 * lyx + extra;
-  return std::isfinite(bw) && std::isfinite(bh) && bw <= box_cols && bh <= box_rows;
-}
-
 // d/dyu [B(r) yu] = B + B' yu^2 / r >= B - |B'| r: positive on [0, rmax] => every column's row coordinate increases with
 // the row.  1024 samples of B - |B'| r and the same Lipschitz slack as radial_curvature_bound; a folding model fails.
 bool radial_monotone_in_y(const dcp::MapArgs& m, int64_t H, int64_t W) {
@@ -645,8 +585,6 @@ int dcp_set_option(const char* key_in, int value) {
   } else if (!strcmp(key, "box_table")) {
     if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "box_table must be 0, 1 or 2");
     dcp::set_box_table(value);        // 0: every wave of remap_wg_kernel evaluates its tile's corners; 1: once per tile by box_table_kernel where it pays
-  } else if (!strcmp(key, "spline_rowfuse")) {
-    dcp::set_spline_rowfuse(value ? 1 : 0);      // 0: orders 2 / 3 keep their separate row pass (rounds 2-4), A/B
   } else if (!strcmp(key, "spline_wg")) {
     dcp::set_spline_wg(value ? 1 : 0);
   } else if (!strcmp(key, "spline_tiled")) {
@@ -680,7 +618,6 @@ int dcp_get_option(const char* key_in, int* value) {
   else if (!strcmp(key, "wg_per_cu")) *value = g_wg_per_cu;
   else if (!strcmp(key, "spline_tiled")) *value = dcp::get_spline_tiled();
   else if (!strcmp(key, "spline_wg")) *value = dcp::get_spline_wg();
-  else if (!strcmp(key, "spline_rowfuse")) *value = dcp::get_spline_rowfuse();
   else if (!strcmp(key, "box_table")) *value = dcp::get_box_table();
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;
   else if (!strcmp(key, "int_exact")) *value = g_int_exact;
@@ -720,11 +657,6 @@ int dcp_debug_counters(uint64_t* out, int n, int reset) {
   DCP_HIP(dcp::read_lds_stats(v, reset != 0));
   out[0] = v[0];
   out[1] = v[1];
-  if (n >= 3) {         // tiles of the row-fused spline gather whose box did not fit its slab (the host's bound says: none)
-    unsigned long long f = 0;
-    DCP_HIP(dcp::read_fused_overflow(&f, reset != 0));
-    out[2] = f;
-  }
   return DCP_OK;
 }
 

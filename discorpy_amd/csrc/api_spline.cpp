@@ -121,8 +121,6 @@ int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, i
   a.order = order;
   a.mode = mode;
   a.exact_sum = exact_sum;
-  a.rowfuse_ok = (map.tile_dev_ok >= 2 && (order == 2 || order == 3) &&
-                  wg_boxes_all_fit(map_kind == 0 ? dcp::kRadial : dcp::kPersp, map, H, W, order, 144.0, 45.0)) ? 1 : 0;
   a.pad = (mode == dcp::kModeNearest || mode == dcp::kModeGridConstant) ? 12 : 0;
   a.Hp = a.H + 2 * a.pad;
   a.Wp = a.W + 2 * a.pad;

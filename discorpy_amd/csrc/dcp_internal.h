@@ -130,7 +130,6 @@ struct SplineArgs {
   double poles[2];
   double zpow[2][2];       // [axis][pole]: z^n (reflect) or z^(n-1) (mirror), evaluated on the host
   int32_t exact_sum;       // 1: the taps are accumulated in scipy's order, t += (c wy) wx; 0: factorised and fused (the LDS-staged gather only)
-  int32_t rowfuse_ok;      // the host's rigorous bound: every 128 x 32 tile's tap box fits 144 x 45 (spline_wg_rowfused_kernel has no fallback)
 };
 
 struct LaunchOpts {
@@ -175,9 +174,6 @@ hipError_t launch_coords(const ImageArgs& img, const CoordArgs& ca, int sampler,
 hipError_t launch_coord_map(MapKind kind, const ImageArgs& img, const MapArgs& map, float* ymap, float* xmap,
                             hipStream_t stream);
 bool stack_wg_would_take(const StackArgs& st, const MapArgs& map, const LaunchOpts& opts);
-void set_spline_rowfuse(int v);
-int get_spline_rowfuse();
-hipError_t read_fused_overflow(unsigned long long* out, bool reset);
 hipError_t launch_stack(const StackArgs& st, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream);
 

@@ -28,9 +28,6 @@
 namespace dcp {
 
 constexpr int kSplBlock = 256;
-int g_spline_rowfuse = 1;        // option x_spline_rowfuse: 0 keeps the separate row pass of orders 2 / 3 (A/B)
-void set_spline_rowfuse(int v) { g_spline_rowfuse = v; }
-int get_spline_rowfuse() { return g_spline_rowfuse; }
 int g_spline_wg = 1;             // 0: the (order + 1)^2 taps always gathered from global memory (option spline_wg)
 void set_spline_wg(int v) { g_spline_wg = v; }
 int get_spline_wg() { return g_spline_wg; }
@@ -1344,337 +1341,6 @@ __global__ void __launch_bounds__(256, ORDER >= 5 ? 2 : 3) spline_wg_kernel(cons
   }
 }
 
-// ---- the gather with the ROW prefilter folded into its box staging (round 5; orders 2 and 3, one pole) -----------------------
-// spline_wg_kernel reads the fully filtered plane; the row pass before it reads and writes that whole float64 plane once more
-// (134 + 134 MB of a 4096^2 frame's 737).  Here the workgroup stages its box from the COLUMN-filtered plane (a.scratch), HP columns
-// wider on either side, runs the row recursion on the rows of the box in LDS -- thread (row, segment) = 16 rows x 16 segments of 9
-// outputs per pass, the recursion restarted HP samples early exactly as spline_row_lds_kernel restarts it, causal and anti-causal
-// values of a segment in registers, results written back in place -- and gathers from the slab.  The row-filtered plane is never
-// written: 40 -> 24 B per pixel (+ the halo columns).  Tiles at the line ends run the same recursion with the exact end formulas;
-// tiles whose taps fold at the plane's edge (reflect / mirror / nearest kinds) fold them into the slab.  The host takes this path
-// only when a rigorous bound says EVERY tile's box fits the slab (api_core.cpp: wg_boxes_all_fit): there is no filtered plane to
-// fall back to.
-constexpr int kFbRows = kSwBoxH;                 // 45 rows of the box
-constexpr int kFbSeg = 9, kFbNSeg = 16;          // 16 segments of 9 outputs = the 144 columns of the widest box
-static_assert(kFbSeg * kFbNSeg == kSwBoxW, "the segments cover the widest box");
-template <int HP>
-struct FusedBox {
-  static constexpr int PD = kSwBoxW + 2 * HP;               // doubles per slab row (even: 16-byte LDS-DMA)
-  static constexpr int CH = PD / 2;                         // 16-byte chunks per slab row
-  static constexpr int NJ = (kFbRows * CH + 255) / 256;     // loads per wave that cover the slab
-  static constexpr int J = kFbSeg + HP;                     // causal values a thread keeps
-};
-__device__ unsigned long long g_fused_overflow;   // tiles whose box did not fit (the host's bound says: none; read by dcp_debug_counters)
-
-template <int KIND, int ORDER, int NF, bool EXACT>
-__global__ void __launch_bounds__(256, 2) spline_wg_rowfused_kernel(const SplineArgs a, const MapArgs map, void* dst, const double z, const double lam) {
-  constexpr int HP = ORDER == 2 ? 26 : 34;
-  using G = FusedBox<HP>;
-  constexpr int PD = G::PD, CH = G::CH, NJ = G::NJ, J = G::J, SEG = kFbSeg;
-  constexpr int RW = KIND == kRadial ? 2 : 4;
-  // (the slab holds every chunk the NJ loads of the four waves can write: no lane of a load needs masking)
-  __shared__ __attribute__((aligned(16))) double s_box[NJ * 256 * 2];
-  __shared__ double s_row[4][16][RW];
-  __shared__ double s_coef[NF < 0 ? kMaxFact : 1];
-  static_assert(sizeof(s_box) + sizeof(s_row) + sizeof(s_coef) <= 160 * 1024 / 2, "two workgroups per CU");
-  typedef __attribute__((address_space(3))) void* lds_ptr;
-  const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int lane = (int)threadIdx.x & 63;
-  const int wx = wave & 1, wy = wave >> 1;
-  const int tx = blockIdx.x, ty = blockIdx.y;
-  const int y0 = __builtin_amdgcn_readfirstlane(ty * kSwTH + wy * 16);
-  const int x = tx * kSwTW + wx * 64 + lane;
-  const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
-  const int n = a.Wp;
-  // ---- corner pixels -> hull of the taps' base positions in the padded plane (as spline_wg_kernel)
-  int cx0, cx1, cy0, cy1;
-  {
-    const double X = (double)min(tx * kSwTW + (lane & 1) * (kSwTW - 1), a.W - 1);
-    const double Y = (double)min(ty * kSwTH + ((lane >> 1) & 1) * (kSwTH - 1), a.H - 1);
-    double xd, yd;
-    corner_coord<KIND, NF>(map, X, Y, &xd, &yd);
-    const int cxi = (int)round_clip_f32(xd, wmaxf) + a.pad, cyi = (int)round_clip_f32(yd, hmaxf) + a.pad;
-    const int xa = __builtin_amdgcn_readlane(cxi, 0), xb = __builtin_amdgcn_readlane(cxi, 1);
-    const int xc_ = __builtin_amdgcn_readlane(cxi, 2), xd_ = __builtin_amdgcn_readlane(cxi, 3);
-    const int ya = __builtin_amdgcn_readlane(cyi, 0), yb = __builtin_amdgcn_readlane(cyi, 1);
-    const int yc_ = __builtin_amdgcn_readlane(cyi, 2), yd_ = __builtin_amdgcn_readlane(cyi, 3);
-    cx0 = min(min(xa, xb), min(xc_, xd_));
-    cx1 = max(max(xa, xb), max(xc_, xd_));
-    cy0 = min(min(ya, yb), min(yc_, yd_));
-    cy1 = max(max(ya, yb), max(yc_, yd_));
-  }
-  const int bx0 = cx0 - 1 - ORDER / 2, by0 = cy0 - 1 - ORDER / 2;
-  int bx1 = cx1 + 2 + (ORDER + 1) / 2, by1 = cy1 + 2 + (ORDER + 1) / 2;
-  if (bx1 - bx0 + 1 > kSwBoxW || by1 - by0 + 1 > kFbRows) {        // cannot happen under the host's bound: counted, the box cut
-    if (threadIdx.x == 0) atomicAdd(&g_fused_overflow, 1ull);
-    bx1 = min(bx1, bx0 + kSwBoxW - 1);
-    by1 = min(by1, by0 + kFbRows - 1);
-  }
-  const int bh = by1 - by0 + 1;
-  const bool inside = bx0 >= 0 && by0 >= 0 && bx1 <= a.Wp - 1 && by1 <= a.Hp - 1;      // no tap folds
-  const bool interior_x = bx0 - HP >= 0 && bx1 + HP <= n - 1;                           // no line end within reach of the recursion
-  // slab column 0 <-> plane column `so`.  A box that starts left of the plane gets an EVEN `so`: the 16-byte chunk that holds plane
-  // column 0 of row 0 then starts AT element 0 instead of straddling the start of the buffer
-  const int so = (bx0 - HP >= 0) ? bx0 - HP : ((bx0 - HP) & ~1);
-  // ---- fill from the column-filtered plane
-  const uint32_t rstep = (uint32_t)a.Wp * 8u;
-  const unsigned long long plane_bytes = (unsigned long long)a.Hp * rstep;
-  const long long last_row = min(by1, a.Hp - 1);
-  const unsigned long long rows_end = (unsigned long long)(last_row + 1) * rstep;
-  const __amdgpu_buffer_rsrc_t src_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.scratch, 0, (int)(uint32_t)(rows_end < plane_bytes ? rows_end : plane_bytes), 0x00020000);
-  const int nchunk = bh * CH;
-  const uint32_t org = ((uint32_t)by0 * (uint32_t)a.Wp + (uint32_t)so) * 8u;          // (32-bit wrap: a negative origin lands out of range)
-  auto issue_fill = [&](auto jc) {
-    constexpr int j = decltype(jc)::value;
-    if constexpr (j < NJ) {
-      if ((j * 4 + wave) * 64 < nchunk) {
-        const int c = (j * 4 + wave) * 64 + lane;
-        const int row = c / CH, k = c - row * CH;                                      // (constant divisor)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(src_rsrc, (lds_ptr)((unsigned char*)s_box + (j * 4 + wave) * 1024), 16,
-                                                 org + (uint32_t)row * rstep + (uint32_t)k * 16u, 0, 0, 0);
-      }
-    }
-  };
-  if (lane < 16) fill_row<KIND, RW>(map, s_row[wave], lane, (double)min(y0 + lane, a.H - 1));
-  if constexpr (NF < 0 && KIND != kPersp) {
-    if ((int)threadIdx.x < map.nfact) s_coef[threadIdx.x] = map.fact[threadIdx.x];
-    __syncthreads();
-  }
-  // ---- phase 1: the float32 coordinates of this wave's 16 rows, the loads going out in front of them
-  const int rows = __builtin_amdgcn_readfirstlane(max(0, min(16, a.H - y0)));
-  const ColCtx col = make_col<KIND, NF>(map, min(x, a.W - 1));
-  float xf[16], yf[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    if (k == 0) { issue_fill(std::integral_constant<int, 0>{}); issue_fill(std::integral_constant<int, 16>{}); }
-    if (k == 1) { issue_fill(std::integral_constant<int, 1>{}); issue_fill(std::integral_constant<int, 17>{}); }
-    if (k == 2) { issue_fill(std::integral_constant<int, 2>{}); issue_fill(std::integral_constant<int, 18>{}); }
-    if (k == 3) issue_fill(std::integral_constant<int, 3>{});
-    if (k == 4) issue_fill(std::integral_constant<int, 4>{});
-    if (k == 5) issue_fill(std::integral_constant<int, 5>{});
-    if (k == 6) issue_fill(std::integral_constant<int, 6>{});
-    if (k == 7) issue_fill(std::integral_constant<int, 7>{});
-    if (k == 8) issue_fill(std::integral_constant<int, 8>{});
-    if (k == 9) issue_fill(std::integral_constant<int, 9>{});
-    if (k == 10) issue_fill(std::integral_constant<int, 10>{});
-    if (k == 11) issue_fill(std::integral_constant<int, 11>{});
-    if (k == 12) issue_fill(std::integral_constant<int, 12>{});
-    if (k == 13) issue_fill(std::integral_constant<int, 13>{});
-    if (k == 14) issue_fill(std::integral_constant<int, 14>{});
-    if (k == 15) issue_fill(std::integral_constant<int, 15>{});
-    static_assert(NJ <= 19, "two loads in front of the first three coordinate rows, one in front of the others");
-    double xd, yd;
-    map_coord<KIND, NF, RW>(map, s_row[wave], s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
-    xf[k] = round_clip_f32(xd, wmaxf);
-    yf[k] = round_clip_f32(yd, hmaxf);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  // ---- the row recursion on the rows of the box: 16 rows x 16 segments per pass
-  {
-    const int seg = (int)threadIdx.x & 15, rsub = (int)threadIdx.x >> 4;      // 16 consecutive lanes = the 16 segments of one row
-#pragma unroll 1
-    for (int p = 0; p * 16 < bh; ++p) {
-      const int rr = p * 16 + rsub;
-      const int prow = by0 + rr;
-      const bool live = rr < bh && prow >= 0 && prow < a.Hp;
-      double* const line = s_box + rr * PD - so;              // line[i]: sample i of this plane row
-      const int s0u = bx0 + seg * SEG;                        // this thread's outputs: plane columns [s0, s1)
-      const int s0 = max(s0u, 0), s1 = min(min(s0u + SEG, bx1 + 1), n);
-      double cs[J];
-      if (interior_x) {
-        if (live) {
-          // every sample of the thread's reach into registers FIRST (the compiler otherwise sinks each LDS read next to its use and
-          // waits for it alone: 39 exposed LDS latencies per pass), scaled by lam on the way; the causal values overwrite them
-          double w[HP];
-#pragma unroll
-          for (int i = 0; i < HP; ++i) w[i] = line[s0 - HP + i];
-#pragma unroll
-          for (int j = 0; j < J; ++j) cs[j] = line[s0 + j];
-#pragma unroll
-          for (int i = 0; i < HP; i += 6)
-            asm volatile("" : "+v"(w[i]), "+v"(w[i + 1 < HP ? i + 1 : i]), "+v"(w[i + 2 < HP ? i + 2 : i]), "+v"(w[i + 3 < HP ? i + 3 : i]),
-                              "+v"(w[i + 4 < HP ? i + 4 : i]), "+v"(w[i + 5 < HP ? i + 5 : i]));
-          double t = 0.0;
-#pragma unroll
-          for (int i = 0; i < HP; ++i) t = w[i] * lam + z * t;
-#pragma unroll
-          for (int j = 0; j < J; ++j) {
-            t = cs[j] * lam + z * t;
-            cs[j] = t;
-          }
-          t = 0.0;
-#pragma unroll
-          for (int j = J - 1; j >= 0; --j) {
-            t = z * (t - cs[j]);
-            cs[j] = t;
-          }
-        }
-      } else if (live && s1 > s0) {
-        // a line end within reach (the first / last tile columns): the same recursions with every bound per thread and the exact
-        // end formulas of spline_row_lds_kernel
-        const int a1 = min(min(n, s1 + HP), so + PD);
-        double t = 0.0;
-        int i = max(0, s0 - HP);
-        bool first_exact = false;
-        if (i == 0) {
-          const double x0 = line[0] * lam;
-          double z_i = z, acc = x0;
-          const int m = min(min(a.filter_kind == kSplReflect ? n - 1 : n - 2, kHorizon), so + PD - 1);
-          for (int k = 1; k <= m; ++k) {
-            acc += z_i * (line[k] * lam);
-            z_i *= z;
-          }
-          t = a.filter_kind == kSplReflect ? acc * z / (1.0 - z_i * z_i) + x0 : acc;
-          first_exact = true;
-          i = 1;
-        }
-        for (; i < s0; ++i) t = line[i] * lam + z * t;
-        const double c_before = t;
-#pragma unroll
-        for (int j = 0; j < J; ++j) {
-          cs[j] = 0.0;
-          if (s0 + j < a1) {
-            if (!(first_exact && s0 + j == 0)) t = line[s0 + j] * lam + z * t;
-            cs[j] = t;
-          }
-        }
-        t = 0.0;
-#pragma unroll
-        for (int j = J - 1; j >= 0; --j) {
-          const int idx = s0 + j;
-          if (idx < a1) {
-            if (a1 == n && idx == n - 1) {
-              if (a.filter_kind == kSplReflect) t = cs[j] * (z / (z - 1.0));
-              else t = (z / (z * z - 1.0)) * (cs[j] + z * (j > 0 ? cs[j > 0 ? j - 1 : 0] : c_before));
-            } else {
-              t = z * (t - cs[j]);
-            }
-            cs[j] = t;
-          }
-        }
-      }
-      __syncthreads();                                        // every thread of the pass has read its inputs
-      if (live) {
-#pragma unroll
-        for (int j = 0; j < SEG; ++j)
-          if (s0 + j < s1) line[s0 + j] = cs[j];
-      }
-    }
-  }
-  __syncthreads();
-  if (rows == 0 || x >= a.W) return;
-  // ---- phase 2: the taps out of the slab
-  const double padd = (double)a.pad;
-  if (inside) {
-    // no tap folds: base address + constant offsets, sixteen rows unrolled (spline_wg_kernel's code on the wider slab)
-    const int org = by0 * PD + so;
-    auto value = [&](int k) -> double {
-      double wyv[6], wxv[6];
-      int sy, sx;
-      if constexpr (EXACT) {
-        sy = spline_weights<ORDER>((double)yf[k] + padd, wyv);
-        sx = spline_weights<ORDER>((double)xf[k] + padd, wxv);
-      } else {
-        sy = spline_weights<ORDER, true>((double)yf[k] + padd, wyv);
-        sx = spline_weights<ORDER, true>((double)xf[k] + padd, wxv);
-      }
-      DCP_BOUNDS((sy * PD + sx - org) * 8, (ORDER * PD + ORDER + 1) * 8, sizeof(s_box), 10);
-      const double* base = s_box + (sy * PD + sx - org);
-      double t = 0.0;
-      if constexpr (EXACT) {
-#pragma unroll
-        for (int j = 0; j <= ORDER; ++j) {
-          const double* row = base + j * PD;
-#pragma unroll
-          for (int q = 0; q <= ORDER; ++q) t += (row[q] * wyv[j]) * wxv[q];
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j <= ORDER; ++j) {
-          const double* row = base + j * PD;
-          double r = row[0] * wxv[0];
-#pragma unroll
-          for (int q = 1; q <= ORDER; ++q) r = __builtin_fma(row[q], wxv[q], r);
-          t = j == 0 ? r * wyv[0] : __builtin_fma(r, wyv[j], t);
-        }
-      }
-      return t;
-    };
-    if (a.dst_dtype == kF32 && (uint64_t)a.H * (uint64_t)a.W * 4u < (1ull << 32)) {
-      const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((uint32_t)a.H * (uint32_t)a.W * 4u), 0x00020000);
-      const uint32_t xoff = ((uint32_t)y0 * (uint32_t)a.W + (uint32_t)x) * 4u, row_bytes = (uint32_t)a.W * 4u;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        if (k >= rows) continue;
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((float)value(k)), drs, xoff, (uint32_t)k * row_bytes, DCP_SPLINE_OUT_AUX);
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        if (k >= rows) continue;
-        store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, value(k));
-      }
-    }
-  } else {
-    // a tile at the plane's edge: its taps fold as the boundary mode says, into rows / columns of the slab.  One ROLLED loop over the
-    // rows (sixteen unrolled copies of the folding gather were most of a 340 KB kernel that lived on instruction-cache misses)
-#pragma unroll 1
-    for (int k = 0; k < rows; ++k) {
-      double xd, yd;            // (evaluated again -- the same values -- rather than indexing the register arrays with a loop variable)
-      map_coord<KIND, NF, RW>(map, s_row[wave], s_coef, col, k, wmaxf, hmaxf, &xd, &yd);
-      double wyv[6], wxv[6];
-      const int sy = spline_weights<ORDER>((double)round_clip_f32(yd, hmaxf) + padd, wyv);
-      const int sx = spline_weights<ORDER>((double)round_clip_f32(xd, wmaxf) + padd, wxv);
-      int ry[ORDER + 1], rx[ORDER + 1];
-#pragma unroll
-      for (int q = 0; q <= ORDER; ++q) {
-        ry[q] = (spline_fold(sy + q, a.Hp, a.mode) - by0) * PD;
-        rx[q] = spline_fold(sx + q, a.Wp, a.mode) - so;
-        DCP_BOUNDS((ry[q] + rx[q]) * 8, 8, sizeof(s_box), 11);
-      }
-      double t = 0.0;
-#pragma unroll
-      for (int j = 0; j <= ORDER; ++j) {
-#pragma unroll
-        for (int q = 0; q <= ORDER; ++q) t += (s_box[ry[j] + rx[q]] * wyv[j]) * wxv[q];
-      }
-      store_any(dst, a.dst_dtype, (size_t)(y0 + k) * (size_t)a.W + (size_t)x, t);
-    }
-  }
-}
-
-hipError_t read_fused_overflow(unsigned long long* out, bool reset) {
-  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fused_overflow), sizeof(unsigned long long));
-  if (e != hipSuccess || !reset) return e;
-  const unsigned long long zero = 0;
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_fused_overflow), &zero, sizeof(zero));
-}
-
-template <int KIND, int NF>
-static hipError_t launch_spline_rowfused_nf(const SplineArgs& a, const MapArgs& map, void* dst, double z, double lam, hipStream_t stream) {
-  const dim3 grid((unsigned)((a.W + kSwTW - 1) / kSwTW), (unsigned)((a.H + kSwTH - 1) / kSwTH));
-#define DCP_SWF(ORD)                                                                                                                  \
-  if (a.exact_sum) hipLaunchKernelGGL((spline_wg_rowfused_kernel<KIND, ORD, NF, true>), grid, dim3(256), 0, stream, a, map, dst, z, lam); \
-  else hipLaunchKernelGGL((spline_wg_rowfused_kernel<KIND, ORD, NF, false>), grid, dim3(256), 0, stream, a, map, dst, z, lam)
-  if (a.order == 2) { DCP_SWF(2); } else { DCP_SWF(3); }
-#undef DCP_SWF
-  return hipGetLastError();
-}
-
-template <int KIND>
-static hipError_t launch_spline_rowfused(const SplineArgs& a, const MapArgs& map_in, void* dst, double z, double lam, hipStream_t stream) {
-  if constexpr (KIND == kPersp) {
-    return launch_spline_rowfused_nf<KIND, 0>(a, map_in, dst, z, lam, stream);
-  } else {
-    if (map_in.nfact > 5) return launch_spline_rowfused_nf<KIND, -1>(a, map_in, dst, z, lam, stream);
-    MapArgs map = map_in;
-    for (int i = map.nfact < 0 ? 0 : map.nfact; i < 5; ++i) map.fact[i] = 0.0;
-    map.nfact = 5;
-    return launch_spline_rowfused_nf<KIND, 5>(a, map, dst, z, lam, stream);
-  }
-}
-
 template <int KIND, int NF>
 static hipError_t launch_spline_wg_nf(const SplineArgs& a, const MapArgs& map, void* dst, hipStream_t stream) {
   const dim3 grid((unsigned)((a.W + kSwTW - 1) / kSwTW), (unsigned)((a.H + kSwTH - 1) / kSwTH));
@@ -1742,12 +1408,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     halo += hp[p];
   }
   const int samples = kTfSamples;
-  bool col_stream = false, col_lds = false, row_scan = false, row_lds = false, row_fused = false;
-  // certified radial / perspective maps on frames of at least one workgroup tile: the taps out of LDS
-  const bool wg = (map_kind == 0 || map_kind == 1) && map.tile_dev_ok >= 2 && g_spline_wg && a.H >= kSwTH && a.W >= kSwTW &&
-                  (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH;
-  // ... and, when the host's bound says every tile's box fits the slab, with the row pass folded into the gather's staging
-  const bool fuse_rows = wg && g_spline_rowfuse && a.rowfuse_ok && (a.order == 2 || a.order == 3) && a.mode != kModeGridWrap && a.mode != kModeWrap;
+  bool col_stream = false, col_lds = false, row_scan = false, row_lds = false;
   if (tiled && samples - 2 * halo >= 32) {
     TileFilter f;
     f.kind = a.filter_kind;
@@ -1831,10 +1492,9 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       // one pole: staged once at an odd pitch, recursions in registers (spline_row_lds_kernel)
       const int core = hp[0] == 34 ? RowLds<34>::CORE : RowLds<26>::CORE;
       const dim3 g4((unsigned)((f.nlines + kRlRows - 1) / kRlRows), (unsigned)((f.n + core - 1) / core));
-      if (fuse_rows && hp[0] == (a.order == 2 ? 26 : 34)) row_fused = true;          // no row pass: the gather recurses on its own box
-      else if (hp[0] == 34) hipLaunchKernelGGL((spline_row_lds_kernel<34>), g4, dim3(256), 0, stream, f, (uint32_t)ext1);
+      if (hp[0] == 34) hipLaunchKernelGGL((spline_row_lds_kernel<34>), g4, dim3(256), 0, stream, f, (uint32_t)ext1);
       else hipLaunchKernelGGL((spline_row_lds_kernel<26>), g4, dim3(256), 0, stream, f, (uint32_t)ext1);
-      row_lds = !row_fused;
+      row_lds = true;
     } else if (a.npoles == 1 && g_spline_tiled == 4 && f.nlines <= 4 * 65535) {
       // one pole, option spline_tiled = 4 only: the cross-lane scan along the rows (no LDS) -- measured at 84 us per 4096^2 plane
       // against the tile kernel's 72 (VALU-bound: ~50 instructions per 64 samples and scan step), kept for A/B runs
@@ -1879,19 +1539,17 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
   if (e != hipSuccess) return e;
   const int64_t total = map_kind == 2 ? ca.npts : (int64_t)a.H * a.W;
   if (total == 0) return hipSuccess;
+  // certified radial / perspective maps on frames of at least one workgroup tile: the taps out of LDS
+  const bool wg = (map_kind == 0 || map_kind == 1) && map.tile_dev_ok >= 2 && g_spline_wg && a.H >= kSwTH && a.W >= kSwTW &&
+                  (int64_t)a.Hp * a.Wp * 8 < ((int64_t)1 << 32) && a.Hp < 65535 * kSwTH;
   {
     char name[160];
     const char* colk = col_lds ? "spline_col_lds_kernel" : col_stream ? "spline_col_stream_kernel" : "spline_tile_filter_kernel";
     const char* rowk = row_scan ? "spline_row_scan_kernel" : row_lds ? "spline_row_lds_kernel" : "spline_tile_filter_kernel";
     if (!tiled) snprintf(name, sizeof(name), "spline_causal / anticausal / transpose kernels + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     else if (!col_stream && !row_scan && !row_lds) snprintf(name, sizeof(name), "spline_tile_filter_kernel x 2 + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
-    else if (row_fused) snprintf(name, sizeof(name), "%s + spline_wg_rowfused_kernel<order=%d>", colk, a.order);
     else snprintf(name, sizeof(name), "%s + %s + %s<order=%d>", colk, rowk, wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     set_last_kernel_name(name);
-  }
-  if (row_fused) {
-    if (map_kind == 0) return launch_spline_rowfused<kRadial>(a, map, dst, a.poles[0], lam, stream);
-    return launch_spline_rowfused<kPersp>(a, map, dst, a.poles[0], lam, stream);
   }
   if (wg) {
     if (map_kind == 0) return launch_spline_wg<kRadial>(a, map, dst, stream);

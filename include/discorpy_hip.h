@@ -368,8 +368,7 @@ int dcp_map_points_perspective_f64(const double* yx_in, double* yx_out, int64_t 
 
 /* Diagnostics of the LDS-staged gather on the current device: out[0] = wave tiles whose source
  * box did not fit the LDS slab, out[1] = wave tiles whose containment vote failed (both fall back
- * to the direct gather); with n >= 3 also out[2] = tiles of the row-fused spline gather whose box did not fit its slab (the host
- * takes that path only under a bound that says none can: anything but 0 is a bug).  Synchronises the device. */
+ * to the direct gather).  Synchronises the device. */
 int dcp_debug_counters(uint64_t* out, int n, int reset);
 
 /* The bounds-checking debug build (make -C discorpy_amd/csrc bounds -> lib/libdiscorpy_hip_bounds.so, loaded through DCP_LIB_PATH;

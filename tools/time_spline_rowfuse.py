@@ -1,5 +1,7 @@
 #!/usr/bin/env python
-"""A/B on one box: orders 2 / 3 on a device-resident 4096^2 float32 frame (mode reflect) with the row prefilter folded into the
+"""(Lab record: needs the library of commit adad739, where `spline_wg_rowfused_kernel` and the option `x_spline_rowfuse` exist -- the
+kernel was measured and NOT kept: profiles/LAB_NOTEBOOK.md, round 5; `tools/variant_from_git.sh` builds from a revision.)
+A/B on one box: orders 2 / 3 on a device-resident 4096^2 float32 frame (mode reflect) with the row prefilter folded into the
 gather's box staging (option x_spline_rowfuse = 1: spline_col_lds_kernel + spline_wg_rowfused_kernel, round 5) against the three
 launches of round 4 (= 0: + spline_row_lds_kernel + spline_wg_kernel).  Pixels differing between the two and against the oracle."""
 import os
