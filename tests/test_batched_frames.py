@@ -279,3 +279,29 @@ def test_unwarp_images_backward_on_a_3d_array_of_one_calibration(hip, orc):
     got = out.cpu().numpy()
     for i in range(n):
         assert np.array_equal(got[i], orc.unwarp_image_backward(frames[i], xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", ["uint16", "int32", "float64"])
+def test_a_3d_device_array_of_another_element_type_takes_the_stack_kernel(hip, orc, dt):
+    """Frames of a detector (uint16) or of any other element type in one (n, H, W) device array under one calibration: the stack
+    kernel of that type (scipy's blend and store, as frame by frame), every frame equal to its single call and to the oracle."""
+    torch = pytest.importorskip("torch")
+    if not hasattr(torch, dt):
+        pytest.skip("torch has no %s" % dt)
+    H, W, n = 2048, 2200, 3
+    c2 = configs.cfg2()
+    s = 4096.0 / W
+    xc, yc = c2["xcenter"] / s, c2["ycenter"] / s
+    fact = [v * s ** k for k, v in enumerate(c2["list_fact"])]
+    frames = np.stack([(noise(500 + i, (H, W)) * (60000.0 if dt != "float64" else 1.0)).astype(dt) for i in range(n)])
+    t = torch.from_numpy(frames.view(np.int16) if dt == "uint16" and not hasattr(torch, "uint16") else frames).cuda()
+    out = pp.unwarp_images_backward(t, xc, yc, fact)
+    tag = {"uint16": "16-bit", "int32": "32-bit", "float64": "float64"}[dt]
+    assert hip.last_kernel().startswith("stack_wg_kernel<NF=5,scipy," + tag), hip.last_kernel()
+    got = out.cpu().numpy()
+    assert got.shape == (n, H, W) and got.dtype == frames.dtype
+    for i in range(n):
+        assert np.array_equal(got[i], orc.unwarp_image_backward(frames[i], xc, yc, fact, poly=orc.POLY_KERNEL))
+    one = pp.unwarp_image_backward(t[1], xc, yc, fact)
+    assert np.array_equal(one.cpu().numpy(), got[1])
