@@ -687,14 +687,16 @@ const char* dcp_debug_last_kernel(void) { return dcp::last_kernel_name(); }
 
 int dcp_debug_tile_certificate(int map_kind, int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact,
                                int nfact, const double* list_coef) {
-  if (map_kind != DCP_MAP_RADIAL && map_kind != DCP_MAP_PERSPECTIVE) return fail(DCP_ERR_INVALID_ARG, "map_kind must be radial or perspective");
-  if (map_kind == DCP_MAP_PERSPECTIVE && !list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
+  if (map_kind != DCP_MAP_RADIAL && map_kind != DCP_MAP_PERSPECTIVE && map_kind != DCP_MAP_FUSED)
+    return fail(DCP_ERR_INVALID_ARG, "map_kind must be radial, perspective or fused");
+  if (map_kind != DCP_MAP_RADIAL && !list_coef) return fail(DCP_ERR_INVALID_ARG, "null homography pointer");
   dcp::MapArgs map;
   int rc;
-  if ((rc = fill_map(&map, xcenter, ycenter, map_kind == DCP_MAP_RADIAL ? list_fact : nullptr, map_kind == DCP_MAP_RADIAL ? nfact : 0,
-                     map_kind == DCP_MAP_PERSPECTIVE ? list_coef : nullptr)) != DCP_OK)
+  if ((rc = fill_map(&map, xcenter, ycenter, map_kind != DCP_MAP_PERSPECTIVE ? list_fact : nullptr, map_kind != DCP_MAP_PERSPECTIVE ? nfact : 0,
+                     map_kind != DCP_MAP_RADIAL ? list_coef : nullptr)) != DCP_OK)
     return rc;
-  return tile_deviation_certified(map_kind == DCP_MAP_RADIAL ? dcp::kRadial : dcp::kPersp, map, height, width);
+  return tile_deviation_certified(map_kind == DCP_MAP_RADIAL ? dcp::kRadial : map_kind == DCP_MAP_PERSPECTIVE ? dcp::kPersp : dcp::kFused, map, height,
+                                  width);
 }
 
 int dcp_malloc(void** ptr, size_t bytes, int device) {

@@ -385,7 +385,8 @@ const char* dcp_debug_last_kernel(void);
 
 /* The host's tile-deviation certificate for a calibration on a height x width frame (needs no GPU): 0 = none (the staged
  * kernels verify every pixel), 1 = holds for 64 x 16 wave tiles, 2 = also for 128 x 32 workgroup tiles (remap_wg_kernel,
- * stack_wg_kernel, remap_wg_batch_kernel).  map_kind DCP_MAP_RADIAL (list_fact) or DCP_MAP_PERSPECTIVE (list_coef).
+ * stack_wg_kernel, remap_wg_batch_kernel).  map_kind DCP_MAP_RADIAL (list_fact), DCP_MAP_PERSPECTIVE (list_coef) or DCP_MAP_FUSED (both:
+ * 0 or 2).
  * Negative: a DCP_ERR_* code.  For tests and for callers that want to know which kernel their calibration will take. */
 int dcp_debug_tile_certificate(int map_kind, int64_t height, int64_t width, double xcenter, double ycenter, const double* list_fact,
                                int nfact, const double* list_coef);
