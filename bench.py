@@ -1713,6 +1713,12 @@ def main(argv=None):
             out["cfg5_us"], out["cfg5_frac"] = pick("cfg5_frame8192_radial9", "launch_us"), pick("cfg5_frame8192_radial9", "frac")
             out["color_4096x3_us"], out["color_4096x3_frac"] = pick("color_4096x3", "launch_us"), pick("color_4096x3", "frac")
             out["cubic_spline_us"] = pick("cfg2_order3_cubic_spline", "launch_us")
+            # the bit-equal-to-scipy blend and order 0 of the headline workload (the headline itself is timed on the default f64lerp
+            # blend, within one float32 ulp of scipy's operation order)
+            out["cfg2_scipy_exact_us"], out["cfg2_scipy_exact_frac"] = pick("cfg2_scipy_exact_blend", "launch_us"), pick("cfg2_scipy_exact_blend", "frac")
+            out["cfg2_order0_us"], out["cfg2_order0_frac"] = pick("cfg2_order0_nearest", "launch_us"), pick("cfg2_order0_nearest", "frac")
+        if isinstance(batched, dict) and "error" not in batched:
+            out["batched_same_calibration_us_per_frame"], out["batched_same_calibration_frac"] = batched["us_per_frame"], batched["frac_of_hbm_peak"]
         if box is not None:
             out["box"] = box
         if others is not None:
