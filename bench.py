@@ -1625,7 +1625,13 @@ def main(argv=None):
                                                      shape=[D_, 2560, W_], note="every row of every projection in one launch")
         except Exception as e:      # noqa: BLE001
             scaling = {"error": repr(e)}
-        if world > 1 and isinstance(scaling, dict) and "error" not in scaling:
+        all_ok = isinstance(scaling, dict) and "error" not in scaling
+        if world > 1:          # what follows is collective: every rank must take the same branch
+            import torch
+            flag = torch.tensor([1 if all_ok else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            all_ok = bool(int(flag[0]))
+        if world > 1 and all_ok:
             try:
                 scaling["rccl"] = torch_rccl_report(dist, backend, world, rank, dev_index, torch_dbg_dir)
                 if "error" in scaling["rccl"]:          # the entry fails, not the bench
@@ -1635,14 +1641,32 @@ def main(argv=None):
         # the exchange without torch (native RCCL through the C ABI; peer copies): child processes of rank 0, the other ranks wait
         # (on a one-GPU test box -- DCP_BENCH_DEVICE set -- only when DCP_RCCL_PATH names the tests' stand-in for librccl: RCCL
         # itself refuses two ranks on one device)
-        if world > 1 and (os.environ.get("DCP_BENCH_DEVICE") is None or os.environ.get("DCP_RCCL_PATH")) and isinstance(scaling, dict) \
-                and "error" not in scaling:
+        if world > 1 and (os.environ.get("DCP_BENCH_DEVICE") is None or os.environ.get("DCP_RCCL_PATH")) and all_ok:
             sync()
+            # the other ranks wait for rank 0's children on the HOST (the job's key-value store): an RCCL barrier would park a spinning
+            # kernel on every other GPU while the children are being timed on those very GPUs
+            store = None
+            try:
+                from torch.distributed.distributed_c10d import _get_default_store
+                store = _get_default_store()
+            except Exception:      # noqa: BLE001
+                store = None
             if rank == 0:
                 try:
                     scaling["without_torch"] = native_exchange_variants(a, world, a.depth)
                 except Exception as e:      # noqa: BLE001
                     scaling["without_torch"] = {"error": repr(e)}
+                if store is not None:
+                    try:
+                        store.set("dcp_native_variants_done", "1")
+                    except Exception:      # noqa: BLE001
+                        store = None
+            elif store is not None:
+                try:
+                    import datetime
+                    store.wait(["dcp_native_variants_done"], datetime.timedelta(seconds=1800))
+                except Exception:      # noqa: BLE001
+                    pass
             if dist is not None:
                 dist.barrier()
 
