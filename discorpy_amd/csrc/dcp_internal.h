@@ -196,6 +196,8 @@ int get_box_table();
 int get_spline_wg();
 void set_spline_tiled(int v);   // 0: chunked prefilter passes + transposes even where the one-pass tiles qualify (option "spline_tiled")
 int get_spline_tiled();
+void set_pf2d_chunk(int v);     // rows per chunk of spline_prefilter2d_kernel (option "pf2d_chunk"; 0 = automatic)
+int get_pf2d_chunk();
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream);
 // typed_kernels.hip: map_kind 0 radial, 1 perspective, 2 fused, 3 explicit coordinates

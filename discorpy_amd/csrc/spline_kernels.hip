@@ -35,6 +35,9 @@ int g_spline_tiled = 1;          // option spline_tiled (A/B runs and tests): 0 
                                  // register column pass, then the tile kernel along the rows); 2 the LDS tile kernel on both axes; 3 as 1 with the unstaged column
                                  // stream kernel; 4 tile kernel down the columns, cross-lane scan along the rows
 void set_spline_tiled(int v) { g_spline_tiled = v; }
+int g_pf2d_chunk = 0;            // option pf2d_chunk (A/B runs): rows per chunk of spline_prefilter2d_kernel, 0 = chosen from the plane and the chip
+void set_pf2d_chunk(int v) { g_pf2d_chunk = v; }
+int get_pf2d_chunk() { return g_pf2d_chunk; }
 int get_spline_tiled() { return g_spline_tiled; }
 
 __global__ void __launch_bounds__(kSplBlock) spline_expand_kernel(const SplineArgs a) {
@@ -843,6 +846,156 @@ __global__ void __launch_bounds__(256, 3) spline_row_lds_kernel(const TileFilter
   }
 }
 
+// ---- BOTH axes of the one-pole prefilter in ONE pass over the plane: float32 image -> final coefficient plane -----------------
+// The column pass writes a float64 plane (8 B per sample) that the row pass reads back and writes again: 12 + 16 of the spline
+// path's 40 bytes per pixel.  Here a workgroup owns a STRIPE of 252 columns -- CORE columns it writes and HP on both sides -- and
+// walks down it in steps of R = 32 rows: thread = column runs the column recursions in registers as spline_col_stream_kernel
+// does (the causal state carries from step to step, only the anti-causal pass restarts HP rows below the step from values the
+// next step reuses), but its R results go into an LDS tile of 32 x 252 float64 at an odd pitch instead of to memory.  After one
+// barrier thread (row, segment) -- 32 rows x 8 segments of SEG columns -- runs the row recursions over SEG + 2 HP samples of its
+// row as spline_row_lds_kernel does, the results go back into the tile in place and leave as contiguous row pieces.  The
+// column-filtered plane never exists in memory: 4 B read (each source row once per stripe: 252 / CORE = 1.37 loads per sample, the
+// neighbour's share out of the L2) + 8 B written per sample.  The rows of the next step are loaded into registers in front of
+// the row pass and arrive under it.  Vertically the stripe is cut into chunks of `chunk_rows` rows (a multiple of R) so that the
+// launch fills the chip; a chunk pays HP rows of causal warm-up above and HP rows of look-ahead below.
+// No line end is special here: rows and columns outside the plane are READ AT THEIR MIRROR IMAGES (half-sample symmetric for the
+// reflect kind, whole-sample for mirror), which is the extension scipy's exact initial values stand for once z^n has underflowed
+// (the condition of every one-pass kernel) -- a recursion started from zero HP samples outside the plane reaches the edge with
+// the exact value up to |z|^HP <= 2^-64 of the signal, the error every restart inside the plane has too.  Same arithmetic per
+// sample as the two kernels it replaces (t = x lam + z t; t = z (t - c)); single coefficients may differ in the last bit as they
+// do between any two of the prefilter paths.
+#ifndef DCP_PF2D_WAVES
+#define DCP_PF2D_WAVES 2
+#endif
+template <int HP>
+struct Pf2d {
+  static constexpr int R = 32;                           // rows per step
+  static constexpr int NCOL = 252;                       // columns of a stripe incl. both halos (threads 252..255 idle in the column pass)
+  static constexpr int PITCH = 253;                      // odd: the 32 rows of one column fall into 32 distinct bank pairs; 32 x 253 x 8 B = 63.25 KB
+  static constexpr int SEGS = 256 / R;                   // row-pass segments per row
+  static constexpr int SEG = (NCOL - 2 * HP) / SEGS;     // outputs per row-pass thread: 23 (HP = 34) / 25 (HP = 26)
+  static constexpr int CORE = SEGS * SEG;                // columns a stripe writes: 184 / 200
+};
+
+template <int HP>
+__global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const uint32_t src_bytes, const int chunk_rows) {
+  using G = Pf2d<HP>;
+  constexpr int R = G::R, NCOL = G::NCOL, PITCH = G::PITCH, SEG = G::SEG, CORE = G::CORE, NC = R + HP, J = SEG + HP;
+  __shared__ double s_t[R * PITCH];
+  const int tid = (int)threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int H = f.n, W = f.nlines;                             // rows, columns of the plane
+  const int g0 = (int)blockIdx.x * CORE;                       // first column the stripe writes
+  const int Y0 = (int)blockIdx.y * chunk_rows;                 // first row the chunk writes
+  const int Yend = min(H, Y0 + chunk_rows);
+  const double z = f.z[0], lam = f.lam;
+  const int sym = f.kind == kSplReflect ? 1 : 0;               // index i < 0 reads -i - sym, i >= n reads 2 n - 2 + sym - i
+  // ---- column pass: thread = column g0 - HP + tid of the (mirrored) plane
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)f.in, 0, (int)src_bytes, 0x00020000);
+  int gc = g0 - HP + min(tid, NCOL - 1);
+  gc = gc < 0 ? -gc - sym : gc;
+  gc = gc >= W ? 2 * W - 2 + sym - gc : gc;
+  gc = max(0, min(gc, W - 1));                                 // (a stripe that ends far past the plane: those columns are never used)
+  const uint32_t voff = (uint32_t)gc * 4u;
+  const uint32_t rstep = (uint32_t)f.in_ss * 4u;
+  auto ld = [&](int row) -> float {                            // (row is wave-uniform: the row offset travels in an SGPR)
+    int r = __builtin_amdgcn_readfirstlane(row);
+    r = r < 0 ? -r - sym : r;
+    r = r >= H ? 2 * H - 2 + sym - r : r;
+    r = max(0, min(r, H - 1));
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)r * rstep, 0));
+  };
+  int r0 = Y0;                                                 // first row of the current step
+  double tc = 0.0;                                             // the causal state
+  double C[NC];                                                // causal values of rows r0 .. r0 + R + HP - 1
+  {
+    float pre[HP];
+#pragma unroll
+    for (int j = 0; j < HP; ++j) pre[j] = ld(r0 - HP + j);
+#pragma unroll
+    for (int j = 0; j < HP; ++j) tc = (double)pre[j] * lam + z * tc;
+  }
+  {
+    float pre[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j) pre[j] = ld(r0 + j);
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+      tc = (double)pre[j] * lam + z * tc;
+      C[j] = tc;
+    }
+  }
+  // ---- row pass geometry: thread (row_l, seg)
+  const int row_l = tid % R, seg = tid / R;                    // 32 consecutive lanes = the 32 rows of one segment: conflict-free LDS passes
+  const double* a = s_t + row_l * PITCH + seg * SEG;           // a[i]: column-filtered sample g0 - HP + seg SEG + i of this thread's row
+  double* const colw = s_t + min(tid, NCOL);                   // (threads 252..255 write the pad column)
+  const int c_n = min(CORE, W - g0);
+  for (;;) {
+    // ---- anti-causal down the columns: back over the HP rows below the step from zero, then through the step into the tile
+    {
+      double ta = 0.0;
+#pragma unroll
+      for (int j = NC - 1; j >= 0; --j) {
+        ta = z * (ta - C[j]);
+        if (j < R) colw[j * PITCH] = ta;
+      }
+    }
+    // the next step's new rows, in flight under the row pass
+    const bool more = r0 + R < Yend;                           // (workgroup-uniform)
+    float nx[R];
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j);
+    }
+    lds_barrier();                                             // the tile is complete
+    // ---- row pass: causal from HP samples in front of the segment through SEG + HP samples, anti-causal back
+    double cs[J];
+    {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < HP; ++i) t = a[i] * lam + z * t;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        t = a[HP + j] * lam + z * t;
+        cs[j] = t;
+      }
+      t = 0.0;
+#pragma unroll
+      for (int j = J - 1; j >= 0; --j) {
+        t = z * (t - cs[j]);
+        cs[j] = t;
+      }
+    }
+    lds_barrier();                                             // every thread has read its inputs: the results may overwrite them
+    {
+      double* w = s_t + row_l * PITCH + seg * SEG + HP;
+#pragma unroll
+      for (int j = 0; j < SEG; ++j) w[j] = cs[j];
+    }
+    lds_barrier();
+    // ---- the core of the step, contiguous row pieces
+#pragma unroll
+    for (int q = 0; q < R / 4; ++q) {
+      const int rr = q * 4 + wave;
+      if (r0 + rr >= Yend) break;
+      double* o = f.out + (int64_t)(r0 + rr) * f.out_ls + g0;
+      const double* r = s_t + rr * PITCH + HP;
+      for (int idx = lane; idx < c_n; idx += 64) o[idx] = r[idx];
+    }
+    if (!more) break;
+    // ---- the next step: the window moves down R rows, the causal recursion runs on through the new rows
+    r0 += R;
+#pragma unroll
+    for (int j = 0; j < HP; ++j) C[j] = C[j + R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      tc = (double)nx[j] * lam + z * tc;
+      C[HP + j] = tc;
+    }
+    lds_barrier();                                             // the tile has been read out: the next step may overwrite it
+  }
+}
+
 // ---- the row pass (axis 1) as a cross-lane scan: no LDS, no barrier, every access a contiguous 512 bytes ---------------
 // Along a row the recursion runs ACROSS the lanes of a wave.  c_i = x_i + z c_(i-1) over the 64 samples of a block is an
 // inclusive scan with multiplier z -- six steps v_i += z^d v_(i-d), d = 1, 2, 4, .., 32 (the neighbour's value through the LDS
@@ -1408,7 +1561,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     halo += hp[p];
   }
   const int samples = kTfSamples;
-  bool col_stream = false, col_lds = false, row_scan = false, row_lds = false;
+  bool col_stream = false, col_lds = false, row_scan = false, row_lds = false, fused2d = false;
   if (tiled && samples - 2 * halo >= 32) {
     TileFilter f;
     f.kind = a.filter_kind;
@@ -1446,7 +1599,32 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ls = 1;
     f.out_ss = a.Wp;
     dim3 grid((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
-    if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {
+    const double ext_src = ((double)(a.H - 1) * (double)a.src_stride + (double)a.W) * 4.0;
+    if (direct && a.npoles == 1 && g_spline_tiled == 6 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride == 1 && ext_src < 4294967000.0) {
+      // float32 source, one pole: both axes in one pass, the column-filtered plane stays in LDS (spline_prefilter2d_kernel)
+      f.in = a.src;
+      f.in_ls = 1;
+      f.in_ss = a.src_stride;
+      f.out = a.coef;
+      f.out_ls = a.Wp;
+      f.out_ss = 1;
+      const int core = hp[0] == 34 ? Pf2d<34>::CORE : Pf2d<26>::CORE;
+      const int stripes = (a.Wp + core - 1) / core;
+      int ncu = 0, dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+      // chunks of rows: one resident round of workgroups (DCP_PF2D_WAVES per CU) where the plane is tall enough, never under 64 rows
+      int chunk = g_pf2d_chunk;
+      if (chunk <= 0) {
+        const int want = (DCP_PF2D_WAVES * ncu) / stripes;                       // chunks per stripe that fill the chip once
+        chunk = want > 0 ? (a.Hp + want - 1) / want : a.Hp;
+      }
+      chunk = ((chunk + 31) / 32) * 32;
+      if (chunk < 64) chunk = 64;
+      const dim3 g5((unsigned)stripes, (unsigned)((a.Hp + chunk - 1) / chunk));
+      if (hp[0] == 34) hipLaunchKernelGGL((spline_prefilter2d_kernel<34>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, chunk);
+      else hipLaunchKernelGGL((spline_prefilter2d_kernel<26>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, chunk);
+      fused2d = true;
+    } else if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {
       // float32 source, one pole (orders 2 and 3): the register-streaming column pass, no LDS
       f.in = a.src;
       f.in_ls = a.src_cstride;
@@ -1477,6 +1655,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       f.in_ss = a.Wp;
       launch(I0{}, std::false_type{}, SL{}, grid);
     }
+    if (!fused2d) {
     // axis 1: lines are the rows; B -> A
     f.n = a.Wp;
     f.nlines = a.Hp;
@@ -1488,7 +1667,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ss = 1;
     grid = dim3((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
     const double ext1 = (double)a.Hp * (double)a.Wp * 8.0;
-    if (a.npoles == 1 && (g_spline_tiled == 1 || g_spline_tiled == 5) && ext1 < 4294967000.0 && (hp[0] == 26 || hp[0] == 34)) {
+    if (a.npoles == 1 && (g_spline_tiled == 1 || g_spline_tiled == 5 || g_spline_tiled == 6) && ext1 < 4294967000.0 && (hp[0] == 26 || hp[0] == 34)) {
       // one pole: staged once at an odd pitch, recursions in registers (spline_row_lds_kernel)
       const int core = hp[0] == 34 ? RowLds<34>::CORE : RowLds<26>::CORE;
       const dim3 g4((unsigned)((f.nlines + kRlRows - 1) / kRlRows), (unsigned)((f.n + core - 1) / core));
@@ -1503,6 +1682,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       row_scan = true;
     } else {
       launch(I1{}, std::false_type{}, SL{}, grid);
+    }
     }
   } else {
     tiled = false;
@@ -1546,7 +1726,8 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     char name[160];
     const char* colk = col_lds ? "spline_col_lds_kernel" : col_stream ? "spline_col_stream_kernel" : "spline_tile_filter_kernel";
     const char* rowk = row_scan ? "spline_row_scan_kernel" : row_lds ? "spline_row_lds_kernel" : "spline_tile_filter_kernel";
-    if (!tiled) snprintf(name, sizeof(name), "spline_causal / anticausal / transpose kernels + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
+    if (fused2d) snprintf(name, sizeof(name), "spline_prefilter2d_kernel + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
+    else if (!tiled) snprintf(name, sizeof(name), "spline_causal / anticausal / transpose kernels + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     else if (!col_stream && !row_scan && !row_lds) snprintf(name, sizeof(name), "spline_tile_filter_kernel x 2 + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     else snprintf(name, sizeof(name), "%s + %s + %s<order=%d>", colk, rowk, wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     set_last_kernel_name(name);
