@@ -31,9 +31,10 @@ constexpr int kSplBlock = 256;
 int g_spline_wg = 1;             // 0: the (order + 1)^2 taps always gathered from global memory (option spline_wg)
 void set_spline_wg(int v) { g_spline_wg = v; }
 int get_spline_wg() { return g_spline_wg; }
-int g_spline_tiled = 1;          // option spline_tiled (A/B runs and tests): 0 the chunked passes + transposes; 1 the fastest kernels (one pole, float32 source: the LDS-staged
-                                 // register column pass, then the tile kernel along the rows); 2 the LDS tile kernel on both axes; 3 as 1 with the unstaged column
-                                 // stream kernel; 4 tile kernel down the columns, cross-lane scan along the rows
+int g_spline_tiled = 1;          // option spline_tiled (A/B runs and tests): 0 the chunked passes + transposes; 1 the fastest kernels (one pole, float32 source: both axes
+                                 // in one launch, spline_prefilter2d_kernel; otherwise as 6); 2 the LDS tile kernel on both axes; 3 as 6 with the unstaged column
+                                 // stream kernel; 4 tile kernel down the columns, cross-lane scan along the rows; 6 the two launches of rounds 3-5 (the LDS-staged
+                                 // register column pass, then the register row pass behind an odd-pitch LDS staging)
 void set_spline_tiled(int v) { g_spline_tiled = v; }
 int g_pf2d_chunk = 0;            // option pf2d_chunk (A/B runs): rows per chunk of spline_prefilter2d_kernel, 0 = chosen from the plane and the chip
 void set_pf2d_chunk(int v) { g_pf2d_chunk = v; }
@@ -878,7 +879,7 @@ struct Pf2d {
 };
 
 template <int HP>
-__global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const uint32_t src_bytes, const int chunk_rows) {
+__global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const uint32_t src_bytes, const uint32_t out_bytes, const int chunk_rows) {
   using G = Pf2d<HP>;
   constexpr int R = G::R, NCOL = G::NCOL, PITCH = G::PITCH, SEG = G::SEG, CORE = G::CORE, NC = R + HP, J = SEG + HP;
   __shared__ double s_t[R * PITCH];
@@ -896,7 +897,7 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   gc = gc < 0 ? -gc - sym : gc;
   gc = gc >= W ? 2 * W - 2 + sym - gc : gc;
   gc = max(0, min(gc, W - 1));                                 // (a stripe that ends far past the plane: those columns are never used)
-  const uint32_t voff = (uint32_t)gc * 4u;
+  const uint32_t voff = (uint32_t)gc * (uint32_t)f.in_ls * 4u;
   const uint32_t rstep = (uint32_t)f.in_ss * 4u;
   auto ld = [&](int row) -> float {                            // (row is wave-uniform: the row offset travels in an SGPR)
     int r = __builtin_amdgcn_readfirstlane(row);
@@ -930,6 +931,8 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   const double* a = s_t + row_l * PITCH + seg * SEG;           // a[i]: column-filtered sample g0 - HP + seg SEG + i of this thread's row
   double* const colw = s_t + min(tid, NCOL);                   // (threads 252..255 write the pad column)
   const int c_n = min(CORE, W - g0);
+  const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)f.out, 0, (int)out_bytes, 0x00020000);
+  const uint32_t ovoff = (uint32_t)(g0 + lane) * 8u, orow = (uint32_t)f.out_ls * 8u;
   for (;;) {
     // ---- anti-causal down the columns: back over the HP rows below the step from zero, then through the step into the tile
     {
@@ -942,11 +945,11 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
     }
     // the next step's new rows, in flight under the row pass
     const bool more = r0 + R < Yend;                           // (workgroup-uniform)
+    // (also behind the chunk's last step, where nobody uses them: a conditional load costs the register allocation more than
+    // R loads out of the L2 -- the chunk below is reading the same rows)
     float nx[R];
-    if (more) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j);
-    }
+    for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j);
     lds_barrier();                                             // the tile is complete
     // ---- row pass: causal from HP samples in front of the segment through SEG + HP samples, anti-causal back
     double cs[J];
@@ -978,9 +981,17 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
     for (int q = 0; q < R / 4; ++q) {
       const int rr = q * 4 + wave;
       if (r0 + rr >= Yend) break;
-      double* o = f.out + (int64_t)(r0 + rr) * f.out_ls + g0;
-      const double* r = s_t + rr * PITCH + HP;
-      for (int idx = lane; idx < c_n; idx += 64) o[idx] = r[idx];
+      const uint32_t so = (uint32_t)(r0 + rr) * orow;          // (wave-uniform: an SGPR)
+      const double* r = s_t + rr * PITCH + HP + lane;
+#pragma unroll
+      for (int k = 0; k < (CORE + 63) / 64; ++k) {
+        if (lane + 64 * k < c_n) {
+          typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+          const unsigned long long b = (unsigned long long)__double_as_longlong(r[64 * k]);
+          const u32x2_t pk = {(uint32_t)b, (uint32_t)(b >> 32)};
+          __builtin_amdgcn_raw_buffer_store_b64(pk, ors, ovoff + 512u * k, so, 0);
+        }
+      }
     }
     if (!more) break;
     // ---- the next step: the window moves down R rows, the causal recursion runs on through the new rows
@@ -1599,11 +1610,14 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ls = 1;
     f.out_ss = a.Wp;
     dim3 grid((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
-    const double ext_src = ((double)(a.H - 1) * (double)a.src_stride + (double)a.W) * 4.0;
-    if (direct && a.npoles == 1 && g_spline_tiled == 6 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride == 1 && ext_src < 4294967000.0) {
+    // (columns of an interleaved image -- a channel of an (H, W, C) array -- are read in place: 4-byte loads at the pixel pitch)
+    const double ext_src = ((double)(a.H - 1) * (double)a.src_stride + (double)(a.W - 1) * (double)a.src_cstride + 1.0) * 4.0;
+    const double ext_plane = (double)a.Hp * (double)a.Wp * 8.0;
+    if (direct && a.npoles == 1 && g_spline_tiled == 1 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride >= 1 && a.src_stride >= 0 && ext_src < 4294967000.0 &&
+        ext_plane < 4294967000.0) {
       // float32 source, one pole: both axes in one pass, the column-filtered plane stays in LDS (spline_prefilter2d_kernel)
       f.in = a.src;
-      f.in_ls = 1;
+      f.in_ls = a.src_cstride;
       f.in_ss = a.src_stride;
       f.out = a.coef;
       f.out_ls = a.Wp;
@@ -1621,8 +1635,8 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       chunk = ((chunk + 31) / 32) * 32;
       if (chunk < 64) chunk = 64;
       const dim3 g5((unsigned)stripes, (unsigned)((a.Hp + chunk - 1) / chunk));
-      if (hp[0] == 34) hipLaunchKernelGGL((spline_prefilter2d_kernel<34>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, chunk);
-      else hipLaunchKernelGGL((spline_prefilter2d_kernel<26>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, chunk);
+      if (hp[0] == 34) hipLaunchKernelGGL((spline_prefilter2d_kernel<34>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk);
+      else hipLaunchKernelGGL((spline_prefilter2d_kernel<26>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk);
       fused2d = true;
     } else if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {
       // float32 source, one pole (orders 2 and 3): the register-streaming column pass, no LDS

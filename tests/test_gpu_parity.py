@@ -340,14 +340,18 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
             res = {}
             # 1: the default (one-pole orders: the register column pass for float32 frames that need no padding, the register row
             # pass behind an odd-pitch LDS staging); 2: the LDS tile kernel on both axes; 0: the plain kernels
-            for fast in (1, 2, 0):
+            # 1: the default (one-pole orders: both axes in one launch for float32 frames that need no padding); 6: the two launches of
+            # rounds 3-5 (the register column pass, the register row pass behind an odd-pitch LDS staging); 2: the LDS tile kernel on both
+            # axes; 0: the plain kernels
+            for fast in (1, 6, 2, 0):
                 F.set_option("x_spline_tiled", fast)
                 F.set_option("x_spline_wg", 1 if fast else 0)
                 res[fast] = (pp.unwarp_image_backward(*a, order=order, mode=mode),
                              pp.correct_perspective_image(img, coef, order=order, mode=mode))
-                one_pole = fast == 1 and order <= 3
+                one_pole = fast in (1, 6) and order <= 3
                 direct = one_pole and mode not in ("nearest", "grid-constant")        # (those two pad the plane first)
-                pre = ("spline_col_lds_kernel + spline_row_lds_kernel" if direct else
+                pre = ("spline_prefilter2d_kernel" if direct and fast == 1 else
+                       "spline_col_lds_kernel + spline_row_lds_kernel" if direct else
                        "spline_tile_filter_kernel + spline_row_lds_kernel" if one_pole else "spline_tile_filter_kernel x 2")
                 want_name = (pre + " + spline_wg_kernel<order=%d>" if fast else
                              "spline_causal / anticausal / transpose kernels + spline_remap_kernel<order=%d>") % order
@@ -356,7 +360,7 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
                     orc.correct_perspective_image(img, coef, order=order, mode=mode))
             for k in (0, 1):
                 assert np.count_nonzero(res[1][k] != res[0][k]) <= 4 and np.count_nonzero(res[2][k] != res[0][k]) <= 4, (order, mode, k)
-                assert np.count_nonzero(res[1][k] != res[2][k]) <= 4, (order, mode, k)
+                assert np.count_nonzero(res[1][k] != res[2][k]) <= 4 and np.count_nonzero(res[1][k] != res[6][k]) <= 4, (order, mode, k)
                 assert spline_close(res[1][k], want[k]) and np.count_nonzero(res[1][k] != want[k]) <= 8, (order, mode, k)
     finally:
         F.set_option("x_spline_tiled", 1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The one-launch 2-D prefilter (spline_prefilter2d_kernel, option x_spline_tiled = 6) against the two-launch prefilter (= 1)
+"""The one-launch 2-D prefilter (spline_prefilter2d_kernel, option x_spline_tiled = 1, the default) against the two-launch prefilter (= 6)
 and the oracle on frames with partial stripes / chunks, both one-pole orders and both boundary kinds; then us per 4096^2 frame of
 each, and of the fused kernel by rows per chunk.
 
@@ -23,7 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--chunks", default="0,64,128,192,256,384,512")
     ap.add_argument("--reps", type=int, default=30)
-    ap.add_argument("--fast", type=int, default=6)
+    ap.add_argument("--fast", type=int, default=1)
+    ap.add_argument("--slow", type=int, default=6)
     a = ap.parse_args()
     orc.build()
     orc.set_threads(min(32, orc.max_threads()))
@@ -31,25 +32,25 @@ def main():
     F.require_device()
     c = configs.cfg2()
     bad = 0
-    for shape in ((1100, 1347), (256, 256), (300, 2100), (2100, 300), (1024, 4096), (2000, 1500)):
+    for shape in ((1100, 1347), (600, 2100), (2100, 700), (1024, 4096), (2000, 1500), (569, 571)):
         img = np.random.default_rng(5).random(shape, dtype=np.float32)
         for order, mode in [(3, "reflect"), (3, "mirror"), (2, "reflect"), (2, "mirror"), (3, "grid-mirror")]:
             args = (img, c["xcenter"] * shape[1] / 4096, 0.45 * shape[0], c["list_fact"])
             want = orc.unwarp_image_backward(*args, order=order, mode=mode, poly=orc.POLY_KERNEL)
             res = {}
             names = {}
-            for t in (1, a.fast):
+            for t in (a.slow, a.fast):
                 F.set_option("x_spline_tiled", t)
-                for ch in ((0,) if t == 1 else (0, 64, 96)):
+                for ch in ((0,) if t == a.slow else (0, 64, 96)):
                     F.set_option("x_pf2d_chunk", ch)
                     res[(t, ch)] = pp.unwarp_image_backward(*args, order=order, mode=mode)
                     names[(t, ch)] = F.last_kernel()
             F.set_option("x_pf2d_chunk", 0)
             for key in sorted(res):
-                if key[0] == 1:
+                if key[0] == a.slow:
                     continue
                 d_or = int(np.count_nonzero(res[key] != want))
-                d_ab = int(np.count_nonzero(res[key] != res[(1, 0)]))
+                d_ab = int(np.count_nonzero(res[key] != res[(a.slow, 0)]))
                 mx = float(np.max(np.abs(res[key].astype(np.float64) - want)))
                 ok = d_or <= 8 and d_ab <= 4 and mx < 1e-5 and "prefilter2d" in names[key]
                 bad += not ok
@@ -70,7 +71,7 @@ def main():
             F.check(L.dcp_unwarp_image_spline_f32(srcs[i % ring].ptr, dsts[i % ring].ptr, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, order, 0,
                                                   F.MEM_DEVICE, dev, None))
         for rep in range(2):
-            F.set_option("x_spline_tiled", 1)
+            F.set_option("x_spline_tiled", a.slow)
             t = bench.timed_launches(run, a.reps, dev, settle_ms=300.0)
             print("order %d two-launch prefilter: %8.2f us  %s" % (order, t, F.last_kernel()), flush=True)
             F.set_option("x_spline_tiled", a.fast)
