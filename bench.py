@@ -509,9 +509,9 @@ def other_configs(a, dev, srcs, dsts, img0):
     ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.correct_perspective_image(img0, c3["list_coef"], blend=orc.BLEND_F64LERP))
     out["cfg3_perspective_only"] = entry(us, H * W, 8, k, ok)
 
-    # order 3 (scipy's prefiltered cubic B-spline, the reference's `order` argument; mode "reflect"): two one-pass LDS tile
-    # prefilters + the LDS-staged 16-tap gather.  Algorithmic bytes: 4 read + 4 written per pixel, as for order 1 -- the
-    # float64 coefficient plane in between is the algorithm's own traffic.
+    # order 3 (scipy's prefiltered cubic B-spline, the reference's `order` argument; mode "reflect"): the prefilter of both axes
+    # in one launch (the column-filtered plane stays in LDS) + the LDS-staged 16-tap gather.  Algorithmic bytes: 4 read + 4
+    # written per pixel, as for order 1 -- the float64 coefficient plane in between is the algorithm's own traffic.
     def cubic(i):
         F.check(L.dcp_unwarp_image_spline_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c2["xcenter"], c2["ycenter"], fa, nf,
                                               3, 0, F.MEM_DEVICE, dev, None))
@@ -523,8 +523,22 @@ def other_configs(a, dev, srcs, dsts, img0):
     # (lines longer than one prefilter tile restart the recursion inside a halo: equal to the serial oracle up to the odd
     # float32 ulp)
     ok = np.count_nonzero(got != want) <= 32 and float(np.max(np.abs(got.astype(np.float64) - want))) <= 1e-5
-    out["cfg2_order3_cubic_spline"] = entry(us, H * W, 8, k, ok,
-                                            note="three launches per frame; pixels differing from the oracle by one float32 ulp: %d"
+    # HBM bytes per frame of the path's launches (FETCH_SIZE x 2 + WRITE_SIZE, tools/pmc_spline.sh on the GPU box, committed under
+    # profiles/): applies when the summary was taken on the kernels this run launched
+    sp_traffic, sp_src = None, None
+    try:
+        j = json.load(open(os.path.join(ROOT, "profiles", "pmc_spline_latest.json")))
+        names = sorted(n.split("<")[0] for n in j["kernels"])
+        if all(n in k for n in names):
+            sp_traffic = j["total_bytes_per_frame"]
+            sp_src = "profiles/pmc_spline_latest.json: rocprofv3 PMC passes of %s (by construction %d B per pixel), not measured in this run" % (
+                " + ".join(names), j["by_design_bytes_per_frame"] // (H * W))
+        else:
+            sp_src = "none: profiles/pmc_spline_latest.json is of %s" % " + ".join(names)
+    except (OSError, ValueError, KeyError):
+        pass
+    out["cfg2_order3_cubic_spline"] = entry(us, H * W, 8, k, ok, traffic=sp_traffic, traffic_source=sp_src,
+                                            note="two launches per frame (prefilter of both axes, gather); pixels differing from the oracle by one float32 ulp: %d"
                                                  % int(np.count_nonzero(got != want)))
 
     # 16-bit detector frames (the element type tomography cameras deliver): the same kernel on narrower slab rows, scipy's

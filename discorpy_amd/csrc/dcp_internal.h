@@ -198,6 +198,8 @@ void set_spline_tiled(int v);   // 0: chunked prefilter passes + transposes even
 int get_spline_tiled();
 void set_pf2d_chunk(int v);     // rows per chunk of spline_prefilter2d_kernel (option "pf2d_chunk"; 0 = automatic)
 int get_pf2d_chunk();
+void set_pf2d_xcd(int v);       // 0: spline_prefilter2d_kernel's tiles in plain launch order (option "pf2d_xcd")
+int get_pf2d_xcd();
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream);
 // typed_kernels.hip: map_kind 0 radial, 1 perspective, 2 fused, 3 explicit coordinates

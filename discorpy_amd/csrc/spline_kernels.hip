@@ -39,6 +39,9 @@ void set_spline_tiled(int v) { g_spline_tiled = v; }
 int g_pf2d_chunk = 0;            // option pf2d_chunk (A/B runs): rows per chunk of spline_prefilter2d_kernel, 0 = chosen from the plane and the chip
 void set_pf2d_chunk(int v) { g_pf2d_chunk = v; }
 int get_pf2d_chunk() { return g_pf2d_chunk; }
+int g_pf2d_xcd = 1;              // option pf2d_xcd (A/B runs): 0 = tiles in plain row-major launch order (neighbouring stripes on different XCDs)
+void set_pf2d_xcd(int v) { g_pf2d_xcd = v; }
+int get_pf2d_xcd() { return g_pf2d_xcd; }
 int get_spline_tiled() { return g_spline_tiled; }
 
 __global__ void __launch_bounds__(kSplBlock) spline_expand_kernel(const SplineArgs a) {
@@ -879,16 +882,13 @@ struct Pf2d {
 };
 
 template <int HP>
-__global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const uint32_t src_bytes, const uint32_t out_bytes, const int chunk_rows) {
+__device__ __forceinline__ void pf2d_body(const TileFilter& f, const uint32_t src_bytes, const uint32_t out_bytes, const int stripe, const int Y0, const int Yend, double* s_t) {
   using G = Pf2d<HP>;
   constexpr int R = G::R, NCOL = G::NCOL, PITCH = G::PITCH, SEG = G::SEG, CORE = G::CORE, NC = R + HP, J = SEG + HP;
-  __shared__ double s_t[R * PITCH];
   const int tid = (int)threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int H = f.n, W = f.nlines;                             // rows, columns of the plane
-  const int g0 = (int)blockIdx.x * CORE;                       // first column the stripe writes
-  const int Y0 = (int)blockIdx.y * chunk_rows;                 // first row the chunk writes
-  const int Yend = min(H, Y0 + chunk_rows);
+  const int g0 = stripe * CORE;                                // first column the stripe writes
   const double z = f.z[0], lam = f.lam;
   const int sym = f.kind == kSplReflect ? 1 : 0;               // index i < 0 reads -i - sym, i >= n reads 2 n - 2 + sym - i
   // ---- column pass: thread = column g0 - HP + tid of the (mirrored) plane
@@ -899,30 +899,38 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   gc = max(0, min(gc, W - 1));                                 // (a stripe that ends far past the plane: those columns are never used)
   const uint32_t voff = (uint32_t)gc * (uint32_t)f.in_ls * 4u;
   const uint32_t rstep = (uint32_t)f.in_ss * 4u;
-  auto ld = [&](int row) -> float {                            // (row is wave-uniform: the row offset travels in an SGPR)
+  // (row is wave-uniform: the row offset travels in an SGPR.  Only the steps at the top and the bottom of the plane mirror their
+  // rows -- a dozen scalar instructions per load, and a wave issues one instruction per four cycles whatever its kind)
+  auto ld = [&](int row, auto mirrored) -> float {
     int r = __builtin_amdgcn_readfirstlane(row);
-    r = r < 0 ? -r - sym : r;
-    r = r >= H ? 2 * H - 2 + sym - r : r;
-    r = max(0, min(r, H - 1));
+    if constexpr (decltype(mirrored)::value) {
+      r = r < 0 ? -r - sym : r;
+      r = r >= H ? 2 * H - 2 + sym - r : r;
+      r = max(0, min(r, H - 1));
+    }
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)r * rstep, 0));
   };
   int r0 = Y0;                                                 // first row of the current step
   double tc = 0.0;                                             // the causal state
   double C[NC];                                                // causal values of rows r0 .. r0 + R + HP - 1
   {
-    float pre[HP];
+    float pre[HP], pre2[NC];
+    if (r0 - HP >= 0 && r0 + NC <= H) {
 #pragma unroll
-    for (int j = 0; j < HP; ++j) pre[j] = ld(r0 - HP + j);
+      for (int j = 0; j < HP; ++j) pre[j] = ld(r0 - HP + j, std::false_type{});
+#pragma unroll
+      for (int j = 0; j < NC; ++j) pre2[j] = ld(r0 + j, std::false_type{});
+    } else {
+#pragma unroll
+      for (int j = 0; j < HP; ++j) pre[j] = ld(r0 - HP + j, std::true_type{});
+#pragma unroll
+      for (int j = 0; j < NC; ++j) pre2[j] = ld(r0 + j, std::true_type{});
+    }
 #pragma unroll
     for (int j = 0; j < HP; ++j) tc = (double)pre[j] * lam + z * tc;
-  }
-  {
-    float pre[NC];
-#pragma unroll
-    for (int j = 0; j < NC; ++j) pre[j] = ld(r0 + j);
 #pragma unroll
     for (int j = 0; j < NC; ++j) {
-      tc = (double)pre[j] * lam + z * tc;
+      tc = (double)pre2[j] * lam + z * tc;
       C[j] = tc;
     }
   }
@@ -943,13 +951,20 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
         if (j < R) colw[j * PITCH] = ta;
       }
     }
-    // the next step's new rows, in flight under the row pass
+    // the next step's new rows, in flight under the row pass (the chunk's last step, where nobody uses them, loads one cached row
+    // R times instead: registers that are defined on one path only cost the register allocation a dozen spills)
     const bool more = r0 + R < Yend;                           // (workgroup-uniform)
-    // (also behind the chunk's last step, where nobody uses them: a conditional load costs the register allocation more than
-    // R loads out of the L2 -- the chunk below is reading the same rows)
     float nx[R];
+    if (!more) {
 #pragma unroll
-    for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j);
+      for (int j = 0; j < R; ++j) nx[j] = ld(min(r0, H - 1), std::false_type{});
+    } else if (r0 + NC + R <= H) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::false_type{});
+    } else {
+#pragma unroll
+      for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::true_type{});
+    }
     lds_barrier();                                             // the tile is complete
     // ---- row pass: causal from HP samples in front of the segment through SEG + HP samples, anti-causal back
     double cs[J];
@@ -1005,6 +1020,25 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
     }
     lds_barrier();                                             // the tile has been read out: the next step may overwrite it
   }
+}
+
+template <int HP>
+__global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const uint32_t src_bytes, const uint32_t out_bytes, const int chunk_rows, const int stripes,
+                                                                                 const int chunks, const int xcd_order) {
+  using G = Pf2d<HP>;
+  __shared__ double s_t[G::R * G::PITCH];
+  // Workgroups go round-robin to the 8 XCDs (blockIdx.x & 7), each with its own L2: XCD k takes a contiguous run of tiles in
+  // row-major order (stripe fastest), so that the stripes that share 2 HP columns -- neighbours that read the same source rows
+  // at about the same time -- meet in one L2 (FETCH_SIZE 162 -> MB per 4096^2 frame, profiles/r05k_pmc_spline.txt)
+  const int ntiles = stripes * chunks;
+  const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+  const int q = ntiles >> 3, rem = ntiles & 7;
+  const int t = xcd_order ? xcd * q + min(xcd, rem) + j : (int)blockIdx.x;
+  if (xcd_order && j >= q + (xcd < rem ? 1 : 0)) return;        // (the grid is rounded up to a multiple of 8)
+  const int chunk = t / stripes, stripe = t - chunk * stripes;
+  const int Y0 = chunk * chunk_rows;                           // first row the chunk writes
+  const int Yend = min(f.n, Y0 + chunk_rows);
+  pf2d_body<HP>(f, src_bytes, out_bytes, stripe, Y0, Yend, s_t);
 }
 
 // ---- the row pass (axis 1) as a cross-lane scan: no LDS, no barrier, every access a contiguous 512 bytes ---------------
@@ -1634,9 +1668,13 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       }
       chunk = ((chunk + 31) / 32) * 32;
       if (chunk < 64) chunk = 64;
-      const dim3 g5((unsigned)stripes, (unsigned)((a.Hp + chunk - 1) / chunk));
-      if (hp[0] == 34) hipLaunchKernelGGL((spline_prefilter2d_kernel<34>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk);
-      else hipLaunchKernelGGL((spline_prefilter2d_kernel<26>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk);
+      const int chunks = (a.Hp + chunk - 1) / chunk;
+      const int xcd_order = g_pf2d_xcd;
+      const dim3 g5((unsigned)(xcd_order ? ((stripes * chunks + 7) / 8) * 8 : stripes * chunks));
+      if (hp[0] == 34)
+        hipLaunchKernelGGL((spline_prefilter2d_kernel<34>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order);
+      else
+        hipLaunchKernelGGL((spline_prefilter2d_kernel<26>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order);
       fused2d = true;
     } else if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {
       // float32 source, one pole (orders 2 and 3): the register-streaming column pass, no LDS

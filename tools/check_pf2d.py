@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--fast", type=int, default=1)
     ap.add_argument("--slow", type=int, default=6)
+    ap.add_argument("--xcd", default="1")                      # x_pf2d_xcd values to time (0: plain launch order)
+    ap.add_argument("--skip-parity", action="store_true")
     a = ap.parse_args()
     orc.build()
     orc.set_threads(min(32, orc.max_threads()))
@@ -32,7 +34,7 @@ def main():
     F.require_device()
     c = configs.cfg2()
     bad = 0
-    for shape in ((1100, 1347), (600, 2100), (2100, 700), (1024, 4096), (2000, 1500), (569, 571)):
+    for shape in () if a.skip_parity else ((1100, 1347), (600, 2100), (2100, 700), (1024, 4096), (2000, 1500), (569, 571)):
         img = np.random.default_rng(5).random(shape, dtype=np.float32)
         for order, mode in [(3, "reflect"), (3, "mirror"), (2, "reflect"), (2, "mirror"), (3, "grid-mirror")]:
             args = (img, c["xcenter"] * shape[1] / 4096, 0.45 * shape[0], c["list_fact"])
@@ -75,11 +77,14 @@ def main():
             t = bench.timed_launches(run, a.reps, dev, settle_ms=300.0)
             print("order %d two-launch prefilter: %8.2f us  %s" % (order, t, F.last_kernel()), flush=True)
             F.set_option("x_spline_tiled", a.fast)
-            for ch in [int(v) for v in a.chunks.split(",")]:
-                F.set_option("x_pf2d_chunk", ch)
-                t = bench.timed_launches(run, a.reps, dev, settle_ms=300.0)
-                print("order %d fused prefilter, chunk %4d: %8.2f us  %s" % (order, ch, t, F.last_kernel()), flush=True)
+            for xcd in [int(v) for v in a.xcd.split(",")]:
+                F.set_option("x_pf2d_xcd", xcd)
+                for ch in [int(v) for v in a.chunks.split(",")]:
+                    F.set_option("x_pf2d_chunk", ch)
+                    t = bench.timed_launches(run, a.reps, dev, settle_ms=300.0)
+                    print("order %d fused prefilter, xcd order %d, chunk %4d: %8.2f us  %s" % (order, xcd, ch, t, F.last_kernel()), flush=True)
             F.set_option("x_pf2d_chunk", 0)
+            F.set_option("x_pf2d_xcd", 1)
     F.set_option("x_spline_tiled", 1)
     sys.exit(1 if bad else 0)
 

@@ -1,5 +1,6 @@
 #!/bin/bash
-# HBM traffic of the three launches of the cubic-spline path on a 4096^2 float32 frame (tools/time_spline.py --orders 3 --variants 1):
+# HBM traffic of the launches of the cubic-spline path on a 4096^2 float32 frame (tools/time_spline.py --orders 3 --variants ${VARIANT:-1};
+# VARIANT=6: the three launches of rounds 3-5):
 # FETCH_SIZE and WRITE_SIZE in separate rocprofv3 counter passes (counters never together with --stats / trace domains other than
 # --kernel-trace), converted as tools/summarize_prof.py does (KB; reads x 2 -- the calibration of tools/calib_copy.hip, which is
 # re-run here on kernels that move exactly 1 GiB each way) and set against what each launch moves BY CONSTRUCTION.
@@ -10,7 +11,7 @@ mkdir -p $ROOT/gpurun_out
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/psp_$c /tmp/psc_$c
-  (cd $ROOT && timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/psp_$c -o out -- python tools/time_spline.py --orders 3 --variants 1 --reps 12 > /tmp/psp_$c.log 2>&1)
+  (cd $ROOT && timeout 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/psp_$c -o out -- python tools/time_spline.py --orders 3 --variants ${VARIANT:-1} --reps 12 > /tmp/psp_$c.log 2>&1)
 done
 hipcc --offload-arch=gfx950 -O3 -o /tmp/calib_copy $ROOT/tools/calib_copy.hip > /tmp/psc_build.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -39,7 +40,7 @@ acc = collect("psp", lambda k: "spline" in k)
 H = W = 4096
 P = H * W
 # bytes each launch moves by construction (float32 frame 4 B / px, float64 coefficient plane 8 B / px)
-by_design = {"spline_col": (4 * P, 8 * P), "spline_row": (8 * P, 8 * P), "spline_wg": (8 * P, 4 * P)}
+by_design = {"spline_col": (4 * P, 8 * P), "spline_row": (8 * P, 8 * P), "spline_wg": (8 * P, 4 * P), "spline_prefilter2d": (4 * P, 8 * P)}
 out = {"frame": [H, W], "order": 3, "kernels": {}, "calibration": calib,
        "conversion": "FETCH_SIZE / WRITE_SIZE are in KB; reads x 2 on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section; checked above)"}
 tot_r = tot_w = 0.0
@@ -54,8 +55,10 @@ for k, v in sorted(acc.items()):
     print("%-56s read %7.1f MB (design %6.1f)  written %7.1f MB (design %6.1f)  n=%d" % (k[:56], rd / 1e6, d[0] / 1e6, wr / 1e6, d[1] / 1e6, len(v["FETCH_SIZE"])))
 out["total_bytes_per_frame"] = tot_r + tot_w
 out["algorithmic_bytes_per_frame"] = 8 * P
-out["by_design_bytes_per_frame"] = 40 * P
-print("per frame: %.1f MB measured, %.1f MB by design (40 B / px), %.1f MB algorithmic (8 B / px): %.2f x algorithmic" % (
-    (tot_r + tot_w) / 1e6, 40 * P / 1e6, 8 * P / 1e6, (tot_r + tot_w) / (8 * P)))
+design = sum(sum(by_design[f]) for f in by_design if any(k.startswith(f) for k in acc))
+out["by_design_bytes_per_frame"] = design
+print("per frame: %.1f MB measured, %.1f MB by design (%d B / px), %.1f MB algorithmic (8 B / px): %.2f x algorithmic" % (
+    (tot_r + tot_w) / 1e6, design / 1e6, design // P, 8 * P / 1e6, (tot_r + tot_w) / (8 * P)))
 json.dump(out, open(os.path.join(root, "gpurun_out", "pmc_spline.json"), "w"), indent=1)
+# (copy to profiles/pmc_spline_latest.json to have bench.py quote it as the cubic entry's `traffic`)
 PY
