@@ -1029,7 +1029,7 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   __shared__ double s_t[G::R * G::PITCH];
   // Workgroups go round-robin to the 8 XCDs (blockIdx.x & 7), each with its own L2: XCD k takes a contiguous run of tiles in
   // row-major order (stripe fastest), so that the stripes that share 2 HP columns -- neighbours that read the same source rows
-  // at about the same time -- meet in one L2 (FETCH_SIZE 162 -> MB per 4096^2 frame, profiles/r05k_pmc_spline.txt)
+  // at about the same time -- meet in one L2 (FETCH_SIZE x 2: 162 -> 93 MB per 4096^2 frame, profiles/r05k_pmc_spline*.txt)
   const int ntiles = stripes * chunks;
   const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
   const int q = ntiles >> 3, rem = ntiles & 7;
