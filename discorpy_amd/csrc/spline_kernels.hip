@@ -881,8 +881,16 @@ struct Pf2d {
   static constexpr int CORE = SEGS * SEG;                // columns a stripe writes: 184 / 200
 };
 
-template <int HP>
-__device__ __forceinline__ void pf2d_body(const TileFilter& f, const uint32_t src_bytes, const uint32_t out_bytes, const int stripe, const int Y0, const int Yend, double* s_t) {
+// PAD: the plane is the image with `pad` samples added on every side ('nearest': the edge sample repeated, 'grid-constant':
+// zeros -- what spline_expand_kernel would write into a float64 copy first); the recursions run over the padded plane, the
+// loads clamp into the image or return zero.
+struct Pf2dPad {
+  int32_t pad, Hs, Ws, zero_outside;      // samples added per side; rows / columns of the source image; 1: zeros outside it
+};
+
+template <int HP, bool PAD>
+__device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd, const uint32_t src_bytes, const uint32_t out_bytes, const int stripe, const int Y0,
+                                          const int Yend, double* s_t) {
   using G = Pf2d<HP>;
   constexpr int R = G::R, NCOL = G::NCOL, PITCH = G::PITCH, SEG = G::SEG, CORE = G::CORE, NC = R + HP, J = SEG + HP;
   const int tid = (int)threadIdx.x;
@@ -897,6 +905,12 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const uint32_t sr
   gc = gc < 0 ? -gc - sym : gc;
   gc = gc >= W ? 2 * W - 2 + sym - gc : gc;
   gc = max(0, min(gc, W - 1));                                 // (a stripe that ends far past the plane: those columns are never used)
+  bool col_zero = false;                                       // PAD, zeros outside: this thread's column lies in the padding
+  if constexpr (PAD) {
+    gc -= pd.pad;
+    col_zero = pd.zero_outside && (gc < 0 || gc >= pd.Ws);
+    gc = max(0, min(gc, pd.Ws - 1));
+  }
   const uint32_t voff = (uint32_t)gc * (uint32_t)f.in_ls * 4u;
   const uint32_t rstep = (uint32_t)f.in_ss * 4u;
   // (row is wave-uniform: the row offset travels in an SGPR.  Only the steps at the top and the bottom of the plane mirror their
@@ -908,14 +922,26 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const uint32_t sr
       r = r >= H ? 2 * H - 2 + sym - r : r;
       r = max(0, min(r, H - 1));
     }
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)r * rstep, 0));
+    if constexpr (PAD) {
+      r -= pd.pad;                                             // row of the source image
+      if constexpr (decltype(mirrored)::value) {               // (plain loads stay inside the image: no clamp, no zero rows)
+        if (pd.zero_outside && (r < 0 || r >= pd.Hs)) return 0.0f;
+        r = max(0, min(r, pd.Hs - 1));
+      }
+      const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)r * rstep, 0));
+      return col_zero ? 0.0f : v;
+    } else {
+      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)r * rstep, 0));
+    }
   };
+  // rows [plain_lo, plain_hi) of the plane are read as they are: no mirror, and with PAD inside the image
+  const int plain_lo = PAD ? pd.pad : 0, plain_hi = PAD ? H - pd.pad : H;
   int r0 = Y0;                                                 // first row of the current step
   double tc = 0.0;                                             // the causal state
   double C[NC];                                                // causal values of rows r0 .. r0 + R + HP - 1
   {
     float pre[HP], pre2[NC];
-    if (r0 - HP >= 0 && r0 + NC <= H) {
+    if (r0 - HP >= plain_lo && r0 + NC <= plain_hi) {
 #pragma unroll
       for (int j = 0; j < HP; ++j) pre[j] = ld(r0 - HP + j, std::false_type{});
 #pragma unroll
@@ -957,8 +983,8 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const uint32_t sr
     float nx[R];
     if (!more) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) nx[j] = ld(min(r0, H - 1), std::false_type{});
-    } else if (r0 + NC + R <= H) {
+      for (int j = 0; j < R; ++j) nx[j] = ld(min(r0, H - 1), std::true_type{});
+    } else if (r0 + NC >= plain_lo && r0 + NC + R <= plain_hi) {
 #pragma unroll
       for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::false_type{});
     } else {
@@ -1022,9 +1048,9 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const uint32_t sr
   }
 }
 
-template <int HP>
-__global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const uint32_t src_bytes, const uint32_t out_bytes, const int chunk_rows, const int stripes,
-                                                                                 const int chunks, const int xcd_order) {
+template <int HP, bool PAD = false>
+__global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const Pf2dPad pd, const uint32_t src_bytes, const uint32_t out_bytes,
+                                                                                 const int chunk_rows, const int stripes, const int chunks, const int xcd_order) {
   using G = Pf2d<HP>;
   __shared__ double s_t[G::R * G::PITCH];
   // Workgroups go round-robin to the 8 XCDs (blockIdx.x & 7), each with its own L2: XCD k takes a contiguous run of tiles in
@@ -1038,7 +1064,7 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   const int chunk = t / stripes, stripe = t - chunk * stripes;
   const int Y0 = chunk * chunk_rows;                           // first row the chunk writes
   const int Yend = min(f.n, Y0 + chunk_rows);
-  pf2d_body<HP>(f, src_bytes, out_bytes, stripe, Y0, Yend, s_t);
+  pf2d_body<HP, PAD>(f, pd, src_bytes, out_bytes, stripe, Y0, Yend, s_t);
 }
 
 // ---- the row pass (axis 1) as a cross-lane scan: no LDS, no barrier, every access a contiguous 512 bytes ---------------
@@ -1592,11 +1618,14 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
   double lam = 1.0;
   for (int p = 0; p < a.npoles; ++p) lam *= (1.0 - a.poles[p]) * (1.0 - 1.0 / a.poles[p]);
   const bool direct = a.src_dtype == kF32 && a.pad == 0;
-  if (!direct) {
+  bool expanded = false;
+  auto expand = [&]() {                     // the image as a float64 plane (padded modes, element types other than float32), once
+    if (direct || expanded) return;
     const int64_t plane = (int64_t)a.Hp * a.Wp;
     hipLaunchKernelGGL(spline_expand_kernel, dim3((unsigned)((plane + kSplBlock - 1) / kSplBlock)), dim3(kSplBlock), 0,
                        stream, a);
-  }
+    expanded = true;
+  };
   // the one-pass tiles when both axes qualify (reflect / mirror kind, z^n underflowed to zero for every pole)
   bool tiled = (a.filter_kind == kSplReflect || a.filter_kind == kSplMirror) && a.Hp >= kTfSamples && a.Wp >= kTfSamples && g_spline_tiled;
   int halo = 0, hp[2] = {0, 0};
@@ -1647,9 +1676,17 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     // (columns of an interleaved image -- a channel of an (H, W, C) array -- are read in place: 4-byte loads at the pixel pitch)
     const double ext_src = ((double)(a.H - 1) * (double)a.src_stride + (double)(a.W - 1) * (double)a.src_cstride + 1.0) * 4.0;
     const double ext_plane = (double)a.Hp * (double)a.Wp * 8.0;
-    if (direct && a.npoles == 1 && g_spline_tiled == 1 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride >= 1 && a.src_stride >= 0 && ext_src < 4294967000.0 &&
-        ext_plane < 4294967000.0) {
+    // (the padded modes too: 'nearest' and 'grid-constant' filter the image with 12 samples added per side, which the loads of this
+    // kernel produce by clamping / zeroing instead of reading a float64 copy that spline_expand_kernel would have to write first)
+    const bool padded_f32 = a.src_dtype == kF32 && a.pad > 0 && (a.mode == kModeNearest || a.mode == kModeGridConstant) && a.H > 0 && a.W > 0;
+    if ((direct || padded_f32) && a.npoles == 1 && g_spline_tiled == 1 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride >= 1 && a.src_stride >= 0 &&
+        ext_src < 4294967000.0 && ext_plane < 4294967000.0) {
       // float32 source, one pole: both axes in one pass, the column-filtered plane stays in LDS (spline_prefilter2d_kernel)
+      Pf2dPad pd;
+      pd.pad = a.pad;
+      pd.Hs = a.H;
+      pd.Ws = a.W;
+      pd.zero_outside = a.mode == kModeGridConstant ? 1 : 0;
       f.in = a.src;
       f.in_ls = a.src_cstride;
       f.in_ss = a.src_stride;
@@ -1671,10 +1708,16 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       const int chunks = (a.Hp + chunk - 1) / chunk;
       const int xcd_order = g_pf2d_xcd;
       const dim3 g5((unsigned)(xcd_order ? ((stripes * chunks + 7) / 8) * 8 : stripes * chunks));
-      if (hp[0] == 34)
-        hipLaunchKernelGGL((spline_prefilter2d_kernel<34>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order);
-      else
-        hipLaunchKernelGGL((spline_prefilter2d_kernel<26>), g5, dim3(256), 0, stream, f, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order);
+#define DCP_PF2D(HPV, PADV) \
+  hipLaunchKernelGGL((spline_prefilter2d_kernel<HPV, PADV>), g5, dim3(256), 0, stream, f, pd, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order)
+      if (padded_f32) {
+        if (hp[0] == 34) DCP_PF2D(34, true);
+        else DCP_PF2D(26, true);
+      } else {
+        if (hp[0] == 34) DCP_PF2D(34, false);
+        else DCP_PF2D(26, false);
+      }
+#undef DCP_PF2D
       fused2d = true;
     } else if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {
       // float32 source, one pole (orders 2 and 3): the register-streaming column pass, no LDS
@@ -1702,6 +1745,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       f.in_ss = a.src_stride;
       launch(I0{}, std::true_type{}, SL{}, grid);
     } else {
+      expand();
       f.in = a.coef;
       f.in_ls = 1;
       f.in_ss = a.Wp;
@@ -1760,6 +1804,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     }
   };
   if (!tiled) {
+    expand();
     filter_axis(a.coef, a.scratch, a.Hp, a.Wp, 0, direct);   // float32: the first pass reads the image itself
     hipLaunchKernelGGL(spline_transpose_kernel, dim3((unsigned)((a.Wp + 31) / 32), (unsigned)((a.Hp + 31) / 32)),
                        dim3(kSplBlock), 0, stream, (const double*)a.coef, a.scratch, a.Hp, a.Wp);

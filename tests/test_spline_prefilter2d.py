@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 FUSED = "spline_prefilter2d_kernel + spline_wg_kernel<order=%d>"
 TWO = "spline_col_lds_kernel + spline_row_lds_kernel + spline_wg_kernel<order=%d>"
+PADDED = "spline_tile_filter_kernel + spline_row_lds_kernel + spline_wg_kernel<order=%d>"
 
 
 def ulps(a, b):
@@ -30,19 +31,22 @@ def options(hip):
 
 @pytest.mark.parametrize("shape", [(1100, 1347), (569, 571), (600, 2100), (2100, 700)])
 def test_one_launch_prefilter_against_the_oracle_and_the_two_launches(options, orc, shape):
-    """Partial stripes (184 / 200 columns) and partial steps (32 rows) on both axes, both one-pole orders, the three boundary
-    modes that need no padding: the default takes the one-launch prefilter, is within the restart error of the two-launch path
-    (<= 4 pixels one float32 ulp apart) and of the serial oracle (<= 8), whatever the rows per chunk and the tile order."""
+    """Partial stripes (184 / 200 columns) and partial steps (32 rows) on both axes, both one-pole orders, both boundary kinds of
+    the filter, and the two modes that pad the image by 12 samples (edge values / zeros): the default takes the one-launch
+    prefilter, is within the restart error of the path it replaces (<= 4 pixels one float32 ulp apart) and of the serial oracle
+    (<= 8), whatever the rows per chunk and the tile order."""
     F = options
     c = configs.cfg2()
     img = noise(shape[0] + shape[1], shape)
     coef = [1.02, 0.015, -9.0, -0.012, 0.99, 6.0, 2.0e-6, -1.5e-6]
-    for order, mode in [(3, "reflect"), (3, "mirror"), (2, "reflect"), (2, "grid-mirror")]:
+    for order, mode in [(3, "reflect"), (3, "mirror"), (2, "reflect"), (2, "grid-mirror"), (3, "nearest"), (2, "grid-constant"), (3, "grid-constant"),
+                        (3, "constant"), (2, "wrap")]:
         a = (img, c["xcenter"] * shape[1] / 4096.0, 0.45 * shape[0], c["list_fact"])
         want = orc.unwarp_image_backward(*a, order=order, mode=mode, poly=orc.POLY_KERNEL)
         F.set_option("x_spline_tiled", 6)
         two = pp.unwarp_image_backward(*a, order=order, mode=mode)
-        assert F.last_kernel() == TWO % order, F.last_kernel()
+        # ('nearest' and 'grid-constant' filter the image with 12 samples added per side: a float64 copy + one pass per axis there)
+        assert F.last_kernel() == (PADDED if mode in ("nearest", "grid-constant") else TWO) % order, F.last_kernel()
         F.set_option("x_spline_tiled", 1)
         for chunk, xcd in ((0, 1), (64, 1), (96, 0)):
             F.set_option("x_pf2d_chunk", chunk)

@@ -36,7 +36,7 @@ def main():
     bad = 0
     for shape in () if a.skip_parity else ((1100, 1347), (600, 2100), (2100, 700), (1024, 4096), (2000, 1500), (569, 571)):
         img = np.random.default_rng(5).random(shape, dtype=np.float32)
-        for order, mode in [(3, "reflect"), (3, "mirror"), (2, "reflect"), (2, "mirror"), (3, "grid-mirror")]:
+        for order, mode in [(3, "reflect"), (3, "mirror"), (2, "reflect"), (2, "mirror"), (3, "grid-mirror"), (3, "nearest"), (2, "grid-constant"), (3, "grid-constant")]:
             args = (img, c["xcenter"] * shape[1] / 4096, 0.45 * shape[0], c["list_fact"])
             want = orc.unwarp_image_backward(*args, order=order, mode=mode, poly=orc.POLY_KERNEL)
             res = {}
