@@ -1,20 +1,46 @@
-import os, sys
+#!/usr/bin/env python
+"""us per device-resident 4096^2 float32 frame through dcp_unwarp_image_spline_f32 for every spline order x boundary mode, with the
+kernels each call launched (run under `rocprofv3 --kernel-trace --stats` for the split).
+
+    python tools/time_spline_modes.py [--orders 2,3,4,5] [--modes reflect,mirror,nearest,grid-constant,constant,wrap]
+"""
+import argparse
+import os
+import sys
+
 import numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import bench
-from discorpy_amd import _ffi as F, configs
-L = F.lib(); F.require_device()
-c = configs.cfg2(); H, W = c["shape"]; fa, nf = F.fact_array(c["list_fact"])
-rng = np.random.default_rng(2)
-srcs = [F.DeviceBuffer(H*W*4, -1).upload(rng.random((H, W), dtype=np.float32)) for _ in range(4)]
-dsts = [F.DeviceBuffer(H*W*4, -1) for _ in range(4)]
-MODES = {"reflect": 0, "nearest": None}
-# boundary mode indices as the Python front end passes them
-from discorpy_amd.post import postprocessing as pp
-for order in (2, 3, 4, 5):
-    for mode in ("reflect", "mirror", "nearest", "grid-constant", "constant", "wrap"):
-        m = pp._spline_mode(mode, None)
-        def run(i):
-            F.check(L.dcp_unwarp_image_spline_f32(srcs[i % 4].ptr, dsts[i % 4].ptr, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, order, m, F.MEM_DEVICE, -1, None))
-        t = bench.timed_launches(run, 12, -1, settle_ms=150.0)
-        print("order %d %-14s %8.1f us  %s" % (order, mode, t, F.last_kernel()), flush=True)
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bench  # noqa: E402
+from discorpy_amd import _ffi as F  # noqa: E402
+from discorpy_amd import configs  # noqa: E402
+from discorpy_amd.post import postprocessing as pp  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--orders", default="2,3,4,5")
+    ap.add_argument("--modes", default="reflect,mirror,nearest,grid-constant,constant,wrap")
+    ap.add_argument("--reps", type=int, default=12)
+    a = ap.parse_args()
+    L = F.lib()
+    F.require_device()
+    c = configs.cfg2()
+    H, W = c["shape"]
+    fa, nf = F.fact_array(c["list_fact"])
+    rng = np.random.default_rng(2)
+    srcs = [F.DeviceBuffer(H * W * 4, -1).upload(rng.random((H, W), dtype=np.float32)) for _ in range(4)]
+    dsts = [F.DeviceBuffer(H * W * 4, -1) for _ in range(4)]
+    for order in [int(v) for v in a.orders.split(",")]:
+        for mode in a.modes.split(","):
+            m = pp._spline_mode(mode, None)
+
+            def run(i):
+                F.check(L.dcp_unwarp_image_spline_f32(srcs[i % 4].ptr, dsts[i % 4].ptr, H, W, W, 1, c["xcenter"], c["ycenter"], fa, nf, order, m,
+                                                      F.MEM_DEVICE, -1, None))
+            t = bench.timed_launches(run, a.reps, -1, settle_ms=150.0)
+            print("order %d %-14s %8.1f us  %s" % (order, mode, t, F.last_kernel()), flush=True)
+
+
+if __name__ == "__main__":
+    main()
