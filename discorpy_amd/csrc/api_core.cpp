@@ -593,6 +593,8 @@ int dcp_set_option(const char* key_in, int value) {
     dcp::set_pf2d_chunk(value < 0 ? 0 : value);
   } else if (!strcmp(key, "pf2d_xcd")) {
     dcp::set_pf2d_xcd(value ? 1 : 0);
+  } else if (!strcmp(key, "spline_xcd")) {
+    dcp::set_spline_xcd(value ? 1 : 0);
   } else if (!strcmp(key, "tile_cert")) {
     g_tile_cert = value ? 1 : 0;      // 0: never use the host's tile-deviation certificate (remap_lds_kernel then votes)
   } else if (!strcmp(key, "stack_chunk_kb")) {
@@ -623,6 +625,7 @@ int dcp_get_option(const char* key_in, int* value) {
   else if (!strcmp(key, "spline_tiled")) *value = dcp::get_spline_tiled();
   else if (!strcmp(key, "pf2d_chunk")) *value = dcp::get_pf2d_chunk();
   else if (!strcmp(key, "pf2d_xcd")) *value = dcp::get_pf2d_xcd();
+  else if (!strcmp(key, "spline_xcd")) *value = dcp::get_spline_xcd();
   else if (!strcmp(key, "spline_wg")) *value = dcp::get_spline_wg();
   else if (!strcmp(key, "box_table")) *value = dcp::get_box_table();
   else if (!strcmp(key, "stack_wg")) *value = g_stack_wg;

@@ -130,6 +130,7 @@ struct SplineArgs {
   double poles[2];
   double zpow[2][2];       // [axis][pole]: z^n (reflect) or z^(n-1) (mirror), evaluated on the host
   int32_t exact_sum;       // 1: the taps are accumulated in scipy's order, t += (c wy) wx; 0: factorised and fused (the LDS-staged gather only)
+  int32_t xcd_remap;       // spline_wg_kernel: 1 = every XCD owns a run of neighbouring tile columns (set by launch_spline; option "spline_xcd")
 };
 
 struct LaunchOpts {
@@ -200,6 +201,8 @@ void set_pf2d_chunk(int v);     // rows per chunk of spline_prefilter2d_kernel (
 int get_pf2d_chunk();
 void set_pf2d_xcd(int v);       // 0: spline_prefilter2d_kernel's tiles in plain launch order (option "pf2d_xcd")
 int get_pf2d_xcd();
+void set_spline_xcd(int v);     // 0: spline_wg_kernel's tiles in plain launch order (option "spline_xcd")
+int get_spline_xcd();
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,
                          hipStream_t stream);
 // typed_kernels.hip: map_kind 0 radial, 1 perspective, 2 fused, 3 explicit coordinates

@@ -42,6 +42,9 @@ int get_pf2d_chunk() { return g_pf2d_chunk; }
 int g_pf2d_xcd = 1;              // option pf2d_xcd (A/B runs): 0 = tiles in plain row-major launch order (neighbouring stripes on different XCDs)
 void set_pf2d_xcd(int v) { g_pf2d_xcd = v; }
 int get_pf2d_xcd() { return g_pf2d_xcd; }
+int g_spline_xcd = 1;            // option spline_xcd (A/B runs): 0 = spline_wg_kernel's tiles in plain row-major launch order
+void set_spline_xcd(int v) { g_spline_xcd = v; }
+int get_spline_xcd() { return g_spline_xcd; }
 int get_spline_tiled() { return g_spline_tiled; }
 
 __global__ void __launch_bounds__(kSplBlock) spline_expand_kernel(const SplineArgs a) {
@@ -1397,7 +1400,18 @@ __global__ void __launch_bounds__(256, ORDER >= 5 ? 2 : 3) spline_wg_kernel(cons
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = (int)threadIdx.x & 63;
   const int wx = wave & 1, wy = wave >> 1;
-  const int tx = blockIdx.x, ty = blockIdx.y;
+  // tile order: workgroups go round-robin to the 8 XCDs (blockIdx.x & 7: the grid's x extent is a multiple of 8), each with its own
+  // L2 -- XCD s owns a run of neighbouring tile columns and sweeps it row by row, so the box columns and rows that neighbouring
+  // tiles share are fetched into one L2 (remap_wg_kernel's order; a.xcd_remap = 0: plain row-major, A/B)
+  int tx = blockIdx.x;
+  const int ty = blockIdx.y;
+  if (a.xcd_remap) {
+    const int tiles_x = (a.W + kSwTW - 1) / kSwTW;
+    const int s_ = (int)blockIdx.x & 7, c_ = (int)blockIdx.x >> 3;
+    const int wq = tiles_x >> 3, wr = tiles_x & 7;
+    if (c_ >= wq + (s_ < wr ? 1 : 0)) return;                // (workgroup-uniform, before any barrier)
+    tx = s_ * wq + min(s_, wr) + c_;
+  }
   const int y0 = __builtin_amdgcn_readfirstlane(ty * kSwTH + wy * 16);
   const int x = tx * kSwTW + wx * 64 + lane;
   const float wmaxf = (float)(a.W - 1), hmaxf = (float)(a.H - 1);
@@ -1569,7 +1583,8 @@ __global__ void __launch_bounds__(256, ORDER >= 5 ? 2 : 3) spline_wg_kernel(cons
 
 template <int KIND, int NF>
 static hipError_t launch_spline_wg_nf(const SplineArgs& a, const MapArgs& map, void* dst, hipStream_t stream) {
-  const dim3 grid((unsigned)((a.W + kSwTW - 1) / kSwTW), (unsigned)((a.H + kSwTH - 1) / kSwTH));
+  const unsigned tiles_x = (unsigned)((a.W + kSwTW - 1) / kSwTW);
+  const dim3 grid(a.xcd_remap ? ((tiles_x + 7u) / 8u) * 8u : tiles_x, (unsigned)((a.H + kSwTH - 1) / kSwTH));
 #define DCP_SWG(ORD)                                                                                                        \
   if (a.exact_sum) hipLaunchKernelGGL((spline_wg_kernel<KIND, ORD, NF, true>), grid, dim3(256), 0, stream, a, map, dst);    \
   else hipLaunchKernelGGL((spline_wg_kernel<KIND, ORD, NF, false>), grid, dim3(256), 0, stream, a, map, dst)
@@ -1584,7 +1599,9 @@ static hipError_t launch_spline_wg_nf(const SplineArgs& a, const MapArgs& map, v
 }
 
 template <int KIND>
-static hipError_t launch_spline_wg(const SplineArgs& a, const MapArgs& map_in, void* dst, hipStream_t stream) {
+static hipError_t launch_spline_wg(const SplineArgs& a_in, const MapArgs& map_in, void* dst, hipStream_t stream) {
+  SplineArgs a = a_in;
+  a.xcd_remap = g_spline_xcd;
   if constexpr (KIND == kPersp) {
     return launch_spline_wg_nf<KIND, 0>(a, map_in, dst, stream);          // (no polynomial)
   } else {
