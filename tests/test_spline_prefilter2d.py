@@ -25,7 +25,7 @@ def ulps(a, b):
 @pytest.fixture
 def options(hip):
     yield hip
-    for key, val in (("x_spline_tiled", 1), ("x_spline_wg", 1), ("x_pf2d_chunk", 0), ("x_pf2d_xcd", 1)):
+    for key, val in (("x_spline_tiled", 1), ("x_spline_wg", 1), ("x_pf2d_chunk", 0), ("x_pf2d_xcd", 1), ("x_spline_xcd", 1)):
         hip.set_option(key, val)
 
 
@@ -63,6 +63,23 @@ def test_one_launch_prefilter_against_the_oracle_and_the_two_launches(options, o
         assert F.last_kernel() == FUSED % order, F.last_kernel()
         d = ulps(got, orc.correct_perspective_image(img, coef, order=order, mode=mode))
         assert d.max() <= 1 and np.count_nonzero(d) <= 8, (order, mode)
+
+
+def test_gather_tile_order_does_not_change_a_bit(options):
+    """spline_wg_kernel deals its tiles to the XCDs in runs of neighbouring tile columns (remap_wg_kernel's order); in plain launch
+    order (x_spline_xcd = 0) every pixel is the same -- widths that leave the last XCDs a tile column short included."""
+    F = options
+    for shape in ((700, 128 * 11 + 37), (640, 128 * 3), (600, 2100)):
+        img = noise(shape[1], shape)
+        a = (img, 0.52 * shape[1], 0.47 * shape[0], [1.0, -2e-5, 3e-8])
+        coef = [1.01, 0.01, -5.0, -0.008, 0.99, 4.0, 1.5e-6, -1.0e-6]
+        res = {}
+        for xcd in (1, 0):
+            F.set_option("x_spline_xcd", xcd)
+            res[xcd] = (pp.unwarp_image_backward(*a, order=3), pp.correct_perspective_image(img, coef, order=2))
+            assert "spline_wg_kernel" in F.last_kernel(), F.last_kernel()
+        F.set_option("x_spline_xcd", 1)
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), shape
 
 
 def test_lines_too_short_for_the_one_pass_kernels_keep_the_serial_recursion(options, orc):
