@@ -36,12 +36,22 @@ __device__ unsigned long long g_trace[65536 * 12];
 #define DCP_LAB_DEFINITIONS_SPLINE                                                                              \
   __device__ unsigned long long g_tf_trace[2][4096][8];                                                         \
   __device__ unsigned long long g_tf_trace_r[2][4096][8];                                                       \
+  __device__ unsigned long long g_pf2d_trace[1024][8][8];                                                       \
+  extern "C" __attribute__((visibility("default"))) int dcp_experiment_read_pf2d_trace(unsigned long long* out) { \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pf2d_trace), sizeof(g_pf2d_trace));                       \
+  }                                                                                                             \
   extern "C" __attribute__((visibility("default"))) int dcp_experiment_read_tf_trace(unsigned long long* out) { \
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tf_trace), sizeof(g_tf_trace));                           \
   }                                                                                                             \
   extern "C" __attribute__((visibility("default"))) int dcp_experiment_read_tf_trace_r(unsigned long long* out) { \
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tf_trace_r), sizeof(g_tf_trace_r));                       \
   }
+// ---- per-step phase timestamps of spline_prefilter2d_kernel (tools/trace_pf2d.py): wave 0 of the first 1024 workgroups, eight steps
+#define PF2D_TRACE(slot)                                                                                        \
+  do {                                                                                                          \
+    const int st_ = (r0 - Y0) / R;                                                                              \
+    if (threadIdx.x == 0 && blockIdx.x < 1024 && st_ < 8) g_pf2d_trace[blockIdx.x][st_][slot] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #define TF_TRACE(slot)                                                                                          \
   do {                                                                                                          \
     if (threadIdx.x == 0 && tile < 4096) g_tf_trace[AXIS][tile][slot] = __builtin_amdgcn_s_memtime();           \

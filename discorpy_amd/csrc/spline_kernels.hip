@@ -973,6 +973,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
   const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)f.out, 0, (int)out_bytes, 0x00020000);
   const uint32_t ovoff = (uint32_t)(g0 + lane) * 8u, orow = (uint32_t)f.out_ls * 8u;
   for (;;) {
+    PF2D_TRACE(0);
     // ---- anti-causal down the columns: back over the HP rows below the step from zero, then through the step into the tile
     {
       double ta = 0.0;
@@ -996,7 +997,9 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
 #pragma unroll
       for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::true_type{});
     }
+    PF2D_TRACE(1);
     lds_barrier();                                             // the tile is complete
+    PF2D_TRACE(2);
     // ---- row pass: causal from HP samples in front of the segment through SEG + HP samples, anti-causal back
     double cs[J];
     {
@@ -1015,6 +1018,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
         cs[j] = t;
       }
     }
+    PF2D_TRACE(3);
     lds_barrier();                                             // every thread has read its inputs: the results may overwrite them
     {
       double* w = s_t + row_l * PITCH + seg * SEG + HP;
@@ -1022,7 +1026,9 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
       for (int j = 0; j < SEG; ++j) w[j] = cs[j];
     }
     lds_barrier();
-    // ---- the core of the step, contiguous row pieces
+    PF2D_TRACE(4);
+    // ---- the core of the step, contiguous row pieces (8 bytes per lane: the rows dealt to the lanes as one list of pairs -- 16-byte
+    // stores, a wave's kilobyte straddling two row pieces -- measured 3 % slower, profiles/r05p_ab_store16.txt)
 #pragma unroll
     for (int q = 0; q < R / 4; ++q) {
       const int rr = q * 4 + wave;
@@ -1039,6 +1045,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
         }
       }
     }
+    PF2D_TRACE(5);
     if (!more) break;
     // ---- the next step: the window moves down R rows, the causal recursion runs on through the new rows
     r0 += R;
@@ -1049,7 +1056,11 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
       tc = val(nx[j]) * lam + z * tc;
       C[HP + j] = tc;
     }
+    r0 -= R;
+    PF2D_TRACE(6);
     lds_barrier();                                             // the tile has been read out: the next step may overwrite it
+    PF2D_TRACE(7);
+    r0 += R;
   }
 }
 
