@@ -891,7 +891,9 @@ struct Pf2dPad {
   int32_t pad, Hs, Ws, zero_outside;      // samples added per side; rows / columns of the source image; 1: zeros outside it
 };
 
-template <int HP, bool PAD>
+// ST: element type of the source image (kF32, or the integer types cameras deliver -- kU8 / kU16 / kI16: every one exact in float64,
+// read as raw bits and converted where a row is used)
+template <int HP, bool PAD, int ST>
 __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd, const uint32_t src_bytes, const uint32_t out_bytes, const int stripe, const int Y0,
                                           const int Yend, double* s_t) {
   using G = Pf2d<HP>;
@@ -914,11 +916,18 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     col_zero = pd.zero_outside && (gc < 0 || gc >= pd.Ws);
     gc = max(0, min(gc, pd.Ws - 1));
   }
-  const uint32_t voff = (uint32_t)gc * (uint32_t)f.in_ls * 4u;
-  const uint32_t rstep = (uint32_t)f.in_ss * 4u;
+  constexpr uint32_t ES = ST == kF32 ? 4u : (ST == kU8 ? 1u : 2u);
+  static_assert(ST == kF32 || ST == kU8 || ST == kU16 || ST == kI16, "source element types of the one-launch prefilter");
+  const uint32_t voff = (uint32_t)gc * (uint32_t)f.in_ls * ES;
+  const uint32_t rstep = (uint32_t)f.in_ss * ES;
+  auto ld_raw = [&](uint32_t so) -> uint32_t {                 // the element's bits, zero-extended
+    if constexpr (ST == kF32) return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, so, 0);
+    else if constexpr (ST == kU8) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, so, 0);
+    else return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, so, 0);
+  };
   // (row is wave-uniform: the row offset travels in an SGPR.  Only the steps at the top and the bottom of the plane mirror their
   // rows -- a dozen scalar instructions per load, and a wave issues one instruction per four cycles whatever its kind)
-  auto ld = [&](int row, auto mirrored) -> float {
+  auto ld = [&](int row, auto mirrored) -> uint32_t {
     int r = __builtin_amdgcn_readfirstlane(row);
     if constexpr (decltype(mirrored)::value) {
       r = r < 0 ? -r - sym : r;
@@ -928,24 +937,27 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     if constexpr (PAD) {
       r -= pd.pad;                                             // row of the source image
       if constexpr (decltype(mirrored)::value) {               // (plain loads stay inside the image: no clamp, no zero rows)
-        if (pd.zero_outside && (r < 0 || r >= pd.Hs)) return 0.0f;
+        if (pd.zero_outside && (r < 0 || r >= pd.Hs)) return 0u;  // (the bits of 0.0f and of the integer 0)
         r = max(0, min(r, pd.Hs - 1));
       }
-      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)r * rstep, 0));
-    } else {
-      return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, (uint32_t)r * rstep, 0));
     }
+    return ld_raw((uint32_t)r * rstep);
   };
   // (a column in zero padding: applied where a loaded value is USED -- a select right behind the load would make the wave wait for
   // every prefetched row at once: 91 us instead of 51 per 4096^2 plane)
-  auto val = [&](float v) -> double { return (double)((PAD && col_zero) ? 0.0f : v); };
+  auto val = [&](uint32_t bits) -> double {
+    const uint32_t b = (PAD && col_zero) ? 0u : bits;
+    if constexpr (ST == kF32) return (double)__uint_as_float(b);
+    else if constexpr (ST == kI16) return (double)(int)(short)b;
+    else return (double)b;
+  };
   // rows [plain_lo, plain_hi) of the plane are read as they are: no mirror, and with PAD inside the image
   const int plain_lo = PAD ? pd.pad : 0, plain_hi = PAD ? H - pd.pad : H;
   int r0 = Y0;                                                 // first row of the current step
   double tc = 0.0;                                             // the causal state
   double C[NC];                                                // causal values of rows r0 .. r0 + R + HP - 1
   {
-    float pre[HP], pre2[NC];
+    uint32_t pre[HP], pre2[NC];
     if (r0 - HP >= plain_lo && r0 + NC <= plain_hi) {
 #pragma unroll
       for (int j = 0; j < HP; ++j) pre[j] = ld(r0 - HP + j, std::false_type{});
@@ -986,7 +998,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     // the next step's new rows, in flight under the row pass (the chunk's last step, where nobody uses them, loads one cached row
     // R times instead: registers that are defined on one path only cost the register allocation a dozen spills)
     const bool more = r0 + R < Yend;                           // (workgroup-uniform)
-    float nx[R];
+    uint32_t nx[R];
     if (!more) {
 #pragma unroll
       for (int j = 0; j < R; ++j) nx[j] = ld(min(r0, H - 1), std::true_type{});
@@ -1064,7 +1076,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
   }
 }
 
-template <int HP, bool PAD = false>
+template <int HP, bool PAD = false, int ST = kF32>
 __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const Pf2dPad pd, const uint32_t src_bytes, const uint32_t out_bytes,
                                                                                  const int chunk_rows, const int stripes, const int chunks, const int xcd_order) {
   using G = Pf2d<HP>;
@@ -1080,7 +1092,7 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   const int chunk = t / stripes, stripe = t - chunk * stripes;
   const int Y0 = chunk * chunk_rows;                           // first row the chunk writes
   const int Yend = min(f.n, Y0 + chunk_rows);
-  pf2d_body<HP, PAD>(f, pd, src_bytes, out_bytes, stripe, Y0, Yend, s_t);
+  pf2d_body<HP, PAD, ST>(f, pd, src_bytes, out_bytes, stripe, Y0, Yend, s_t);
 }
 
 // ---- the row pass (axis 1) as a cross-lane scan: no LDS, no barrier, every access a contiguous 512 bytes ---------------
@@ -1704,12 +1716,14 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     f.out_ss = a.Wp;
     dim3 grid((unsigned)((f.nlines + kTfLines - 1) / kTfLines), (unsigned)((f.n + f.core - 1) / f.core));
     // (columns of an interleaved image -- a channel of an (H, W, C) array -- are read in place: 4-byte loads at the pixel pitch)
-    const double ext_src = ((double)(a.H - 1) * (double)a.src_stride + (double)(a.W - 1) * (double)a.src_cstride + 1.0) * 4.0;
+    const double ext_src = ((double)(a.H - 1) * (double)a.src_stride + (double)(a.W - 1) * (double)a.src_cstride + 1.0) * (double)elem_size(a.src_dtype);
     const double ext_plane = (double)a.Hp * (double)a.Wp * 8.0;
     // (the padded modes too: 'nearest' and 'grid-constant' filter the image with 12 samples added per side, which the loads of this
     // kernel produce by clamping / zeroing instead of reading a float64 copy that spline_expand_kernel would have to write first)
-    const bool padded_f32 = a.src_dtype == kF32 && a.pad > 0 && (a.mode == kModeNearest || a.mode == kModeGridConstant) && a.H > 0 && a.W > 0;
-    if ((direct || padded_f32) && a.npoles == 1 && g_spline_tiled == 1 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride >= 1 && a.src_stride >= 0 &&
+    // Element types: float32 and the integer types cameras deliver (uint8, uint16, int16), read in place -- the others take the float64 copy.
+    const bool pf2d_type = a.src_dtype == kF32 || a.src_dtype == kU8 || a.src_dtype == kU16 || a.src_dtype == kI16;
+    const bool padded_f32 = pf2d_type && a.pad > 0 && (a.mode == kModeNearest || a.mode == kModeGridConstant) && a.H > 0 && a.W > 0;
+    if (((pf2d_type && a.pad == 0) || padded_f32) && a.npoles == 1 && g_spline_tiled == 1 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride >= 1 && a.src_stride >= 0 &&
         ext_src < 4294967000.0 && ext_plane < 4294967000.0) {
       // float32 source, one pole: both axes in one pass, the column-filtered plane stays in LDS (spline_prefilter2d_kernel)
       Pf2dPad pd;
@@ -1738,15 +1752,23 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       const int chunks = (a.Hp + chunk - 1) / chunk;
       const int xcd_order = g_pf2d_xcd;
       const dim3 g5((unsigned)(xcd_order ? ((stripes * chunks + 7) / 8) * 8 : stripes * chunks));
-#define DCP_PF2D(HPV, PADV) \
-  hipLaunchKernelGGL((spline_prefilter2d_kernel<HPV, PADV>), g5, dim3(256), 0, stream, f, pd, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order)
-      if (padded_f32) {
-        if (hp[0] == 34) DCP_PF2D(34, true);
-        else DCP_PF2D(26, true);
-      } else {
-        if (hp[0] == 34) DCP_PF2D(34, false);
-        else DCP_PF2D(26, false);
+#define DCP_PF2D(HPV, PADV, STV) \
+  hipLaunchKernelGGL((spline_prefilter2d_kernel<HPV, PADV, STV>), g5, dim3(256), 0, stream, f, pd, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order)
+#define DCP_PF2D_T(STV)                 \
+  if (padded_f32) {                     \
+    if (hp[0] == 34) DCP_PF2D(34, true, STV);  \
+    else DCP_PF2D(26, true, STV);       \
+  } else {                              \
+    if (hp[0] == 34) DCP_PF2D(34, false, STV); \
+    else DCP_PF2D(26, false, STV);      \
+  }
+      switch (a.src_dtype) {
+        case kU8: DCP_PF2D_T(kU8); break;
+        case kU16: DCP_PF2D_T(kU16); break;
+        case kI16: DCP_PF2D_T(kI16); break;
+        default: DCP_PF2D_T(kF32); break;
       }
+#undef DCP_PF2D_T
 #undef DCP_PF2D
       fused2d = true;
     } else if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {

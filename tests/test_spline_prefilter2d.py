@@ -82,6 +82,33 @@ def test_gather_tile_order_does_not_change_a_bit(options):
         assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), shape
 
 
+@pytest.mark.parametrize("dtype", ["uint8", "uint16", "int16"])
+def test_integer_frames_are_read_in_place(options, orc, dtype):
+    """The integer element types cameras deliver take the one-launch prefilter too (their values are exact in float64: no float64 copy
+    of the image first) -- plain, padded modes, an interleaved channel; results are scipy's rounded integers (a float64 sum on a half
+    may round the other way: at most a handful of pixels one unit apart)."""
+    F = options
+    dt = np.dtype(dtype)
+    info = np.iinfo(dt)
+    rng = np.random.default_rng(41)
+    shape = (700, 1100)
+    img = rng.integers(info.min, info.max, size=shape, endpoint=True, dtype=np.int64).astype(dt)
+    rgb = rng.integers(info.min, info.max, size=shape + (3,), endpoint=True, dtype=np.int64).astype(dt)
+    a = (0.47 * shape[1], 0.55 * shape[0], [1.0, -3e-5, 4e-8])
+    for order, mode, src in [(3, "reflect", img), (2, "mirror", img), (3, "nearest", img), (2, "grid-constant", img), (3, "reflect", rgb[:, :, 1])]:
+        got = pp.unwarp_image_backward(src, *a, order=order, mode=mode)
+        assert F.last_kernel() == FUSED % order, F.last_kernel()
+        want = orc.unwarp_image_backward(np.ascontiguousarray(src), *a, order=order, mode=mode, poly=orc.POLY_KERNEL)
+        assert got.dtype == dt and want.dtype == dt
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 3, (dtype, order, mode, int(d.max()), int(np.count_nonzero(d)))
+        F.set_option("x_spline_tiled", 6)
+        old = pp.unwarp_image_backward(src, *a, order=order, mode=mode)
+        assert "prefilter2d" not in F.last_kernel(), F.last_kernel()
+        F.set_option("x_spline_tiled", 1)
+        assert np.count_nonzero(got != old) <= 3, (dtype, order, mode)
+
+
 def test_lines_too_short_for_the_one_pass_kernels_keep_the_serial_recursion(options, orc):
     """z^n has not underflowed on a 300-sample line (cubic: n > 565, quadratic: n > 423): the chunked passes, bit-equal to the oracle."""
     F = options
