@@ -60,6 +60,12 @@ def parse(argv=None):
     ap.add_argument("--min-timed-ms", type=float, default=300.0,
                     help="lower bound of the timed region used to choose --cycles 0: a 14 ms region (20 steps x 24 frames) lost 25 %% "
                          "to 4.7 ms of one-off host latency on the driver's box in round 4")
+    ap.add_argument("--dispatch", default="two_streams", choices=["two_streams", "ordered", "any_order"],
+                    help="how the independent per-frame launches of the headline leave the host: two_streams (default) alternates the "
+                         "ring's frames over two streams of the library (dcp_stream_create), so that two frames are in flight and the "
+                         "drain of one runs under the ramp of the other; ordered = one stream, every launch behind the previous one's "
+                         "last workgroup (rounds 1-5); any_order = one stream, DCP_MEM_DEVICE_UNORDERED (barrier bit cleared).  "
+                         "profiles/r06a_dispatch_modes.txt, tools/time_dispatch.py")
     ap.add_argument("--blend", default="f64lerp", choices=sorted(BLEND_NAMES))
     ap.add_argument("--order", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -236,7 +242,8 @@ def e2e_child():
     except (AttributeError, OSError):
         pass
     res = {"hip_runtime": hip_runtime_path(), "cpus_inherited": inherited,
-           "cpus_now": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+           "cpus_now": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+           "blend": pp._default_blend(True) + " (blend=None on NumPy arrays: scipy's exact operation order, the reference's result bit for bit)"}
     c2 = configs.cfg2()
     img = np.random.default_rng(c2["seed"]).random(c2["shape"], dtype=np.float32)
 
@@ -1429,18 +1436,47 @@ def main(argv=None):
         srcs.append(RingFrame(ring_src, i * frame_bytes).upload(img))
         dsts.append(RingFrame(ring_dst, i * frame_bytes))
 
+    # how the launches leave the host (--dispatch): the frames are independent -- one calibration per call, one call per frame
+    lstreams = [F.Stream(dev), F.Stream(dev)] if a.dispatch == "two_streams" else []
+    frame_mem = F.MEM_DEVICE_UNORDERED if a.dispatch == "any_order" else F.MEM_DEVICE
+    launch_no = [0]
+
     def ring_pass():
         for s, d in zip(srcs, dsts):
+            st = lstreams[launch_no[0] & 1].ptr if lstreams else None
+            launch_no[0] += 1
             rc = L.dcp_unwarp_image_f32(s.ptr, d.ptr, H, W, W, 1, cfg["xcenter"], cfg["ycenter"], fa, nf,
-                                        a.order, 1, blend, F.MEM_DEVICE, dev, None)
+                                        a.order, 1, blend, frame_mem, dev, st)
             if rc:
                 F.check(rc)
 
     def sync():
+        for st in lstreams:
+            st.synchronize()
         F.check(L.dcp_stream_synchronize(dev, None))
         if dist is not None:
             import torch
             torch.cuda.synchronize()
+
+    # device time of a region that runs on BOTH streams: the start event is recorded on the first and the second waits for it (nothing
+    # of the region starts before it); at the end the first stream waits for an event of the second before the stop event is
+    # recorded on it -- elapsed(start, stop) covers every launch of the region on either stream, gaps included
+    join_ev = [F.Event(dev) for _ in range(4)] if lstreams else []
+
+    def mark_begin(e):
+        if lstreams:
+            e.record(lstreams[0].ptr)
+            lstreams[1].wait_event(e)
+        else:
+            e.record()
+
+    def mark_end(e, k=0):
+        if lstreams:
+            join_ev[k].record(lstreams[1].ptr)
+            lstreams[0].wait_event(join_ev[k])
+            e.record(lstreams[0].ptr)
+        else:
+            e.record()
 
     # let the clocks reach their sustained level before anything is counted: ring passes for at least --settle-ms, then on until three
     # consecutive passes agree to 1.5 % (device time per pass; at most 8 x --settle-ms) -- a cold box ramps for longer than a warm one,
@@ -1451,9 +1487,9 @@ def main(argv=None):
         s0, s1 = F.Event(dev), F.Event(dev)
         recent = []
         while True:
-            s0.record()
+            mark_begin(s0)
             ring_pass()
-            s1.record()
+            mark_end(s1, 1)
             s1.synchronize()
             recent = (recent + [s0.elapsed_ms(s1)])[-3:]
             settle["passes"] += 1
@@ -1468,10 +1504,10 @@ def main(argv=None):
     cycles, probe_ms = a.cycles, None
     if cycles <= 0:
         p0, p1 = F.Event(dev), F.Event(dev)
-        p0.record()
+        mark_begin(p0)
         ring_pass()
         ring_pass()
-        p1.record()
+        mark_end(p1, 2)
         p1.synchronize()
         probe_ms = p0.elapsed_ms(p1) / 2.0
         cycles = max(1, int(np.ceil(a.min_timed_ms / (a.steps * max(probe_ms, 1e-3)))))
@@ -1503,10 +1539,10 @@ def main(argv=None):
     sync()
     e0, e1 = F.Event(dev), F.Event(dev)
     t0 = time.perf_counter()
-    e0.record()
+    mark_begin(e0)
     for _ in range(a.steps):
         step()
-    e1.record()
+    mark_end(e1)
     t_enq = time.perf_counter()            # every launch of the K steps is in the queue (the call blocks while the queue is full)
     sync()
     t_sync = time.perf_counter()
@@ -1515,7 +1551,7 @@ def main(argv=None):
     sync()
     wall = time.perf_counter() - t0
     enqueue_ms, sync_ms = (t_enq - t0) * 1e3, (t_sync - t_enq) * 1e3
-    dev_ms = e0.elapsed_ms(e1)            # HIP events on the launch stream: device time of the K steps, gaps between launches included
+    dev_ms = e0.elapsed_ms(e1)            # HIP events on the launch stream(s): device time of the K steps, gaps between launches included
     headline_kernel = F.last_kernel()
     if dist is not None:
         import torch
@@ -1721,6 +1757,15 @@ def main(argv=None):
             "host_enqueue_us_per_launch": round(enqueue_ms * 1e3 / launches, 3), "sync_ms": round(sync_ms, 3),
             "host_call_us_per_launch_idle_queue": round(host_call_us, 3),
             "launch_us": round(launch_us, 3),
+            # which dispatch mode produced `value`: the per-frame entry point, one calibration per call, in every mode
+            "dispatch": {"mode": a.dispatch,
+                         "what": {"two_streams": "the ring's frames alternate over two streams made with dcp_stream_create -- two independent "
+                                                 "frames in flight, the drain of one under the ramp of the other; launch_us = timed region / launches",
+                                  "ordered": "one stream: every launch starts when the previous one's last workgroup has retired",
+                                  "any_order": "one stream, DCP_MEM_DEVICE_UNORDERED: dispatch packets without the barrier bit"}[a.dispatch],
+                         "single_stream_launch_us": None if not isinstance(dist_launch, dict) else dist_launch.get("back_to_back_mean_us"),
+                         "ab": "profiles/r06a_dispatch_modes.txt, profiles/r06b_dispatch_streams.txt (tools/time_dispatch.py: ordered / any-order / "
+                               "2..8 streams / one batched launch on two boxes)"},
             "launch_us_median": None if not isinstance(dist_launch, dict) else dist_launch.get("median_us"),
             "launch_us_p90": None if not isinstance(dist_launch, dict) else dist_launch.get("p90_us"),
             "data": "synthetic (numpy default_rng uniform [0,1) float32 frames, device-resident)",
@@ -1736,6 +1781,13 @@ def main(argv=None):
                          "traffic_source": traffic_source,
                          # true: the kernel sources were edited after the counters were collected (SHA-256 over discorpy_amd/csrc)
                          "traffic_stale": traffic_stale, "kernel": headline_kernel, "launch_us": round(launch_us, 3),
+                         "dispatch": a.dispatch,
+                         # the same launches on ONE stream, back to back (no events in between), measured after the timed region: what
+                         # `rocprofv3 --kernel-trace --stats` of an --dispatch ordered run reports as the kernel's average duration;
+                         # with two frames in flight rocprofv3's per-kernel duration is about twice launch_us (two kernels overlap)
+                         "single_stream": None if not (isinstance(dist_launch, dict) and dist_launch.get("back_to_back_mean_us")) else {
+                             "launch_us": dist_launch["back_to_back_mean_us"],
+                             "frac": round(configs.BYTES_PER_PIXEL * pix_per_launch / (dist_launch["back_to_back_mean_us"] * 1e-6) / 1e9 / configs.HBM_PEAK_GBPS, 4)},
                          "algorithmic_bytes_per_launch": int(configs.BYTES_PER_PIXEL * pix_per_launch),
                          "d2d_copy_same_frames_GBps": copy_gbps, "per_launch_distribution": dist_launch},
             "verified_vs_oracle": verified,

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("DCP_LIB_PATH") or os.path.join(_HERE, "lib", "libdisc
 
 OK, ERR_INVALID_ARG, ERR_HIP, ERR_UNSUPPORTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
+MEM_DEVICE_UNORDERED = 0x101      # DCP_MEM_DEVICE_UNORDERED: device pointers, the launch may overlap the previous one of its stream
 BLEND_SCIPY, BLEND_F64LERP, BLEND_F32LERP = 0, 1, 2
 COORD_F32, COORD_F64 = 0, 1
 COPY_H2D, COPY_D2H, COPY_D2D = 0, 1, 2
@@ -112,6 +113,7 @@ SIGNATURES = {
     "dcp_stream_synchronize": (_int, [_int, _vp]),
     "dcp_event_create": (_int, [C.POINTER(_vp), _int]),
     "dcp_event_record": (_int, [_vp, _vp]),
+    "dcp_stream_wait_event": (_int, [_vp, _vp]),
     "dcp_event_synchronize": (_int, [_vp]),
     "dcp_event_elapsed_ms": (_int, [_vp, _vp, C.POINTER(C.c_float)]),
     "dcp_event_destroy": (_int, [_vp]),
@@ -329,6 +331,10 @@ class Stream:
 
     def synchronize(self):
         check(lib().dcp_stream_synchronize(self.device, self.ptr))
+
+    def wait_event(self, event):
+        """Work enqueued on this stream from now on starts after `event` (an Event recorded on any stream) has completed."""
+        check(lib().dcp_stream_wait_event(self.ptr, event.ptr))
 
     def __del__(self):
         try:

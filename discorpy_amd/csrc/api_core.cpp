@@ -25,7 +25,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0}, g_store_wait{1}, g_fused_wg{1};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0}, g_store_wait{1}, g_fused_wg{1}, g_any_order{0};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -42,6 +42,7 @@ dcp::LaunchOpts current_opts() {
   o.int_exact = g_int_exact.load();
   o.tall_tiles = g_tall_tiles.load();
   o.store_wait = g_store_wait.load();
+  o.any_order = g_any_order.load();
   return o;
 }
 
@@ -312,13 +313,16 @@ int tile_deviation_certified(int kind, const dcp::MapArgs& m, int64_t H, int64_t
           gx[3] = std::max(gx[3], std::fabs(m.coef[4] * d - m.coef[7] * ny));
         }
       const double d2 = dmin * dmin;
-      const double qw = (127.0 * gx[0] + 31.0 * gx[1]) / d2 + 1e-3, qh = (127.0 * gx[2] + 31.0 * gx[3]) / d2 + 1e-3;
+      // + the float32 rounding of the positions at both ends of the box: two half-ulps at the largest coordinate of the frame (2^-24
+      // relative each), never less than the 1e-3 px of frames below 8192 px (a fixed 1e-3 stopped being a bound above that)
+      const double slack = std::max(1e-3, 2.0 * (double)std::max(W, H) * 0x1p-23);
+      const double qw = (127.0 * gx[0] + 31.0 * gx[1]) / d2 + slack, qh = (127.0 * gx[2] + 31.0 * gx[3]) / d2 + slack;
       double rmax = 0.0;
       for (double x : {0.0, (double)(W - 1)})
         for (double y : {0.0, (double)(H - 1)}) rmax = std::max(rmax, std::hypot(x - m.xc, y - m.yc));
       const double k2 = radial_curvature_bound(m, rmax * (1.0 + 1e-12) + 1e-9);
       const double dev = (qw * qw + qh * qh) / 8.0 * k2;
-      if (std::isfinite(dev) && dev <= kTileDevLimit && g_fused_wg.load()) ok = 2;
+      if (std::isfinite(dev) && dev <= kTileDevLimit) ok = 2;          // (the A/B switch x_fused_wg is applied by the caller, outside this cache)
     }
   }
   if (ok == 2 && !wg_boxes_mostly_fit(kind, m, H, W)) ok = kind == dcp::kFused ? 0 : 1;
@@ -524,12 +528,25 @@ const char* dcp_last_error(void) { return dcpapi::last_error(); }
 // tests that force a kernel) and answers only to its name with an "x_" prefix -- undocumented in the header, free to change.
 static const char* const kStableOptions[] = {"stack_chunk_kb", "host_duplex", "host_bands", "host_direct", "host_direct_applies", "tile_cert",
                                              "lds_gather"};
+// The unprefixed spellings the round-4 header documented for what are now lab switches: accepted for one more release,
+// with one warning per process on stderr -- a caller written against that header keeps working and is told what to change.
+static const char* const kDeprecatedAliases[] = {"tile_rows", "xcd_remap", "coef_lds", "d_chunk", "pipe_depth", "stack_lds", "wg_box", "wg_per_cu",
+                                                 "stack_wg", "spline_tiled", "spline_wg", "int_exact", "box_table", "tall_tiles", "store_wait"};
 static const char* option_name(const char* key) {
   bool stable = false;
   const bool lab = !strncmp(key, "x_", 2);
   const char* name = lab ? key + 2 : key;
   for (const char* k : kStableOptions) stable = stable || !strcmp(name, k);
-  return lab == stable ? "" : name;          // a stable key with the prefix, or a lab key without it: unknown
+  if (!lab && !stable) {
+    for (const char* k : kDeprecatedAliases)
+      if (!strcmp(name, k)) {
+        static std::atomic<bool> warned{false};
+        if (!warned.exchange(true))
+          fprintf(stderr, "libdiscorpy_hip: option \"%s\" is a lab switch now -- spell it \"x_%s\" (the unprefixed name is accepted until the next release)\n", name, name);
+        return name;
+      }
+  }
+  return lab == stable ? "" : name;          // a stable key with the prefix, or an unknown lab key without it: unknown
 }
 
 int dcp_set_option(const char* key_in, int value) {
@@ -570,11 +587,13 @@ int dcp_set_option(const char* key_in, int value) {
     if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "host_direct must be 0, 1 or 2");
     g_host_direct = value;            // 0: a host frame's result is always staged on the device and copied back; 1: written straight into a
                                       // registered destination when the runtime cannot overlap an upload with a download; 2: whenever registered
+  } else if (!strcmp(key, "any_order")) {
+    g_any_order = value ? 1 : 0;      // 1: EVERY whole-frame device launch as with DCP_MEM_DEVICE_UNORDERED (A/B runs; the per-call flag is the interface)
   } else if (!strcmp(key, "store_wait")) {
     g_store_wait = value ? 1 : 0;     // 0: stack_wg_kernel waits for its own stores at every projection (rounds 2-3), A/B
   } else if (!strcmp(key, "fused_wg")) {
     g_fused_wg = value ? 1 : 0;       // 0: the fused perspective o radial map always on the per-wave kernel with the per-pixel vote (rounds 1-4), A/B
-    for (auto& e : g_cert_cache) e.kind = -1;      // the calling thread's cached certificates were made under the old setting
+                                      // (read where the certificate is USED -- dcp_unwarp_fused_f32 --, not where it is cached: every thread sees a change)
   } else if (!strcmp(key, "tall_tiles")) {
     g_tall_tiles = value < 0 ? 0 : (value > 2 ? 2 : value);     // 1: sheared radial maps (level-1 certificate, boxes of 64 x 32 tiles fit 80 x 56) on 64 x 32 workgroup tiles instead of the
                                       // per-wave-box kernel.  Default 0: measured SLOWER on BASELINE config 5 (128-131 us against 113-116, tools/time_cfg5.py)
@@ -611,6 +630,7 @@ int dcp_get_option(const char* key_in, int* value) {
   const char* key = option_name(key_in);
   if (!strcmp(key, "tile_rows")) *value = g_tile_rows;
   else if (!strcmp(key, "xcd_remap")) *value = g_xcd_remap;
+  else if (!strcmp(key, "any_order")) *value = g_any_order;
   else if (!strcmp(key, "coef_lds")) *value = g_coef_lds;
   else if (!strcmp(key, "d_chunk")) *value = g_d_chunk;
   else if (!strcmp(key, "pipe_depth")) *value = g_pipe_depth;
@@ -786,6 +806,12 @@ int dcp_event_create(void** event, int device) {
 
 int dcp_event_record(void* event, void* stream) {
   DCP_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+  return DCP_OK;
+}
+
+int dcp_stream_wait_event(void* stream, void* event) {
+  if (!event) return fail(DCP_ERR_INVALID_ARG, "null event");
+  DCP_HIP(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
   return DCP_OK;
 }
 

@@ -251,7 +251,11 @@ int run_image(dcp::MapKind kind, const float* src, float* dst, int64_t H, int64_
   memset(&img, 0, sizeof(img));
   img.H = (int32_t)H;
   img.W = (int32_t)W;
-  const dcp::LaunchOpts opts = current_opts();
+  dcp::LaunchOpts opts = current_opts();
+  if (mem_kind == DCP_MEM_DEVICE_UNORDERED) {      // device pointers, and the launch need not wait for earlier work of `stream`
+    opts.any_order = 1;
+    mem_kind = DCP_MEM_DEVICE;
+  }
   if (mem_kind == DCP_MEM_DEVICE) {
     img.src = src;
     img.dst = dst;
@@ -647,7 +651,7 @@ int dcp_unwarp_fused_f32(const float* src, float* dst, int64_t height, int64_t w
     return run_typed(2, src, dst, dcp::kF32, height, width, src_row_stride, src_col_stride, map, nullptr, nullptr, 0, 0, order,
                      0, mem_kind, device, stream);
   if ((rc = check_image(src, dst, height, width, src_row_stride, src_col_stride)) != DCP_OK) return rc;
-  map.tile_dev_ok = g_tile_cert.load() ? tile_deviation_certified(dcp::kFused, map, height, width) : 0;
+  map.tile_dev_ok = (g_tile_cert.load() && g_fused_wg.load()) ? tile_deviation_certified(dcp::kFused, map, height, width) : 0;
   return run_image(dcp::kFused, src, dst, height, width, src_row_stride, src_col_stride, map, sampler, true,
                    mem_kind, device, stream);
 }

@@ -260,7 +260,11 @@ int make_stack_call(StackCall* c, const void* vol, void* out, int dtype, int out
   c->row_stride = row_stride;
   c->row_start = row_start;
   c->nrows = nrows;
-  c->round_f32 = coord_round_f32;
+  // coord_round_f32 = 2: float32 coordinates under unwarp_image_backward's semantics -- the `depth` projections are FRAMES of a 3-D
+  // array, every coordinate is clipped to the whole image (postprocessing.py:144-145) and there is no row band to crop or reflect
+  // in, whatever the model does (a folding model just reads other rows of the frame)
+  const bool frames = coord_round_f32 == 2;
+  c->round_f32 = coord_round_f32 != 0;
   c->mem_kind = mem_kind;
   c->device = device;
   c->stream = stream;
@@ -276,7 +280,8 @@ int make_stack_call(StackCall* c, const void* vol, void* out, int dtype, int out
   // inside that band (postprocessing.py:289-312).  Under a model whose row coordinate increases with the row nothing can
   // leave the band; otherwise (a folding model) the band goes to the kernel, which then checks every pixel.
   c->rb0 = c->rbh = 0;
-  if (coord_round_f32 && nrows > 0 && height > 0 && width > 0 && std::isfinite(row_start) &&
+  if (frames && !rows_inside) return fail(DCP_ERR_INVALID_ARG, "coord_round_f32 = 2 (whole frames) needs the requested rows inside the frame");
+  if (!frames && coord_round_f32 && nrows > 0 && height > 0 && width > 0 && std::isfinite(row_start) &&
       (!rows_inside || !radial_monotone_in_y(c->map, height, width))) {
     int64_t b0 = 0, b1 = height;
     reference_chunk_band(c->map, height, width, row_start, row_start + (double)(nrows - 1), &b0, &b1);
@@ -305,9 +310,8 @@ int frames_as_stack(const float* src0, float* dst0, int nframes, int64_t height,
   StackCall c;
   if (height > 65535 || height < 2 || width < 2 || (double)height * (double)row_stride * 4.0 > 4294967040.0) return DCP_OK;
   if ((rc = make_stack_call(&c, src0, dst0, dcp::kF32, 0, nframes, height, width, 0, height, pitch, row_stride, xcenter, ycenter,
-                            list_fact, nfact, 0.0, height, 1, blend_mode, DCP_MEM_DEVICE, device, stream)) != DCP_OK)
+                            list_fact, nfact, 0.0, height, 2, blend_mode, DCP_MEM_DEVICE, device, stream)) != DCP_OK)
     return rc;
-  if (c.rbh != 0) return DCP_OK;
   dcp::StackArgs st;
   memset(&st, 0, sizeof(st));
   st.D = nframes;

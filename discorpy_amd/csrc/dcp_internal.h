@@ -148,6 +148,8 @@ struct LaunchOpts {
   int int_exact = 1;       // integer element types: the exact factorised blend where it is provably exact (0: scipy's operation order everywhere)
   int stack_wg = 1;        // stack_wg_kernel (one box per workgroup, two slabs) for chunks of rows under a certified map: 0 never,
                            // 1 when the launch has enough workgroups (float32 and 8- / 16-bit integers), 2 whenever eligible
+  int any_order = 0;       // 1: whole-frame launches leave with the AQL barrier bit cleared (hipExtAnyOrderLaunch): the packet may start
+                           // while earlier packets of its stream still run (DCP_MEM_DEVICE_UNORDERED; the caller vouches for independence)
 };
 
 // launchers (unwarp_kernels.hip)

@@ -1828,6 +1828,18 @@ static void note_kernel(const char* kernel, int kind, int nf, int sampler, const
   else snprintf(g_last_kernel, sizeof(g_last_kernel), "%s<NF=%d,%s%s>", kernel, nf, sampler_name(sampler), extra);
 }
 const char* last_kernel_name() { return g_last_kernel; }
+
+// Whole-frame launches of the staged kernels.  LaunchOpts::any_order (DCP_MEM_DEVICE_UNORDERED of the C ABI) clears the barrier bit
+// of the dispatch packet (hipExtAnyOrderLaunch): the command processor may then start the workgroups of this frame while the last
+// workgroups of the previous packet of the SAME stream still run -- the drain of frame z under the ramp of frame z + 1, what
+// remap_wg_batch_kernel gets from blockIdx.z, for callers that hand over one frame per call.  Set per launch_image / launch_wg_typed call.
+static thread_local int t_any_order = 0;
+#include <hip/hip_ext.h>
+#define DCP_LAUNCH_FRAME(kernel, grid, block, lds, stream, ...)                                                                  \
+  do {                                                                                                                            \
+    if (t_any_order) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, nullptr, hipExtAnyOrderLaunch, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                       \
+  } while (0)
 void set_last_kernel_name(const char* name) { snprintf(g_last_kernel, sizeof(g_last_kernel), "%s", name); }
 
 template <int KIND, int NF, int SAMPLER, bool ROUND32, bool PAIR>
@@ -1865,7 +1877,7 @@ static hipError_t launch_lds(const ImageArgs& img_in, const MapArgs& map, hipStr
   dim3 grid(img.tiles_x * img.tiles_y);
   if (img.xcd_remap == 2) grid = dim3(8 * ((img.tiles_x + 7) / 8), img.tiles_y);   // see the kernel's tile order
   note_kernel("remap_lds_kernel", KIND, NF, SAMPLER, VOTE ? ",vote" : ",certified");
-  hipLaunchKernelGGL((remap_lds_kernel<KIND, NF, SAMPLER, VOTE>), grid, dim3(64 * kLdsBW), 0, stream, img, map);
+  DCP_LAUNCH_FRAME((remap_lds_kernel<KIND, NF, SAMPLER, VOTE>), grid, dim3(64 * kLdsBW), 0, stream, img, map);
   return hipGetLastError();
 }
 
@@ -1887,7 +1899,7 @@ static hipError_t launch_wg(const ImageArgs& img_in, const MapArgs& map, hipStre
     const hipError_t e = hipFuncSetAttribute((const void*)remap_wg_kernel<KIND, NF, SAMPLER, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad);
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), pad, stream, img, map);
+  DCP_LAUNCH_FRAME((remap_wg_kernel<KIND, NF, SAMPLER>), grid, dim3(256), pad, stream, img, map);
   return hipGetLastError();
 }
 
@@ -1980,10 +1992,10 @@ static hipError_t launch_wg_typed_t(const ImageArgs& img_in, const MapArgs& map,
   const dim3 grid(img.xcd_remap == 2 ? 8 * ((img.tiles_x + 7) / 8) : img.tiles_x, img.tiles_y);
   if (order == 0) {
     note_kernel("remap_wg_kernel", KIND, NF, kNearest, sizeof(T) == 2 ? ",16-bit" : ",8-bit");
-    hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, kNearest, T>), grid, dim3(256), 0, stream, img, map);
+    DCP_LAUNCH_FRAME((remap_wg_kernel<KIND, NF, kNearest, T>), grid, dim3(256), 0, stream, img, map);
   } else {
     note_kernel("remap_wg_kernel", KIND, NF, kScipy, sizeof(T) == 2 ? ",16-bit" : ",8-bit");
-    hipLaunchKernelGGL((remap_wg_kernel<KIND, NF, kScipy, T>), grid, dim3(256), 0, stream, img, map);
+    DCP_LAUNCH_FRAME((remap_wg_kernel<KIND, NF, kScipy, T>), grid, dim3(256), 0, stream, img, map);
   }
   return hipGetLastError();
 }
@@ -2009,6 +2021,7 @@ static hipError_t launch_wg_typed_k(MapKind kind, const ImageArgs& img, const Ma
 hipError_t launch_wg_typed(MapKind kind, const ImageArgs& img_in, const MapArgs& map, int order, int dtype, const LaunchOpts& opts,
                            hipStream_t stream, bool* taken) {
   *taken = false;
+  t_any_order = opts.any_order;
   const int es = elem_size(dtype);
   if ((kind != kRadial && kind != kPersp) || (order != 0 && order != 1) || map.tile_dev_ok < 2 || !opts.wg_box || !opts.lds_gather ||
       opts.xcd_remap != 2 || opts.coef_lds)
@@ -2088,6 +2101,7 @@ static hipError_t launch_generic(const ImageArgs& img, const MapArgs& map, int s
 hipError_t launch_image(MapKind kind, const ImageArgs& img_in, const MapArgs& map, int sampler, bool round_f32,
                         const LaunchOpts& opts, hipStream_t stream) {
   ImageArgs img = img_in;
+  t_any_order = opts.any_order;
   int tr = opts.tile_rows;
   if (tr < 1) tr = 1;
   if (tr > kMaxTileRows) tr = kMaxTileRows;

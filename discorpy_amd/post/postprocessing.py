@@ -118,12 +118,16 @@ def _cai_to_host(a):
     return out
 
 
-def _default_blend():
-    return os.environ.get("DISCORPY_AMD_BLEND", "f64lerp")
+def _default_blend(host=False):
+    """``blend=None``: host (NumPy) arrays get scipy's exact operation order -- the result is then the reference's bit for bit given
+    the same float32 coordinates, and the kernel hides under the PCIe transfers anyway; device-resident arrays get the
+    factorised float64 form (<= 1 float32 ulp from scipy's, 5-10 % faster where the kernel is what is timed).  The environment
+    variable DISCORPY_AMD_BLEND overrides both, DISCORPY_AMD_HOST_BLEND the host default only."""
+    return os.environ.get("DISCORPY_AMD_BLEND", os.environ.get("DISCORPY_AMD_HOST_BLEND", "scipy") if host else "f64lerp")
 
 
-def _blend_code(blend):
-    name = _default_blend() if blend is None else blend
+def _blend_code(blend, host=False):
+    name = _default_blend(host) if blend is None else blend
     try:
         return F.BLEND_BY_NAME[str(name).lower()]
     except KeyError:
@@ -418,8 +422,8 @@ def unwarp_image_backward(mat, xcenter, ycenter, list_fact, order=1, mode="refle
             return out
         return res
     order = _check_order_mode(order, mode)
-    bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
+    bcode = _blend_code(blend, img.mem == F.MEM_HOST)
     fact = _coefs(list_fact, "list_fact")
     fa, nf = F.fact_array(fact)
     out, optr = img.empty((height, width), out=out)
@@ -491,7 +495,6 @@ def unwarp_images_backward(mats, xcenter, ycenter, list_fact, order=1, mode="ref
     frames = [mats[i] for i in range(mats.shape[0])] if stacked else list(mats)
     n = len(frames)
     order = _check_order_mode(order, mode)
-    bcode = _blend_code(blend)
     xcs, ycs = _per_frame(xcenter, n, "xcenter"), _per_frame(ycenter, n, "ycenter")
     per_frame_fact = len(list_fact) > 0 and np.ndim(list_fact[0]) > 0
     if per_frame_fact and len(list_fact) != n:
@@ -506,14 +509,20 @@ def unwarp_images_backward(mats, xcenter, ycenter, list_fact, order=1, mode="ref
         return mats if stacked else []
     # A (n, height, width) DEVICE array of an integer type or float64 under ONE calibration, bilinear: the frames are the projections
     # of a stack whose every row is wanted -- the stack kernel on that element type (uint16: 0.59 of the HBM peak against 0.27
-    # frame by frame), the same pixels (scipy's blend and store either way).  float32 takes the same route inside the C ABI.
+    # frame by frame), the same pixels (scipy's blend and store either way).  coord_round_f32 = 2 asks for unwarp_image_backward's
+    # semantics -- coordinates clipped to the whole image, no row band -- so folding models give what the frame-by-frame calls give.
+    # Arrays the stack entry point cannot address in place (column-strided or overlapping views) go frame by frame below.
+    # float32 takes the same route inside the C ABI.
     if (stacked and order == 1 and n >= 2 and out is None and not per_frame_fact and np.ndim(xcenter) == 0 and np.ndim(ycenter) == 0
             and (_is_torch(mats) and mats.is_cuda or _is_cai(mats))
             and str(mats.dtype).replace("torch.", "") in ("uint8", "int8", "uint16", "int16", "uint32", "int32", "float64")
             and 2 <= mats.shape[1] <= 65535 and mats.shape[2] >= 2):
-        return _stack_rows(mats, xcs[0], ycs[0], facts[0], 0.0, int(mats.shape[1]), True, blend)
+        ps, rs, cs = _Image(mats, 3).strides
+        if cs == 1 and rs >= mats.shape[2] and ps >= (mats.shape[1] - 1) * rs + mats.shape[2]:
+            return _stack_rows(mats, xcs[0], ycs[0], facts[0], 0.0, int(mats.shape[1]), 2, blend)
     imgs = [_Image(f, 2).dense_rows() for f in frames]
     first = imgs[0]
+    bcode = _blend_code(blend, first.mem == F.MEM_HOST)
     uniform = all(im.f32 and im.shape == first.shape and im.strides == first.strides and im.mem == first.mem and
                   im.device == first.device and im.stream == first.stream and im.torch == first.torch for im in imgs)
     nf = max(len(f) for f in facts)
@@ -648,7 +657,7 @@ def _stack_rows_centres(mat3D, xcenters, ycenters, list_fact, row_start, nrows, 
             F.require_device()
             xa, ya = (C.c_double * k)(*xcs), (C.c_double * k)(*ycs)
             F.check(F.lib().dcp_unwarp_stack_rows_centres_f32(vol.ptr, optr, depth, height, width, ps if depth > 1 else height * rs, rs, xa, ya, k,
-                                                              fa, nf, float(row_start), int(nrows), int(round_f32), _blend_code(blend), vol.mem,
+                                                              fa, nf, float(row_start), int(nrows), int(round_f32), _blend_code(blend, vol.mem == F.MEM_HOST), vol.mem,
                                                               vol.device, vol.stream))
         return res
     blocks = [_stack_rows(mat3D, xcs[i], ycs[i], list_fact, row_start, nrows, round_f32, blend, out_float32=out_float32) for i in range(k)]
@@ -722,7 +731,7 @@ def _stack_rows_lazy(src, xcenter, ycenter, list_fact, row_start, nrows, round_f
     (``:221-228``, ``:295-301``) only the row band the requested rows can reach is read from each projection --
     ``src[d0:d1, band, :]`` per depth chunk, the next chunk being read while this one is on the GPU."""
     from concurrent.futures import ThreadPoolExecutor
-    bcode = _blend_code(blend)
+    bcode = _blend_code(blend, True)                  # an out-of-core stack is host data
     (depth, height, width) = src.shape
     dtype = np.dtype(src.dtype)
     code = _dtype_code(dtype)
@@ -767,8 +776,8 @@ def _stack_rows(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32,
         if devices is not None:
             raise ValueError("devices= needs a NumPy stack in memory")
         return _stack_rows_lazy(mat3D, xcenter, ycenter, list_fact, row_start, nrows, round_f32, blend, out_float32, out)
-    bcode = _blend_code(blend)
     vol = _Image(mat3D, 3)
+    bcode = _blend_code(blend, vol.mem == F.MEM_HOST)
     depth, height, width = vol.shape
     if depth == 0:
         return vol.empty((0, nrows, width), out_float32, out=out)[0]
@@ -841,8 +850,8 @@ def correct_perspective_image(mat, list_coef, order=1, mode="reflect", map_index
             return out
         return res
     order = _check_order_mode(order, mode)
-    bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
+    bcode = _blend_code(blend, img.mem == F.MEM_HOST)
     if map_index is not None:
         ymap, xmap = map_index[0], map_index[1]
         res = remap_coordinates(mat, ymap, xmap, order=order, mode=mode, blend=blend).reshape((height, width))
@@ -939,8 +948,8 @@ def unwarp_perspective_fused(mat, xcenter, ycenter, list_fact, list_coef, order=
         raise ValueError("!!! Eight coefficients are required !!!")
     (height, width) = mat.shape
     order = _check_order_mode(order, mode)
-    bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
+    bcode = _blend_code(blend, img.mem == F.MEM_HOST)
     fa, nf = F.fact_array(_coefs(list_fact, "list_fact"))
     ca, _ = F.fact_array(_coefs(list_coef, "list_coef"))
     out, optr = img.empty((height, width), out=out)
@@ -970,8 +979,8 @@ def remap_coordinates(mat, ycoords, xcoords, order=1, mode="reflect", *, blend=N
     """
     (height, width) = mat.shape
     order = _check_order_mode(order, mode)
-    bcode = _blend_code(blend)
     img = _Image(mat, 2).dense_rows()
+    bcode = _blend_code(blend, img.mem == F.MEM_HOST)
     staged = None
     if img.torch:
         import torch

@@ -130,7 +130,7 @@ def _unwarp_interleaved(mat_pad, xcenter, ycenter, list_fact, order, blend=None)
     out, optr = img.empty((h, w, c))
     F.require_device()
     F.check(F.lib().dcp_unwarp_color_image(img.ptr, optr, img.code, h, w, c, rs, ps, float(xcenter), float(ycenter),
-                                           fa, nf, order, _pp._blend_code(blend), img.mem, img.device, img.stream))
+                                           fa, nf, order, _pp._blend_code(blend, img.mem == F.MEM_HOST), img.mem, img.device, img.stream))
     return out
 
 

@@ -44,6 +44,14 @@ extern "C" {
 
 #define DCP_MEM_HOST 0
 #define DCP_MEM_DEVICE 1
+/* DCP_MEM_DEVICE for callers that hand over INDEPENDENT frames one call at a time (a camera loop, the channels of demo_06.py:111-113):
+ * the kernel is enqueued on `stream` with the barrier bit of its dispatch packet cleared (hipExtAnyOrderLaunch), so its first
+ * workgroups may start while the last workgroups of the PREVIOUS kernel on that stream still run -- the drain of one frame under
+ * the ramp of the next, which is what dcp_unwarp_images_f32 gets from one launch (profiles/r06a_dispatch_modes.txt).  The caller
+ * vouches that the call reads nothing an unfinished earlier call on the stream writes and writes nothing it reads or writes;
+ * events, copies and synchronisations on the stream still wait for every earlier launch.  Accepted by dcp_unwarp_image_f32,
+ * dcp_perspective_image_f32 and dcp_unwarp_fused_f32 (orders 0 / 1); DCP_ERR_INVALID_ARG elsewhere. */
+#define DCP_MEM_DEVICE_UNORDERED 0x101
 
 #define DCP_BLEND_SCIPY 0
 #define DCP_BLEND_F64LERP 1
@@ -142,7 +150,12 @@ int dcp_remap_coords_mode_f32(const float* src, float* dst, int64_t height, int6
  * and :255-313 (unwarp_chunk_slices_backward: coord_round_f32 = 1) over a (depth, height, width)
  * stack: out[d, r, x] (dense, depth x nrows x width) = projection d sampled bilinearly at the
  * radial source coordinate of output pixel (row_start + r, x).  proj_stride / row_stride are the
- * element strides of `vol` between projections / rows. */
+ * element strides of `vol` between projections / rows.
+ * coord_round_f32 = 2: float32 coordinates under unwarp_image_backward's semantics (:141-148) -- the projections are the FRAMES of a
+ * (n, height, width) array corrected with one calibration: every coordinate is clipped to the whole frame and the chunk function's
+ * row band [yd_min, yd_max) (:289-301) plays no part, so a model that folds rows gives exactly what n calls of
+ * dcp_unwarp_image_f32 give.  The requested rows must lie inside the frame.  (dcp_unwarp_images_f32 routes frames of one
+ * calibration this way by itself; dcp_unwarp_stack_rows_typed accepts the value too.) */
 int dcp_unwarp_stack_rows_f32(const float* vol, float* out, int64_t depth, int64_t height, int64_t width,
                               int64_t proj_stride, int64_t row_stride, double xcenter, double ycenter,
                               const double* list_fact, int nfact, double row_start, int64_t nrows,
@@ -411,6 +424,10 @@ int dcp_stream_destroy(void* stream);
 int dcp_stream_synchronize(int device, void* stream);
 int dcp_event_create(void** event, int device);
 int dcp_event_record(void* event, void* stream);
+/* work enqueued on `stream` after this call starts only when `event` (recorded on any stream of the device) has completed --
+ * hipStreamWaitEvent: how a caller who spreads independent frames over two streams (two frames in flight: the drain of one under the
+ * ramp of the other, profiles/r06a_dispatch_modes.txt) forks from and joins back into one stream without a host synchronisation */
+int dcp_stream_wait_event(void* stream, void* event);
 int dcp_event_synchronize(void* event);
 int dcp_event_elapsed_ms(void* start, void* stop, float* ms);
 int dcp_event_destroy(void* event);

@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# blend=None: host (NumPy) inputs get scipy's exact operation order, device-resident ones the factorised float64 form
+# (discorpy_amd/post/postprocessing.py _default_blend).  DISCORPY_AMD_HOST_BLEND moves the host default -- a run of the GPU suite
+# under DISCORPY_AMD_HOST_BLEND=f32 fails every test that names the wrong default for the kind of array it passes.
+HOST = os.environ.get("DISCORPY_AMD_HOST_BLEND", "scipy")
+DEV = "f64lerp"
+
+
+def oblend(orc, name):
+    """The oracle's code of a blend name ("scipy", "f64lerp", "f32")."""
+    return {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32": orc.BLEND_F32LERP}[name]
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

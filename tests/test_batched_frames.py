@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import noise
+from conftest import HOST, noise, oblend
 
 from discorpy_amd import _ffi as F
 from discorpy_amd import configs
@@ -138,14 +138,15 @@ def test_python_front_end_numpy_torch_and_colour_planes(hip, orc):
     cals = _calibrations(n, H, W, 8)
     xcs, ycs, facts = [c[0] for c in cals], [c[1] for c in cals], [c[2] for c in cals]
     want = [orc.unwarp_image_backward(f, *c, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP) for f, c in zip(frames, cals)]
+    want_host = [orc.unwarp_image_backward(f, *c, poly=orc.POLY_KERNEL, blend=oblend(orc, HOST)) for f, c in zip(frames, cals)]
     # NumPy frames (host path: frame by frame inside the C call), per-frame calibrations of different lengths
     got = pp.unwarp_images_backward(frames, xcs, ycs, facts)
-    assert isinstance(got, list) and all(np.array_equal(g, w) for g, w in zip(got, want))
+    assert isinstance(got, list) and all(np.array_equal(g, w) for g, w in zip(got, want_host))
     # one 3-D array, one shared calibration
     got = pp.unwarp_images_backward(np.stack(frames), xcs[0], ycs[0], facts[0])
     assert got.shape == (n, H, W)
     for i in range(n):
-        assert np.array_equal(got[i], orc.unwarp_image_backward(frames[i], *cals[0], poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+        assert np.array_equal(got[i], orc.unwarp_image_backward(frames[i], *cals[0], poly=orc.POLY_KERNEL, blend=oblend(orc, HOST)))
     # other element types and spline orders go image by image, same results as the single calls
     u16 = [(f * 60000).astype(np.uint16) for f in frames]
     got = pp.unwarp_images_backward(u16, xcs, ycs, facts)
@@ -305,3 +306,48 @@ def test_a_3d_device_array_of_another_element_type_takes_the_stack_kernel(hip, o
         assert np.array_equal(got[i], orc.unwarp_image_backward(frames[i], xc, yc, fact, poly=orc.POLY_KERNEL))
     one = pp.unwarp_image_backward(t[1], xc, yc, fact)
     assert np.array_equal(one.cpu().numpy(), got[1])
+
+
+@pytest.mark.gpu
+def test_a_3d_device_array_under_a_folding_model_gives_what_the_single_calls_give(hip, orc):
+    """the stack shortcut used the chunk function's semantics -- crop to the row band [yd_min, yd_max) spanned
+    by the first and last rows and reflect inside it (postprocessing.py:289-312) -- for FRAMES, whose reference is
+    unwarp_image_backward: clip to the whole image (:144-145).  Under a model that folds rows the two differ, or the band is empty
+    (the call failed).  Frames now travel with coord_round_f32 = 2 (whole-frame clip, no band) -- the float32 route inside the C ABI
+    and the typed route of the front end alike -- and device arrays the stack entry point cannot address in place (column-strided
+    views) go frame by frame instead of raising."""
+    torch = pytest.importorskip("torch")
+    H, W, n = 300, 420, 3
+    frames = np.stack([(noise(900 + i, (H, W)) * 60000.0).astype(np.uint16) for i in range(n)])
+    ff = np.stack([noise(910 + i, (H, W)) for i in range(n)])
+    L = hip.lib()
+    for xc, yc, fact in ((210.0, 150.0, [1.0, -9e-3, 1.5e-5]),       # folds: B changes sign inside the frame
+                         (200.0, 140.0, [-1.0, 0.0]),                # point reflection: rows reversed, first row maps below the last
+                         (500.0, 900.0, [0.0, 0.0, 1e-9])):          # everything onto the centre row, outside the frame: a band of (nearly) nothing
+        t = torch.from_numpy(frames.view(np.int16) if not hasattr(torch, "uint16") else frames).cuda()
+        out = pp.unwarp_images_backward(t, xc, yc, fact).cpu().numpy().view(np.uint16)
+        for i in range(n):
+            want = orc.unwarp_image_backward(frames[i], xc, yc, fact, poly=orc.POLY_KERNEL)
+            if hasattr(torch, "uint16"):
+                assert np.array_equal(out[i], want), (fact, i)
+            assert np.array_equal(out[i].view(t.cpu().numpy().dtype), pp.unwarp_image_backward(t[i], xc, yc, fact).cpu().numpy()), (fact, i)
+        # float32 frames through dcp_unwarp_images_f32 (frames_as_stack declines or runs them with the whole-frame clip; never an error)
+        tf = torch.from_numpy(ff).cuda()
+        gotf = pp.unwarp_images_backward(tf, xc, yc, fact).cpu().numpy()
+        for i in range(n):
+            assert np.array_equal(gotf[i], orc.unwarp_image_backward(ff[i], xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)), (fact, i)
+        # the C entry point itself with coord_round_f32 = 2 against per-frame oracle results, and = 1 (chunk semantics) untouched
+        src = hip.DeviceBuffer(ff.nbytes).upload(ff)
+        dst = hip.DeviceBuffer(ff.nbytes)
+        fa, nf = hip.fact_array(fact)
+        hip.check(L.dcp_unwarp_stack_rows_f32(src.ptr, dst.ptr, n, H, W, H * W, W, xc, yc, fa, nf, 0.0, H, 2, hip.BLEND_F64LERP, hip.MEM_DEVICE, -1, None))
+        assert np.array_equal(dst.download((n, H, W), np.float32), gotf), fact
+        src.free()
+        dst.free()
+    # a column-strided 3-D device view (one channel of interleaved frames): frame by frame, not a ValueError
+    inter = torch.from_numpy(np.stack([frames, frames[::-1]], axis=-1).astype(np.int16 if not hasattr(torch, "uint16") else np.uint16)).cuda()
+    view = inter[:, :, :, 0]
+    assert view.stride(2) == 2
+    got = pp.unwarp_images_backward(view, 210.0, 150.0, [1.0, 1e-4])
+    for i in range(n):
+        assert torch.equal(got[i], pp.unwarp_image_backward(view[i].contiguous(), 210.0, 150.0, [1.0, 1e-4]))

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import golden, noise
+from conftest import DEV, HOST, golden, noise, oblend
 
 from discorpy_amd import _ffi as F
 from discorpy_amd.post import postprocessing as pp
@@ -78,7 +78,7 @@ def test_device_stack_many_centres_and_chunks(hip, orc):
     got = pp.unwarp_chunk_slices_backward_centres(t, xs[:7], ys[:7], fact, 100, 131)
     torch.cuda.synchronize()
     got = got.cpu().numpy()
-    host = pp.unwarp_chunk_slices_backward_centres(vol, xs[:7], ys[:7], fact, 100, 131)
+    host = pp.unwarp_chunk_slices_backward_centres(vol, xs[:7], ys[:7], fact, 100, 131, blend=DEV)
     assert got.shape == host.shape == (7, D, 32, W) and np.array_equal(got, host)
     for k in range(7):
         assert np.array_equal(got[k], orc.unwarp_chunk_slices_backward(vol, xs[k], ys[k], fact, 100, 131, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
@@ -97,7 +97,7 @@ def test_centres_folding_model_other_dtypes_and_strided_host_stack(hip, orc):
     got = pp.unwarp_slice_backward_centres(fvol, [fx + 2.0, fx], [fy - 1.0, fy], fold, s0 + 3)
     assert F.last_kernel().startswith("stack_centres_kernel")
     for k, (cx, cy) in enumerate([(fx + 2.0, fy - 1.0), (fx, fy)]):
-        assert np.array_equal(got[k], orc.unwarp_slice_backward(fvol, cx, cy, fold, s0 + 3, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+        assert np.array_equal(got[k], orc.unwarp_slice_backward(fvol, cx, cy, fold, s0 + 3, poly=orc.POLY_KERNEL, blend=oblend(orc, HOST)))
     D, H, W = 4, 120, 200
     vol = noise(12, (D, H, W))
     cents = [(100.0, 60.0), (104.0, 57.5), (93.0, 64.0)]
@@ -115,4 +115,4 @@ def test_centres_folding_model_other_dtypes_and_strided_host_stack(hip, orc):
     got = pp.unwarp_slice_backward_centres(view, xs, ys, fact, 77)
     for k, (cx, cy) in enumerate(cents):
         assert np.array_equal(got[k], orc.unwarp_slice_backward(np.ascontiguousarray(view), cx, cy, fact, 77, poly=orc.POLY_KERNEL,
-                                                                blend=orc.BLEND_F64LERP))
+                                                                blend=oblend(orc, HOST)))

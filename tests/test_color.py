@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import golden, noise, typed_image
+from conftest import HOST, golden, noise, typed_image
 
 pytestmark = pytest.mark.gpu
 
@@ -15,7 +15,7 @@ FACT5 = [1.00227490554, -9.3601153805625e-06, 8.78436609375e-09, -4.793288022186
 
 
 def planes_from_oracle(orc, rgb, xc, yc, fact, order, blend):
-    ob = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP}[blend]
+    ob = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32": orc.BLEND_F32LERP}[blend]
     if rgb.dtype == np.float32:
         return np.stack([orc.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, c]), xc, yc, fact, order=order, poly=orc.POLY_KERNEL, blend=ob)
                          for c in range(rgb.shape[2])], axis=2)
@@ -39,7 +39,7 @@ def test_float32_colour_equals_the_oracle_and_three_single_plane_calls(hip, orc,
         got = util.unwarp_color_image_backward(rgb, xc, yc, fact, order=order, blend=blend)
         assert hip.last_kernel().startswith("remap_wg_color_kernel" if staged else "typed_channels_kernel"), hip.last_kernel()
         assert got.dtype == np.float32 and got.shape == rgb.shape
-        want = planes_from_oracle(orc, rgb, xc, yc, fact, order, blend or "f64lerp")
+        want = planes_from_oracle(orc, rgb, xc, yc, fact, order, blend or HOST)
         assert np.array_equal(got, want), (order, blend, int((got != want).sum()))
         for c in range(shape[2]):           # what three K1 calls give
             assert np.array_equal(got[:, :, c], pp.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, c]), xc, yc, fact, order=order, blend=blend))
@@ -86,16 +86,16 @@ def test_what_the_staged_kernel_declines_gives_the_same_values(hip, orc):
         for blend in (None, "scipy"):
             got = util.unwarp_color_image_backward(img, xc, yc, fact, blend=blend)
             assert hip.last_kernel().startswith("typed_channels_kernel")
-            assert np.array_equal(got, planes_from_oracle(orc, img, xc, yc, fact, 1, blend or "f64lerp")), (ch, blend)
+            assert np.array_equal(got, planes_from_oracle(orc, img, xc, yc, fact, 1, blend or HOST)), (ch, blend)
     rgba = noise(8, (300, 640, 4))
     view = rgba[:, :, :3]                                    # pixel stride 4, three channels
     got = util.unwarp_color_image_backward(view, xc, yc, fact)
-    assert np.array_equal(got, planes_from_oracle(orc, np.ascontiguousarray(view), xc, yc, fact, 1, "f64lerp"))
+    assert np.array_equal(got, planes_from_oracle(orc, np.ascontiguousarray(view), xc, yc, fact, 1, HOST))
     fold = [1.0, -4e-3, 6e-6]                                # folds inside the frame: no certificate
     img = noise(9, (400, 640, 3))
     got = util.unwarp_color_image_backward(img, 320.0, 200.0, fold)
     assert hip.last_kernel().startswith("typed_channels_kernel")
-    assert np.array_equal(got, planes_from_oracle(orc, img, 320.0, 200.0, fold, 1, "f64lerp"))
+    assert np.array_equal(got, planes_from_oracle(orc, img, 320.0, 200.0, fold, 1, HOST))
 
 
 def test_device_resident_4096_rgb_and_a_band_of_rows(hip, orc):
@@ -154,11 +154,12 @@ def test_sheared_map_on_64x32_workgroup_tiles_is_an_equal_and_slower_alternative
     xc, yc = c5["xcenter"] / s, c5["ycenter"] / s
     img = noise(41, (H, W))
     want = orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+    host_blend = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32": orc.BLEND_F32LERP}[HOST]
     try:
         hip.set_option("x_tall_tiles", 1)
         got = pp.unwarp_image_backward(img[:1024], xc, yc, fact)          # (a host frame below the banded path's threshold: one launch)
         assert "64x32 tiles" in hip.last_kernel(), hip.last_kernel()
-        w2 = orc.unwarp_image_backward(np.ascontiguousarray(img[:1024]), xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+        w2 = orc.unwarp_image_backward(np.ascontiguousarray(img[:1024]), xc, yc, fact, poly=orc.POLY_KERNEL, blend=host_blend)
         assert np.array_equal(got, w2)
         hip.set_option("x_tall_tiles", 0)
         assert np.array_equal(pp.unwarp_image_backward(img[:1024], xc, yc, fact), w2) and hip.last_kernel().startswith("remap_lds_kernel")

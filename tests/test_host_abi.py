@@ -51,11 +51,17 @@ def test_options_round_trip():
         F.set_option(key, old)
     with pytest.raises(ValueError, match="unknown option"):
         F.set_option("no_such_knob", 1)
-    for key in ("tile_rows", "wg_box", "x_host_duplex", "x_tile_cert", "x_", ""):
+    for key in ("fused_wg", "any_order", "pf2d_chunk", "x_host_duplex", "x_tile_cert", "x_", ""):
         with pytest.raises(ValueError, match="unknown option"):
             F.set_option(key, 1)
         with pytest.raises(ValueError, match="unknown option"):
             F.get_option(key)
+    # the unprefixed spellings the round-4 header documented stay accepted as deprecated aliases of the x_ names
+    for key, val in (("tile_rows", 8), ("wg_box", 0), ("stack_wg", 2), ("int_exact", 0), ("spline_tiled", 3), ("xcd_remap", 1)):
+        old = F.get_option("x_" + key)
+        F.set_option(key, val)
+        assert F.get_option("x_" + key) == val and F.get_option(key) == val
+        F.set_option("x_" + key, old)
     # the header documents the stable options and nothing else of them
     hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "discorpy_hip.h")).read()
     doc = hdr[hdr.index("/* Options (process-wide)"):hdr.index("int dcp_set_option")]

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import noise
+from conftest import HOST, noise
 
 from discorpy_amd import _ffi as F
 from discorpy_amd import _pool
@@ -31,10 +31,11 @@ def test_direct_write_into_registered_host_memory_equals_the_staged_path(hip, or
     img = noise(501, (H, W))
     xc, yc, fact = 1010.4, 1120.7, [1.0, -8e-6, 6e-9, -2e-12]
     coef = [0.98, -0.012, 20.5, 0.009, 1.01, -14.0, 4e-6, -3e-6]
-    want = {"radial": orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP),
+    hb = {"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32": orc.BLEND_F32LERP}[HOST]        # NumPy frames: the host default blend
+    want = {"radial": orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=hb),
             "nearest": orc.unwarp_image_backward(img, xc, yc, fact, order=0, poly=orc.POLY_KERNEL),
-            "persp": orc.correct_perspective_image(img, coef, blend=orc.BLEND_F64LERP),
-            "fused": orc.unwarp_fused(img, xc, yc, fact, coef, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)}
+            "persp": orc.correct_perspective_image(img, coef, blend=hb),
+            "fused": orc.unwarp_fused(img, xc, yc, fact, coef, poly=orc.POLY_KERNEL, blend=hb)}
     L = hip.lib()
     try:
         for mode in (2, 0, 1):                            # always direct when registered / never / decided by the runtime probe
@@ -75,7 +76,8 @@ def test_a_destination_registered_only_in_part_takes_the_staged_path(hip, orc):
     H, W = 2200, 2100
     img = noise(502, (H, W))
     xc, yc, fact = 1010.4, 1120.7, [1.0, -8e-6, 6e-9, -2e-12]
-    want = orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)
+    want = orc.unwarp_image_backward(img, xc, yc, fact, poly=orc.POLY_KERNEL,
+                                     blend={"scipy": orc.BLEND_SCIPY, "f64lerp": orc.BLEND_F64LERP, "f32": orc.BLEND_F32LERP}[HOST])
     L = hip.lib()
     out = np.zeros((H, W), np.float32)
     half = (out.nbytes // 2) & ~4095

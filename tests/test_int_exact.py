@@ -5,7 +5,7 @@ Reference behaviour: output dtype = input dtype, scipy's integer rounding (postp
 import numpy as np
 import pytest
 
-from conftest import typed_image
+from conftest import HOST, oblend, typed_image
 
 from discorpy_amd import _ffi as F
 from discorpy_amd.post import postprocessing as pp
@@ -63,4 +63,4 @@ def test_short_coefficient_vectors_run_the_four_term_kernels_zero_padded(hip, or
     got = pp.unwarp_slice_backward_centres(volf, [c[0] for c in cents], [c[1] for c in cents], fact, 140)
     assert "NF=4" in F.last_kernel(), F.last_kernel()
     for k, (cx, cy) in enumerate(cents):
-        assert np.array_equal(got[k], orc.unwarp_slice_backward(volf, cx, cy, fact, 140, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+        assert np.array_equal(got[k], orc.unwarp_slice_backward(volf, cx, cy, fact, 140, poly=orc.POLY_KERNEL, blend=oblend(orc, HOST)))

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, noise
+from conftest import HOST, ROOT, noise, oblend
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "helpers"))
 import fake_h5py  # noqa: E402
@@ -225,7 +225,7 @@ def test_example_04_call_sequence_on_hdf_datasets(hip, orc, h5, tmp_path, dtype)
     # one sinogram (float32 result whatever the input type, postprocessing.py:224)
     one = post.unwarp_slice_backward(src, xcenter, ycenter, list_fact, 100)
     assert one.dtype == np.float32 and np.array_equal(one, orc.unwarp_slice_backward(native, xcenter, ycenter, list_fact, 100, poly=orc.POLY_KERNEL,
-                                                                                    blend=orc.BLEND_F64LERP if dtype == "<f4" else orc.BLEND_SCIPY))
+                                                                                    blend=oblend(orc, HOST) if dtype == "<f4" else orc.BLEND_SCIPY))
     # the whole corrected stack, streamed into a new file in passes of 64 rows
     dst = losa.open_hdf_stream(str(tmp_path / "out" / "corrected.hdf"), (D, H, W), key_path="entry/data", data_type=native.dtype.name,
                                options={"entry/xcenter": xcenter, "entry/ycenter": ycenter})

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of library variants on ONE box: for every discorpy_amd/lib/variants/lib_*.so run "$@" under rocprofv3 --kernel-trace --stats
 # and print the kernels' average durations.   tools/ab_variants.sh python tools/time_spline.py --orders 3 --variants 1
+case "${1:-}" in -h|--help) sed -n '2,3p' "$0" | sed 's/^# \{0,1\}//'; exit 0;; esac
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 for lib in $ROOT/discorpy_amd/lib/variants/lib_*.so; do

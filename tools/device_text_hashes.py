@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """SHA-256 of the .text section of every gfx950 code object of a library: two builds whose hashes agree contain byte-identical
 kernels (what a refactoring of the kernel sources must show).    python tools/device_text_hashes.py [lib.so]"""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import hashlib
 import os
 import subprocess

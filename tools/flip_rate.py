@@ -6,6 +6,10 @@ ORC_POLY_KERNEL (fused final step, what the HIP kernels compute) and ORC_POLY_KE
 
     python tools/flip_rate.py [trials]
 """
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import os
 import sys
 

@@ -12,6 +12,10 @@ Shapes from 1 x 1 to ~1500 x 1500, centres inside and far outside the image, pol
 folding maps (which exercise the LDS kernel's "box does not fit" / "vote failed" fallbacks), strong homographies,
 strided sources, every blend mode, stacks, explicit coordinates, element types, spline orders and boundary modes.
 """
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import os
 import sys
 import time

@@ -6,6 +6,10 @@ the scale of the data).
 
     python tools/fuzz_pf2d.py [cases] [seed]
 """
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import os
 import sys
 import time

@@ -7,6 +7,10 @@ reference's source is stored.  SURVEY.md section 8(c) lists the cases G1..G9.
 
     PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
 """
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import os
 import sys
 

@@ -8,6 +8,10 @@ Classes: f64 = VALU ops on doubles (v_*_f64, conversions to/from f64), f32fast =
 VALU ops that issue a wave64 in 2 cycles on CDNA4), valu = every other vector ALU op (4 cycles), trans = v_rsq/rcp/sqrt_f64
 (quarter rate: 16 cycles), lds = ds_*, vmem = buffer_/global_ loads and stores, salu = s_* (own issue port).
 """
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import re
 import sys
 

@@ -5,6 +5,10 @@ tools/isa_count.py.
 
     python tools/kernel_asm.py file.s <substring of the mangled kernel name> [out.s]
 """
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import re
 import sys
 

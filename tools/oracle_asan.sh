@@ -2,6 +2,7 @@
 # The oracle's golden suite (every reference fixture under tests/golden) with the C restatement built under AddressSanitizer and
 # UndefinedBehaviorSanitizer -- SURVEY.md section 5's sanitizer hook.  CPU only; writes nothing outside the repo.
 #     tools/oracle_asan.sh [pytest args]
+case "${1:-}" in -h|--help) sed -n '2,4p' "$0" | sed 's/^# \{0,1\}//'; exit 0;; esac
 set -e
 cd "$(dirname "$0")/.."
 make -C oracle asan >/dev/null

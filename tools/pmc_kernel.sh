@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of every kernel a command launches whose name contains $KERNELS (comma separated), averaged per launch:
-#   KERNELS=rowfused,spline_wg_kernel tools/pmc_kernel.sh python tools/time_spline_rowfuse.py
+#   KERNELS=spline_prefilter2d,spline_wg_kernel tools/pmc_kernel.sh python tools/time_spline.py --orders 3
+case "${1:-}" in -h|--help) sed -n '2,3p' "$0" | sed 's/^# \{0,1\}//'; exit 0;; esac
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 cd /tmp

@@ -5,6 +5,7 @@
 # --kernel-trace), converted as tools/summarize_prof.py does (KB; reads x 2 -- the calibration of tools/calib_copy.hip, which is
 # re-run here on kernels that move exactly 1 GiB each way) and set against what each launch moves BY CONSTRUCTION.
 #   tools/pmc_spline.sh            (writes gpurun_out/pmc_spline.json + prints a table)
+case "${1:-}" in -h|--help) sed -n '2,7p' "$0" | sed 's/^# \{0,1\}//'; exit 0;; esac
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 mkdir -p $ROOT/gpurun_out

@@ -3,6 +3,7 @@
 #   tools/profile.sh <tag> [extra bench.py args]
 # Writes gpurun_out/prof_<tag>/<pass>/..., then tools/summarize_prof.py condenses them.
 # Timing and counters are collected in SEPARATE runs (PMC passes carry --kernel-trace only).
+case "${1:-}" in -h|--help) sed -n '2,5p' "$0" | sed 's/^# \{0,1\}//'; exit 0;; esac
 set -u
 TAG=${1:-run}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}

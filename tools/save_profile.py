@@ -1,5 +1,9 @@
 """Copy the judged part of a tools/profile.sh run from gpurun_out/ (scratch) into profiles/ (tracked):
    python tools/save_profile.py gpurun_out/prof_r01 r01 [--latest]"""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import json
 import os
 import shutil

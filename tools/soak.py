@@ -1,3 +1,9 @@
+"""Leak check: 3000 randomised calls through the Python front end (NumPy and torch inputs, every entry point); prints the
+process RSS and the free device memory every 500 calls -- both must stay flat.    python tools/soak.py"""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import sys, time, os, resource
 import numpy as np, torch
 sys.path.insert(0, ".")

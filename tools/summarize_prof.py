@@ -1,4 +1,8 @@
 """Condense the rocprofv3 CSV output of tools/profile.sh into one text/JSON summary."""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import csv
 import glob
 import json

@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """A/B on one box: BASELINE config 5 (8192^2, 9-term fisheye model) on 64 x 32 workgroup tiles (option tall_tiles = 1:
 remap_wg_color_kernel, one channel, second tile shape) against the per-wave-box kernel (tall_tiles = 0: remap_lds_kernel)."""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import os
 import sys
 

@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """us per 4096^2 launch of the frame kernels by element type / sampler, no verification (for the ablation variants of
 tools/variants.sh, selected with DCP_LIB_PATH).  python tools/time_frames.py [label]"""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import os
 import sys
 

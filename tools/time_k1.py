@@ -1,6 +1,10 @@
 """Sustained per-launch time of the cfg2 frame kernel (HIP events, ring of 24 frame pairs, 300 ms of launches
 first so the clock has settled).  DCP_LIB_PATH selects the build; argv: tag [key=value options].
     DCP_LIB_PATH=discorpy_amd/lib/libdcp_r01.so python tools/time_k1.py r01"""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import sys
 import time
 import numpy as np

@@ -3,6 +3,10 @@ against the generic one-thread-per-voxel typed_stack_kernel (stack_wg = 0).  cfg
 
     python tools/time_typed_stack.py [depth]
 """
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import os, sys, time
 import numpy as np
 import torch

@@ -1,5 +1,9 @@
 """Per-wave phase timeline of one cfg2 launch of remap_lds_kernel (the lab build: `make -C discorpy_amd/csrc lab`, DCP_LIB_PATH=discorpy_amd/lib/libdiscorpy_hip_lab.so):
 DCP_LIB_PATH=discorpy_amd/lib/libdcp_var_trace.so python tools/trace_k1.py [blend order]"""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import ctypes as C
 import os
 import sys

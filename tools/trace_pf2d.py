@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """Phase timeline of spline_prefilter2d_kernel (the lab build: `make -C discorpy_amd/csrc lab`, DCP_LIB_PATH=discorpy_amd/lib/libdiscorpy_hip_lab.so):
 per step of wave 0 of every workgroup, s_memtime ticks (100 MHz) between the phase boundaries."""
+import sys as _sys
+if {"-h", "--help"} & set(_sys.argv[1:]):          # every tool answers --help without touching the GPU
+    print(__doc__)
+    raise SystemExit(0)
 import ctypes as C
 import os
 import sys

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B reference: libdcp_var_<name>.so with unwarp_kernels.hip taken from a git revision (default HEAD) and everything else from the
 # working tree (same C ABI, so the current Python binding loads it):  tools/variant_from_git.sh name [rev] ["-DFLAGS"]
+case "${1:-}" in -h|--help) sed -n '2,3p' "$0" | sed 's/^# \{0,1\}//'; exit 0;; esac
 set -e
 N=$1; REV=${2:-HEAD}; FLAGS=${3:-}
 cd "$(dirname "$0")/../discorpy_amd/csrc"

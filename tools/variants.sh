@@ -1,6 +1,7 @@
 #!/bin/bash
 # Builds experiment variants of the library: tools/variants.sh name "-DFLAG=.." [name2 "-D.."] ...
 # FILE=spline_kernels.hip tools/variants.sh ...  rebuilds that translation unit instead of unwarp_kernels.hip.
+case "${1:-}" in -h|--help) sed -n '2,3p' "$0" | sed 's/^# \{0,1\}//'; exit 0;; esac
 set -e
 cd "$(dirname "$0")/../discorpy_amd/csrc"
 FILE=${FILE:-unwarp_kernels.hip}
