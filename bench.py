@@ -163,23 +163,62 @@ def cpu_baseline(cfg, img, blend, threads):
 
 # ----------------------------------------------------------------------------------------- timing helpers
 
-def timed_launches(fn, reps, dev, settle_ms=120.0):
+# How INDEPENDENT per-frame launches leave the host (--dispatch): the headline and every other one-launch-per-frame entry use the
+# same mode.  two_streams: launch i goes to stream i & 1 of two library streams (dstream), timed regions fork from / join into the
+# first of them (timed_launches(..., dispatch=True)).  Entries whose launches depend on each other (the two-pass chain, the spline
+# path's shared coefficient plane, stacks, batches) stay on the default stream.
+_DISPATCH = {"mode": "ordered", "streams": [], "join": None}
+
+
+def set_dispatch(mode, dev):
+    _DISPATCH["mode"] = mode
+    _DISPATCH["streams"] = [F.Stream(dev), F.Stream(dev)] if mode == "two_streams" else []
+    _DISPATCH["join"] = F.Event(dev) if mode == "two_streams" else None
+
+
+def dstream(i):
+    st = _DISPATCH["streams"]
+    return st[i & 1].ptr if st else None
+
+
+def dmem():
+    return F.MEM_DEVICE_UNORDERED if _DISPATCH["mode"] == "any_order" else F.MEM_DEVICE
+
+
+def dsync(dev):
+    for st in _DISPATCH["streams"]:
+        st.synchronize()
+    F.check(F.lib().dcp_stream_synchronize(dev, None))
+
+
+def timed_launches(fn, reps, dev, settle_ms=120.0, dispatch=False):
     """Average device time of fn(i) per call: HIP events on the launch stream around `reps` back-to-back calls, after
-    `settle_ms` of the same calls (clock ramp)."""
+    `settle_ms` of the same calls (clock ramp).  dispatch=True: fn(i) launches on dstream(i) -- under two_streams the start event is
+    recorded on the first stream and the second waits for it, the stop event on the first behind an event of the second."""
     L = F.lib()
+    st = _DISPATCH["streams"] if dispatch else []
     t0 = time.perf_counter()
     i = 0
     while (time.perf_counter() - t0) * 1e3 < settle_ms or i < 3:
         fn(i)
         i += 1
         if i % 64 == 0:
-            F.check(L.dcp_stream_synchronize(dev, None))
-    F.check(L.dcp_stream_synchronize(dev, None))
+            dsync(dev) if st else F.check(L.dcp_stream_synchronize(dev, None))
+    dsync(dev) if st else F.check(L.dcp_stream_synchronize(dev, None))
     e0, e1 = F.Event(dev), F.Event(dev)
-    e0.record()
+    if st:
+        e0.record(st[0].ptr)
+        st[1].wait_event(e0)
+    else:
+        e0.record()
     for r in range(reps):
         fn(r)
-    e1.record()
+    if st:
+        _DISPATCH["join"].record(st[1].ptr)
+        st[0].wait_event(_DISPATCH["join"])
+        e1.record(st[0].ptr)
+    else:
+        e1.record()
     e1.synchronize()
     return e0.elapsed_ms(e1) * 1e3 / reps
 
@@ -366,6 +405,11 @@ def entry(us, pixels, bytes_per_pixel, kernel, verified, **more):
     return d
 
 
+def pf_entry(*args, **more):
+    """entry() of a one-launch-per-independent-frame workload: timed under the bench's dispatch mode."""
+    return entry(*args, dispatch=_DISPATCH["mode"], **more)
+
+
 class RingFrame:
     """One frame of the ring: a view (pointer + length) into the ring's single allocation."""
 
@@ -480,41 +524,45 @@ def other_configs(a, dev, srcs, dsts, img0):
 
     def radial(i, order, blend):
         F.check(L.dcp_unwarp_image_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c2["xcenter"], c2["ycenter"], fa, nf,
-                                       order, 1, blend, F.MEM_DEVICE, dev, None))
+                                       order, 1, blend, dmem(), dev, dstream(i)))
 
     def persp(i, src, dst):
-        F.check(L.dcp_perspective_image_f32(src[i % nring].ptr, dst[i % nring].ptr, H, W, W, 1, ca, 1, F.BLEND_F64LERP, F.MEM_DEVICE,
-                                            dev, None))
+        F.check(L.dcp_perspective_image_f32(src[i % nring].ptr, dst[i % nring].ptr, H, W, W, 1, ca, 1, F.BLEND_F64LERP, dmem(),
+                                            dev, dstream(i)))
 
     def fused(i):
         F.check(L.dcp_unwarp_fused_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c3["xcenter"], c3["ycenter"], fa, nf,
-                                       ca, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+                                       ca, 1, F.BLEND_F64LERP, dmem(), dev, dstream(i)))
 
     a2 = (img0, c2["xcenter"], c2["ycenter"], c2["list_fact"])
     # config 2, scipy's exact operation order (bit-equal to the reference; the headline's f64lerp is <= 1 float32 ulp from it)
-    us = timed_launches(lambda i: radial(i, 1, F.BLEND_SCIPY), reps, dev)
+    us = timed_launches(lambda i: radial(i, 1, F.BLEND_SCIPY), reps, dev, dispatch=True)
     k = F.last_kernel()
     radial(0, 1, F.BLEND_SCIPY)
+    dsync(dev)
     ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.unwarp_image_backward(*a2, poly=orc.POLY_KERNEL, blend=orc.BLEND_SCIPY))
-    out["cfg2_scipy_exact_blend"] = entry(us, H * W, 8, k, ok)
-    us = timed_launches(lambda i: radial(i, 0, F.BLEND_SCIPY), reps, dev)
+    out["cfg2_scipy_exact_blend"] = pf_entry(us, H * W, 8, k, ok)
+    us = timed_launches(lambda i: radial(i, 0, F.BLEND_SCIPY), reps, dev, dispatch=True)
     k = F.last_kernel()
     radial(0, 0, F.BLEND_SCIPY)
+    dsync(dev)
     ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.unwarp_image_backward(*a2, order=0, poly=orc.POLY_KERNEL))
-    out["cfg2_order0_nearest"] = entry(us, H * W, 8, k, ok)
+    out["cfg2_order0_nearest"] = pf_entry(us, H * W, 8, k, ok)
     # config 3: homography fused with the radial map in one resampling (north star), and what the reference does (two passes)
-    us = timed_launches(fused, reps, dev)
+    us = timed_launches(fused, reps, dev, dispatch=True)
     k = F.last_kernel()
     fused(0)
+    dsync(dev)
     ok = np.array_equal(download(dsts[0].ptr, (H, W), dev),
                         orc.unwarp_fused(img0, c3["xcenter"], c3["ycenter"], c3["list_fact"], c3["list_coef"], poly=orc.POLY_KERNEL,
                                          blend=orc.BLEND_F64LERP))
-    out["cfg3_fused"] = entry(us, H * W, 8, k, ok)
-    us = timed_launches(lambda i: persp(i, srcs, dsts), reps, dev)
+    out["cfg3_fused"] = pf_entry(us, H * W, 8, k, ok)
+    us = timed_launches(lambda i: persp(i, srcs, dsts), reps, dev, dispatch=True)
     k = F.last_kernel()
     persp(0, srcs, dsts)
+    dsync(dev)
     ok = np.array_equal(download(dsts[0].ptr, (H, W), dev), orc.correct_perspective_image(img0, c3["list_coef"], blend=orc.BLEND_F64LERP))
-    out["cfg3_perspective_only"] = entry(us, H * W, 8, k, ok)
+    out["cfg3_perspective_only"] = pf_entry(us, H * W, 8, k, ok)
 
     # order 3 (scipy's prefiltered cubic B-spline, the reference's `order` argument; mode "reflect"): the prefilter of both axes
     # in one launch (the column-filtered plane stays in LDS) + the LDS-staged 16-tap gather.  Algorithmic bytes: 4 read + 4
@@ -556,19 +604,24 @@ def other_configs(a, dev, srcs, dsts, img0):
 
     def radial_u16(i):
         F.check(L.dcp_unwarp_image_typed(s16[i % 4].ptr, d16[i % 4].ptr, F.DTYPE_BY_NAME["uint16"], H, W, W, 1, c2["xcenter"], c2["ycenter"],
-                                         fa, nf, 1, 0, F.MEM_DEVICE, dev, None))
-    us = timed_launches(radial_u16, reps, dev)
+                                         fa, nf, 1, 0, F.MEM_DEVICE, dev, dstream(i)))
+    us = timed_launches(radial_u16, reps, dev, dispatch=True)
     k = F.last_kernel()
     radial_u16(0)
+    dsync(dev)
     got = np.empty((H, W), np.uint16)
     F.check(L.dcp_memcpy(got.ctypes.data, d16[0].ptr, got.nbytes, F.COPY_D2H, dev, None))
     ok = np.array_equal(got, orc.unwarp_image_backward(u16, c2["xcenter"], c2["ycenter"], c2["list_fact"], poly=orc.POLY_KERNEL))
-    out["cfg2_uint16_frame"] = entry(us, H * W, 4, k, ok, note="uint16 in, uint16 out: 4 algorithmic bytes per pixel")
+    out["cfg2_uint16_frame"] = pf_entry(us, H * W, 4, k, ok, note="uint16 in, uint16 out: 4 algorithmic bytes per pixel")
     for b in s16 + d16:
         b.free()
 
-    def two_pass(i):
-        radial(i, 1, F.BLEND_F64LERP)                # srcs[i] -> dsts[i]
+    def radial_default_stream(i):
+        F.check(L.dcp_unwarp_image_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c2["xcenter"], c2["ycenter"], fa, nf,
+                                       1, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
+
+    def two_pass(i):                                 # (frame i + 1 reads what frame i wrote: one stream, in order)
+        radial_default_stream(i)                     # srcs[i] -> dsts[i]
         # dsts[i] -> srcs[i + 1]: the chain runs frame to frame through the ring
         F.check(L.dcp_perspective_image_f32(dsts[i % nring].ptr, srcs[(i + 1) % nring].ptr, H, W, W, 1, ca, 1, F.BLEND_F64LERP,
                                             F.MEM_DEVICE, dev, None))
@@ -577,7 +630,7 @@ def other_configs(a, dev, srcs, dsts, img0):
     # re-uploaded for its check)
     us = timed_launches(two_pass, reps // 2, dev)
     srcs[0].upload(img0)
-    radial(0, 1, F.BLEND_F64LERP)
+    radial_default_stream(0)
     F.check(L.dcp_perspective_image_f32(dsts[0].ptr, dsts[1].ptr, H, W, W, 1, ca, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
     want = orc.correct_perspective_image(orc.unwarp_image_backward(*a2, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP), c3["list_coef"],
                                          blend=orc.BLEND_F64LERP)
@@ -600,16 +653,17 @@ def config5(a, dev):
 
     def run(i):
         F.check(L.dcp_unwarp_image_f32(src[i % nring].ptr, dst[i % nring].ptr, H, W, W, 1, c5["xcenter"], c5["ycenter"], fa, nf, 1, 1,
-                                       F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
-    us = timed_launches(run, max(24, min(120, a.steps)), dev)
+                                       F.BLEND_F64LERP, dmem(), dev, dstream(i)))
+    us = timed_launches(run, max(24, min(120, a.steps)), dev, dispatch=True)
     k = F.last_kernel()
     run(0)
+    dsync(dev)
     ok = np.array_equal(download(dst[0].ptr, (H, W), dev),
                         orc.unwarp_image_backward(img, c5["xcenter"], c5["ycenter"], c5["list_fact"], poly=orc.POLY_KERNEL,
                                                   blend=orc.BLEND_F64LERP))
     for b in src + dst:
         b.free()
-    return entry(us, H * W, 8, k, ok, shape=[H, W], nfact=nf)
+    return pf_entry(us, H * W, 8, k, ok, shape=[H, W], nfact=nf)
 
 
 def color_frame(a, dev):
@@ -629,17 +683,18 @@ def color_frame(a, dev):
 
     def run(i):
         F.check(L.dcp_unwarp_color_image(src[i % nring].ptr, dst[i % nring].ptr, F.DTYPE_F32, H, W, NC, W * NC, NC, c2["xcenter"], c2["ycenter"],
-                                         fa, nf, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, None))
-    us = timed_launches(run, max(24, min(240, a.steps * 2)), dev)
+                                         fa, nf, 1, F.BLEND_F64LERP, F.MEM_DEVICE, dev, dstream(i)))
+    us = timed_launches(run, max(24, min(240, a.steps * 2)), dev, dispatch=True)
     k = F.last_kernel()
     run(0)
+    dsync(dev)
     got = np.empty((H, W, NC), np.float32)
     F.check(L.dcp_memcpy(got.ctypes.data, dst[0].ptr, got.nbytes, F.COPY_D2H, dev, None))
     ok = all(np.array_equal(got[:, :, c], orc.unwarp_image_backward(np.ascontiguousarray(rgb[:, :, c]), c2["xcenter"], c2["ycenter"], c2["list_fact"],
                                                                     poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP)) for c in range(NC))
     for b in src + dst:
         b.free()
-    return entry(us, H * W, 8 * NC, k, ok, shape=[H, W, NC],
+    return pf_entry(us, H * W, 8 * NC, k, ok, shape=[H, W, NC],
                  note="interleaved float32 RGB, one coordinate and three blends per pixel; 24 algorithmic bytes per pixel")
 
 
@@ -1437,8 +1492,9 @@ def main(argv=None):
         dsts.append(RingFrame(ring_dst, i * frame_bytes))
 
     # how the launches leave the host (--dispatch): the frames are independent -- one calibration per call, one call per frame
-    lstreams = [F.Stream(dev), F.Stream(dev)] if a.dispatch == "two_streams" else []
-    frame_mem = F.MEM_DEVICE_UNORDERED if a.dispatch == "any_order" else F.MEM_DEVICE
+    set_dispatch(a.dispatch, dev)
+    lstreams = _DISPATCH["streams"]
+    frame_mem = dmem()
     launch_no = [0]
 
     def ring_pass():

@@ -24,7 +24,7 @@ const char* last_error();
     }                                                                                                      \
   } while (0)
 
-extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb, g_stack_lds, g_host_duplex, g_host_bands, g_tile_cert, g_wg_box, g_wg_per_cu, g_stack_wg, g_int_exact, g_host_direct, g_tall_tiles, g_store_wait, g_fused_wg, g_any_order;
+extern std::atomic<int> g_tile_rows, g_xcd_remap, g_coef_lds, g_d_chunk, g_pipe_depth, g_lds_gather, g_stack_chunk_kb, g_stack_lds, g_host_duplex, g_host_bands, g_tile_cert, g_wg_box, g_wg_per_cu, g_stack_wg, g_int_exact, g_host_direct, g_tall_tiles, g_store_wait, g_fused_wg, g_any_order, g_host_band_sync;
 dcp::LaunchOpts current_opts();
 
 // Selects `device` for the calling thread for the lifetime of the object (no-op for device < 0).

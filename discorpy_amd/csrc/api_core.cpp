@@ -25,7 +25,7 @@ int fail(int code, const char* fmt, ...) {
 
 const char* last_error() { return g_err; }
 
-std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0}, g_store_wait{1}, g_fused_wg{1}, g_any_order{0};
+std::atomic<int> g_tile_rows{16}, g_xcd_remap{2}, g_coef_lds{0}, g_d_chunk{16}, g_pipe_depth{2}, g_lds_gather{1}, g_stack_chunk_kb{24576}, g_stack_lds{1}, g_host_duplex{1}, g_host_bands{6}, g_tile_cert{1}, g_wg_box{1}, g_wg_per_cu{0}, g_stack_wg{1}, g_int_exact{1}, g_host_direct{1}, g_tall_tiles{0}, g_store_wait{1}, g_fused_wg{1}, g_any_order{0}, g_host_band_sync{0};
 
 dcp::LaunchOpts current_opts() {
   dcp::LaunchOpts o;
@@ -587,6 +587,8 @@ int dcp_set_option(const char* key_in, int value) {
     if (value < 0 || value > 2) return fail(DCP_ERR_INVALID_ARG, "host_direct must be 0, 1 or 2");
     g_host_direct = value;            // 0: a host frame's result is always staged on the device and copied back; 1: written straight into a
                                       // registered destination when the runtime cannot overlap an upload with a download; 2: whenever registered
+  } else if (!strcmp(key, "host_band_sync")) {
+    g_host_band_sync = value ? 1 : 0; // 1: the banded host path synchronises its upload stream after every band's kernel (rounds 1-5) instead of handing the downloader an event
   } else if (!strcmp(key, "any_order")) {
     g_any_order = value ? 1 : 0;      // 1: EVERY whole-frame device launch as with DCP_MEM_DEVICE_UNORDERED (A/B runs; the per-call flag is the interface)
   } else if (!strcmp(key, "store_wait")) {
@@ -612,6 +614,8 @@ int dcp_set_option(const char* key_in, int value) {
     dcp::set_pf2d_chunk(value < 0 ? 0 : value);
   } else if (!strcmp(key, "pf2d_xcd")) {
     dcp::set_pf2d_xcd(value ? 1 : 0);
+  } else if (!strcmp(key, "pf2d_two_pole")) {
+    dcp::set_pf2d_two_pole(value ? 1 : 0);
   } else if (!strcmp(key, "spline_xcd")) {
     dcp::set_spline_xcd(value ? 1 : 0);
   } else if (!strcmp(key, "tile_cert")) {
@@ -631,6 +635,7 @@ int dcp_get_option(const char* key_in, int* value) {
   if (!strcmp(key, "tile_rows")) *value = g_tile_rows;
   else if (!strcmp(key, "xcd_remap")) *value = g_xcd_remap;
   else if (!strcmp(key, "any_order")) *value = g_any_order;
+  else if (!strcmp(key, "host_band_sync")) *value = g_host_band_sync;
   else if (!strcmp(key, "coef_lds")) *value = g_coef_lds;
   else if (!strcmp(key, "d_chunk")) *value = g_d_chunk;
   else if (!strcmp(key, "pipe_depth")) *value = g_pipe_depth;
@@ -645,6 +650,7 @@ int dcp_get_option(const char* key_in, int* value) {
   else if (!strcmp(key, "spline_tiled")) *value = dcp::get_spline_tiled();
   else if (!strcmp(key, "pf2d_chunk")) *value = dcp::get_pf2d_chunk();
   else if (!strcmp(key, "pf2d_xcd")) *value = dcp::get_pf2d_xcd();
+  else if (!strcmp(key, "pf2d_two_pole")) *value = dcp::get_pf2d_two_pole();
   else if (!strcmp(key, "spline_xcd")) *value = dcp::get_spline_xcd();
   else if (!strcmp(key, "spline_wg")) *value = dcp::get_spline_wg();
   else if (!strcmp(key, "box_table")) *value = dcp::get_box_table();

@@ -13,6 +13,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <vector>
 #include <thread>
 #include <vector>
 
@@ -75,6 +76,39 @@ bool runtime_overlaps_directions() {
   return overlaps;
 }
 
+// Row boundaries of the bands a host frame of H rows travels in (run_host_banded, run_host_direct): start[k] .. start[k + 1].
+// Nominal height = H / nbands rounded up to 64 rows; the first bands grow 128, 256, 512 .. up to it and the last ones shrink the same
+// way, so that the stretch during which only ONE direction of the link is busy -- the first upload, the last download -- is short.
+// Frames too small for that (fewer than four nominal bands' worth of rows) are cut evenly.
+static std::vector<int64_t> band_plan(int64_t H, int64_t nbands) {
+  if (nbands < 1) nbands = 1;
+  int64_t big = ((H + nbands - 1) / nbands + 63) / 64 * 64;
+  if (big > 65535) big = 65535 / 64 * 64;
+  std::vector<int64_t> head;
+  for (int64_t r = 128; r < big; r *= 2) head.push_back(r);
+  int64_t ramp = 0;
+  for (int64_t r : head) ramp += r;
+  std::vector<int64_t> start{0};
+  if (nbands < 3 || 2 * ramp + 2 * big > H) {
+    for (int64_t r = big; r < H; r += big) start.push_back(r);
+    start.push_back(H);
+    return start;
+  }
+  int64_t r = 0;
+  for (int64_t h : head) start.push_back(r += h);
+  const int64_t tail0 = (H - ramp) / 64 * 64;          // where the closing ramp begins (every boundary a multiple of 64 rows)
+  while (r + big <= tail0) start.push_back(r += big);
+  if (tail0 - r >= 64) start.push_back(r = tail0);     // (a short band in front of the ramp; under 64 rows the ramp's first band takes them)
+  for (size_t i = head.size(); i-- > 0;) {
+    r = H;
+    for (size_t j = 0; j < i; ++j) r -= head[j];
+    if (i > 0) r = r / 64 * 64;
+    if (r > start.back()) start.push_back(r);
+  }
+  if (start.back() != H) start.push_back(H);
+  return start;
+}
+
 // Host frame, radial map, order 1: the frame goes through the GPU in bands of output rows so that PCIe carries data
 // in both directions at once.  Output rows [r, r + n) only need the source rows host_row_band() reports, so while
 // this thread uploads the source top to bottom and launches one stack-kernel band (depth 1: a band of image rows is
@@ -96,10 +130,28 @@ int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix
   DCP_HIP(g_host_streams.get(&s_up, &s_down));
   int cur_dev = 0;
   DCP_HIP(hipGetDevice(&cur_dev));
-  const int64_t nbands = g_host_bands.load();
-  int64_t rows_per = ((H + nbands - 1) / nbands + 63) / 64 * 64;
-  if (rows_per > 65535) rows_per = 65535 / 64 * 64;
-  const int64_t nb = (H + rows_per - 1) / rows_per;
+  // bands of output rows: `host_bands` equal ones would leave the first band's upload and the last band's download uncovered by the
+  // other direction (2 / host_bands of the transfer time); the plan below opens with 128, 256, 512 .. rows, runs at the nominal band
+  // height and closes .., 512, 256, 128 -- head and tail shrink to ~3 % of a 4096-row frame each
+  // (twice `host_bands` nominal bands here: 1.77-1.85 ms against 1.85-1.87 per 4096^2 frame on /opt/rocm's runtime, profiles/r06g_host_bands.txt;
+  // the direct-write path, whose bands are kernels storing over PCIe, is best at `host_bands` itself)
+  const std::vector<int64_t> start = band_plan(H, 2 * (int64_t)g_host_bands.load());
+  const int64_t nb = (int64_t)start.size() - 1;
+  // one event per band, recorded behind its kernel: the downloader's stream waits for it on the device, this thread goes straight
+  // on to the next upload (round 6; it used to synchronise the stream after every band: ~25 us x bands on the upload's critical path)
+  thread_local std::vector<hipEvent_t> ev;
+  thread_local int ev_dev = -1;
+  if (ev_dev != cur_dev) {
+    for (auto e : ev) (void)hipEventDestroy(e);
+    ev.clear();
+    ev_dev = cur_dev;
+  }
+  while ((int64_t)ev.size() < nb) {
+    hipEvent_t e = nullptr;
+    DCP_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    ev.push_back(e);
+  }
+  hipEvent_t* const band_done = ev.data();      // (the downloader thread must not name `ev`: a thread_local is ITS OWN, empty, vector there)
 
   std::mutex mu;
   std::condition_variable cv;
@@ -114,9 +166,11 @@ int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix
         cv.wait(lock, [&] { return computed > k || abort_down; });
         if (abort_down) break;
       }
-      const int64_t r0 = k * rows_per, n = (r0 + rows_per > H ? H - r0 : rows_per);
-      e = hipMemcpyAsync((char*)dst + (size_t)r0 * row_bytes, (const char*)ddst + (size_t)r0 * row_bytes, (size_t)n * row_bytes,
-                         hipMemcpyDeviceToHost, s_down);
+      const int64_t r0 = start[(size_t)k], n = start[(size_t)k + 1] - r0;
+      e = hipStreamWaitEvent(s_down, band_done[k], 0);             // band k's kernel has finished (recorded before `computed` moved)
+      if (e == hipSuccess)
+        e = hipMemcpyAsync((char*)dst + (size_t)r0 * row_bytes, (const char*)ddst + (size_t)r0 * row_bytes, (size_t)n * row_bytes,
+                           hipMemcpyDeviceToHost, s_down);
       if (e == hipSuccess) e = hipStreamSynchronize(s_down);
     }
     std::lock_guard<std::mutex> lock(mu);
@@ -125,7 +179,7 @@ int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix
   hipError_t up_err = hipSuccess;
   int64_t uploaded = 0;      // source rows [0, uploaded) are on the device
   for (int64_t k = 0; k < nb && up_err == hipSuccess; ++k) {
-    const int64_t r0 = k * rows_per, n = (r0 + rows_per > H ? H - r0 : rows_per);
+    const int64_t r0 = start[(size_t)k], n = start[(size_t)k + 1] - r0;
     int64_t b0 = 0, b1 = H;
     source_rows(r0, n, &b0, &b1);
     // the source arrives top to bottom; a band whose rows reach further down simply waits for more of it
@@ -139,7 +193,8 @@ int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix
     }
     if (b0 < 0 || b1 > uploaded) { up_err = hipErrorInvalidValue; break; }   // cannot happen: need >= b1
     up_err = launch_band(dsrc, (char*)ddst + (size_t)r0 * row_bytes, r0, n, s_up);
-    if (up_err == hipSuccess) up_err = hipStreamSynchronize(s_up);
+    if (up_err == hipSuccess) up_err = hipEventRecord(band_done[k], s_up);
+    if (up_err == hipSuccess && g_host_band_sync.load()) up_err = hipStreamSynchronize(s_up);      // (A/B: rounds 1-5 waited here for every band)
     if (up_err != hipSuccess) break;
     {
       std::lock_guard<std::mutex> lock(mu);
@@ -153,8 +208,11 @@ int run_host_banded(const void* src, void* dst, int64_t H, int64_t W, size_t pix
     cv.notify_all();
   }
   downloader.join();
+  // (whatever happened, nothing of this call is left running: the kernels read the staging buffer the next call reuses)
+  const hipError_t drain = hipStreamSynchronize(s_up);
   if (up_err != hipSuccess) return fail(DCP_ERR_HIP, "banded frame upload / kernel failed: %s", hipGetErrorString(up_err));
   if (down_err != hipSuccess) return fail(DCP_ERR_HIP, "banded frame download failed: %s", hipGetErrorString(down_err));
+  if (drain != hipSuccess) return fail(DCP_ERR_HIP, "banded frame: %s", hipGetErrorString(drain));
   return DCP_OK;
 }
 

@@ -203,6 +203,8 @@ void set_pf2d_chunk(int v);     // rows per chunk of spline_prefilter2d_kernel (
 int get_pf2d_chunk();
 void set_pf2d_xcd(int v);       // 0: spline_prefilter2d_kernel's tiles in plain launch order (option "pf2d_xcd")
 int get_pf2d_xcd();
+void set_pf2d_two_pole(int v);  // 0: the two-pole spline orders (4, 5) on spline_tile_filter_kernel, one launch per axis (option "pf2d_two_pole")
+int get_pf2d_two_pole();
 void set_spline_xcd(int v);     // 0: spline_wg_kernel's tiles in plain launch order (option "spline_xcd")
 int get_spline_xcd();
 hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, const CoordArgs& ca, void* dst,

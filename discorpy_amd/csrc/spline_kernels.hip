@@ -42,6 +42,9 @@ int get_pf2d_chunk() { return g_pf2d_chunk; }
 int g_pf2d_xcd = 1;              // option pf2d_xcd (A/B runs): 0 = tiles in plain row-major launch order (neighbouring stripes on different XCDs)
 void set_pf2d_xcd(int v) { g_pf2d_xcd = v; }
 int get_pf2d_xcd() { return g_pf2d_xcd; }
+int g_pf2d_two_pole = 1;         // option pf2d_two_pole (A/B runs): 0 = orders 4 / 5 keep the tile filter, one launch per axis (rounds 2-5)
+void set_pf2d_two_pole(int v) { g_pf2d_two_pole = v; }
+int get_pf2d_two_pole() { return g_pf2d_two_pole; }
 int g_spline_xcd = 1;            // option spline_xcd (A/B runs): 0 = spline_wg_kernel's tiles in plain row-major launch order
 void set_spline_xcd(int v) { g_spline_xcd = v; }
 int get_spline_xcd() { return g_spline_xcd; }
@@ -874,15 +877,22 @@ __global__ void __launch_bounds__(256, 3) spline_row_lds_kernel(const TileFilter
 #ifndef DCP_PF2D_WAVES
 #define DCP_PF2D_WAVES 2
 #endif
-template <int HP>
+template <int HP, int RR = 32>
 struct Pf2d {
-  static constexpr int R = 32;                           // rows per step
+  static constexpr int R = RR;                           // rows per step (32; 16 for the long horizons of the two-pole orders' first pole)
   static constexpr int NCOL = 252;                       // columns of a stripe incl. both halos (threads 252..255 idle in the column pass)
-  static constexpr int PITCH = 253;                      // odd: the 32 rows of one column fall into 32 distinct bank pairs; 32 x 253 x 8 B = 63.25 KB
+  static constexpr int PITCH = 253;                      // odd: the rows of one column fall into distinct bank pairs; 32 x 253 x 8 B = 63.25 KB
   static constexpr int SEGS = 256 / R;                   // row-pass segments per row
   static constexpr int SEG = (NCOL - 2 * HP) / SEGS;     // outputs per row-pass thread: 23 (HP = 34) / 25 (HP = 26)
   static constexpr int CORE = SEGS * SEG;                // columns a stripe writes: 184 / 200
 };
+// Orders 4 and 5 (two poles) as TWO passes of this kernel, one pole each (round 6): scipy filters every line with pole 1 and then
+// with pole 2, axis by axis -- P2y P1y P2x P1x; the four operators commute (the two axes act on different indices, and the two
+// poles of one axis are functions of the same mirrored shift), so P2y P2x (P1y P1x image) is the same plane up to the rounding of
+// float64 sums.  Pass 1 reads the image (pole 1: |z| = 0.36 / 0.43 -- restart horizons of 44 / 53 samples, steps of 16 rows so that
+// the two register windows still fit two waves per SIMD) and writes a float64 plane, pass 2 reads that plane (ST = kF64; pole 2:
+// |z| = 0.014 / 0.043, horizon 16) and writes the coefficient plane.  Each pass carries its own gain (1 - z)(1 - 1/z).
+constexpr int kF64Src = 100;                             // ST of the second pass (not an element type of the ABI)
 
 // PAD: the plane is the image with `pad` samples added on every side ('nearest': the edge sample repeated, 'grid-constant':
 // zeros -- what spline_expand_kernel would write into a float64 copy first); the recursions run over the padded plane, the
@@ -893,10 +903,10 @@ struct Pf2dPad {
 
 // ST: element type of the source image (kF32, or the integer types cameras deliver -- kU8 / kU16 / kI16: every one exact in float64,
 // read as raw bits and converted where a row is used)
-template <int HP, bool PAD, int ST>
+template <int HP, bool PAD, int ST, int RR>
 __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd, const uint32_t src_bytes, const uint32_t out_bytes, const int stripe, const int Y0,
                                           const int Yend, double* s_t) {
-  using G = Pf2d<HP>;
+  using G = Pf2d<HP, RR>;
   constexpr int R = G::R, NCOL = G::NCOL, PITCH = G::PITCH, SEG = G::SEG, CORE = G::CORE, NC = R + HP, J = SEG + HP;
   const int tid = (int)threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -916,18 +926,24 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     col_zero = pd.zero_outside && (gc < 0 || gc >= pd.Ws);
     gc = max(0, min(gc, pd.Ws - 1));
   }
-  constexpr uint32_t ES = ST == kF32 ? 4u : (ST == kU8 ? 1u : 2u);
-  static_assert(ST == kF32 || ST == kU8 || ST == kU16 || ST == kI16, "source element types of the one-launch prefilter");
+  constexpr uint32_t ES = ST == kF64Src ? 8u : (ST == kF32 ? 4u : (ST == kU8 ? 1u : 2u));
+  static_assert(ST == kF32 || ST == kU8 || ST == kU16 || ST == kI16 || ST == kF64Src, "source element types of the one-launch prefilter");
+  static_assert(!(PAD && ST == kF64Src), "the second pass of a two-pole order reads a plane that is padded already");
+  typedef unsigned int u32x2_raw __attribute__((ext_vector_type(2)));
+  using raw_t = typename std::conditional<ST == kF64Src, unsigned long long, uint32_t>::type;      // what a prefetch register holds
   const uint32_t voff = (uint32_t)gc * (uint32_t)f.in_ls * ES;
   const uint32_t rstep = (uint32_t)f.in_ss * ES;
-  auto ld_raw = [&](uint32_t so) -> uint32_t {                 // the element's bits, zero-extended
-    if constexpr (ST == kF32) return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, so, 0);
+  auto ld_raw = [&](uint32_t so) -> raw_t {                    // the element's bits, zero-extended
+    if constexpr (ST == kF64Src) {
+      const u32x2_raw v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, so, 0);
+      return (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    } else if constexpr (ST == kF32) return __builtin_amdgcn_raw_buffer_load_b32(rs, voff, so, 0);
     else if constexpr (ST == kU8) return (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, voff, so, 0);
     else return (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, so, 0);
   };
   // (row is wave-uniform: the row offset travels in an SGPR.  Only the steps at the top and the bottom of the plane mirror their
   // rows -- a dozen scalar instructions per load, and a wave issues one instruction per four cycles whatever its kind)
-  auto ld = [&](int row, auto mirrored) -> uint32_t {
+  auto ld = [&](int row, auto mirrored) -> raw_t {
     int r = __builtin_amdgcn_readfirstlane(row);
     if constexpr (decltype(mirrored)::value) {
       r = r < 0 ? -r - sym : r;
@@ -937,7 +953,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     if constexpr (PAD) {
       r -= pd.pad;                                             // row of the source image
       if constexpr (decltype(mirrored)::value) {               // (plain loads stay inside the image: no clamp, no zero rows)
-        if (pd.zero_outside && (r < 0 || r >= pd.Hs)) return 0u;  // (the bits of 0.0f and of the integer 0)
+        if (pd.zero_outside && (r < 0 || r >= pd.Hs)) return (raw_t)0;  // (the bits of 0.0f and of the integer 0)
         r = max(0, min(r, pd.Hs - 1));
       }
     }
@@ -945,9 +961,10 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
   };
   // (a column in zero padding: applied where a loaded value is USED -- a select right behind the load would make the wave wait for
   // every prefetched row at once: 91 us instead of 51 per 4096^2 plane)
-  auto val = [&](uint32_t bits) -> double {
-    const uint32_t b = (PAD && col_zero) ? 0u : bits;
-    if constexpr (ST == kF32) return (double)__uint_as_float(b);
+  auto val = [&](raw_t bits) -> double {
+    const raw_t b = (PAD && col_zero) ? (raw_t)0 : bits;
+    if constexpr (ST == kF64Src) return __longlong_as_double((long long)b);
+    else if constexpr (ST == kF32) return (double)__uint_as_float((uint32_t)b);
     else if constexpr (ST == kI16) return (double)(int)(short)b;
     else return (double)b;
   };
@@ -957,7 +974,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
   double tc = 0.0;                                             // the causal state
   double C[NC];                                                // causal values of rows r0 .. r0 + R + HP - 1
   {
-    uint32_t pre[HP], pre2[NC];
+    raw_t pre[HP], pre2[NC];
     if (r0 - HP >= plain_lo && r0 + NC <= plain_hi) {
 #pragma unroll
       for (int j = 0; j < HP; ++j) pre[j] = ld(r0 - HP + j, std::false_type{});
@@ -998,7 +1015,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     // the next step's new rows, in flight under the row pass (the chunk's last step, where nobody uses them, loads one cached row
     // R times instead: registers that are defined on one path only cost the register allocation a dozen spills)
     const bool more = r0 + R < Yend;                           // (workgroup-uniform)
-    uint32_t nx[R];
+    raw_t nx[R];
     if (!more) {
 #pragma unroll
       for (int j = 0; j < R; ++j) nx[j] = ld(min(r0, H - 1), std::true_type{});
@@ -1076,10 +1093,10 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
   }
 }
 
-template <int HP, bool PAD = false, int ST = kF32>
+template <int HP, bool PAD = false, int ST = kF32, int RR = 32>
 __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel(const TileFilter f, const Pf2dPad pd, const uint32_t src_bytes, const uint32_t out_bytes,
                                                                                  const int chunk_rows, const int stripes, const int chunks, const int xcd_order) {
-  using G = Pf2d<HP>;
+  using G = Pf2d<HP, RR>;
   __shared__ double s_t[G::R * G::PITCH];
   // Workgroups go round-robin to the 8 XCDs (blockIdx.x & 7), each with its own L2: XCD k takes a contiguous run of tiles in
   // row-major order (stripe fastest), so that the stripes that share 2 HP columns -- neighbours that read the same source rows
@@ -1092,7 +1109,7 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   const int chunk = t / stripes, stripe = t - chunk * stripes;
   const int Y0 = chunk * chunk_rows;                           // first row the chunk writes
   const int Yend = min(f.n, Y0 + chunk_rows);
-  pf2d_body<HP, PAD, ST>(f, pd, src_bytes, out_bytes, stripe, Y0, Yend, s_t);
+  pf2d_body<HP, PAD, ST, RR>(f, pd, src_bytes, out_bytes, stripe, Y0, Yend, s_t);
 }
 
 // ---- the row pass (axis 1) as a cross-lane scan: no LDS, no barrier, every access a contiguous 512 bytes ---------------
@@ -1263,6 +1280,30 @@ __device__ __forceinline__ int spline_weights(double x, double* w) {
     w[2] = __builtin_fma(z * z, __builtin_fma(z, 0.5, -1.0), 2.0 / 3.0);
     w[0] = (z * z) * (z * (1.0 / 6.0));
     w[3] = 1.0 - w[0] - w[1] - w[2];
+  } else if constexpr (ORDER == 4 && FAST) {
+    // (round 6) the quartic and quintic weights as fused Horner chains in the same variables as scipy's expressions: 21 / 29 operations
+    // per axis instead of 37 / 53, every weight within a few float64 ulps of scipy's form (the constants 1/6, 1/24, 1/120 rounded once)
+    t2 = t * t;
+    w[2] = __builtin_fma(t2, __builtin_fma(t2, 0.25, -0.625), 115.0 / 192.0);
+    y = 1.0 + t;
+    z = 1.0 - t;
+    w[1] = __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, -1.0 / 6.0, 5.0 / 6.0), -1.25), 5.0 / 24.0), 55.0 / 96.0);
+    w[3] = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, -1.0 / 6.0, 5.0 / 6.0), -1.25), 5.0 / 24.0), 55.0 / 96.0);
+    y = 0.5 - t;
+    y *= y;
+    w[0] = (y * y) * (1.0 / 24.0);
+    w[4] = 1.0 - w[0] - w[1] - w[2] - w[3];
+  } else if constexpr (ORDER == 5 && FAST) {
+    t2 = y * y;
+    w[2] = __builtin_fma(t2, __builtin_fma(t2, __builtin_fma(y, -1.0 / 12.0, 0.25), -0.5), 0.55);
+    t2 = z * z;
+    w[3] = __builtin_fma(t2, __builtin_fma(t2, __builtin_fma(z, -1.0 / 12.0, 0.25), -0.5), 0.55);
+    w[0] = (t2 * t2) * (z * (1.0 / 120.0));
+    y += 1.0;
+    w[1] = __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, 1.0 / 24.0, -0.375), 1.25), -1.75), 0.625), 0.425);
+    y = z + 1.0;
+    w[4] = __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, __builtin_fma(y, 1.0 / 24.0, -0.375), 1.25), -1.75), 0.625), 0.425);
+    w[5] = 1.0 - w[0] - w[1] - w[2] - w[3] - w[4];
   } else if constexpr (ORDER == 2) {
     w[1] = 0.75 - t * t;
     y = 0.5 + t;
@@ -1677,7 +1718,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     halo += hp[p];
   }
   const int samples = kTfSamples;
-  bool col_stream = false, col_lds = false, row_scan = false, row_lds = false, fused2d = false;
+  bool col_stream = false, col_lds = false, row_scan = false, row_lds = false, fused2d = false, two_pass = false;
   if (tiled && samples - 2 * halo >= 32) {
     TileFilter f;
     f.kind = a.filter_kind;
@@ -1723,21 +1764,13 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     // Element types: float32 and the integer types cameras deliver (uint8, uint16, int16), read in place -- the others take the float64 copy.
     const bool pf2d_type = a.src_dtype == kF32 || a.src_dtype == kU8 || a.src_dtype == kU16 || a.src_dtype == kI16;
     const bool padded_f32 = pf2d_type && a.pad > 0 && (a.mode == kModeNearest || a.mode == kModeGridConstant) && a.H > 0 && a.W > 0;
-    if (((pf2d_type && a.pad == 0) || padded_f32) && a.npoles == 1 && g_spline_tiled == 1 && (hp[0] == 26 || hp[0] == 34) && a.src_cstride >= 1 && a.src_stride >= 0 &&
-        ext_src < 4294967000.0 && ext_plane < 4294967000.0) {
-      // float32 source, one pole: both axes in one pass, the column-filtered plane stays in LDS (spline_prefilter2d_kernel)
-      Pf2dPad pd;
-      pd.pad = a.pad;
-      pd.Hs = a.H;
-      pd.Ws = a.W;
-      pd.zero_outside = a.mode == kModeGridConstant ? 1 : 0;
-      f.in = a.src;
-      f.in_ls = a.src_cstride;
-      f.in_ss = a.src_stride;
-      f.out = a.coef;
-      f.out_ls = a.Wp;
-      f.out_ss = 1;
-      const int core = hp[0] == 34 ? Pf2d<34>::CORE : Pf2d<26>::CORE;
+    const bool pf2d_ok = ((pf2d_type && a.pad == 0) || padded_f32) && g_spline_tiled == 1 && a.src_cstride >= 1 && a.src_stride >= 0 && ext_src < 4294967000.0 &&
+                         ext_plane < 4294967000.0;
+    // one launch of spline_prefilter2d_kernel<HPV, PADV, STV, RV>: `tf` names the source (pointer, strides), the pole, its gain and the result plane
+    auto launch_pf2d = [&](auto hpv, auto padv, auto stv, auto rv, const TileFilter& tf, const Pf2dPad& pd, double src_extent) {
+      constexpr int HPV = decltype(hpv)::value, STV = decltype(stv)::value, RV = decltype(rv)::value;
+      constexpr bool PADV = decltype(padv)::value;
+      const int core = Pf2d<HPV, RV>::CORE;
       const int stripes = (a.Wp + core - 1) / core;
       int ncu = 0, dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
@@ -1752,16 +1785,16 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       const int chunks = (a.Hp + chunk - 1) / chunk;
       const int xcd_order = g_pf2d_xcd;
       const dim3 g5((unsigned)(xcd_order ? ((stripes * chunks + 7) / 8) * 8 : stripes * chunks));
-#define DCP_PF2D(HPV, PADV, STV) \
-  hipLaunchKernelGGL((spline_prefilter2d_kernel<HPV, PADV, STV>), g5, dim3(256), 0, stream, f, pd, (uint32_t)ext_src, (uint32_t)ext_plane, chunk, stripes, chunks, xcd_order)
-#define DCP_PF2D_T(STV)                 \
-  if (padded_f32) {                     \
-    if (hp[0] == 34) DCP_PF2D(34, true, STV);  \
-    else DCP_PF2D(26, true, STV);       \
-  } else {                              \
-    if (hp[0] == 34) DCP_PF2D(34, false, STV); \
-    else DCP_PF2D(26, false, STV);      \
-  }
+      hipLaunchKernelGGL((spline_prefilter2d_kernel<HPV, PADV, STV, RV>), g5, dim3(256), 0, stream, tf, pd, (uint32_t)src_extent, (uint32_t)ext_plane, chunk, stripes,
+                         chunks, xcd_order);
+    };
+    // ... the same with the source element type and the padding resolved at run time
+    auto launch_pf2d_src = [&](auto hpv, auto rv, const TileFilter& tf, const Pf2dPad& pd) {
+      using T = std::true_type;
+      using Fa = std::false_type;
+#define DCP_PF2D_T(STV)                                                                                       \
+  if (padded_f32) launch_pf2d(hpv, T{}, std::integral_constant<int, STV>{}, rv, tf, pd, ext_src);             \
+  else launch_pf2d(hpv, Fa{}, std::integral_constant<int, STV>{}, rv, tf, pd, ext_src)
       switch (a.src_dtype) {
         case kU8: DCP_PF2D_T(kU8); break;
         case kU16: DCP_PF2D_T(kU16); break;
@@ -1769,8 +1802,57 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
         default: DCP_PF2D_T(kF32); break;
       }
 #undef DCP_PF2D_T
-#undef DCP_PF2D
+    };
+    Pf2dPad pd;
+    pd.pad = a.pad;
+    pd.Hs = a.H;
+    pd.Ws = a.W;
+    pd.zero_outside = a.mode == kModeGridConstant ? 1 : 0;
+    using I16c = std::integral_constant<int, 16>;
+    using I32c = std::integral_constant<int, 32>;
+    if (pf2d_ok && a.npoles == 1 && (hp[0] == 26 || hp[0] == 34)) {
+      // float32 source, one pole: both axes in one pass, the column-filtered plane stays in LDS (spline_prefilter2d_kernel)
+      f.in = a.src;
+      f.in_ls = a.src_cstride;
+      f.in_ss = a.src_stride;
+      f.out = a.coef;
+      f.out_ls = a.Wp;
+      f.out_ss = 1;
+      if (hp[0] == 34) launch_pf2d_src(std::integral_constant<int, 34>{}, I32c{}, f, pd);
+      else launch_pf2d_src(std::integral_constant<int, 26>{}, I32c{}, f, pd);
       fused2d = true;
+    } else if (pf2d_ok && a.npoles == 2 && (hp[0] == 44 || hp[0] == 53) && hp[1] <= 16 && g_pf2d_two_pole) {
+      // two poles (orders 4, 5): one pass of the same kernel per pole -- image -> scratch plane (pole 1, 16-row steps), scratch plane ->
+      // coefficient plane (pole 2) -- see Pf2d
+      TileFilter p1 = f;
+      p1.npoles = 1;
+      p1.z[0] = a.poles[0];
+      p1.lam = (1.0 - a.poles[0]) * (1.0 - 1.0 / a.poles[0]);
+      p1.in = a.src;
+      p1.in_ls = a.src_cstride;
+      p1.in_ss = a.src_stride;
+      p1.out = a.scratch;
+      p1.out_ls = a.Wp;
+      p1.out_ss = 1;
+      // (order 5's first pole restarts 50 samples out, not 53: |z|^50 = 2^-60.8 of the signal, 0.5 % of a float64 rounding error -- the
+      // three samples are what keeps its two register windows inside 256 VGPRs without scratch)
+      if (hp[0] == 44) launch_pf2d_src(std::integral_constant<int, 44>{}, I16c{}, p1, pd);
+      else launch_pf2d_src(std::integral_constant<int, 50>{}, I16c{}, p1, pd);
+      TileFilter p2 = p1;
+      p2.z[0] = a.poles[1];
+      p2.lam = (1.0 - a.poles[1]) * (1.0 - 1.0 / a.poles[1]);
+      p2.in = a.scratch;
+      p2.in_ls = 1;
+      p2.in_ss = a.Wp;
+      p2.out = a.coef;
+      Pf2dPad none = pd;
+      none.pad = 0;
+      none.Hs = a.Hp;
+      none.Ws = a.Wp;
+      none.zero_outside = 0;
+      launch_pf2d(std::integral_constant<int, 16>{}, std::false_type{}, std::integral_constant<int, kF64Src>{}, I32c{}, p2, none, ext_plane);
+      fused2d = true;
+      two_pass = true;
     } else if (direct && a.npoles == 1 && g_spline_tiled != 2 && g_spline_tiled != 4 && (hp[0] == 26 || hp[0] == 34)) {
       // float32 source, one pole (orders 2 and 3): the register-streaming column pass, no LDS
       f.in = a.src;
@@ -1875,7 +1957,7 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     char name[160];
     const char* colk = col_lds ? "spline_col_lds_kernel" : col_stream ? "spline_col_stream_kernel" : "spline_tile_filter_kernel";
     const char* rowk = row_scan ? "spline_row_scan_kernel" : row_lds ? "spline_row_lds_kernel" : "spline_tile_filter_kernel";
-    if (fused2d) snprintf(name, sizeof(name), "spline_prefilter2d_kernel + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
+    if (fused2d) snprintf(name, sizeof(name), "spline_prefilter2d_kernel%s + %s<order=%d>", two_pass ? " x 2" : "", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     else if (!tiled) snprintf(name, sizeof(name), "spline_causal / anticausal / transpose kernels + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     else if (!col_stream && !row_scan && !row_lds) snprintf(name, sizeof(name), "spline_tile_filter_kernel x 2 + %s<order=%d>", wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);
     else snprintf(name, sizeof(name), "%s + %s + %s<order=%d>", colk, rowk, wg ? "spline_wg_kernel" : "spline_remap_kernel", a.order);

@@ -76,7 +76,8 @@ int dcp_release_scratch(void);
  *   "stack_chunk_kb"  KiB of one projection chunk when a HOST stack is streamed through the GPU (device scratch = 4 chunks; default 24576)
  *   "host_duplex"     host frames of the radial map through the GPU in bands of rows, uploads and downloads at the same time:
  *                     0 never, 1 (default) when a one-off probe finds that the HIP runtime overlaps the two directions, 2 always
- *   "host_bands"      number of those bands (default 6)
+ *   "host_bands"      number of those bands (default 6; where uploads and downloads are both runtime copies the frame travels in twice as
+ *                     many, the first and last ones shorter -- 128, 256, 512 .. rows -- so that the stretch with one direction idle is short)
  *   "host_direct"     0: never write a host frame's result straight into registered host memory; 1 (default): when the runtime
  *                     cannot overlap an upload with a download; 2: whenever the destination is registered
  *   "host_direct_applies"   read-only: 1 if "host_direct" = 1 takes effect on this runtime (measured once; needs a device)

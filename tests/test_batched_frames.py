@@ -351,3 +351,53 @@ def test_a_3d_device_array_under_a_folding_model_gives_what_the_single_calls_giv
     got = pp.unwarp_images_backward(view, 210.0, 150.0, [1.0, 1e-4])
     for i in range(n):
         assert torch.equal(got[i], pp.unwarp_image_backward(view[i].contiguous(), 210.0, 150.0, [1.0, 1e-4]))
+
+
+@pytest.mark.gpu
+def test_independent_frames_over_two_streams_and_with_unordered_packets(hip, orc):
+    """Round 6: callers that hand over INDEPENDENT frames one call at a time may spread them over two streams
+    (dcp_stream_create + dcp_stream_wait_event to fork from / join into one of them: bench.py's default dispatch) or mark the calls
+    DCP_MEM_DEVICE_UNORDERED (dispatch packets without the barrier bit).  Either way every frame is what the ordered call gives --
+    the oracle's pixels -- and events / synchronisations on the streams still cover every launch."""
+    L = hip.lib()
+    c2 = configs.cfg2()
+    H, W, n = 1536, 2048, 6
+    s = 4096.0 / W
+    xc, yc = c2["xcenter"] / s, c2["ycenter"] / s
+    fact = [v * s ** k for k, v in enumerate(c2["list_fact"])]
+    coef = [0.98, -0.012, 20.5, 0.009, 1.01, -14.0, 4e-6, -3e-6]
+    frames = [noise(700 + i, (H, W)) for i in range(n)]
+    src = [hip.DeviceBuffer(f.nbytes).upload(f) for f in frames]
+    dst = [hip.DeviceBuffer(f.nbytes) for f in frames]
+    fa, nf = hip.fact_array(fact)
+    ca, _ = hip.fact_array(coef)
+    want = [orc.unwarp_image_backward(f, xc, yc, fact, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP) for f in frames]
+    s0, s1 = hip.Stream(), hip.Stream()
+    e0, e1, ej = hip.Event(), hip.Event(), hip.Event()
+    for mem, streams in ((hip.MEM_DEVICE, (s0, s1)), (hip.MEM_DEVICE_UNORDERED, (s0, s0)), (hip.MEM_DEVICE_UNORDERED, (s0, s1))):
+        for d in dst:
+            d.upload(np.zeros((H, W), np.float32))
+        e0.record(s0.ptr)
+        s1.wait_event(e0)                               # fork: nothing on s1 starts before e0
+        for rep in range(3):
+            for i in range(n):
+                hip.check(L.dcp_unwarp_image_f32(src[i].ptr, dst[i].ptr, H, W, W, 1, xc, yc, fa, nf, 1, 1, hip.BLEND_F64LERP, mem, -1, streams[i & 1].ptr))
+        ej.record(s1.ptr)
+        s0.wait_event(ej)                               # join: e1 on s0 lies behind every launch of both streams
+        e1.record(s0.ptr)
+        e1.synchronize()                                # ONE wait for everything
+        assert e0.elapsed_ms(e1) > 0.0
+        for i in range(n):
+            assert np.array_equal(dst[i].download((H, W), np.float32), want[i]), (mem, i)
+    # the perspective and fused entry points take the flag too
+    hip.check(L.dcp_perspective_image_f32(src[0].ptr, dst[0].ptr, H, W, W, 1, ca, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE_UNORDERED, -1, s0.ptr))
+    hip.check(L.dcp_unwarp_fused_f32(src[1].ptr, dst[1].ptr, H, W, W, 1, xc, yc, fa, nf, ca, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE_UNORDERED, -1, s0.ptr))
+    s0.synchronize()
+    assert np.array_equal(dst[0].download((H, W), np.float32), orc.correct_perspective_image(frames[0], coef, blend=orc.BLEND_F64LERP))
+    assert np.array_equal(dst[1].download((H, W), np.float32), orc.unwarp_fused(frames[1], xc, yc, fact, coef, poly=orc.POLY_KERNEL, blend=orc.BLEND_F64LERP))
+    # ... and nothing else does: a stack call with it is refused, not silently ordered
+    rc = L.dcp_unwarp_stack_rows_f32(src[0].ptr, dst[0].ptr, 1, H, W, H * W, W, xc, yc, fa, nf, 0.0, 8, 1, hip.BLEND_F64LERP, hip.MEM_DEVICE_UNORDERED, -1, None)
+    assert rc == hip.ERR_INVALID_ARG and "mem_kind" in hip.last_error()
+    assert L.dcp_stream_wait_event(s0.ptr, None) == hip.ERR_INVALID_ARG
+    for b in src + dst:
+        b.free()

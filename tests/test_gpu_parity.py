@@ -351,6 +351,7 @@ def test_spline_one_pass_prefilter_and_lds_gather_against_the_plain_kernels(hip,
                 one_pole = fast in (1, 6) and order <= 3
                 direct = one_pole and mode not in ("nearest", "grid-constant")        # (those two pad the plane first)
                 pre = ("spline_prefilter2d_kernel" if one_pole and fast == 1 else       # (round 5: the padded modes too)
+                       "spline_prefilter2d_kernel x 2" if fast == 1 else                # (round 6: the two-pole orders, one pass per pole)
                        "spline_col_lds_kernel + spline_row_lds_kernel" if direct else
                        "spline_tile_filter_kernel + spline_row_lds_kernel" if one_pole else "spline_tile_filter_kernel x 2")
                 want_name = (pre + " + spline_wg_kernel<order=%d>" if fast else

@@ -25,7 +25,7 @@ def ulps(a, b):
 @pytest.fixture
 def options(hip):
     yield hip
-    for key, val in (("x_spline_tiled", 1), ("x_spline_wg", 1), ("x_pf2d_chunk", 0), ("x_pf2d_xcd", 1), ("x_spline_xcd", 1)):
+    for key, val in (("x_spline_tiled", 1), ("x_spline_wg", 1), ("x_pf2d_chunk", 0), ("x_pf2d_xcd", 1), ("x_spline_xcd", 1), ("x_pf2d_two_pole", 1)):
         hip.set_option(key, val)
 
 
@@ -63,6 +63,63 @@ def test_one_launch_prefilter_against_the_oracle_and_the_two_launches(options, o
         assert F.last_kernel() == FUSED % order, F.last_kernel()
         d = ulps(got, orc.correct_perspective_image(img, coef, order=order, mode=mode))
         assert d.max() <= 1 and np.count_nonzero(d) <= 8, (order, mode)
+
+
+TWO_PASS = "spline_prefilter2d_kernel x 2 + spline_wg_kernel<order=%d>"
+TILE = "spline_tile_filter_kernel x 2 + spline_wg_kernel<order=%d>"
+
+
+@pytest.mark.parametrize("shape", [(1100, 1347), (900, 2100), (2100, 930)])
+def test_two_pole_orders_take_one_pass_of_the_kernel_per_pole(options, orc, shape):
+    """Round 6: orders 4 and 5 -- two poles -- as TWO passes of spline_prefilter2d_kernel, one pole each (image ->
+    scratch plane with the first pole's long restart horizon in 16-row steps, scratch plane -> coefficient plane with the second
+    pole), instead of the tile filter's one launch per axis.  scipy applies P2 P1 along one axis and then along the other; the
+    four operators commute, so the plane is the same up to the rounding of float64 sums: within one float32 ulp of the oracle on
+    a handful of pixels, as at every restart of the one-pass kernels.  Padded modes, integer frames and an interleaved channel
+    included; lines too short for z1^n to underflow (731 / 884 samples) keep the serial recursion."""
+    F = options
+    c = configs.cfg2()
+    img = noise(shape[0] * 3 + shape[1], shape)
+    coef = [1.02, 0.015, -9.0, -0.012, 0.99, 6.0, 2.0e-6, -1.5e-6]
+    a = (img, c["xcenter"] * shape[1] / 4096.0, 0.45 * shape[0], c["list_fact"])
+    for order, mode in [(4, "reflect"), (5, "reflect"), (5, "mirror"), (4, "grid-mirror"), (5, "nearest"), (4, "grid-constant"), (4, "constant"), (5, "wrap")]:
+        want = orc.unwarp_image_backward(*a, order=order, mode=mode, poly=orc.POLY_KERNEL)
+        F.set_option("x_pf2d_two_pole", 0)
+        old = pp.unwarp_image_backward(*a, order=order, mode=mode)
+        assert "prefilter2d" not in F.last_kernel(), F.last_kernel()
+        F.set_option("x_pf2d_two_pole", 1)
+        for chunk, xcd in ((0, 1), (96, 0)):
+            F.set_option("x_pf2d_chunk", chunk)
+            F.set_option("x_pf2d_xcd", xcd)
+            got = pp.unwarp_image_backward(*a, order=order, mode=mode)
+            assert F.last_kernel() == TWO_PASS % order, F.last_kernel()
+            d = ulps(got, want)
+            assert d.max() <= 1 and np.count_nonzero(d) <= 8, (order, mode, chunk, int(d.max()), int(np.count_nonzero(d)))
+            assert np.count_nonzero(got != old) <= 8, (order, mode, chunk, int(np.count_nonzero(got != old)))
+        F.set_option("x_pf2d_chunk", 0)
+        F.set_option("x_pf2d_xcd", 1)
+        got = pp.correct_perspective_image(img, coef, order=order, mode=mode)
+        assert F.last_kernel() == TWO_PASS % order, F.last_kernel()
+        d = ulps(got, orc.correct_perspective_image(img, coef, order=order, mode=mode))
+        assert d.max() <= 1 and np.count_nonzero(d) <= 8, (order, mode)
+    # integer frames and one channel of an interleaved image
+    rng = np.random.default_rng(5)
+    u16 = rng.integers(0, 65535, size=shape, endpoint=True, dtype=np.int64).astype(np.uint16)
+    rgb = noise(77, shape + (3,))
+    for order, src in ((4, u16), (5, u16), (5, rgb[:, :, 2])):
+        got = pp.unwarp_image_backward(src, *a[1:], order=order)
+        assert F.last_kernel() == TWO_PASS % order, F.last_kernel()
+        want = orc.unwarp_image_backward(np.ascontiguousarray(src), *a[1:], order=order, poly=orc.POLY_KERNEL)
+        if src.dtype == np.uint16:
+            di = np.abs(got.astype(np.int64) - want.astype(np.int64))
+            assert di.max() <= 1 and np.count_nonzero(di) <= 3, (order, int(di.max()), int(np.count_nonzero(di)))
+        else:
+            d = ulps(got, want)
+            assert d.max() <= 1 and np.count_nonzero(d) <= 8, order
+    # a 700-sample line: z1^n has not underflowed -- the chunked serial passes, as before
+    short = noise(9, (700, 1200))
+    pp.unwarp_image_backward(short, 600.0, 340.0, [1.0, -2e-5], order=5)
+    assert "prefilter2d" not in F.last_kernel(), F.last_kernel()
 
 
 def test_gather_tile_order_does_not_change_a_bit(options):
