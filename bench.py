@@ -955,6 +955,37 @@ def stack_typed_shard(a, dev, dtype="uint16"):
     return entry(us, D * H * W, 2 * es, k, ok, shape=[D, H, W], note="%s projections, every row: %d algorithmic bytes per voxel" % (dt.name, 2 * es))
 
 
+def uint16_frames_batched(a, dev, n=16):
+    """`n` 4096 x 4096 uint16 detector frames of ONE calibration in one (n, H, W) device array and ONE call -- what
+    post.unwarp_images_backward does with such an array: dcp_unwarp_stack_rows_typed with coord_round_f32 = 2
+    (unwarp_image_backward's semantics: whole-frame clip, no row band), the stack kernel of that element type; the coordinate work of
+    a pixel position is shared by the n frames.  Frame 3 against the oracle's unwarp_image_backward."""
+    L = F.lib()
+    orc = oracle_module(a.cpu_threads)
+    c2 = configs.cfg2()
+    H, W = c2["shape"]
+    fa, nf = F.fact_array(c2["list_fact"])
+    chunk = (np.random.default_rng(c2["seed"] + 9).random((4, H, W), dtype=np.float32) * 60000.0).astype(np.uint16)
+    vol = F.DeviceBuffer(n * H * W * 2, dev)
+    out = F.DeviceBuffer(n * H * W * 2, dev)
+    for d in range(0, n, 4):
+        F.check(L.dcp_memcpy(vol.ptr + d * H * W * 2, chunk.ctypes.data, chunk.nbytes, F.COPY_H2D, dev, None))
+    code = F.DTYPE_BY_NAME["uint16"]
+
+    def run(_i):
+        F.check(L.dcp_unwarp_stack_rows_typed(vol.ptr, out.ptr, code, 0, n, H, W, H * W, W, c2["xcenter"], c2["ycenter"], fa, nf, 0.0, H, 2,
+                                              F.MEM_DEVICE, dev, None))
+    us = timed_launches(run, 24, dev, settle_ms=60.0) / n
+    k = F.last_kernel()
+    got = np.empty((H, W), np.uint16)
+    F.check(L.dcp_memcpy(got.ctypes.data, out.ptr + 3 * H * W * 2, got.nbytes, F.COPY_D2H, dev, None))
+    ok = np.array_equal(got, orc.unwarp_image_backward(chunk[3], c2["xcenter"], c2["ycenter"], c2["list_fact"], poly=orc.POLY_KERNEL))
+    vol.free()
+    out.free()
+    return entry(us, H * W, 4, k, ok, frames_per_call=n, note="per frame of %d uint16 frames of one calibration in one call (a 3-D device array through "
+                 "unwarp_images_backward): 4 algorithmic bytes per pixel" % n)
+
+
 def stack_one_gpu_cases(a, dev):
     """other_configs entries of config 4 on one GPU: one sinogram of a depth-256 shard (unwarp_slice_backward, float64
     coordinates, launch-bound) -- the whole-stack number is stack_scaling's compute_only at N = 1."""
@@ -1708,6 +1739,7 @@ def main(argv=None):
     if others is not None and "error" not in others:
         for name, fn in (("cfg5_frame8192_radial9", lambda: config5(a, dev)), ("color_4096x3", lambda: color_frame(a, dev)), ("cfg4_one_sinogram", lambda: stack_one_gpu_cases(a, dev)),
                          ("cfg4_grid_search_121_centres", lambda: grid_search_centres(a, dev)),
+                         ("cfg2_uint16_frames_batched", lambda: uint16_frames_batched(a, dev)),
                          ("cfg4_uint16_shard64", lambda: stack_typed_shard(a, dev, "uint16")),
                          ("cfg4_int32_shard64", lambda: stack_typed_shard(a, dev, "int32")), ("cfg4_float64_shard64", lambda: stack_typed_shard(a, dev, "float64"))):
             try:
