@@ -883,14 +883,24 @@ struct Pf2d {
   static constexpr int NCOL = 252;                       // columns of a stripe incl. both halos (threads 252..255 idle in the column pass)
   static constexpr int PITCH = 253;                      // odd: the rows of one column fall into distinct bank pairs; 32 x 253 x 8 B = 63.25 KB
   static constexpr int SEGS = 256 / R;                   // row-pass segments per row
-  static constexpr int SEG = (NCOL - 2 * HP) / SEGS;     // outputs per row-pass thread: 23 (HP = 34) / 25 (HP = 26)
-  static constexpr int CORE = SEGS * SEG;                // columns a stripe writes: 184 / 200
+  static constexpr bool XCH = HP >= 40;                  // (see below)
+  static constexpr int SEGC = XCH ? (NCOL - HP) / SEGS : 0;                  // XCH: causal values per thread, 26 (HP = 44) / 25 (HP = 48)
+  static constexpr int SEG0 = (NCOL - 2 * HP) / SEGS;
+  // outputs per row-pass thread: 23 (HP = 34) / 25 (HP = 26); XCH: the anti-causal warm-ups must find causal values, CORE + HP <= SEGS SEGC
+  static constexpr int SEG = XCH && (SEGS * SEGC - HP) / SEGS < SEG0 ? (SEGS * SEGC - HP) / SEGS : SEG0;      // XCH: 20 (HP = 44) / 19 (HP = 48)
+  static constexpr int CORE = SEGS * SEG;                // columns a stripe writes: 184 / 200 (XCH: 160 / 152)
+  // Long horizons (the first pole of orders 4 / 5): a row-pass thread that keeps the causal values of its segment AND of the HP
+  // samples behind it in registers (J = SEG + HP doubles, 3 HP + 2 SEG dependent steps) leaves room for 16-row steps only.  XCH: the
+  // threads EXCHANGE the causal values through the tile instead -- causal pass over SEGC columns each (core + right halo, warm-up HP),
+  // barrier, write, barrier, anti-causal pass over SEG outputs each with its warm-up read from the neighbours' causal values:
+  // 2 HP + SEGC + SEG steps, SEGC live doubles, two barriers more per step -- and 32-row steps again.
+  static_assert(!XCH || (HP + SEGS * SEGC <= NCOL && CORE + HP <= SEGS * SEGC), "the causal segments end inside the stripe and cover the anti-causal warm-ups");
 };
 // Orders 4 and 5 (two poles) as TWO passes of this kernel, one pole each (round 6): scipy filters every line with pole 1 and then
 // with pole 2, axis by axis -- P2y P1y P2x P1x; the four operators commute (the two axes act on different indices, and the two
 // poles of one axis are functions of the same mirrored shift), so P2y P2x (P1y P1x image) is the same plane up to the rounding of
-// float64 sums.  Pass 1 reads the image (pole 1: |z| = 0.36 / 0.43 -- restart horizons of 44 / 53 samples, steps of 16 rows so that
-// the two register windows still fit two waves per SIMD) and writes a float64 plane, pass 2 reads that plane (ST = kF64; pole 2:
+// float64 sums.  Pass 1 reads the image (pole 1: |z| = 0.36 / 0.43 -- restart horizons of 44 / 48 samples, the row pass exchanging its
+// causal values through the tile: XCH above) and writes a float64 plane, pass 2 reads that plane (ST = kF64; pole 2:
 // |z| = 0.014 / 0.043, horizon 16) and writes the coefficient plane.  Each pass carries its own gain (1 - z)(1 - 1/z).
 constexpr int kF64Src = 100;                             // ST of the second pass (not an element type of the ABI)
 
@@ -1016,22 +1026,58 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     // R times instead: registers that are defined on one path only cost the register allocation a dozen spills)
     const bool more = r0 + R < Yend;                           // (workgroup-uniform)
     raw_t nx[R];
-    if (!more) {
+    auto issue_next_rows = [&]() {
+      if (!more) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) nx[j] = ld(min(r0, H - 1), std::true_type{});
-    } else if (r0 + NC >= plain_lo && r0 + NC + R <= plain_hi) {
+        for (int j = 0; j < R; ++j) nx[j] = ld(min(r0, H - 1), std::true_type{});
+      } else if (r0 + NC >= plain_lo && r0 + NC + R <= plain_hi) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::false_type{});
-    } else {
+        for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::false_type{});
+      } else {
 #pragma unroll
-      for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::true_type{});
-    }
+        for (int j = 0; j < R; ++j) nx[j] = ld(r0 + NC + j, std::true_type{});
+      }
+    };
+    // (XCH: the loads go out behind the causal row pass instead -- its SEGC causal values and the column window's carried part would
+    // not fit beside 32 prefetch registers; they still arrive under the anti-causal pass, the write-back and the store-out)
+    if constexpr (!G::XCH) issue_next_rows();
     PF2D_TRACE(1);
     lds_barrier();                                             // the tile is complete
     PF2D_TRACE(2);
     // ---- row pass: causal from HP samples in front of the segment through SEG + HP samples, anti-causal back
-    double cs[J];
-    {
+    double cs[G::XCH ? SEG : J];
+    if constexpr (G::XCH) {
+      constexpr int SEGC = G::SEGC;
+      {
+        const double* ac = s_t + row_l * PITCH + seg * SEGC;   // warm-up over [seg SEGC, + HP), causal values of [HP + seg SEGC, + SEGC)
+        double cc[SEGC];
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < HP; ++i) t = ac[i] * lam + z * t;
+#pragma unroll
+        for (int j = 0; j < SEGC; ++j) {
+          t = ac[HP + j] * lam + z * t;
+          cc[j] = t;
+        }
+        lds_barrier();                                         // every thread has read its column-filtered inputs
+        double* w = s_t + row_l * PITCH + HP + seg * SEGC;
+#pragma unroll
+        for (int j = 0; j < SEGC; ++j) w[j] = cc[j];
+      }
+      issue_next_rows();
+      lds_barrier();                                           // the causal values of the core and of the right halo are in the tile
+      {
+        const double* cr = s_t + row_l * PITCH + HP + seg * SEG;   // this thread's SEG outputs, then HP causal values to warm up on
+        double t = 0.0;
+#pragma unroll
+        for (int i = SEG + HP - 1; i >= SEG; --i) t = z * (t - cr[i]);
+#pragma unroll
+        for (int j = SEG - 1; j >= 0; --j) {
+          t = z * (t - cr[j]);
+          cs[j] = t;
+        }
+      }
+    } else {
       double t = 0.0;
 #pragma unroll
       for (int i = 0; i < HP; ++i) t = a[i] * lam + z * t;
@@ -1808,7 +1854,6 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
     pd.Hs = a.H;
     pd.Ws = a.W;
     pd.zero_outside = a.mode == kModeGridConstant ? 1 : 0;
-    using I16c = std::integral_constant<int, 16>;
     using I32c = std::integral_constant<int, 32>;
     if (pf2d_ok && a.npoles == 1 && (hp[0] == 26 || hp[0] == 34)) {
       // float32 source, one pole: both axes in one pass, the column-filtered plane stays in LDS (spline_prefilter2d_kernel)
@@ -1834,10 +1879,10 @@ hipError_t launch_spline(const SplineArgs& a, int map_kind, const MapArgs& map, 
       p1.out = a.scratch;
       p1.out_ls = a.Wp;
       p1.out_ss = 1;
-      // (order 5's first pole restarts 50 samples out, not 53: |z|^50 = 2^-60.8 of the signal, 0.5 % of a float64 rounding error -- the
-      // three samples are what keeps its two register windows inside 256 VGPRs without scratch)
-      if (hp[0] == 44) launch_pf2d_src(std::integral_constant<int, 44>{}, I16c{}, p1, pd);
-      else launch_pf2d_src(std::integral_constant<int, 50>{}, I16c{}, p1, pd);
+      // (order 5's first pole restarts 48 samples out, not 53: |z|^48 = 2^-58.4 of the signal, 2 % of ONE float64 rounding error where
+      // every sample of the plane carries dozens -- the five samples keep the 80-row column window inside 256 VGPRs without scratch)
+      if (hp[0] == 44) launch_pf2d_src(std::integral_constant<int, 44>{}, I32c{}, p1, pd);
+      else launch_pf2d_src(std::integral_constant<int, 48>{}, I32c{}, p1, pd);
       TileFilter p2 = p1;
       p2.z[0] = a.poles[1];
       p2.lam = (1.0 - a.poles[1]) * (1.0 - 1.0 / a.poles[1]);

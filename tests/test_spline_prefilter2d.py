@@ -72,8 +72,8 @@ TILE = "spline_tile_filter_kernel x 2 + spline_wg_kernel<order=%d>"
 @pytest.mark.parametrize("shape", [(1100, 1347), (900, 2100), (2100, 930)])
 def test_two_pole_orders_take_one_pass_of_the_kernel_per_pole(options, orc, shape):
     """Round 6: orders 4 and 5 -- two poles -- as TWO passes of spline_prefilter2d_kernel, one pole each (image ->
-    scratch plane with the first pole's long restart horizon in 16-row steps, scratch plane -> coefficient plane with the second
-    pole), instead of the tile filter's one launch per axis.  scipy applies P2 P1 along one axis and then along the other; the
+    scratch plane with the first pole's long restart horizon -- its row-pass threads exchange causal values through the tile --,
+    scratch plane -> coefficient plane with the second pole), instead of the tile filter's one launch per axis.  scipy applies P2 P1 along one axis and then along the other; the
     four operators commute, so the plane is the same up to the rounding of float64 sums: within one float32 ulp of the oracle on
     a handful of pixels, as at every restart of the one-pass kernels.  Padded modes, integer frames and an interleaved channel
     included; lines too short for z1^n to underflow (731 / 884 samples) keep the serial recursion."""
