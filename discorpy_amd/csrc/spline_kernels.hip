@@ -883,7 +883,10 @@ struct Pf2d {
   static constexpr int NCOL = 252;                       // columns of a stripe incl. both halos (threads 252..255 idle in the column pass)
   static constexpr int PITCH = 253;                      // odd: the rows of one column fall into distinct bank pairs; 32 x 253 x 8 B = 63.25 KB
   static constexpr int SEGS = 256 / R;                   // row-pass segments per row
-  static constexpr bool XCH = HP >= 40;                  // (see below)
+#ifndef DCP_PF2D_XCH_MIN
+#define DCP_PF2D_XCH_MIN 40
+#endif
+  static constexpr bool XCH = HP >= DCP_PF2D_XCH_MIN;     // (see below)
   static constexpr int SEGC = XCH ? (NCOL - HP) / SEGS : 0;                  // XCH: causal values per thread, 26 (HP = 44) / 25 (HP = 48)
   static constexpr int SEG0 = (NCOL - 2 * HP) / SEGS;
   // outputs per row-pass thread: 23 (HP = 34) / 25 (HP = 26); XCH: the anti-causal warm-ups must find causal values, CORE + HP <= SEGS SEGC
