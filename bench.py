@@ -165,8 +165,8 @@ def cpu_baseline(cfg, img, blend, threads):
 
 # How INDEPENDENT per-frame launches leave the host (--dispatch): the headline and every other one-launch-per-frame entry use the
 # same mode.  two_streams: launch i goes to stream i & 1 of two library streams (dstream), timed regions fork from / join into the
-# first of them (timed_launches(..., dispatch=True)).  Entries whose launches depend on each other (the two-pass chain, the spline
-# path's shared coefficient plane, stacks, batches) stay on the default stream.
+# first of them (timed_launches(..., dispatch=True)).  Entries whose launches depend on each other (the two-pass chain,
+# stacks, batches) stay on the default stream.
 _DISPATCH = {"mode": "ordered", "streams": [], "join": None}
 
 
@@ -569,10 +569,13 @@ def other_configs(a, dev, srcs, dsts, img0):
     # written per pixel, as for order 1 -- the float64 coefficient plane in between is the algorithm's own traffic.
     def cubic(i):
         F.check(L.dcp_unwarp_image_spline_f32(srcs[i % nring].ptr, dsts[i % nring].ptr, H, W, W, 1, c2["xcenter"], c2["ycenter"], fa, nf,
-                                              3, 0, F.MEM_DEVICE, dev, None))
-    us = timed_launches(cubic, max(12, reps // 8), dev)
+                                              3, 0, F.MEM_DEVICE, dev, dstream(i)))
+    # (two streams: every stream keeps its own coefficient planes -- the library holds two workspaces per device --, so the prefilter of
+    # one frame, memory-bound, runs under the gather of the other, LDS- and VALU-bound)
+    us = timed_launches(cubic, max(24, reps // 4), dev, dispatch=True)
     k = F.last_kernel()
     cubic(0)
+    dsync(dev)
     got = download(dsts[0].ptr, (H, W), dev)
     want = orc.unwarp_image_backward(*a2, order=3, mode="reflect", poly=orc.POLY_KERNEL)
     # (lines longer than one prefilter tile restart the recursion inside a halo: equal to the serial oracle up to the odd
@@ -592,7 +595,7 @@ def other_configs(a, dev, srcs, dsts, img0):
             sp_src = "none: profiles/pmc_spline_latest.json is of %s" % " + ".join(names)
     except (OSError, ValueError, KeyError):
         pass
-    out["cfg2_order3_cubic_spline"] = entry(us, H * W, 8, k, ok, traffic=sp_traffic, traffic_source=sp_src,
+    out["cfg2_order3_cubic_spline"] = pf_entry(us, H * W, 8, k, ok, traffic=sp_traffic, traffic_source=sp_src,
                                             note="two launches per frame (prefilter of both axes, gather); pixels differing from the oracle by one float32 ulp: %d"
                                                  % int(np.count_nonzero(got != want)))
 

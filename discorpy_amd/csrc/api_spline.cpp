@@ -13,44 +13,102 @@ using namespace dcpapi;
 
 namespace {
 
-// Per-device float64 coefficient workspace (grow-only).  Reused across calls; a call on a stream
-// other than the previous one first waits for the device so that the old user is done.
+// Per-device float64 coefficient workspaces (grow-only): kSlots of them, so that spline calls on TWO streams -- independent frames
+// handed over alternately, INTEGRATION.md section 7 -- each keep their planes and the prefilter of one frame (memory-bound) runs
+// under the gather of the other (LDS- and VALU-bound) instead of waiting for the device (rounds 2-5: one workspace, and a call on
+// another stream than the last one synchronised the device first).  A slot remembers the stream that used it last and an event
+// recorded behind that use; a call on another stream waits for the event ON THE DEVICE (hipStreamWaitEvent), never on the host.
+// A slot's mutex is held by run_spline from acquire() until its last kernel is enqueued (host callers: until the result is back),
+// so two host threads never interleave their passes over one slot's planes; calls on different GPUs run side by side.
 struct SplineWorkspace {
-  std::mutex use[64];      // per device: held by run_spline from get() until its last kernel is enqueued (host callers: until
-                           // the result is back), so two host threads never interleave their passes over that device's planes
-                           // -- calls on different GPUs run side by side
-  std::mutex mu;
-  void* buf[64] = {};
-  size_t cap[64] = {};
-  hipStream_t last[64] = {};
-  hipError_t get(size_t bytes, hipStream_t stream, double** out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(mu);
-    if (buf[dev] && last[dev] != stream) {
-      e = hipDeviceSynchronize();
-      if (e != hipSuccess) return e;
-    }
-    if (cap[dev] < bytes) {
-      if (buf[dev]) {
-        e = hipDeviceSynchronize();
-        if (e != hipSuccess) return e;
-        (void)hipFree(buf[dev]);
-        buf[dev] = nullptr;
-        cap[dev] = 0;
+  static constexpr int kSlots = 2;
+  struct Slot {
+    std::mutex use;
+    void* buf = nullptr;
+    size_t cap = 0;
+    hipStream_t last = nullptr;
+    bool used = false;
+    hipEvent_t done = nullptr;
+    unsigned long long tick = 0;
+  };
+  std::mutex mu;                     // the tables below (never held while waiting for a slot)
+  Slot slot[64][kSlots];
+  unsigned long long clock = 0;
+
+  // The slot for a call on `stream` of the current device, LOCKED (release() unlocks), its planes grown to `bytes` and ordered behind
+  // the slot's previous use.  Preference: the slot this stream used last; a slot never used; the least recently used one.
+  hipError_t acquire(size_t bytes, hipStream_t stream, int dev, Slot** out) {
+    int order[kSlots];
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      int n = 0;
+      for (int k = 0; k < kSlots; ++k)
+        if (slot[dev][k].used && slot[dev][k].last == stream) order[n++] = k;
+      for (int k = 0; k < kSlots; ++k)
+        if (!slot[dev][k].used) order[n++] = k;
+      for (int pass = 0; pass < kSlots; ++pass) {          // the rest, least recently used first
+        int best = -1;
+        for (int k = 0; k < kSlots; ++k) {
+          bool taken = false;
+          for (int i = 0; i < n; ++i) taken = taken || order[i] == k;
+          if (!taken && (best < 0 || slot[dev][k].tick < slot[dev][best].tick)) best = k;
+        }
+        if (best >= 0) order[n++] = best;
       }
-      e = hipMalloc(&buf[dev], bytes);
-      if (e != hipSuccess) return e;
-      cap[dev] = bytes;
     }
-    last[dev] = stream;
-    *out = (double*)buf[dev];
+    Slot* s = nullptr;
+    // a slot of this stream is taken even if another thread holds it right now (calls on one stream are ordered anyway); otherwise
+    // the first free one in preference order, and if every slot is busy, wait for the preferred one
+    if (slot[dev][order[0]].used && slot[dev][order[0]].last == stream) {
+      s = &slot[dev][order[0]];
+      s->use.lock();
+    } else {
+      for (int i = 0; i < kSlots && !s; ++i)
+        if (slot[dev][order[i]].use.try_lock()) s = &slot[dev][order[i]];
+      if (!s) {
+        s = &slot[dev][order[0]];
+        s->use.lock();
+      }
+    }
+    hipError_t e = hipSuccess;
+    if (!s->done) e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+    if (e == hipSuccess && s->cap < bytes) {
+      if (s->buf) {                                          // the previous user must be done before its planes go away
+        e = hipEventSynchronize(s->done);
+        if (e == hipSuccess) e = hipFree(s->buf);
+        s->buf = nullptr;
+        s->cap = 0;
+      }
+      if (e == hipSuccess) e = hipMalloc(&s->buf, bytes);
+      if (e == hipSuccess) s->cap = bytes;
+    }
+    // another stream used these planes last: this call's kernels start behind that use (nothing to wait for on the same stream)
+    if (e == hipSuccess && s->used && s->last != stream) e = hipStreamWaitEvent(stream, s->done, 0);
+    if (e != hipSuccess) {
+      s->use.unlock();
+      return e;
+    }
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      s->used = true;
+      s->last = stream;
+      s->tick = ++clock;
+    }
+    *out = s;
     return hipSuccess;
+  }
+  // every kernel of the call has been enqueued on `stream`: mark the end of the use and let the next caller in
+  void release(Slot* s, hipStream_t stream) {
+    (void)hipEventRecord(s->done, stream);
+    s->use.unlock();
   }
 };
 SplineWorkspace g_spline_ws;
+struct SlotGuard {           // releases the slot on every return path of run_spline
+  SplineWorkspace::Slot* s;
+  hipStream_t st;
+  ~SlotGuard() { g_spline_ws.release(s, st); }
+};
 
 int spline_poles(int order, double* z) {
   switch (order) {
@@ -75,16 +133,20 @@ namespace dcpapi {
 int release_spline_workspace() {
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess) return DCP_OK;      // no runtime / no device: nothing was ever allocated
-  for (int dev = 0; dev < 64; ++dev) {
-    std::lock_guard<std::mutex> exclusive(g_spline_ws.use[dev]);
-    std::lock_guard<std::mutex> lock(g_spline_ws.mu);
-    if (!g_spline_ws.buf[dev]) continue;
-    DCP_HIP(hipSetDevice(dev));
-    DCP_HIP(hipDeviceSynchronize());
-    (void)hipFree(g_spline_ws.buf[dev]);
-    g_spline_ws.buf[dev] = nullptr;
-    g_spline_ws.cap[dev] = 0;
-  }
+  for (int dev = 0; dev < 64; ++dev)
+    for (int k = 0; k < SplineWorkspace::kSlots; ++k) {
+      SplineWorkspace::Slot& sl = g_spline_ws.slot[dev][k];
+      std::lock_guard<std::mutex> exclusive(sl.use);
+      if (!sl.buf) continue;
+      DCP_HIP(hipSetDevice(dev));
+      DCP_HIP(hipDeviceSynchronize());
+      (void)hipFree(sl.buf);
+      std::lock_guard<std::mutex> lock(g_spline_ws.mu);
+      sl.buf = nullptr;
+      sl.cap = 0;
+      sl.used = false;
+      sl.last = nullptr;
+    }
   (void)hipSetDevice(prev);
   return DCP_OK;
 }
@@ -138,8 +200,10 @@ int run_spline(int map_kind, const void* src, void* dst, int dtype, int64_t H, i
   int cur_dev = 0;
   DCP_HIP(hipGetDevice(&cur_dev));                           // (DeviceScope above has selected it)
   if (cur_dev < 0 || cur_dev >= 64) return fail(DCP_ERR_UNSUPPORTED, "device index %d", cur_dev);
-  std::lock_guard<std::mutex> exclusive(g_spline_ws.use[cur_dev]);
-  DCP_HIP(g_spline_ws.get(2 * plane, st, &a.coef));
+  SplineWorkspace::Slot* slot = nullptr;
+  DCP_HIP(g_spline_ws.acquire(2 * plane, st, cur_dev, &slot));
+  SlotGuard guard{slot, st};
+  a.coef = (double*)slot->buf;
   a.scratch = a.coef + (size_t)a.Hp * (size_t)a.Wp;
   dcp::CoordArgs ca;
   memset(&ca, 0, sizeof(ca));

@@ -219,3 +219,42 @@ def test_cfg2_frame_at_order_3(options, orc):
     assert d.max() <= 1 and np.count_nonzero(d) <= 32, (int(d.max()), int(np.count_nonzero(d)))
     src.free()
     dst.free()
+
+
+def test_spline_frames_on_two_streams_keep_their_own_planes(options, orc):
+    """Round 6: the library keeps TWO coefficient workspaces per device, so spline calls on two streams -- independent frames handed
+    over alternately, bench.py's default dispatch -- do not wait for each other (the prefilter of one frame runs under the gather
+    of the other); a third stream reuses the least recently used workspace behind an event of its last user.  Every frame is what
+    the single-stream call gives."""
+    F = options
+    L = F.lib()
+    c = configs.cfg2()
+    H, W, n = 1200, 1500, 6
+    fa, nf = F.fact_array(c["list_fact"])
+    xc, yc = c["xcenter"] * W / 4096.0, 0.45 * H
+    frames = [noise(800 + i, (H, W)) for i in range(n)]
+    src = [F.DeviceBuffer(f.nbytes).upload(f) for f in frames]
+    dst = [F.DeviceBuffer(f.nbytes) for f in frames]
+    streams = [F.Stream(), F.Stream(), F.Stream()]
+    for order in (3, 5):
+        want = []
+        for i in range(n):
+            F.check(L.dcp_unwarp_image_spline_f32(src[i].ptr, dst[i].ptr, H, W, W, 1, xc, yc, fa, nf, order, 0, F.MEM_DEVICE, -1, streams[0].ptr))
+            streams[0].synchronize()
+            want.append(dst[i].download((H, W), np.float32))
+            dst[i].upload(np.zeros((H, W), np.float32))
+        assert max(ulps(want[0], orc.unwarp_image_backward(frames[0], xc, yc, c["list_fact"], order=order, poly=orc.POLY_KERNEL)).max(), 0) <= 1
+        for ns in (2, 3):
+            for rep in range(4):
+                for i in range(n):
+                    F.check(L.dcp_unwarp_image_spline_f32(src[i].ptr, dst[i].ptr, H, W, W, 1, xc, yc, fa, nf, order, 0, F.MEM_DEVICE, -1,
+                                                          streams[(i + rep) % ns].ptr))
+            for st in streams:
+                st.synchronize()
+            for i in range(n):
+                assert np.array_equal(dst[i].download((H, W), np.float32), want[i]), (order, ns, i)
+    F.release_scratch()                    # both workspaces go; the next call allocates again
+    F.check(L.dcp_unwarp_image_spline_f32(src[0].ptr, dst[0].ptr, H, W, W, 1, xc, yc, fa, nf, 3, 0, F.MEM_DEVICE, -1, None))
+    F.check(L.dcp_stream_synchronize(-1, None))
+    for b in src + dst:
+        b.free()
