@@ -157,7 +157,7 @@ def cpu_baseline(cfg, img, blend, threads):
                       "(numpy-order polynomial, scipy blend), %d OpenMP threads (%d logical CPUs visible, %d usable "
                       "under the affinity mask / cgroup quota), %.2f s wall.  The reference itself (Python: numpy + scipy, it "
                       "cannot use more than one core and may not travel to this box) measured on one core of the build container: "
-                      "1.97 s per frame = 8.5 Mpixels/s (profiles/r01c_reference_cpu_build_container.txt, tools/time_reference.py)"
+                      "1.97 s per frame = 8.5 Mpixels/s (profiles/rounds_1-4/r01c_reference_cpu_build_container.txt, tools/time_reference.py)"
                       % (frames, img.shape[0], img.shape[1], t, ncores, usable_cpus(), dt)}
 
 
@@ -381,7 +381,7 @@ def end_to_end_numpy():
     import subprocess
     out = {"what": "NumPy in -> NumPy out through discorpy_amd.post.postprocessing (host arrays: H2D + kernel + D2H, median of "
                    "repeated calls); the reference on one core: cfg2 1965 ms, slice of a depth-64 stack 6.7 ms "
-                   "(profiles/r01c_reference_cpu_build_container.txt)"}
+                   "(profiles/rounds_1-4/r01c_reference_cpu_build_container.txt)"}
     for label, env in (("default_runtime", {}), ("system_rocm_runtime", {"DISCORPY_AMD_SYSTEM_HIP": "1"})):
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--e2e-child"], capture_output=True, text=True, timeout=300,

@@ -1106,7 +1106,7 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
     lds_barrier();
     PF2D_TRACE(4);
     // ---- the core of the step, contiguous row pieces (8 bytes per lane: the rows dealt to the lanes as one list of pairs -- 16-byte
-    // stores, a wave's kilobyte straddling two row pieces -- measured 3 % slower, profiles/r05p_ab_store16.txt)
+    // stores, a wave's kilobyte straddling two row pieces -- measured 3 % slower, profiles/round_5/r05p_ab_store16.txt)
 #pragma unroll
     for (int q = 0; q < R / 4; ++q) {
       const int rr = q * 4 + wave;
@@ -1149,7 +1149,7 @@ __global__ void __launch_bounds__(256, DCP_PF2D_WAVES) spline_prefilter2d_kernel
   __shared__ double s_t[G::R * G::PITCH];
   // Workgroups go round-robin to the 8 XCDs (blockIdx.x & 7), each with its own L2: XCD k takes a contiguous run of tiles in
   // row-major order (stripe fastest), so that the stripes that share 2 HP columns -- neighbours that read the same source rows
-  // at about the same time -- meet in one L2 (FETCH_SIZE x 2: 162 -> 93 MB per 4096^2 frame, profiles/r05k_pmc_spline*.txt)
+  // at about the same time -- meet in one L2 (FETCH_SIZE x 2: 162 -> 93 MB per 4096^2 frame, profiles/round_5/r05k_pmc_spline*.txt)
   const int ntiles = stripes * chunks;
   const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
   const int q = ntiles >> 3, rem = ntiles & 7;

@@ -1093,7 +1093,7 @@ __global__ void __launch_bounds__(256, (NF < 0 ? 4 : (NF == 1 ? 5 : DCP_WG_WAVES
 
 // remap_wg_kernel over a batch of frames of one shape, each with its OWN source, destination, centre and coefficient
 // vector: blockIdx.z = frame.  A per-frame launch spends ~3.5 us before its first tile completes and ~9 us draining
-// its last workgroups (profiles/r02b_phase_timeline_wg_f64lerp.txt: a third of a 4096^2 launch); here the tail of
+// its last workgroups (profiles/rounds_1-4/r02b_phase_timeline_wg_f64lerp.txt: a third of a 4096^2 launch); here the tail of
 // frame z runs under the head of frame z + 1.  The per-frame arguments travel in the KERNEL ARGUMENTS (a table of
 // BatchEntry<NF>, indexed by the workgroup's frame: scalar loads from the kernarg segment, no device-side table whose
 // lifetime would have to outlast the launch), which bounds a launch to BatchTable<NF>::kMax frames; longer batches are

@@ -40,7 +40,7 @@ def test_bench_line_carries_every_config_verified(hip):
     assert oc["color_4096x3"]["kernel"].startswith("remap_wg_color_kernel<NF=5,f64lerp,float32 x 3>") and oc["color_4096x3"]["algorithmic_bytes_per_pixel"] == 24
     ss = j["stack_scaling"]
     assert ss["compute_plus_allgather"] is None and ss["verified_vs_oracle"] is True and ss["compute_only"]["ms_per_step"] > 0
-    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and "profiles/r01c_reference_cpu" in j["cpu_baseline"]["sample"]
+    assert j["cpu_baseline"]["kind"] == "port" and j["cpu_baseline"]["value"] > 0 and "profiles/rounds_1-4/r01c_reference_cpu" in j["cpu_baseline"]["sample"]
     # the multi-frame launch (every frame its own calibration) beside the per-launch headline, checked against the oracle
     bd = j["batched_distinct_calibrations"]
     assert bd["verified_vs_oracle"] is True and bd["kernel"].startswith("remap_wg_batch_kernel<Radial,NF=5,f64lerp") and bd["us_per_frame"] > 0

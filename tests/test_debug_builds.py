@@ -1,6 +1,6 @@
 """SURVEY.md section 5's hooks: the CPU restatement under AddressSanitizer + UndefinedBehaviorSanitizer, and the bounds-checking build
 of the kernels (every LDS tap of the staged kernels checked against its slab).  The sanitizer run is CPU-only; the bounds-checking
-library is exercised by tools/fuzz_parity.py --bounds (profiles/r04*_fuzz_bounds_build.txt) and, when it has been built, here."""
+library is exercised by tools/fuzz_parity.py --bounds (profiles/rounds_1-4/r04*_fuzz_bounds_build.txt) and, when it has been built, here."""
 import os
 import shutil
 import subprocess

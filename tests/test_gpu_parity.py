@@ -1257,7 +1257,7 @@ def test_frame_larger_than_4_gib(hip, orc):
 def test_randomised_differential_campaign(hip, orc):
     """600 seeded random cases of tools/fuzz_parity.py (shapes, centres, models from mild to folding, homographies,
     strides, blends, stacks, coordinates, element types, spline orders and modes): HIP == oracle, bit for bit at
-    orders 0/1.  profiles/r01c_fuzz_parity.txt holds a 32 000-case run."""
+    orders 0/1.  profiles/rounds_1-4/r01c_fuzz_parity.txt holds a 32 000-case run."""
     import importlib.util
     import os
     from conftest import ROOT
