@@ -1010,7 +1010,10 @@ __device__ __forceinline__ void pf2d_body(const TileFilter& f, const Pf2dPad& pd
   // ---- row pass geometry: thread (row_l, seg)
   const int row_l = tid % R, seg = tid / R;                    // 32 consecutive lanes = the 32 rows of one segment: conflict-free LDS passes
   const double* a = s_t + row_l * PITCH + seg * SEG;           // a[i]: column-filtered sample g0 - HP + seg SEG + i of this thread's row
-  double* const colw = s_t + min(tid, NCOL);                   // (threads 252..255 write the pad column)
+  // (threads 252..255 have no column of their own: they recurse on a copy of column NCOL - 1 and all four write the tile's PAD column
+  // -- index NCOL, the 253rd double of a row, which exists only to make the pitch odd and which nothing ever reads: a write sink, four
+  // same-address stores of dead values per row, kept unpredicated so that the column pass stays branch-free)
+  double* const colw = s_t + min(tid, NCOL);
   const int c_n = min(CORE, W - g0);
   const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc((void*)f.out, 0, (int)out_bytes, 0x00020000);
   const uint32_t ovoff = (uint32_t)(g0 + lane) * 8u, orow = (uint32_t)f.out_ls * 8u;
