@@ -39,6 +39,7 @@ struct SplineWorkspace {
   // the slot's previous use.  Preference: the slot this stream used last; a slot never used; the least recently used one.
   hipError_t acquire(size_t bytes, hipStream_t stream, int dev, Slot** out) {
     int order[kSlots];
+    bool own = false;                  // the preferred slot was last used by this very stream (read under `mu`, like every table entry)
     {
       std::lock_guard<std::mutex> lock(mu);
       int n = 0;
@@ -55,11 +56,12 @@ struct SplineWorkspace {
         }
         if (best >= 0) order[n++] = best;
       }
+      own = slot[dev][order[0]].used && slot[dev][order[0]].last == stream;
     }
     Slot* s = nullptr;
     // a slot of this stream is taken even if another thread holds it right now (calls on one stream are ordered anyway); otherwise
     // the first free one in preference order, and if every slot is busy, wait for the preferred one
-    if (slot[dev][order[0]].used && slot[dev][order[0]].last == stream) {
+    if (own) {
       s = &slot[dev][order[0]];
       s->use.lock();
     } else {
@@ -82,7 +84,8 @@ struct SplineWorkspace {
       if (e == hipSuccess) e = hipMalloc(&s->buf, bytes);
       if (e == hipSuccess) s->cap = bytes;
     }
-    // another stream used these planes last: this call's kernels start behind that use (nothing to wait for on the same stream)
+    // another stream used these planes last: this call's kernels start behind that use (nothing to wait for on the same stream).
+    // (`used` / `last` of a slot whose `use` mutex this thread holds change only under that mutex)
     if (e == hipSuccess && s->used && s->last != stream) e = hipStreamWaitEvent(stream, s->done, 0);
     if (e != hipSuccess) {
       s->use.unlock();

@@ -1,7 +1,7 @@
 // Microbenchmark (lab, not product): the direct-write host scheme in isolation -- a pageable 64 MiB frame goes up in B bands on one
 // stream (linear copies), a kernel on a second stream, behind an event per band, copies the band into pinned host memory (the shader's
 // stores cross PCIe while the copy engine uploads).  What does the link give this scheme, by band count?
-//   hipcc -O2 --offload-arch=gfx950 tools/ubench/direct_write.hip -o /tmp/direct_write && /tmp/direct_write
+//   hipcc -O2 --offload-arch=gfx950 tools/attic/ubench_host/direct_write.hip -o /tmp/direct_write && /tmp/direct_write
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>

@@ -2,7 +2,7 @@
 // hipHostMalloc ("malloc") or mmap + hipHostRegister ("reg" / "regshared", what the Python pool hands out); source pages plain or
 // MADV_HUGEPAGE (numpy's); argv: <malloc|reg|regshared> <host_bands or 0> <plain|huge> [direct].  A C++ process runs on /opt/rocm's HIP
 // runtime, the Python front end on the one bundled with PyTorch whenever torch is installed (discorpy_amd/_ffi.py).
-//   hipcc -O2 tools/ubench/host_call.cpp -Iinclude -Ldiscorpy_amd/lib -ldiscorpy_hip -Wl,-rpath,$PWD/discorpy_amd/lib -o tools/ubench/host_call
+//   hipcc -O2 tools/attic/ubench_host/host_call.cpp -Iinclude -Ldiscorpy_amd/lib -ldiscorpy_hip -Wl,-rpath,$PWD/discorpy_amd/lib -o tools/attic/ubench_host/host_call
 #include <hip/hip_runtime.h>
 #include <sys/mman.h>
 #include <algorithm>

@@ -3,7 +3,7 @@
 //   (b) from a registered buffer (the PCIe floor),
 //   (c) staged by T host threads through a pinned buffer in chunks of C KiB, one hipMemcpyAsync per chunk,
 // each alone and with a 64 MiB download from the device into pinned memory running on a second stream.
-//   hipcc -O2 -pthread tools/ubench/staged_upload.cpp -o /tmp/staged_upload && /tmp/staged_upload
+//   hipcc -O2 -pthread tools/attic/ubench_host/staged_upload.cpp -o /tmp/staged_upload && /tmp/staged_upload
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>

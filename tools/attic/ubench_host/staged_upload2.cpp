@@ -1,6 +1,6 @@
 // Microbenchmark (lab, not product), second part: the upload of a FRESH pageable 64 MiB frame (a buffer the runtime has not seen:
 // its pin cache cannot help), whole or in 24 bands, 1-D and 2-D copies, against staging through pinned memory by host threads.
-//   hipcc -O2 -pthread tools/ubench/staged_upload2.cpp -o /tmp/staged_upload2 && /tmp/staged_upload2
+//   hipcc -O2 -pthread tools/attic/ubench_host/staged_upload2.cpp -o /tmp/staged_upload2 && /tmp/staged_upload2
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>

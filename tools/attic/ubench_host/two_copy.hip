@@ -1,6 +1,6 @@
 // Microbenchmark (lab, not product): the two-copy host scheme enqueued from ONE thread -- a pageable 64 MiB frame goes up in B bands
 // (linear copies, stream 1), a device kernel per band behind it, an event, the band's download into PINNED host memory on stream 2.
-//   hipcc -O2 --offload-arch=gfx950 tools/ubench/two_copy.hip -o /tmp/two_copy && /tmp/two_copy
+//   hipcc -O2 --offload-arch=gfx950 tools/attic/ubench_host/two_copy.hip -o /tmp/two_copy && /tmp/two_copy
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
