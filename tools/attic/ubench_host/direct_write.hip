@@ -14,6 +14,17 @@ static double now() { return std::chrono::duration<double>(std::chrono::steady_c
 __global__ void copy_kernel(const float4* __restrict__ in, float4* __restrict__ out, size_t n) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = in[i];
 }
+// the frame kernels' store shape: 4 bytes per lane, a wave writes 256 contiguous bytes of one row, 16 rows per wave
+__global__ void copy_kernel_b32(const float* __restrict__ in, float* __restrict__ out, size_t n, int W) {
+  const size_t tiles_x = W / 64;
+  for (size_t t = blockIdx.x * 4 + (threadIdx.x >> 6); t * 16 * 64 < n; t += (size_t)gridDim.x * 4) {
+    const size_t tx = t % tiles_x, ty = t / tiles_x;
+    for (int k = 0; k < 16; ++k) {
+      const size_t i = (ty * 16 + k) * W + tx * 64 + (threadIdx.x & 63);
+      if (i < n) __builtin_nontemporal_store(in[i], &out[i]);
+    }
+  }
+}
 int main() {
   const size_t n = 64u << 20;
   char* page = (char*)aligned_alloc(4096, n);
@@ -44,6 +55,20 @@ int main() {
   timeit("upload alone (pageable, one copy)", [&] { CK(hipMemcpyAsync(d0, page, n, hipMemcpyHostToDevice, s_up)); });
   timeit("kernel device -> pinned host alone (64 MiB, 2048 workgroups)", [&] { hipLaunchKernelGGL(copy_kernel, dim3(2048), dim3(256), 0, s_k, (const float4*)d0, (float4*)pin, n / 16); });
   timeit("kernel device -> pinned host alone (64 MiB, 256 workgroups)", [&] { hipLaunchKernelGGL(copy_kernel, dim3(256), dim3(256), 0, s_k, (const float4*)d0, (float4*)pin, n / 16); });
+  timeit("kernel device -> pinned host alone, 4-byte nt stores in 64 x 16 wave tiles", [&] { hipLaunchKernelGGL(copy_kernel_b32, dim3(2048), dim3(256), 0, s_k, (const float*)d0, (float*)pin, n / 4, 4096); });
+  for (int B : {6, 12}) {
+    char what[128];
+    snprintf(what, sizeof(what), "pageable source, %2d bands, 4-byte nt stores in wave tiles", B);
+    timeit(what, [&] {
+      for (int k = 0; k < B; ++k) {
+        const size_t o = n / B / 65536 * 65536 * k, len = (k == B - 1) ? n - o : n / B / 65536 * 65536;
+        CK(hipMemcpyAsync(d0 + o, page + o, len, hipMemcpyHostToDevice, s_up));
+        CK(hipEventRecord(ev[k], s_up));
+        CK(hipStreamWaitEvent(s_k, ev[k], 0));
+        hipLaunchKernelGGL(copy_kernel_b32, dim3(1024), dim3(256), 0, s_k, (const float*)(d0 + o), (float*)(pin + o), len / 4, 4096);
+      }
+    });
+  }
   for (int src_kind = 0; src_kind < 2; ++src_kind)
     for (int B : {1, 3, 6, 12, 24}) {
       char what[128];
