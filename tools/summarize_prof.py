@@ -22,13 +22,29 @@ def main(out):
         for row in csv.DictReader(open(f)):
             summary["kernels"][row["Name"]] = {k: row[k] for k in row if k != "Name"}
     durations = defaultdict(list)
+    spans = defaultdict(list)
     for f in find(os.path.join(out, "trace"), "*kernel_trace.csv"):
         for row in csv.DictReader(open(f)):
-            durations[row["Kernel_Name"]].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            t0, t1 = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+            durations[row["Kernel_Name"]].append(t1 - t0)
+            spans[row["Kernel_Name"]].append((t0, t1))
     for k, v in durations.items():
         v.sort()
+        # busy_union_ns_per_call: the time during which AT LEAST ONE launch of this kernel was running, divided by the launches --
+        # with independent frames in flight on two streams (bench.py --dispatch two_streams) two launches overlap, every one of them
+        # lasts about twice the per-frame time, and this is the figure that corresponds to the bench line's launch_us
+        iv = sorted(spans[k])
+        union, cur0, cur1 = 0, iv[0][0], iv[0][1]
+        for a0, a1 in iv[1:]:
+            if a0 <= cur1:
+                cur1 = max(cur1, a1)
+            else:
+                union += cur1 - cur0
+                cur0, cur1 = a0, a1
+        union += cur1 - cur0
         summary["kernels"].setdefault(k, {})["trace"] = {
-            "calls": len(v), "avg_ns": sum(v) / len(v), "median_ns": v[len(v) // 2], "min_ns": v[0], "max_ns": v[-1]}
+            "calls": len(v), "avg_ns": sum(v) / len(v), "median_ns": v[len(v) // 2], "min_ns": v[0], "max_ns": v[-1],
+            "busy_union_ns_per_call": union / len(v), "overlap_factor": sum(v) / union}
     # counter passes: counter_collection.csv, one row per (dispatch, counter)
     for d in sorted(os.listdir(out)):
         p = os.path.join(out, d)
